@@ -1,0 +1,239 @@
+"""
+Hand-canonicalised problem families (cvxpy-free), following SURVEY.md Appendix B: what cvxpy's
+QP canonicalisation yields for the reference's example / test problems.
+
+  nonneg_ls   `examples/main.py:16-25`, `tests/test_diff.py:14-25`
+  mpc         `examples/MPC.ipynb` cell 1/3, `tests/test_E2E_QP.py:44-73`
+  portfolio   `examples/portfolio.ipynb` cell 1/3/7, `tests/test_E2E_QP.py:76-110`
+
+cvxpy replaces every `sum_squares(affine(theta, x))` by a new variable t with `t == affine` and an
+objective term t't (P = 2I on the t block, constant), `abs(v)` by t with v <= t, -v <= t, and
+`minimum(0, w)` by t <= 0, t <= w.  The ordering of variables inside x and of rows inside the
+equality / inequality blocks follows cvxpy's internal `var_offsets` and is not derivable without
+cvxpy; the orders chosen here are fixed and documented per family.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .canon_builder import CanonBuilder, cmul
+from .descriptor import FamilyDescriptor
+
+
+# ------------------------------------------------------------------------------------------------
+def nonneg_ls(m: int = 3, n: int = 2, sparsity=((0, 0, 1), (0, 1, 1)), seed: int = 1,
+              name: str = 'nonneg_LS') -> FamilyDescriptor:
+    """minimise ||A x - b||^2  s.t. x >= 0   (`examples/main.py:16-25`).
+
+    x = [x (n); t (m)];  eq: A x - t = b (m rows);  ineq: -x <= 0 (n rows).
+    Default values as the example: np.random.seed(1); A.data = randn(nnz); b = randn(m).
+    """
+    cb = CanonBuilder(name)
+    if sparsity is not None:
+        A = cb.param('A', (m, n), kind='sparse', sparsity=sparsity)
+    else:
+        A = cb.param('A', (m, n))
+    b = cb.param('b', (m,))
+    x = cb.var('x', (n,))
+    t = cb.aux(m)
+    cb.sum_squares(t)
+    for i in range(m):
+        ent = [(x[j], A[i, j]) for j in range(n) if A.structurally_nonzero(i, j)]
+        ent.append((t[i], -1.0))
+        cb.eq(ent, b[i])
+    rows = [cb.ineq([(x[j], -1.0)], 0.0) for j in range(n)]
+    cb.dual('d0', rows, (n,))
+
+    rng = np.random.RandomState(seed)
+    if sparsity is not None:
+        Aval = rng.randn(len(sparsity[0]))
+    else:
+        Aval = rng.randn(m, n)
+    bval = rng.randn(m)
+    return cb.build({'A': Aval, 'b': bval})
+
+
+# ------------------------------------------------------------------------------------------------
+def mpc_dynamics(n: int, m: int, td: float = 0.1):
+    """Discrete double integrator: n/2 positions + n/2 velocities, m force inputs acting on the
+    first m velocity states (for n=6, m=3 this is `examples/MPC.ipynb` cell 3 exactly; for
+    n=12, m=4 it is the builder-defined extension named in SURVEY.md section 8(d))."""
+    h = n // 2
+    A_cont = np.zeros((n, n))
+    A_cont[:h, h:] = np.eye(h)
+    B_cont = np.zeros((n, m))
+    B_cont[h:h + m, :] = np.eye(m)
+    return np.eye(n) + td * A_cont, td * B_cont
+
+
+def mpc(n: int = 6, m: int = 3, H: int = 10, sparse_params: bool = False, terminal_index=None,
+        const: float = 0.0, x_init=None, name: str = 'MPC') -> FamilyDescriptor:
+    """
+    minimise ||Psqrt X[:,T]||^2 + ||Qsqrt X[:,:H]||_F^2 + ||Rsqrt U||_F^2 (+ const)
+    s.t.     X[:,1:] == A X[:,:H] + B U ;  |U| <= 1 ;  X[:,0] == x_init
+    (`examples/MPC.ipynb` cell 1: T = H, dense parameters;
+     `tests/test_E2E_QP.py:44-73`: T = H-1, const = 1, diag cost parameters, sparse A, B.)
+
+    x = [U (m*H); X (n*(H+1)); tP (n); tQ (n*H); tR (m*H); tA (m*H)]
+    eq   = [tP - Psqrt X_T = 0 (n); tQ_k - Qsqrt X_k = 0 (n*H); tR_k - Rsqrt U_k = 0 (m*H);
+            X_{k+1} - A X_k - B U_k = 0 (n*H); X_0 = x_init (n)]
+    ineq = [U - tA <= 0 (m*H); -U - tA <= 0 (m*H); tA <= 1 (m*H)]
+    user duals: dynamics (n x H), |U| <= 1 (m x H), init (n).
+    """
+    T = H if terminal_index is None else terminal_index
+    cb = CanonBuilder(name)
+    if sparse_params:
+        Psqrt = cb.param('Psqrt', (n, n), kind='diag')
+        Qsqrt = cb.param('Qsqrt', (n, n), kind='diag')
+        Rsqrt = cb.param('Rsqrt', (m, m), kind='diag')
+        nzA = [(i, i) for i in range(n)] + [(i, n // 2 + i) for i in range(n // 2)]
+        Ap = cb.param('A', (n, n), kind='sparse', sparsity=tuple(zip(*nzA)))
+        nzB = [(n // 2 + i, i) for i in range(min(m, n // 2))]
+        Bp = cb.param('B', (n, m), kind='sparse', sparsity=tuple(zip(*nzB)))
+    else:
+        Psqrt = cb.param('Psqrt', (n, n))
+        Qsqrt = cb.param('Qsqrt', (n, n))
+        Rsqrt = cb.param('Rsqrt', (m, m))
+        Ap = cb.param('A', (n, n))
+        Bp = cb.param('B', (n, m))
+    xi = cb.param('x_init', (n,))
+
+    U = cb.var('U', (m, H))
+    X = cb.var('X', (n, H + 1))
+    tP = cb.aux(n)
+    tQ = cb.aux(n * H).reshape((n, H), order='F')
+    tR = cb.aux(m * H).reshape((m, H), order='F')
+    tA = cb.aux(m * H).reshape((m, H), order='F')
+
+    cb.sum_squares(tP)
+    cb.sum_squares(tQ.ravel(order='F'))
+    cb.sum_squares(tR.ravel(order='F'))
+    if const:
+        cb.const(const)
+
+    def mat_rows(t_idx, Mp, nrow, ncol, v_idx):
+        for i in range(nrow):
+            ent = [(t_idx[i], 1.0)]
+            ent += [(v_idx[j], cmul(Mp[i, j], -1.0)) for j in range(ncol)
+                    if Mp.structurally_nonzero(i, j)]
+            cb.eq(ent, 0.0)
+
+    mat_rows(tP, Psqrt, n, n, X[:, T])
+    for k in range(H):
+        mat_rows(tQ[:, k], Qsqrt, n, n, X[:, k])
+    for k in range(H):
+        mat_rows(tR[:, k], Rsqrt, m, m, U[:, k])
+    dyn_rows = []
+    for k in range(H):
+        for i in range(n):
+            ent = [(X[i, k + 1], 1.0)]
+            ent += [(X[j, k], cmul(Ap[i, j], -1.0)) for j in range(n)
+                    if Ap.structurally_nonzero(i, j)]
+            ent += [(U[j, k], cmul(Bp[i, j], -1.0)) for j in range(m)
+                    if Bp.structurally_nonzero(i, j)]
+            dyn_rows.append(cb.eq(ent, 0.0))
+    init_rows = [cb.eq([(X[i, 0], 1.0)], xi[i]) for i in range(n)]
+    for k in range(H):
+        for i in range(m):
+            cb.ineq([(U[i, k], 1.0), (tA[i, k], -1.0)], 0.0)
+    for k in range(H):
+        for i in range(m):
+            cb.ineq([(U[i, k], -1.0), (tA[i, k], -1.0)], 0.0)
+    abs_rows = []
+    for k in range(H):
+        for i in range(m):
+            abs_rows.append(cb.ineq([(tA[i, k], 1.0)], 1.0))
+    cb.dual('d0', dyn_rows, (n, H))
+    cb.dual('d1', abs_rows, (m, H))
+    cb.dual('d2', init_rows, (n,))
+
+    Ad, Bd = mpc_dynamics(n, m)
+    if x_init is None:
+        x_init = np.array([2, 2, 2, -1, -1, 1], dtype=float) if n == 6 else \
+            np.concatenate([2 * np.ones(n // 2), -np.ones(n // 2)])
+    vals = {'Psqrt': np.eye(n), 'Qsqrt': np.eye(n), 'Rsqrt': np.sqrt(0.1) * np.eye(m),
+            'A': Ad, 'B': Bd, 'x_init': np.asarray(x_init, dtype=float)}
+    return cb.build(vals)
+
+
+# ------------------------------------------------------------------------------------------------
+def portfolio(n: int = 100, m: int = 10, seed: int = 0, name: str = 'portfolio') -> FamilyDescriptor:
+    """
+    maximise a'w - ||Sig_f_sqrt f||^2 - ||d_sqrt * w||^2 - k_tc'|delta_w| + k_sh' min(0, w)
+    s.t. f == F'w ; 1'w == 1 ; ||w||_1 <= L ; delta_w == w - w_prev
+    (`examples/portfolio.ipynb` cell 1; defaults = cell 3 with np.random.seed(0)).
+
+    Canonical (minimise the negative):
+    x = [w (n); delta_w (n); f (m); t1 (m); t2 (n); ta (n); tm (n); tn (n)]
+    eq   = [t1 - Sig_f_sqrt f = 0 (m); t2 - d_sqrt*w = 0 (n); f - F'w = 0 (m); 1'w = 1 (1);
+            delta_w - w = -w_prev (n)]
+    ineq = [dw - ta <= 0 (n); -dw - ta <= 0 (n); tm <= 0 (n); tm - w <= 0 (n);
+            w - tn <= 0 (n); -w - tn <= 0 (n); 1'tn <= L (1)]
+    """
+    cb = CanonBuilder(name)
+    cb.is_maximization = True
+    a = cb.param('a', (n,))
+    F = cb.param('F', (n, m))
+    Sig = cb.param('Sig_f_sqrt', (m, m))
+    dsq = cb.param('d_sqrt', (n,))
+    ktc = cb.param('k_tc', (n,))
+    ksh = cb.param('k_sh', (n,))
+    wprev = cb.param('w_prev', (n,))
+    Lp = cb.param('L', ())
+
+    w = cb.var('w', (n,))
+    dw = cb.var('delta_w', (n,))
+    f = cb.var('f', (m,))
+    t1 = cb.aux(m)
+    t2 = cb.aux(n)
+    ta = cb.aux(n)
+    tm = cb.aux(n)
+    tn = cb.aux(n)
+
+    cb.sum_squares(t1)
+    cb.sum_squares(t2)
+    for i in range(n):
+        cb.lin(w[i], cmul(a[i], -1.0))
+        cb.lin(ta[i], ktc[i])
+        cb.lin(tm[i], cmul(ksh[i], -1.0))
+
+    for i in range(m):
+        cb.eq([(t1[i], 1.0)] + [(f[j], cmul(Sig[i, j], -1.0)) for j in range(m)], 0.0)
+    for i in range(n):
+        cb.eq([(t2[i], 1.0), (w[i], cmul(dsq[i], -1.0))], 0.0)
+    rows_f = [cb.eq([(f[j], 1.0)] + [(w[i], cmul(F[i, j], -1.0)) for i in range(n)], 0.0)
+              for j in range(m)]
+    rows_sum = [cb.eq([(w[i], 1.0) for i in range(n)], 1.0)]
+    rows_dw = [cb.eq([(dw[i], 1.0), (w[i], -1.0)], cmul(wprev[i], -1.0)) for i in range(n)]
+
+    for i in range(n):
+        cb.ineq([(dw[i], 1.0), (ta[i], -1.0)], 0.0)
+    for i in range(n):
+        cb.ineq([(dw[i], -1.0), (ta[i], -1.0)], 0.0)
+    for i in range(n):
+        cb.ineq([(tm[i], 1.0)], 0.0)
+    for i in range(n):
+        cb.ineq([(tm[i], 1.0), (w[i], -1.0)], 0.0)
+    for i in range(n):
+        cb.ineq([(w[i], 1.0), (tn[i], -1.0)], 0.0)
+    for i in range(n):
+        cb.ineq([(w[i], -1.0), (tn[i], -1.0)], 0.0)
+    rows_l1 = [cb.ineq([(tn[i], 1.0) for i in range(n)], Lp[()] if False else {Lp.up.col: 1.0})]
+
+    cb.dual('d0', rows_f, (m,))
+    cb.dual('d1', rows_sum, ())
+    cb.dual('d2', rows_l1, ())
+    cb.dual('d3', rows_dw, (n,))
+
+    rng = np.random.RandomState(seed)
+    alpha = rng.randn(n)
+    vals = {'a': alpha, 'F': rng.randn(n, m), 'Sig_f_sqrt': rng.rand(m, m), 'd_sqrt': rng.rand(n),
+            'k_tc': 0.01 * np.ones(n), 'k_sh': 0.05 * np.ones(n)}
+    wp = rng.rand(n)
+    vals['w_prev'] = wp / np.linalg.norm(wp)
+    vals['L'] = 1.6
+    return cb.build(vals)
+
+
+FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio}
