@@ -1,0 +1,380 @@
+"""
+Compiles the fixed LDL' factor of the family KKT matrix into a *solve program* for the GPU:
+a short sequence of fully parallel sparse phases
+
+        w[r]  <-  sum_k coef[k] * w[col[k]]        for all rows r of the phase at once,
+
+executed by one wavefront per problem instance on a work vector w held in LDS.
+
+Why not plain substitution: QDLDL-style forward / backward substitution (the reference's
+`QDLDL_solve`, called inside `osqp_solve`, `cvxpygen/solvers/osqp.py:62`) is a chain of
+N dependent column steps; level scheduling still leaves one step per level of the elimination tree
+(242 levels for the MPC family: a Riccati-like sweep with one row per level).  A wavefront pays a
+full LDS write->read round trip per level, so the phase count, not the flop count, bounds the
+solve.  Here consecutive levels are merged into groups G and the unit-triangular diagonal block of
+each group is inverted on the host (partitioned-inverse representation of L^-1):
+
+    forward  :  y_G = T_G b_G - (T_G L_GE) y_E ,          T_G = L_GG^-1,  E = earlier groups
+    backward :  x_G = T_G' D_G^-1 y_G - (T_G' L_LG') x_L ,                L = later groups
+
+which is exact in exact arithmetic, costs a bounded amount of extra fill, and cuts the number of
+dependent phases by an order of magnitude.  Group boundaries are chosen by dynamic programming on a
+cost model (phase latency vs. multiply-add steps).  Products are formed in extended precision.
+
+The same phase format also carries the sparse products of the termination check
+(A x, P x, A' y) so that one executor serves the whole ADMM iteration.
+
+Phase storage ("chunks"): every phase is cut into chunks of 64 lane-tasks.  In a chunk, a row is
+split over g = 2^k consecutive lanes (g constant inside the chunk); lane t performs `len`
+multiply-adds  acc += val[s][t] * w[col[s][t]]  and the g partial sums are reduced by a butterfly;
+the first lane of the group stores to w[row].  val/col are stored step-major, lane-minor so that a
+wavefront reads 512 contiguous bytes of values per step.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+LANES = 64
+MAX_PENDING = 4          # chunks whose results may be held in registers before the store
+PHASE_COST = 14.0        # fixed cost of a phase, in units of one multiply-add step of a wavefront
+CHUNK_COST = 3.0         # fixed cost of one more chunk inside a phase
+MAX_GROUP_ROWS = 128
+
+
+@dataclass
+class Phase:
+    """out rows (indices into w) and their sparse rows (lists of (col, coef))."""
+    rows: np.ndarray
+    cols: List[np.ndarray]
+    vals: List[np.ndarray]
+    intra: bool = False      # some row reads another row of the same phase -> deferred stores
+    name: str = ''
+
+    @property
+    def nnz(self) -> int:
+        return int(sum(len(c) for c in self.cols))
+
+
+def _levels(N: int, Lp: np.ndarray, Li: np.ndarray) -> np.ndarray:
+    lev = np.zeros(N, dtype=np.int64)
+    for j in range(N):
+        s, e = Lp[j], Lp[j + 1]
+        if e > s:
+            rows = Li[s:e]
+            np.maximum.at(lev, rows, lev[j] + 1)
+    return lev
+
+
+# ------------------------------------------------------------------------------------------------
+def _chunk_plan(lens: Sequence[int]) -> Tuple[float, int, List[Tuple[int, int, List[int]]]]:
+    """Best split of rows with `lens` multiply-adds into chunks.  Returns (cost, n_chunks,
+    [(g, len, [row positions]) ...])."""
+    lens = np.asarray(lens, dtype=np.int64)
+    R = len(lens)
+    if R == 0:
+        return 0.0, 0, []
+    best = None
+    total = int(lens.sum())
+    cand = sorted(set([1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128,
+                       max(1, -(-total // LANES)), int(lens.max())]))
+    for T in cand:
+        g = np.ones(R, dtype=np.int64)
+        need = -(-lens // T)
+        g = np.where(need <= 1, 1, 2 ** np.ceil(np.log2(np.maximum(need, 1))).astype(np.int64))
+        g = np.minimum(g, LANES)
+        chunks = []
+        cost = 0.0
+        for gv in np.unique(g):
+            idx = np.nonzero(g == gv)[0]
+            idx = idx[np.argsort(-lens[idx], kind='stable')]
+            per = LANES // gv
+            for s in range(0, len(idx), per):
+                sel = idx[s:s + per]
+                ln = int(-(-lens[sel].max() // gv)) if len(sel) else 0
+                ln = max(ln, 1)
+                chunks.append((int(gv), ln, [int(v) for v in sel]))
+                cost += ln + CHUNK_COST + 1.5 * np.log2(gv)
+        if best is None or cost < best[0]:
+            best = (cost, len(chunks), chunks)
+    return best
+
+
+def _phase_cost(lens: Sequence[int], intra: bool) -> float:
+    cost, nch, _ = _chunk_plan(lens)
+    if intra and nch > MAX_PENDING:
+        return np.inf
+    return PHASE_COST + cost
+
+
+# ------------------------------------------------------------------------------------------------
+def _approx_cost(lens: np.ndarray, intra: bool) -> float:
+    """Cheap stand-in for `_phase_cost` used inside the dynamic programme."""
+    total = float(lens.sum())
+    steps = max(np.ceil(total / LANES), np.ceil(lens.max() / LANES), 1.0)
+    lanes_needed = total / steps
+    nch = max(1.0, np.ceil(lanes_needed / LANES))
+    if intra and nch > MAX_PENDING:
+        return np.inf
+    split = max(1.0, lens.max() / steps)
+    return PHASE_COST + 1.2 * total / LANES + CHUNK_COST * nch + 1.5 * np.log2(split) + 1.0
+
+
+class _GroupBuilder:
+    """Grows a group of consecutive levels a..b one level at a time, maintaining
+    T = M_GG^-1 and W = -T M_GE (dense over all columns) in extended precision.  Rows are kept in
+    (level, index) order, itself a topological order, so a new level only appends rows."""
+
+    def __init__(self, N, M: sp.csr_matrix, sc: np.ndarray, dtype=np.longdouble):
+        self.N, self.M, self.sc, self.dt = N, M, sc, dtype
+        self.G = np.zeros(0, dtype=np.int64)
+        self.pos = np.full(N, -1, dtype=np.int64)
+        self.T = np.zeros((0, 0), dtype=dtype)
+        self.W = np.zeros((0, N), dtype=dtype)
+
+    def extend(self, rows: np.ndarray) -> None:
+        M, N = self.M, self.N
+        ng, nr = len(self.G), len(rows)
+        Mi = np.zeros((nr, ng), dtype=self.dt)
+        Me = np.zeros((nr, N), dtype=self.dt)
+        for k, r in enumerate(rows):
+            c = M.indices[M.indptr[r]:M.indptr[r + 1]]
+            v = M.data[M.indptr[r]:M.indptr[r + 1]]
+            p = self.pos[c]
+            inn = p >= 0
+            Mi[k, p[inn]] = v[inn]
+            Me[k, c[~inn]] = v[~inn]
+        Tn = np.zeros((ng + nr, ng + nr), dtype=self.dt)
+        Tn[:ng, :ng] = self.T
+        if ng:
+            Tn[ng:, :ng] = -(Mi @ self.T)
+        Tn[ng:, ng:] = np.eye(nr, dtype=self.dt)
+        Wn = -Me
+        if ng:
+            Wn = Wn - Mi @ self.W
+        self.T = Tn
+        self.W = np.vstack([self.W, Wn])
+        self.pos[rows] = ng + np.arange(nr)
+        self.G = np.concatenate([self.G, rows])
+
+    def row_lens(self) -> np.ndarray:
+        return (np.count_nonzero(self.T, axis=1) + np.count_nonzero(self.W, axis=1)).astype(np.int64)
+
+    def phase(self, name: str) -> Phase:
+        G, ng = self.G, len(self.G)
+        Ts = self.T * self.sc[G][None, :]
+        cols, vals = [], []
+        for k in range(ng):
+            ti = np.nonzero(Ts[k, :k + 1])[0]
+            ti = np.concatenate([[k], ti[ti != k]]).astype(np.int64)
+            wi = np.nonzero(self.W[k])[0]
+            cols.append(np.concatenate([G[ti], wi]).astype(np.int64))
+            vals.append(np.concatenate([Ts[k, ti], self.W[k, wi]]).astype(np.float64))
+        intra = bool(np.count_nonzero(self.T) > ng)
+        return Phase(G.copy(), cols, vals, intra=intra, name=name)
+
+
+def _compile_lower(N: int, M: sp.csr_matrix, scale: Optional[np.ndarray], merge: bool, tag: str
+                   ) -> List[Phase]:
+    """Phases computing  w <- M^-1 (scale * w)  for a unit lower-triangular M (CSR, strict part
+    stored, unit diagonal implied)."""
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    Mc = sp.csc_matrix(M)
+    lev = _levels(N, Mc.indptr, Mc.indices)
+    nlev = int(lev.max()) + 1 if N else 0
+    order = np.lexsort((np.arange(N), lev))
+    lev_ptr = np.zeros(nlev + 1, dtype=np.int64)
+    np.add.at(lev_ptr, lev + 1, 1)
+    lev_ptr = np.cumsum(lev_ptr)
+    rows_of = [np.sort(order[lev_ptr[a]:lev_ptr[a + 1]]) for a in range(nlev)]
+    sc = np.ones(N, dtype=np.longdouble) if scale is None else scale.astype(np.longdouble)
+
+    def build(a: int, b: int) -> Phase:
+        gb = _GroupBuilder(N, M, sc)
+        for lv in range(a, b + 1):
+            gb.extend(rows_of[lv])
+        return gb.phase(f'{tag}{a}' if a == b else f'{tag}{a}-{b}')
+
+    if not merge:
+        return [build(a, a) for a in range(nlev)]
+
+    # dynamic programme over level boundaries (cheap cost model, incremental group growth)
+    best = np.full(nlev + 1, np.inf)
+    best[0] = 0.0
+    choice = np.zeros(nlev + 1, dtype=np.int64)
+    for a in range(nlev):
+        gb = _GroupBuilder(N, M, sc, dtype=np.float64)   # cost model only needs the pattern
+        nrows = 0
+        for b in range(a, nlev):
+            nrows += len(rows_of[b])
+            if b > a and nrows > MAX_GROUP_ROWS:
+                break
+            gb.extend(rows_of[b])
+            cst = _approx_cost(gb.row_lens(), b > a)
+            if best[a] + cst < best[b + 1]:
+                best[b + 1] = best[a] + cst
+                choice[b + 1] = a
+            if b > a and cst > 4.0 * PHASE_COST * (b - a + 1):
+                break
+    bounds = []
+    b = nlev
+    while b > 0:
+        a = int(choice[b])
+        bounds.append((a, b - 1))
+        b = a
+    phases = []
+    for a, b in bounds[::-1]:
+        stack = [(a, b)]
+        while stack:
+            x, y = stack.pop(0)
+            ph = build(x, y)
+            _, nch, _ = _chunk_plan([len(c) for c in ph.cols])
+            if ph.intra and nch > MAX_PENDING and y > x:
+                mid = (x + y) // 2
+                stack = [(x, mid), (mid + 1, y)] + stack
+                continue
+            phases.append(ph)
+    return phases
+
+
+def compile_ldl(N: int, Lp: np.ndarray, Li: np.ndarray, Lx: np.ndarray, D: np.ndarray,
+                perm: np.ndarray, merge: bool = True) -> List[Phase]:
+    """Phases for  w <- K^-1 w  with K = P' L D L' P, operating on w in NATURAL order (the
+    permutation is folded into the row / column indices)."""
+    L = sp.csc_matrix((Lx, Li, Lp), shape=(N, N))
+    fwd = _compile_lower(N, sp.csr_matrix(L), None, merge, 'F')
+    # backward: L' x = D^-1 y.  Reverse the index order to obtain a lower-triangular system.
+    J = np.arange(N)[::-1]
+    Lt_rev = sp.csr_matrix(L.T)[J][:, J]
+    bwd = _compile_lower(N, sp.csr_matrix(Lt_rev), (1.0 / D)[J], merge, 'B')
+    out = []
+    for ph in fwd:
+        out.append(Phase(perm[ph.rows], [perm[c] for c in ph.cols], ph.vals, ph.intra, ph.name))
+    for ph in bwd:
+        out.append(Phase(perm[J[ph.rows]], [perm[J[c]] for c in ph.cols], ph.vals, ph.intra,
+                         ph.name))
+    return out
+
+
+def spmv_phase(M: sp.spmatrix, col_offset: int, name: str) -> Phase:
+    """Phase computing (M v) with v = w[col_offset : col_offset + M.shape[1]]; row r of the result
+    is delivered to lane-task r (natural layout, one row per lane, see `pack(natural=True)`)."""
+    M = sp.csr_matrix(M)
+    rows = np.arange(M.shape[0], dtype=np.int64)
+    cols = [M.indices[M.indptr[r]:M.indptr[r + 1]].astype(np.int64) + col_offset for r in rows]
+    vals = [M.data[M.indptr[r]:M.indptr[r + 1]].astype(np.float64) for r in rows]
+    return Phase(rows, cols, vals, intra=False, name=name)
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PackedProgram:
+    """Flat arrays consumed by the HIP executor.
+
+    hdr  int32 [n_chunks, 4]: (len, log2 g, flags, value offset in units of 64 entries)
+          flags bit0: store pending results after this chunk (end of a flush group)
+                bit1: last chunk of the program
+    rows uint16 [n_chunks, 64]: output index for the lane (0xFFFF: none)
+    vals float64 [sum(len), 64];  cols uint16 [sum(len), 64]
+    """
+    hdr: np.ndarray
+    rows: np.ndarray
+    vals: np.ndarray
+    cols: np.ndarray
+    n_phases: int
+    nnz: int
+
+    @property
+    def n_chunks(self) -> int:
+        return int(self.hdr.shape[0])
+
+    @property
+    def steps(self) -> int:
+        return int(self.vals.shape[0])
+
+
+FLAG_FLUSH = 1
+FLAG_LAST = 2
+NO_ROW = 0xFFFF
+
+
+def pack(phases: List[Phase], natural: bool = False) -> PackedProgram:
+    """natural=True: chunk c holds rows 64c .. 64c+63, one row per lane (results are consumed in
+    registers by the lane that owns the element; nothing is stored to w)."""
+    hdr, rows_out, vals_out, cols_out = [], [], [], []
+    off = 0
+    nnz = 0
+    for ph in phases:
+        lens = [len(c) for c in ph.cols]
+        nnz += sum(lens)
+        if natural:
+            plan = []
+            for s in range(0, len(ph.rows), LANES):
+                sel = list(range(s, min(s + LANES, len(ph.rows))))
+                plan.append((1, max(1, max(lens[k] for k in sel)), sel))
+        else:
+            _, _, plan = _chunk_plan(lens)
+        npend = 0
+        for ci, (g, ln, sel) in enumerate(plan):
+            V = np.zeros((ln, LANES))
+            Cc = np.zeros((ln, LANES), dtype=np.uint16)
+            R = np.full(LANES, NO_ROW, dtype=np.uint16)
+            for k, rp in enumerate(sel):
+                base = k * g
+                R[base] = ph.rows[rp] if not natural else ph.rows[rp] % LANES
+                c, v = ph.cols[rp], ph.vals[rp]
+                seg = -(-len(c) // g) if len(c) else 0
+                for t in range(g):
+                    cs, vs = c[t * seg:(t + 1) * seg], v[t * seg:(t + 1) * seg]
+                    V[:len(vs), base + t] = vs
+                    Cc[:len(cs), base + t] = cs
+            npend += 1
+            last_in_phase = ci == len(plan) - 1
+            flush = last_in_phase or (not ph.intra) or npend == MAX_PENDING
+            if ph.intra and npend == MAX_PENDING and not last_in_phase:
+                raise ValueError('phase with intra-group reads needs more pending slots')
+            flags = FLAG_FLUSH if flush else 0
+            if flush:
+                npend = 0
+            hdr.append([ln, int(np.log2(g)), flags, off])
+            rows_out.append(R)
+            vals_out.append(V)
+            cols_out.append(Cc)
+            off += ln
+    if hdr:
+        hdr[-1][2] |= FLAG_LAST
+    return PackedProgram(
+        hdr=np.asarray(hdr, dtype=np.int32).reshape(-1, 4),
+        rows=np.asarray(rows_out, dtype=np.uint16).reshape(-1, LANES),
+        vals=np.concatenate(vals_out, axis=0) if vals_out else np.zeros((0, LANES)),
+        cols=np.concatenate(cols_out, axis=0) if cols_out else np.zeros((0, LANES), dtype=np.uint16),
+        n_phases=len(phases), nnz=nnz)
+
+
+def execute_packed(prog: PackedProgram, w: np.ndarray, natural: bool = False):
+    """Host emulation of the HIP executor (tests): applies the program to w in place.  With
+    natural=True returns the per-chunk lane results instead of storing."""
+    pend = []
+    nat = []
+    for c in range(prog.n_chunks):
+        ln, lg, flags, off = prog.hdr[c]
+        g = 1 << lg
+        acc = np.zeros(LANES)
+        for s in range(ln):
+            acc += prog.vals[off + s] * w[prog.cols[off + s]]
+        red = acc.reshape(LANES // g, g).sum(axis=1)
+        if natural:
+            nat.append(acc.copy())
+            continue
+        pend.append((prog.rows[c][::g], red))
+        if flags & FLAG_FLUSH:
+            for R, v in pend:
+                ok = R != NO_ROW
+                w[R[ok]] = v[ok]
+            pend = []
+    return nat if natural else w
