@@ -1,0 +1,537 @@
+// C-ABI of the MI355X batched-solve backend (declared in include/cpg_hip.h) and the launch code
+// of the OSQP kernels.  Built by hipcc for gfx950 into libcpg_hip.so (see csrc/build.py).
+//
+// With -DCPG_HOST_SIM the same file builds, with g++, into the TEST-ONLY emulator library used by
+// tests/sim (64 lock-stepped host threads per wavefront); the product never loads that build.
+#include "../../include/cpg_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "cpg_osqp_kernel.h"
+
+// ------------------------------------------------------------------------------------ runtime layer
+#ifndef CPG_HOST_SIM
+#include <hip/hip_runtime.h>
+typedef hipStream_t rt_stream_t;
+typedef hipEvent_t rt_event_t;
+#define RT_CHECK(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+            return CPG_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+#else
+#include <pthread.h>
+#include <thread>
+typedef int rt_stream_t;
+typedef double rt_event_t;
+namespace cpgw { thread_local SimThread tls; }
+#define RT_CHECK(expr) do { (void)(expr); } while (0)
+#endif
+
+static thread_local std::string g_err;
+static void set_error(const std::string &s) { g_err = s; }
+
+struct DevBuf {   // one device allocation
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct cpg_solver_s {
+    int device = 0;
+    rt_stream_t stream{};
+    rt_event_t ev0{}, ev1{};
+    bool have_events = false;
+    float last_ms = 0.f;
+    std::vector<void *> owned;          // family / update buffers
+    std::vector<void *> update_owned;
+    cpg::DevFamily F{};
+    cpg::DevUpdate U{};
+    bool have_update = false;
+    cpg::DevSettings S{};
+    int warm_starting = 1;              // accepted for API parity; a batch is always cold-started
+    int waves_per_block = 4, inst_per_wave = 1, blocks_per_cu = 0;
+    int num_cu = 256;
+    size_t lds_limit = 160 * 1024;
+    unsigned *d_counter = nullptr;
+    int n_vary_x = 0, n_vary_z = 0;
+    DevBuf scratch;                     // delta_x / delta_y stash, [waves][G][n + m]
+    // staging for the host-pointer entry point
+    DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status;
+};
+
+// ---- runtime primitives -------------------------------------------------------------------------
+static int rt_malloc(void **p, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipMalloc(p, bytes));
+#else
+    *p = malloc(bytes);
+    if (!*p) { set_error("malloc failed"); return CPG_E_NOMEM; }
+#endif
+    return CPG_OK;
+}
+static int rt_free(void *p) {
+#ifndef CPG_HOST_SIM
+    if (p) RT_CHECK(hipFree(p));
+#else
+    free(p);
+#endif
+    return CPG_OK;
+}
+static int rt_h2d(cpg_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return CPG_OK;
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+#else
+    (void)h; memcpy(dst, src, bytes);
+#endif
+    return CPG_OK;
+}
+static int rt_d2h(cpg_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return CPG_OK;
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+#else
+    (void)h; memcpy(dst, src, bytes);
+#endif
+    return CPG_OK;
+}
+static int rt_sync(cpg_handle_t h) {
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipStreamSynchronize(h->stream));
+#else
+    (void)h;
+#endif
+    return CPG_OK;
+}
+static int rt_set_device(int dev) {
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipSetDevice(dev));
+#else
+    (void)dev;
+#endif
+    return CPG_OK;
+}
+
+template <typename T>
+static int upload(cpg_handle_t h, std::vector<void *> &own, const T *src, size_t count, const T **dst) {
+    void *p = nullptr;
+    int rc = rt_malloc(&p, count * sizeof(T));
+    if (rc) return rc;
+    own.push_back(p);
+    if (count) { rc = rt_h2d(h, p, src, count * sizeof(T)); if (rc) return rc; }
+    *dst = (const T *)p;
+    return CPG_OK;
+}
+
+static int upload_program(cpg_handle_t h, const cpg_program_t &src, cpg::DevProgram *dst) {
+    int rc;
+    dst->n_chunks = src.n_chunks;
+    if ((rc = upload<int>(h, h->owned, src.hdr, (size_t)src.n_chunks * 4, &dst->hdr))) return rc;
+    if ((rc = upload<unsigned short>(h, h->owned, src.rows, (size_t)src.n_chunks * 64, &dst->rows))) return rc;
+    if ((rc = upload<double>(h, h->owned, src.vals, (size_t)src.n_steps * 64, &dst->vals))) return rc;
+    if ((rc = upload<unsigned short>(h, h->owned, src.cols, (size_t)src.n_steps * 64, &dst->cols))) return rc;
+    return CPG_OK;
+}
+static int upload_csr(cpg_handle_t h, std::vector<void *> &own, const cpg_csr_t &src, cpg::DevCsr *dst) {
+    int rc;
+    dst->nnz = src.nnz;
+    if (src.nnz == 0) { dst->ptr = nullptr; dst->idx = nullptr; dst->val = nullptr; return CPG_OK; }
+    if ((rc = upload<int>(h, own, src.ptr, (size_t)src.rows + 1, &dst->ptr))) return rc;
+    if ((rc = upload<int>(h, own, src.idx, (size_t)src.nnz, &dst->idx))) return rc;
+    if ((rc = upload<double>(h, own, src.val, (size_t)src.nnz, &dst->val))) return rc;
+    return CPG_OK;
+}
+
+// ------------------------------------------------------------------------------------ kernels
+#define CPG_BLOCK_MAX 1024
+#ifndef CPG_MIN_WAVES_PER_SIMD
+#define CPG_MIN_WAVES_PER_SIMD 4   // 16 waves per CU: <= 128 VGPRs
+#endif
+
+#ifndef CPG_HOST_SIM
+template <int NSX, int NSZ, int NV, int G>
+__global__ void __launch_bounds__(256, CPG_MIN_WAVES_PER_SIMD)
+osqp_shared_kernel(cpg::DevFamily F, cpg::DevUpdate U, cpg::DevSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cpg::osqp_shared_body<NSX, NSZ, NV, G>(F, U, S, Bt, cpg_lds, wave_global);
+}
+template <int NSX, int NSZ, int NV, int G>
+static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = osqp_shared_kernel<NSX, NSZ, NV, G>;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->F, h->U, h->S, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#else
+// emulator: every block runs as waves*64 host threads; blocks run one after the other
+template <int NSX, int NSZ, int NV, int G>
+static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    for (int b = 0; b < blocks; b++) {
+        std::vector<char> ldsbuf(lds + 64);
+        std::vector<cpgw::SimWave> wv(waves);
+        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
+        pthread_barrier_t block_bar;
+        pthread_barrier_init(&block_bar, nullptr, waves * 64);
+        std::vector<std::thread> th;
+        for (int t = 0; t < waves * 64; t++)
+            th.emplace_back([&, t]() {
+                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
+                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
+                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
+                cpg::osqp_shared_body<NSX, NSZ, NV, G>(h->F, h->U, h->S, Bt, (double *)ldsbuf.data(),
+                                                       b * waves + (t >> 6));
+            });
+        for (auto &t : th) t.join();
+        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
+        pthread_barrier_destroy(&block_bar);
+    }
+    return CPG_OK;
+}
+#endif
+
+// Instantiated kernels: (NSX, NSZ) slot class (NSX = ceil(n/64), NSZ = ceil(m/64)), NV = leading
+// slots with per-instance q / l / u (1: at most 64 parameter-dependent entries; NS: all), G.
+// The smallest class that covers the family is used.
+#ifndef CPG_KERNELS
+#define CPG_KERNELS(X)                                                                              \
+    X(1, 1, 1, 1) X(1, 1, 1, 2) X(4, 4, 1, 1) X(4, 4, 1, 2) X(4, 4, 4, 1) X(8, 8, 1, 1) X(8, 8, 1, 2)   \
+    X(8, 8, 8, 1) X(16, 16, 16, 1)
+#endif
+
+static int launch(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, int G, size_t lds) {
+    const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
+    const int nvx = (h->n_vary_x + 63) / 64, nvz = (h->n_vary_z + 63) / 64;
+    const int nv = nvx > nvz ? nvx : nvz;
+#define X(a, b, v, g)                                                                             \
+    if (nsx <= a && nsz <= b && (nv <= v || (v >= a && v >= b)) && G == g)                        \
+        return launch_t<a, b, v, g>(h, Bt, blocks, waves, lds);
+    CPG_KERNELS(X)
+#undef X
+    set_error("no compiled kernel for this family size / instances-per-wave combination");
+    return CPG_E_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------ C-ABI
+extern "C" {
+
+const char *cpg_hip_last_error(void) { return g_err.c_str(); }
+
+const char *cpg_hip_status_string(int32_t s) {
+    switch (s) {   // OSQP's status strings (what CPG_Info.status holds in the reference)
+        case 1: return "solved";
+        case 2: return "solved inaccurate";
+        case 3: return "primal infeasible";
+        case 4: return "primal infeasible inaccurate";
+        case 5: return "dual infeasible";
+        case 6: return "dual infeasible inaccurate";
+        case 7: return "maximum iterations reached";
+        case 9: return "problem non convex";
+        case 11: return "unsolved";
+        case -2: return "needs refactorization";
+        default: return "unknown";
+    }
+}
+
+int cpg_hip_device_count(int *count) {
+    if (!count) { set_error("count is NULL"); return CPG_E_BADARG; }
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipGetDeviceCount(count));
+#else
+    *count = 1;
+#endif
+    return CPG_OK;
+}
+
+int cpg_hip_set_default_settings(cpg_handle_t h) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    // defaults of the generated solver, cvxpygen/solvers/osqp.py:102-115
+    h->S.max_iter = 4000; h->S.eps_abs = 1e-3; h->S.eps_rel = 1e-3; h->S.eps_prim_inf = 1e-4;
+    h->S.eps_dual_inf = 1e-4; h->S.scaled_termination = 0; h->S.check_termination = 25;
+    h->warm_starting = 1;
+    return CPG_OK;
+}
+
+int cpg_hip_set_setting(cpg_handle_t h, const char *name, double v) {
+    if (!h || !name) { set_error("null argument"); return CPG_E_BADARG; }
+    std::string s(name);
+    if (s == "max_iter") h->S.max_iter = (int)v;
+    else if (s == "eps_abs") h->S.eps_abs = v;
+    else if (s == "eps_rel") h->S.eps_rel = v;
+    else if (s == "eps_prim_inf") h->S.eps_prim_inf = v;
+    else if (s == "eps_dual_inf") h->S.eps_dual_inf = v;
+    else if (s == "scaled_termination") h->S.scaled_termination = (int)v;
+    else if (s == "check_termination") h->S.check_termination = (int)v;
+    else if (s == "warm_starting") h->warm_starting = (int)v;
+    else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
+    return CPG_OK;
+}
+
+int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
+    if (!h || !name || !v) { set_error("null argument"); return CPG_E_BADARG; }
+    std::string s(name);
+    if (s == "max_iter") *v = h->S.max_iter;
+    else if (s == "eps_abs") *v = h->S.eps_abs;
+    else if (s == "eps_rel") *v = h->S.eps_rel;
+    else if (s == "eps_prim_inf") *v = h->S.eps_prim_inf;
+    else if (s == "eps_dual_inf") *v = h->S.eps_dual_inf;
+    else if (s == "scaled_termination") *v = h->S.scaled_termination;
+    else if (s == "check_termination") *v = h->S.check_termination;
+    else if (s == "warm_starting") *v = h->warm_starting;
+    else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
+    return CPG_OK;
+}
+
+int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *out) {
+    if (!f || !out) { set_error("null argument"); return CPG_E_BADARG; }
+    if (f->n <= 0 || f->m < 0 || f->n + f->m >= 0xFFFF) { set_error("bad family dimensions"); return CPG_E_BADARG; }
+    int rc = rt_set_device(device);
+    if (rc) return rc;
+    cpg_handle_t h = new cpg_solver_s();
+    h->device = device;
+#ifndef CPG_HOST_SIM
+    {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) { set_error(std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)); delete h; return CPG_E_HIP; }
+        h->num_cu = prop.multiProcessorCount;
+        h->lds_limit = prop.sharedMemPerBlock;
+        if (h->lds_limit < 160 * 1024 && strstr(prop.gcnArchName, "gfx950")) h->lds_limit = 160 * 1024;
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); delete h; return CPG_E_HIP; }
+        hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); h->have_events = true;
+    }
+#else
+    h->num_cu = 2;
+#endif
+    cpg::DevFamily &F = h->F;
+    F.n = f->n; F.m = f->m; F.n_eq = f->n_eq; F.is_max = f->is_maximization;
+    F.sigma = f->sigma; F.alpha = f->alpha; F.rho = f->rho; F.c = f->c; F.cinv = 1.0 / f->c;
+    std::vector<double> Dinv(f->n), Einv(f->m);
+    for (int i = 0; i < f->n; i++) Dinv[i] = 1.0 / f->D[i];
+    for (int i = 0; i < f->m; i++) Einv[i] = 1.0 / f->E[i];
+#define TRY(x) do { rc = (x); if (rc) { cpg_hip_destroy(h); return rc; } } while (0)
+    TRY(upload<double>(h, h->owned, f->D, f->n, &F.D));
+    TRY(upload<double>(h, h->owned, Dinv.data(), f->n, &F.Dinv));
+    TRY(upload<double>(h, h->owned, f->E, f->m, &F.E));
+    TRY(upload<double>(h, h->owned, Einv.data(), f->m, &F.Einv));
+    TRY(upload<signed char>(h, h->owned, (const signed char *)f->ctype, f->m, &F.ctype));
+    TRY(upload_program(h, f->kkt, &F.kkt));
+    TRY(upload_program(h, f->A_rows, &F.A_rows));
+    TRY(upload_program(h, f->P_rows, &F.P_rows));
+    TRY(upload_program(h, f->At_rows, &F.At_rows));
+    F.n_slots = f->n_slots;
+    if (f->n_slots < f->n + f->m || f->n_slots >= 0xFFFF) { set_error("bad n_slots"); cpg_hip_destroy(h); return CPG_E_BADARG; }
+    TRY(upload<unsigned short>(h, h->owned, f->fpos, (size_t)f->n + f->m, &F.fpos));
+    h->n_vary_x = f->n_vary_x; h->n_vary_z = f->n_vary_z;
+    F.n_prim = f->n_prim; F.n_dual = f->n_dual;
+    TRY(upload<int>(h, h->owned, f->prim_idx, f->n_prim, &F.prim_idx));
+    TRY(upload<int>(h, h->owned, f->dual_idx, f->n_dual, &F.dual_idx));
+    { void *p = nullptr; TRY(rt_malloc(&p, 64)); h->d_counter = (unsigned *)p; }
+    TRY(rt_sync(h));   // Dinv / Einv are stack-lifetime buffers
+#undef TRY
+    cpg_hip_set_default_settings(h);
+    *out = h;
+    return CPG_OK;
+}
+
+static void free_list(std::vector<void *> &v) { for (void *p : v) rt_free(p); v.clear(); }
+static void free_buf(DevBuf &b) { if (b.p) rt_free(b.p); b.p = nullptr; b.bytes = 0; }
+
+int cpg_hip_destroy(cpg_handle_t h) {
+    if (!h) return CPG_OK;
+    rt_set_device(h->device);
+    rt_sync(h);
+    free_list(h->owned); free_list(h->update_owned);
+    if (h->d_counter) rt_free(h->d_counter);
+    free_buf(h->scratch);
+    free_buf(h->s_theta); free_buf(h->s_prim); free_buf(h->s_dual); free_buf(h->s_obj);
+    free_buf(h->s_pri); free_buf(h->s_dua); free_buf(h->s_iter); free_buf(h->s_status);
+#ifndef CPG_HOST_SIM
+    if (h->have_events) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
+    if (h->stream) hipStreamDestroy(h->stream);
+#endif
+    delete h;
+    return CPG_OK;
+}
+
+int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *u) {
+    if (!h || !u) { set_error("null argument"); return CPG_E_BADARG; }
+    if (u->map_q.nnz && u->map_q.rows != h->F.n) { set_error("map_q rows != n"); return CPG_E_BADARG; }
+    if (u->map_u.nnz && u->map_u.rows != h->F.m) { set_error("map_u rows != m"); return CPG_E_BADARG; }
+    {   // parameter-dependent entries must sit inside the leading "varying" prefix
+        const cpg_csr_t *mp[2] = {&u->map_q, &u->map_u};
+        const int lim[2] = {h->n_vary_x, h->n_vary_z};
+        for (int k = 0; k < 2; k++)
+            if (mp[k]->nnz > 0 && mp[k]->ptr[mp[k]->rows] != mp[k]->ptr[lim[k] < mp[k]->rows ? lim[k] : mp[k]->rows]) {
+                set_error("update map touches entries outside the parameter-dependent prefix"); return CPG_E_BADARG; }
+    }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    if ((rc = rt_sync(h))) return rc;
+    free_list(h->update_owned);
+    cpg::DevUpdate &U = h->U;
+    U.np_var = u->np_var; U.d_base = u->d_base;
+    if ((rc = upload<double>(h, h->update_owned, u->q_base, h->F.n, &U.q_base))) return rc;
+    if ((rc = upload<double>(h, h->update_owned, u->u_base, h->F.m, &U.u_base))) return rc;
+    if ((rc = upload_csr(h, h->update_owned, u->map_q, &U.map_q))) return rc;
+    if ((rc = upload_csr(h, h->update_owned, u->map_u, &U.map_u))) return rc;
+    if ((rc = upload_csr(h, h->update_owned, u->map_d, &U.map_d))) return rc;
+    if ((rc = rt_sync(h))) return rc;
+    h->have_update = true;
+    return CPG_OK;
+}
+
+int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, int blocks_per_cu) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    if (waves_per_block < 0 || waves_per_block > 16 || (inst_per_wave != 0 && inst_per_wave != 1 && inst_per_wave != 2)) {
+        set_error("waves_per_block in 0..16, inst_per_wave in {0,1,2}"); return CPG_E_BADARG; }
+    h->waves_per_block = waves_per_block ? waves_per_block : 4;
+    h->inst_per_wave = inst_per_wave ? inst_per_wave : 1;
+    h->blocks_per_cu = blocks_per_cu;
+    return CPG_OK;
+}
+
+static int ensure(DevBuf &b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return CPG_OK;
+    if (b.p) rt_free(b.p);
+    b.p = nullptr; b.bytes = 0;
+    int rc = rt_malloc(&b.p, bytes);
+    if (rc) return rc;
+    b.bytes = bytes;
+    return CPG_OK;
+}
+
+int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta, double *d_prim, double *d_dual,
+                               double *d_obj, int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
+    if (B < 0 || !d_prim || !d_dual || !d_obj || !d_iter || !d_status || !d_pri || !d_dua || (h->U.np_var > 0 && !d_theta)) {
+        set_error("null buffer"); return CPG_E_BADARG; }
+    if (B == 0) return CPG_OK;
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    const int G = h->inst_per_wave, W = h->waves_per_block;
+    const size_t lds = ((size_t)(h->F.n + h->F.m) + (size_t)W * G * h->F.n_slots) * sizeof(double);
+    if (lds > h->lds_limit) { set_error("work vectors do not fit the 160 KiB LDS; lower waves_per_block / inst_per_wave"); return CPG_E_UNSUPPORTED; }
+    const long long ngroups = (B + G - 1) / G;
+    int per_cu = h->blocks_per_cu;
+    if (per_cu <= 0) {   // as many blocks as LDS and the register budget (CPG_MIN_WAVES_PER_SIMD) admit
+        per_cu = (int)(h->lds_limit / (lds ? lds : 1));
+        const int by_regs = (CPG_MIN_WAVES_PER_SIMD * 4) / W;
+        if (per_cu > by_regs) per_cu = by_regs;
+        if (per_cu < 1) per_cu = 1;
+    }
+    long long blocks = (ngroups + W - 1) / W;
+    const long long cap = (long long)h->num_cu * per_cu;
+    if (blocks > cap) blocks = cap;
+    if ((rc = ensure(h->scratch, (size_t)blocks * W * G * (h->F.n + h->F.m) * sizeof(double)))) return rc;
+    cpg::DevBatch Bt;
+    Bt.scratch = (double *)h->scratch.p;
+    Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
+    Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
+    RT_CHECK(hipEventRecord(h->ev0, h->stream));
+#else
+    *h->d_counter = 0;
+#endif
+    rc = launch(h, Bt, (int)blocks, W, G, lds);
+    if (rc) return rc;
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipEventRecord(h->ev1, h->stream));
+#endif
+    return CPG_OK;
+}
+
+int cpg_hip_synchronize(cpg_handle_t h) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    return rt_sync(h);
+}
+
+int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms) {
+    if (!h || !ms) { set_error("null argument"); return CPG_E_BADARG; }
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipEventSynchronize(h->ev1));
+    RT_CHECK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+#else
+    *ms = 0.f;
+#endif
+    return CPG_OK;
+}
+
+int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta, double *prim, double *dual, double *obj,
+                        int32_t *iter, int32_t *status, double *pri_res, double *dua_res) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
+    if (B < 0 || !prim || !dual || !obj || !iter || !status || !pri_res || !dua_res || (h->U.np_var > 0 && !theta)) {
+        set_error("null buffer"); return CPG_E_BADARG; }
+    if (B == 0) return CPG_OK;
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    const size_t b = (size_t)B;
+    if ((rc = ensure(h->s_theta, b * h->U.np_var * sizeof(double)))) return rc;
+    if ((rc = ensure(h->s_prim, b * h->F.n_prim * sizeof(double)))) return rc;
+    if ((rc = ensure(h->s_dual, b * h->F.n_dual * sizeof(double)))) return rc;
+    if ((rc = ensure(h->s_obj, b * sizeof(double)))) return rc;
+    if ((rc = ensure(h->s_pri, b * sizeof(double)))) return rc;
+    if ((rc = ensure(h->s_dua, b * sizeof(double)))) return rc;
+    if ((rc = ensure(h->s_iter, b * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(h->s_status, b * sizeof(int32_t)))) return rc;
+    if ((rc = rt_h2d(h, h->s_theta.p, theta, b * h->U.np_var * sizeof(double)))) return rc;
+    rc = cpg_hip_solve_batch_device(h, B, (const double *)h->s_theta.p, (double *)h->s_prim.p, (double *)h->s_dual.p,
+                                    (double *)h->s_obj.p, (int32_t *)h->s_iter.p, (int32_t *)h->s_status.p,
+                                    (double *)h->s_pri.p, (double *)h->s_dua.p);
+    if (rc) return rc;
+    if ((rc = rt_d2h(h, prim, h->s_prim.p, b * h->F.n_prim * sizeof(double)))) return rc;
+    if ((rc = rt_d2h(h, dual, h->s_dual.p, b * h->F.n_dual * sizeof(double)))) return rc;
+    if ((rc = rt_d2h(h, obj, h->s_obj.p, b * sizeof(double)))) return rc;
+    if ((rc = rt_d2h(h, pri_res, h->s_pri.p, b * sizeof(double)))) return rc;
+    if ((rc = rt_d2h(h, dua_res, h->s_dua.p, b * sizeof(double)))) return rc;
+    if ((rc = rt_d2h(h, iter, h->s_iter.p, b * sizeof(int32_t)))) return rc;
+    if ((rc = rt_d2h(h, status, h->s_status.p, b * sizeof(int32_t)))) return rc;
+    return rt_sync(h);
+}
+
+int cpg_hip_malloc(cpg_handle_t h, size_t bytes, void **dptr) {
+    if (!h || !dptr) { set_error("null argument"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    return rt_malloc(dptr, bytes);
+}
+int cpg_hip_free(cpg_handle_t h, void *dptr) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    return rt_free(dptr);
+}
+int cpg_hip_memcpy_h2d(cpg_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (!h || !dst || !src) { set_error("null argument"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    if ((rc = rt_h2d(h, dst, src, bytes))) return rc;
+    return rt_sync(h);
+}
+int cpg_hip_memcpy_d2h(cpg_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (!h || !dst || !src) { set_error("null argument"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    if ((rc = rt_d2h(h, dst, src, bytes))) return rc;
+    return rt_sync(h);
+}
+
+}  // extern "C"

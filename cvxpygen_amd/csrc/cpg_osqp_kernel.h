@@ -1,0 +1,531 @@
+// Batched embedded-OSQP ADMM kernel for gfx950: one wavefront solves G problem instances of ONE
+// problem family from cold start to termination without leaving the CU.
+//
+// Replaces, per instance, the reference's generated cpg_solve() (cvxpygen/utils.py:1008-1052):
+//   cpg_canonicalize_q/l/u/d (utils.py:279-294)         -> canonicalise()
+//   osqp_update_data_vec     (solvers/osqp.py:39-59)    -> folded: maps are pre-scaled by D, E, c
+//   osqp_solve               (solvers/osqp.py:62)       -> the iteration loop below
+//   cpg_retrieve_prim/dual/info (utils.py:950-985)      -> finalize()
+//
+// Data placement:
+//   registers : iterates x, z, y -- element i lives on lane i % 64, slot i / 64
+//               (NSX = ceil(n/64), NSZ = ceil(m/64) slots, compile-time); the instance's own
+//               q, l, u only for the first NV slots: the device ordering places every entry that
+//               depends on a user parameter first, all other entries are read from the family's
+//               shared base vectors (cache resident)
+//   LDS       : one work vector w[n_slots] per instance: right-hand side / solution of the KKT
+//               system and staging area for the sparse products of the termination test
+//   L2 / HBM  : the family's solve program (shared, read-only, streamed coalesced), theta in,
+//               solutions out, delta_x / delta_y stash written at check iterations only
+#pragma once
+
+#include "cpg_wave.h"
+
+namespace cpg {
+
+#define CPG_INFTY 1e30
+#define CPG_MIN_SCALING 1e-4
+#define CPG_DIV_TOL 1e-30
+#define CPG_NO_ROW 0xFFFF
+#ifndef CPG_ILP
+#define CPG_ILP 2   // unrolled slot iterations the scheduler may interleave in the hot loops
+#endif
+#define CPG_FENCE_EVERY(s) do { if (((s) + 1) % CPG_ILP == 0) cpgw::sched_fence(); } while (0)
+#ifndef CPG_CHUNK_UNROLL
+#define CPG_CHUNK_UNROLL 4
+#endif
+
+struct DevProgram {
+    const int *hdr;
+    const unsigned short *rows;
+    const double *vals;
+    const unsigned short *cols;
+    int n_chunks;
+};
+struct DevCsr {
+    const int *ptr;
+    const int *idx;
+    const double *val;
+    int nnz;
+};
+struct DevFamily {
+    int n, m, n_eq, is_max, n_slots;
+    double sigma, alpha, rho;
+    const double *D, *Dinv, *E, *Einv;
+    double c, cinv;
+    const signed char *ctype;
+    const unsigned short *fpos;   // [n + m] LDS slot holding entry i after the KKT program
+    DevProgram kkt, A_rows, P_rows, At_rows;
+    int n_prim, n_dual;
+    const int *prim_idx, *dual_idx;
+};
+struct DevUpdate {
+    int np_var;
+    // l is implied by the row class: equality rows have l = u, inequality rows l = -inf
+    // (the only two kinds of rows the reference's OSQP canonical form contains,
+    // cvxpygen/solvers/_interface.py:62-79); the binding verifies this when it builds the plan.
+    const double *q_base, *u_base;
+    double d_base;
+    DevCsr map_q, map_u, map_d;
+};
+struct DevSettings {
+    int max_iter, check_termination, scaled_termination;
+    double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+};
+struct DevBatch {
+    long long B;
+    const double *theta;
+    double *prim, *dual, *obj, *pri_res, *dua_res;
+    int *iter, *status;
+    unsigned *counter;
+    double *scratch;   // [total waves][G][n + m]: delta_x | delta_y of the last check iteration
+};
+
+template <int A, int B> struct MinI { static const int v = A < B ? A : B; };
+
+// ------------------------------------------------------------------------------------ executor
+// One chunk: `len` multiply-add steps per lane, then the sum over groups of 2^lg lanes.
+template <int G, bool REDUCE>
+CPG_DEV void do_chunk(const DevProgram &P, int c, const double *w, int ldw, int lane,
+                      double (&out)[G]) {
+    const int len = cpgw::read_first_lane(cpgw::gld(P.hdr, 4u * (unsigned)c + 0u));
+    const int off = cpgw::read_first_lane(cpgw::gld(P.hdr, 4u * (unsigned)c + 3u));
+    const unsigned e0 = (unsigned)off * 64u + (unsigned)lane;
+    double acc[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) acc[g] = 0.0;
+#pragma unroll CPG_CHUNK_UNROLL
+    for (int s = 0; s < len; s++) {
+        const double v = cpgw::gld(P.vals, e0 + 64u * (unsigned)s);
+        const unsigned ci = cpgw::gld(P.cols, e0 + 64u * (unsigned)s);
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = fma(v, w[(unsigned)(g * ldw) + ci], acc[g]);
+    }
+    if (REDUCE) {
+        const int lg = cpgw::read_first_lane(cpgw::gld(P.hdr, 4u * (unsigned)c + 1u));
+#pragma unroll
+        for (int g = 0; g < G; g++) out[g] = cpgw::group_sum_first_dyn(acc[g], lg);
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++) out[g] = acc[g];
+    }
+}
+
+// w <- program(w).  Results are stored right away: the host-side slot allocation guarantees that a
+// chunk never overwrites a slot that a later chunk of the same phase still reads.
+template <int G>
+CPG_DEV void run_program(const DevProgram &P, double *w, int ldw, int lane) {
+#pragma nounroll
+    for (int c = 0; c < P.n_chunks; c++) {
+        double r[G];
+        do_chunk<G, true>(P, c, w, ldw, lane, r);
+        const unsigned row = cpgw::gld(P.rows, (unsigned)c * 64u + (unsigned)lane);
+        cpgw::lds_order();
+        if (row != CPG_NO_ROW) {
+#pragma unroll
+            for (int g = 0; g < G; g++) w[(unsigned)(g * ldw) + row] = r[g];
+        }
+        cpgw::lds_order();
+    }
+}
+
+// natural-layout product: chunk s delivers element lane + 64 s of the result to this lane
+CPG_DEV double natural_chunk(const DevProgram &P, int s, const double *w, int lane) {
+    double o[1];
+    o[0] = 0.0;
+    if (s < P.n_chunks) do_chunk<1, false>(P, s, w, 0, lane, o);
+    return o[0];
+}
+
+// ------------------------------------------------------------------------------------ per-instance state
+template <int NSX, int NSZ, int NV>
+struct Inst {
+    static const int NVX = MinI<NV, NSX>::v, NVZ = MinI<NV, NSZ>::v;
+    double x[NSX], z[NSZ], y[NSZ];
+    double qv[NVX], uv[NVZ];
+    double dconst;
+    long long b;
+    int done;
+};
+
+struct CheckOut {
+    double prim_res, dual_res, obj;
+    int status;
+};
+
+CPG_DEV double csr_row(const DevCsr &mp, unsigned row, const double *theta, double v) {
+    if (mp.nnz > 0) {
+        const unsigned s = (unsigned)cpgw::gld(mp.ptr, row), e = (unsigned)cpgw::gld(mp.ptr, row + 1u);
+        for (unsigned k = s; k < e; k++) v = fma(cpgw::gld(mp.val, k), cpgw::gld(theta, (unsigned)cpgw::gld(mp.idx, k)), v);
+    }
+    return v;
+}
+
+// q / u of entry i (slot s): per-instance register for the leading NV slots, otherwise the family's
+// base vectors staged in LDS (`sh` = [q_base (n) | u_base (m)], shared by the block)
+#define CPG_Q(I, sh, s, i) ((s) < Inst<NSX, NSZ, NV>::NVX ? (I).qv[(s) < Inst<NSX, NSZ, NV>::NVX ? (s) : 0] : (sh)[i])
+#define CPG_U(I, sh, s, i) ((s) < Inst<NSX, NSZ, NV>::NVZ ? (I).uv[(s) < Inst<NSX, NSZ, NV>::NVZ ? (s) : 0] : (sh)[(unsigned)F.n + (i)])
+
+// cpg_canonicalize_q/l/u/d + osqp_update_data_vec for the parameter-dependent entries; returns
+// (wave-uniform) whether a row changed class w.r.t. the family's factor.
+template <int NSX, int NSZ, int NV>
+CPG_DEV bool canonicalise(const DevFamily &F, const DevUpdate &U, const double *theta,
+                          Inst<NSX, NSZ, NV> &I, int lane) {
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) I.x[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { I.z[s] = 0.0; I.y[s] = 0.0; }
+#pragma unroll
+    for (int s = 0; s < Inst<NSX, NSZ, NV>::NVX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        I.qv[s] = (i < (unsigned)F.n) ? csr_row(U.map_q, i, theta, cpgw::gld(U.q_base, i)) : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < Inst<NSX, NSZ, NV>::NVZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        I.uv[s] = 0.0;
+        if (i < (unsigned)F.m) {
+            const double uv = csr_row(U.map_u, i, theta, cpgw::gld(U.u_base, i));
+            I.uv[s] = uv;
+            // an inequality row whose bound became infinite is a free row for OSQP (rho_min)
+            const int ctp = (int)cpgw::gld(F.ctype, i);
+            bad |= (ctp == 0 && uv > CPG_INFTY * CPG_MIN_SCALING) || (ctp == -1 && !(uv > CPG_INFTY * CPG_MIN_SCALING));
+        }
+    }
+    I.dconst = csr_row(U.map_d, 0, theta, U.d_base);
+    return cpgw::wave_any(bad);
+}
+
+// is_primal_infeasible on delta_y (OSQP paper sec. 3.4); wave-uniform result
+template <int NSX, int NSZ, int NV>
+CPG_DEV bool primal_infeasible(const DevFamily &F, const double *sh, const signed char (&ct)[NSZ],
+                               bool unsc, double eps, Inst<NSX, NSZ, NV> &I, double *w, double *sdy,
+                               int lane) {
+    double nrm = 0.0, lhs = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        if (i < (unsigned)F.m) {
+            const double uu = CPG_U(I, sh, s, i);
+            const bool eq = ct[s] == 1;
+            const double ll = eq ? uu : -CPG_INFTY;
+            const bool iu = uu > CPG_INFTY * CPG_MIN_SCALING, il = !eq;
+            double d = cpgw::gld((const double *)sdy, i);
+            if (iu && il) d = 0.0; else if (iu) d = cpgw::dmin2(d, 0.0); else if (il) d = cpgw::dmax2(d, 0.0);
+            cpgw::gst(sdy, i, d);
+            nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.E, i) * d : d));
+            lhs += uu * cpgw::dmax2(d, 0.0) + ll * cpgw::dmin2(d, 0.0);
+        }
+        cpgw::sched_fence();
+    }
+    nrm = cpgw::wave_max_nonneg(nrm);
+    if (!(nrm > CPG_DIV_TOL)) return false;
+    lhs = cpgw::wave_sum(lhs);
+    if (!(lhs < eps * nrm)) return false;
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = cpgw::gld((const double *)sdy, i); }
+    cpgw::lds_order();
+    double r = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const double t = natural_chunk(F.At_rows, s, w, lane);
+        if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cpgw::gld(F.Dinv, i) * t : t));
+        cpgw::sched_fence();
+    }
+    r = cpgw::wave_max_nonneg(r);
+    cpgw::lds_order();
+    return r < eps * nrm;
+}
+
+// is_dual_infeasible on delta_x; wave-uniform result
+template <int NSX, int NSZ, int NV>
+CPG_DEV bool dual_infeasible(const DevFamily &F, const double *sh, const signed char (&ct)[NSZ],
+                             bool unsc, double eps, Inst<NSX, NSZ, NV> &I, double *w, const double *sdx,
+                             int lane) {
+    double nrm = 0.0, qdx = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        if (i < (unsigned)F.n) {
+            const double d = cpgw::gld(sdx, i);
+            nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.D, i) * d : d));
+            qdx += CPG_Q(I, sh, s, i) * d;
+        }
+    }
+    nrm = cpgw::wave_max_nonneg(nrm);
+    if (!(nrm > CPG_DIV_TOL)) return false;
+    const double cs = unsc ? F.c : 1.0;
+    qdx = cpgw::wave_sum(qdx);
+    if (!(qdx < -cs * eps * nrm)) return false;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = cpgw::gld(sdx, i); }
+    cpgw::lds_order();
+    double r = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const double t = natural_chunk(F.P_rows, s, w, lane);
+        if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cpgw::gld(F.Dinv, i) * t : t));
+        cpgw::sched_fence();
+    }
+    r = cpgw::wave_max_nonneg(r);
+    bool res = false;
+    if (r < cs * eps * nrm) {
+        bool viol = false;
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            const double a = natural_chunk(F.A_rows, s, w, lane);
+            if (i < (unsigned)F.m) {
+                const double av = unsc ? cpgw::gld(F.Einv, i) * a : a;
+                if ((CPG_U(I, sh, s, i) < CPG_INFTY * CPG_MIN_SCALING && av > eps * nrm) ||
+                    (ct[s] == 1 && av < -eps * nrm)) viol = true;
+            }
+            cpgw::sched_fence();
+        }
+        res = !cpgw::wave_any(viol);
+    }
+    cpgw::lds_order();
+    return res;
+}
+
+// update_info + check_termination: residuals in the unscaled space (scaled_termination = 0),
+// optimality / infeasibility decisions.  status stays 11 (unsolved) when nothing triggers.
+template <int NSX, int NSZ, int NV>
+CPG_DEV CheckOut check(const DevFamily &F, const double *sh, const signed char (&ct)[NSZ],
+                       const DevSettings &S, Inst<NSX, NSZ, NV> &I, double *w, double *sdx, double *sdy,
+                       int lane, bool approximate) {
+    const bool unsc = !S.scaled_termination;
+    CheckOut o;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = I.x[s]; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = I.y[s]; }
+    cpgw::lds_order();
+    double rp = 0.0, nz = 0.0, na = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const double ax = natural_chunk(F.A_rows, s, w, lane);
+        if (i < (unsigned)F.m) {
+            const double ei = unsc ? cpgw::gld(F.Einv, i) : 1.0;
+            rp = cpgw::dmax2(rp, fabs(ei * (ax - I.z[s])));
+            nz = cpgw::dmax2(nz, fabs(ei * I.z[s]));
+            na = cpgw::dmax2(na, fabs(ei * ax));
+        }
+        cpgw::sched_fence();
+    }
+    double rd = 0.0, nq = 0.0, nat = 0.0, npx = 0.0, quad = 0.0, lin = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const double px = natural_chunk(F.P_rows, s, w, lane);
+        const double aty = natural_chunk(F.At_rows, s, w, lane);
+        if (i < (unsigned)F.n) {
+            const double di = unsc ? cpgw::gld(F.Dinv, i) : 1.0;
+            const double qq = CPG_Q(I, sh, s, i);
+            rd = cpgw::dmax2(rd, fabs(di * (qq + px + aty)));
+            nq = cpgw::dmax2(nq, fabs(di * qq));
+            nat = cpgw::dmax2(nat, fabs(di * aty));
+            npx = cpgw::dmax2(npx, fabs(di * px));
+            quad += I.x[s] * px;
+            lin += qq * I.x[s];
+        }
+        cpgw::sched_fence();
+    }
+    cpgw::lds_order();
+    const double cs = unsc ? F.cinv : 1.0;
+    rp = cpgw::wave_max_nonneg(rp); nz = cpgw::wave_max_nonneg(nz); na = cpgw::wave_max_nonneg(na);
+    rd = cs * cpgw::wave_max_nonneg(rd);
+    const double dn = cs * cpgw::dmax2(cpgw::wave_max_nonneg(nq),
+                                       cpgw::dmax2(cpgw::wave_max_nonneg(nat), cpgw::wave_max_nonneg(npx)));
+    quad = cpgw::wave_sum(quad); lin = cpgw::wave_sum(lin);
+    o.prim_res = rp; o.dual_res = rd; o.obj = (0.5 * quad + lin) * F.cinv;
+
+    const double mult = approximate ? 10.0 : 1.0;
+    const double ea = S.eps_abs * mult, er = S.eps_rel * mult;
+    const double epi = S.eps_prim_inf * mult, edi = S.eps_dual_inf * mult;
+    o.status = 11;
+    if (rp > CPG_INFTY || rd > CPG_INFTY) { o.status = 9; o.obj = NAN; return o; }
+    bool pc = false, dc = false, pic = false, dic = false;
+    if (F.m == 0) pc = true;
+    else if (rp < ea + er * cpgw::dmax2(nz, na)) pc = true;
+    else pic = primal_infeasible<NSX, NSZ, NV>(F, sh, ct, unsc, epi, I, w, sdy, lane);
+    if (rd < ea + er * dn) dc = true;
+    else dic = dual_infeasible<NSX, NSZ, NV>(F, sh, ct, unsc, edi, I, w, sdx, lane);
+    if (pc && dc) o.status = approximate ? 2 : 1;
+    else if (pic) { o.status = approximate ? 4 : 3; o.obj = CPG_INFTY; }
+    else if (dic) { o.status = approximate ? 6 : 5; o.obj = -CPG_INFTY; }
+    return o;
+}
+
+// store_solution + cpg_retrieve_*: unscale, gather the user-facing entries, write the info scalars
+template <int NSX, int NSZ, int NV>
+CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, Inst<NSX, NSZ, NV> &I, double *w,
+                      int lane, int iter, const CheckOut &o) {
+    const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = has_sol ? cpgw::gld(F.D, i) * I.x[s] : NAN; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = has_sol ? F.cinv * cpgw::gld(F.E, i) * I.y[s] : NAN; }
+    cpgw::lds_order();
+    double *pp = Bt.prim + (size_t)I.b * F.n_prim, *dp = Bt.dual + (size_t)I.b * F.n_dual;
+    for (unsigned k = (unsigned)lane; k < (unsigned)F.n_prim; k += 64u) cpgw::gst(pp, k, w[(unsigned)cpgw::gld(F.prim_idx, k)]);
+    for (unsigned k = (unsigned)lane; k < (unsigned)F.n_dual; k += 64u) cpgw::gst(dp, k, w[(unsigned)F.n + (unsigned)cpgw::gld(F.dual_idx, k)]);
+    if (lane == 0) {
+        double ov = o.obj + I.dconst;
+        if (F.is_max) ov = -ov;
+        Bt.obj[I.b] = ov; Bt.iter[I.b] = iter; Bt.status[I.b] = o.status;
+        Bt.pri_res[I.b] = o.prim_res; Bt.dua_res[I.b] = o.dual_res;
+    }
+    cpgw::lds_order();
+    I.done = 1;
+}
+
+// ------------------------------------------------------------------------------------ the kernel body
+template <int NSX, int NSZ, int NV, int G>
+CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevSettings &S,
+                              const DevBatch &Bt, double *lds, int wave_global) {
+    typedef Inst<NSX, NSZ, NV> InstT;
+    const int lane = cpgw::lane_id();
+    const int ldw = F.n_slots;
+    const int N = F.n + F.m;
+    // block-shared copy of the family's base vectors, then one work vector per instance
+    double *sh = lds;
+    for (unsigned t = cpgw::thread_in_block(); t < (unsigned)N; t += cpgw::block_threads())
+        sh[t] = t < (unsigned)F.n ? cpgw::gld(U.q_base, t) : cpgw::gld(U.u_base, t - (unsigned)F.n);
+    cpgw::block_sync();
+    double *w = lds + (size_t)N + (size_t)cpgw::wave_in_block() * G * ldw;
+    double *scr = Bt.scratch + (size_t)wave_global * G * N;
+    const long long ngroups = (Bt.B + G - 1) / G;
+    const double rho_eq = 1e3 * F.rho, rho_in = F.rho, rho_fr = 1e-6;
+    const double ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in, ri_fr = 1.0 / rho_fr;
+    // family constants kept in registers: row class and final LDS slot of every owned entry
+    signed char ct_reg[NSZ];
+    unsigned short fpx[NSX], fpz[NSZ];
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; fpx[s] = (i < (unsigned)F.n) ? cpgw::gld(F.fpos, i) : 0; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        ct_reg[s] = (i < (unsigned)F.m) ? cpgw::gld(F.ctype, i) : 0;
+        fpz[s] = (i < (unsigned)F.m) ? cpgw::gld(F.fpos, (unsigned)F.n + i) : 0;
+    }
+
+    for (;;) {
+        unsigned ig = 0;
+        if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
+        ig = (unsigned)cpgw::read_first_lane((int)ig);
+        if ((long long)ig >= ngroups) break;
+
+        InstT I[G];
+        CheckOut co[G];
+        int n_open = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const long long b = (long long)ig * G + g;
+            I[g].b = b < Bt.B ? b : -1;
+            I[g].done = b < Bt.B ? 0 : 1;
+            co[g].prim_res = 0; co[g].dual_res = 0; co[g].obj = 0; co[g].status = 11;
+            const double *theta = Bt.theta + (size_t)(b < Bt.B ? b : 0) * U.np_var;
+            const bool bad = canonicalise<NSX, NSZ, NV>(F, U, theta, I[g], lane);
+            if (bad) { co[g].status = -2; co[g].obj = NAN; }
+            n_open += I[g].done ? 0 : 1;
+        }
+
+        int iter = 0;
+        bool first = true;
+#pragma nounroll
+        while (n_open > 0) {
+            bool chk = false;
+            const int lane_outer = lane;
+            const int lane = cpgw::opaque(lane_outer);   // per-iteration copy, see cpgw::opaque
+            signed char ct[NSZ];
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) ct[s] = (signed char)cpgw::opaque((int)ct_reg[s]);
+            if (!first) {
+                iter++;
+                chk = (S.check_termination > 0 && iter % S.check_termination == 0) || iter >= S.max_iter;
+                // ---- right-hand side of the KKT system
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    double *wg = w + g * ldw;
+#pragma unroll
+                    for (int s = 0; s < NSX; s++) {
+                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                        if (i < (unsigned)F.n) wg[i] = F.sigma * I[g].x[s] - CPG_Q(I[g], sh, s, i);
+                        CPG_FENCE_EVERY(s);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NSZ; s++) {
+                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                        const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+                        if (i < (unsigned)F.m) wg[(unsigned)F.n + i] = I[g].z[s] - ri * I[g].y[s];
+                        CPG_FENCE_EVERY(s);
+                    }
+                }
+                cpgw::lds_order();
+                run_program<G>(F.kkt, w, ldw, lane);
+                // ---- relaxation, projection on [l, u], dual update
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const double *wg = w + g * ldw;
+                    double *sdx = scr + (size_t)g * N, *sdy = sdx + F.n;
+#pragma unroll
+                    for (int s = 0; s < NSX; s++) {
+                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                        if (i < (unsigned)F.n) {
+                            const double xn = F.alpha * wg[fpx[s]] + (1.0 - F.alpha) * I[g].x[s];
+                            if (chk) cpgw::gst(sdx, i, xn - I[g].x[s]);
+                            I[g].x[s] = xn;
+                        }
+                        CPG_FENCE_EVERY(s);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NSZ; s++) {
+                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                        if (i < (unsigned)F.m) {
+                            const double rv = ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr);
+                            const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+                            const double zp = I[g].z[s], yp = I[g].y[s];
+                            const double zt = (zp - ri * yp) + ri * wg[fpz[s]];
+                            const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
+                            // projection on [l, u]: equality rows have l = u, all others l = -inf
+                            const double uu = CPG_U(I[g], sh, s, i);
+                            const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
+                            const double dyv = rv * (zr - zn);
+                            I[g].z[s] = zn; I[g].y[s] = yp + dyv;
+                            if (chk) cpgw::gst(sdy, i, dyv);
+                        }
+                        CPG_FENCE_EVERY(s);
+                    }
+                }
+                cpgw::lds_order();
+            }
+            first = false;
+            // ---- termination test / bookkeeping (single finalize site)
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (I[g].done) continue;
+                CheckOut o = co[g];
+                double *wg = w + g * ldw;
+                double *sdx = scr + (size_t)g * N, *sdy = sdx + F.n;
+                if (__builtin_expect(o.status == 11 && chk, 0)) {
+#pragma nounroll
+                    for (int pass = 0; pass < 2; pass++) {
+                        if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
+                        o = check<NSX, NSZ, NV>(F, sh, ct, S, I[g], wg, sdx, sdy, lane, pass == 1);
+                    }
+                    if (o.status == 11 && iter >= S.max_iter) o.status = 7;
+                }
+                if (o.status == 11 && iter >= S.max_iter) o.status = 7;   // max_iter == 0
+                co[g] = o;
+                if (__builtin_expect(o.status != 11, 0)) { finalize<NSX, NSZ, NV>(F, Bt, I[g], wg, lane, iter, o); n_open--; }
+            }
+        }
+    }
+}
+
+}  // namespace cpg

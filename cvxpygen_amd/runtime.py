@@ -1,0 +1,434 @@
+"""
+Host side of the batched solver: builds the device plan of a problem family and drives
+libcpg_hip.so (include/cpg_hip.h) through ctypes -- "host code stays Python calling HIP through a
+thin C-ABI / ctypes layer (no PyTorch)".
+
+This is the batched counterpart of the reference's L6/L7 layers: the Python shim
+`cpg_solve` (`cvxpygen/templates/cpg_solver.py.jinja2:40-117`) + the pybind11 module
+`cpg_module.solve(upd, par)` (`cvxpygen/utils.py:1194-1270`).  One `BatchSolver` replaces the
+static workspace the reference emits per problem family (`cvxpygen/utils.py:470-689`).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the constructor
+raises.  (tests/ may inject the lock-step emulator build of the same sources through `lib_path`.)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import osqp_setup as _setup
+from . import solve_program as _sp
+from .canon_builder import canon_lu
+from .descriptor import CPG_INF, FamilyDescriptor
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_u16p = C.POINTER(C.c_uint16)
+_i8p = C.POINTER(C.c_int8)
+
+STATUS_STRINGS = {1: 'solved', 2: 'solved inaccurate', 3: 'primal infeasible',
+                  4: 'primal infeasible inaccurate', 5: 'dual infeasible',
+                  6: 'dual infeasible inaccurate', 7: 'maximum iterations reached',
+                  9: 'problem non convex', 11: 'unsolved', -2: 'needs refactorization'}
+
+# cvxpy-style aliases of the reference (`stgs_translation`, cvxpygen/solvers/osqp.py:110,
+# cvxpygen/solvers/_interface.py:196-199)
+SETTING_ALIASES = {'warm_start': 'warm_starting'}
+SETTINGS_ENABLED = ['max_iter', 'eps_abs', 'eps_rel', 'eps_prim_inf', 'eps_dual_inf',
+                    'scaled_termination', 'check_termination', 'warm_starting']
+
+
+class _Program(C.Structure):
+    _fields_ = [('n_chunks', C.c_int32), ('n_steps', C.c_int32), ('hdr', _ip), ('rows', _u16p),
+                ('vals', _dp), ('cols', _u16p)]
+
+
+class _Csr(C.Structure):
+    _fields_ = [('rows', C.c_int32), ('nnz', C.c_int32), ('ptr', _ip), ('idx', _ip), ('val', _dp)]
+
+
+class _Family(C.Structure):
+    _fields_ = [('n', C.c_int32), ('m', C.c_int32), ('n_eq', C.c_int32), ('is_maximization', C.c_int32),
+                ('sigma', C.c_double), ('alpha', C.c_double), ('rho', C.c_double),
+                ('D', _dp), ('E', _dp), ('c', C.c_double), ('ctype', _i8p),
+                ('n_slots', C.c_int32), ('fpos', _u16p), ('n_vary_x', C.c_int32), ('n_vary_z', C.c_int32),
+                ('kkt', _Program), ('A_rows', _Program), ('P_rows', _Program), ('At_rows', _Program),
+                ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip)]
+
+
+class _Update(C.Structure):
+    _fields_ = [('np_var', C.c_int32), ('q_base', _dp), ('u_base', _dp), ('d_base', C.c_double),
+                ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr)]
+
+
+def default_lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcpg_hip.so')
+
+
+class CpgLibrary:
+    """ctypes view of the C-ABI declared in include/cpg_hip.h."""
+
+    SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_destroy', 'cpg_hip_last_error',
+               'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
+               'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_solve_batch',
+               'cpg_hip_solve_batch_device', 'cpg_hip_synchronize', 'cpg_hip_last_kernel_ms',
+               'cpg_hip_set_launch', 'cpg_hip_malloc', 'cpg_hip_free', 'cpg_hip_memcpy_h2d',
+               'cpg_hip_memcpy_d2h']
+
+    def __init__(self, path: Optional[str] = None):
+        path = path or os.environ.get('CPG_HIP_LIBRARY') or default_lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f'HIP extension {path} not found: build it with `python -m cvxpygen_amd.csrc.build` '
+                '(there is no CPU fallback)')
+        self.path = path
+        L = C.CDLL(path)
+        self.L = L
+        L.cpg_hip_last_error.restype = C.c_char_p
+        L.cpg_hip_status_string.restype = C.c_char_p
+        L.cpg_hip_status_string.argtypes = [C.c_int32]
+        L.cpg_hip_device_count.argtypes = [_ip]
+        L.cpg_hip_create_osqp.argtypes = [C.POINTER(_Family), C.c_int, C.POINTER(C.c_void_p)]
+        L.cpg_hip_destroy.argtypes = [C.c_void_p]
+        L.cpg_hip_set_default_settings.argtypes = [C.c_void_p]
+        L.cpg_hip_set_setting.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.cpg_hip_get_setting.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.cpg_hip_set_update.argtypes = [C.c_void_p, C.POINTER(_Update)]
+        L.cpg_hip_solve_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
+        L.cpg_hip_solve_batch_device.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
+        L.cpg_hip_synchronize.argtypes = [C.c_void_p]
+        L.cpg_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.cpg_hip_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.cpg_hip_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.cpg_hip_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.cpg_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cpg_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+
+    def check(self, rc: int, what: str = '') -> None:
+        if rc != 0:
+            msg = self.L.cpg_hip_last_error().decode()
+            raise RuntimeError(f'{what} failed ({rc}): {msg}')
+
+    def device_count(self) -> int:
+        n = C.c_int32(0)
+        self.check(self.L.cpg_hip_device_count(C.byref(n)), 'cpg_hip_device_count')
+        return n.value
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _program_struct(p: _sp.PackedProgram, keep: list) -> _Program:
+    hdr = np.ascontiguousarray(p.hdr, dtype=np.int32)
+    rows = np.ascontiguousarray(p.rows, dtype=np.uint16)
+    vals = np.ascontiguousarray(p.vals, dtype=np.float64)
+    cols = np.ascontiguousarray(p.cols, dtype=np.uint16)
+    keep += [hdr, rows, vals, cols]
+    return _Program(p.n_chunks, p.steps, hdr.ctypes.data_as(_ip), rows.ctypes.data_as(_u16p),
+                    _d(vals), cols.ctypes.data_as(_u16p))
+
+
+def _csr_struct(M: sp.csr_matrix, keep: list) -> _Csr:
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    ptr = np.ascontiguousarray(M.indptr, dtype=np.int32)
+    idx = np.ascontiguousarray(M.indices, dtype=np.int32)
+    val = np.ascontiguousarray(M.data, dtype=np.float64)
+    keep += [ptr, idx, val]
+    return _Csr(M.shape[0], int(M.nnz), ptr.ctypes.data_as(_ip), idx.ctypes.data_as(_ip), _d(val))
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class FamilyPlan:
+    """Code-generation-time product for one OSQP problem family: scaling, factor, solve program
+    and the device ordering (entries depending on user parameters first)."""
+    desc: FamilyDescriptor
+    osqp: _setup.OsqpPlan
+    ordx: np.ndarray        # device position -> canonical x index
+    ordz: np.ndarray        # device position -> canonical row
+    posx: np.ndarray        # canonical x index -> device position
+    posz: np.ndarray
+    n_vary_x: int
+    n_vary_z: int
+    kkt: _sp.PackedProgram
+    A_rows: _sp.PackedProgram
+    P_rows: _sp.PackedProgram
+    At_rows: _sp.PackedProgram
+    prim_idx: np.ndarray
+    dual_idx: np.ndarray
+    stats: Dict[str, float] = field(default_factory=dict)
+
+
+def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
+                      setup_settings: Optional[Dict[str, float]] = None) -> FamilyPlan:
+    t0 = time.time()
+    n, m, n_eq = desc.n_var, desc.m, desc.n_eq
+    # the shared-factor kernel relies on the two row kinds of the reference's OSQP canonical form
+    Ml, Mu = sp.csr_matrix(desc.maps['l']), sp.csr_matrix(desc.maps['u'])
+    if Ml.shape[0] != n_eq or (abs(Ml - Mu[:n_eq]) > 0).nnz != 0:
+        raise NotImplementedError('rows with finite l != u are not produced by the OSQP canonical '
+                                  'form of the reference and are not supported')
+    canon0 = desc.default_canon()
+    l0, u0 = canon_lu(desc, canon0)
+    plan = _setup.setup(desc.P, canon0['q'], desc.A, l0, u0, settings=setup_settings,
+                        ordering=ordering)
+    NP = desc.NP
+    vary_q = np.diff(sp.csr_matrix(desc.maps['q'])[:, :NP].tocsr().indptr) > 0
+    vary_u = np.diff(Mu[:, :NP].tocsr().indptr) > 0
+    ordx = np.concatenate([np.nonzero(vary_q)[0], np.nonzero(~vary_q)[0]]).astype(np.int64)
+    ordz = np.concatenate([np.nonzero(vary_u)[0], np.nonzero(~vary_u)[0]]).astype(np.int64)
+    posx = np.empty(n, dtype=np.int64); posx[ordx] = np.arange(n)
+    posz = np.empty(m, dtype=np.int64); posz[ordz] = np.arange(m)
+    devpos = np.concatenate([posx, n + posz])
+    N = n + m
+    phases = _sp.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=merge,
+                             devpos=devpos)
+    kkt = _sp.pack(phases, N=N)
+    if kkt.n_slots >= 0xFFFF:
+        raise NotImplementedError('problem family too large for 16-bit LDS slot indices')
+    As = sp.csc_matrix((plan.Ax, desc.A.indices, desc.A.indptr), shape=desc.A.shape)
+    Pu = sp.csc_matrix((plan.Px, desc.P.indices, desc.P.indptr), shape=desc.P.shape)
+    Pf = Pu + sp.triu(Pu, 1).T
+    A_dev = sp.csr_matrix(As)[ordz][:, ordx]
+    P_dev = sp.csr_matrix(Pf)[ordx][:, ordx]
+    A_rows = _sp.pack([_sp.spmv_phase(A_dev, 0, 'A')], natural=True)
+    P_rows = _sp.pack([_sp.spmv_phase(P_dev, 0, 'P')], natural=True)
+    At_rows = _sp.pack([_sp.spmv_phase(sp.csr_matrix(A_dev.T), n, 'At')], natural=True)
+    prim_idx = np.concatenate([posx[v.indices] for v in desc.variables]).astype(np.int32) \
+        if desc.variables else np.zeros(0, dtype=np.int32)
+    dual_idx = np.concatenate([posz[d.indices] for d in desc.duals]).astype(np.int32) \
+        if desc.duals else np.zeros(0, dtype=np.int32)
+    stats = dict(nnzL=len(plan.Li), phases=kkt.n_phases, chunks=kkt.n_chunks, steps=kkt.steps,
+                 nnz_program=kkt.nnz, n_slots=kkt.n_slots, compile_s=time.time() - t0)
+    return FamilyPlan(desc=desc, osqp=plan, ordx=ordx, ordz=ordz, posx=posx, posz=posz,
+                      n_vary_x=int(vary_q.sum()), n_vary_z=int(vary_u.sum()), kkt=kkt, A_rows=A_rows,
+                      P_rows=P_rows, At_rows=At_rows, prim_idx=prim_idx, dual_idx=dual_idx,
+                      stats=stats)
+
+
+@dataclass
+class BatchResult:
+    prim: Dict[str, np.ndarray]
+    dual: Dict[str, np.ndarray]
+    obj_val: np.ndarray
+    iter: np.ndarray
+    status: np.ndarray
+    pri_res: np.ndarray
+    dua_res: np.ndarray
+    solve_time: float = 0.0
+    kernel_ms: float = 0.0
+    prim_flat: Optional[np.ndarray] = None
+    dual_flat: Optional[np.ndarray] = None
+
+    def status_str(self) -> List[str]:
+        return [STATUS_STRINGS.get(int(s), 'unknown') for s in self.status]
+
+
+class BatchSolver:
+    """One problem family on one GPU.  `solve(params)` = the reference's
+    `cpg_solve(prob, updated_params, **kwargs)` for B instances at once."""
+
+    def __init__(self, desc: FamilyDescriptor, device: int = 0, lib_path: Optional[str] = None,
+                 plan: Optional[FamilyPlan] = None, ordering: str = 'mindeg'):
+        if desc.solver != 'OSQP':
+            raise ValueError(f'BatchSolver handles OSQP families, not {desc.solver}')
+        self.desc = desc
+        self.lib = CpgLibrary(lib_path)
+        self.plan = plan or build_family_plan(desc, ordering=ordering)
+        self._keep: list = []
+        self._update_key = None
+        self._update_keep: list = []
+        self.h = C.c_void_p()
+        p, o = self.plan, self.plan.osqp
+        keep = self._keep
+        D = np.ascontiguousarray(o.scaling.D[p.ordx]); E = np.ascontiguousarray(o.scaling.E[p.ordz])
+        ctype = np.ascontiguousarray(o.constr_type[p.ordz], dtype=np.int8)
+        fpos = np.ascontiguousarray(p.kkt.final_pos, dtype=np.uint16)
+        prim_idx = np.ascontiguousarray(p.prim_idx, dtype=np.int32)
+        dual_idx = np.ascontiguousarray(p.dual_idx, dtype=np.int32)
+        keep += [D, E, ctype, fpos, prim_idx, dual_idx]
+        fam = _Family(
+            n=desc.n_var, m=desc.m, n_eq=desc.n_eq, is_maximization=int(desc.is_maximization),
+            sigma=o.settings['sigma'], alpha=o.settings['alpha'], rho=o.settings['rho'],
+            D=_d(D), E=_d(E), c=o.scaling.c, ctype=ctype.ctypes.data_as(_i8p),
+            n_slots=p.kkt.n_slots, fpos=fpos.ctypes.data_as(_u16p),
+            n_vary_x=p.n_vary_x, n_vary_z=p.n_vary_z,
+            kkt=_program_struct(p.kkt, keep), A_rows=_program_struct(p.A_rows, keep),
+            P_rows=_program_struct(p.P_rows, keep), At_rows=_program_struct(p.At_rows, keep),
+            n_prim=len(prim_idx), prim_idx=prim_idx.ctypes.data_as(_ip),
+            n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip))
+        self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), device, C.byref(self.h)),
+                       'cpg_hip_create_osqp')
+        self.np_var = 0
+        self._var_cols = np.zeros(0, dtype=np.int64)
+
+    def close(self):
+        if getattr(self, 'h', None) and self.h.value:
+            self.lib.L.cpg_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- settings --------------------------------------------------------------------------------
+    def apply_settings(self, **kwargs) -> None:
+        """Reference semantics: reset to defaults, then apply the keyword arguments
+        (`cvxpygen/templates/cpg_solver.py.jinja2:55-60`)."""
+        L = self.lib.L
+        self.lib.check(L.cpg_hip_set_default_settings(self.h), 'set_default_settings')
+        for k, v in kwargs.items():
+            name = SETTING_ALIASES.get(k, k)
+            if L.cpg_hip_set_setting(self.h, name.encode(), float(v)) != 0:
+                raise AttributeError(f'Solver setting "{k}" not available.')
+
+    def set_launch(self, waves_per_block=0, inst_per_wave=0, blocks_per_cu=0):
+        self.lib.check(self.lib.L.cpg_hip_set_launch(self.h, waves_per_block, inst_per_wave,
+                                                    blocks_per_cu), 'set_launch')
+
+    # ---- which parameters vary ----------------------------------------------------------------------
+    def set_updated(self, updated_params: Optional[Sequence[str]] = None) -> None:
+        desc, p, o = self.desc, self.plan, self.plan.osqp
+        if updated_params is None:
+            updated_params = desc.param_names
+        names = []
+        for nm in updated_params:
+            desc.param(nm)                       # AttributeError for unknown names, as the reference
+            if nm not in names:
+                names.append(nm)
+        names = [q.name for q in desc.params if q.name in names]     # theta order
+        key = tuple(names)
+        if key == self._update_key:
+            return
+        dep = desc.user_p_name_to_canon_outdated()
+        touched = set()
+        for nm in names:
+            touched.update(dep[nm])
+        if touched & {'P', 'A'}:
+            raise NotImplementedError(
+                'parameters entering P or A need the per-instance refactorisation path '
+                f'(updated: {sorted(touched & {"P", "A"})})')
+        cols = np.concatenate([np.arange(desc.param(nm).col, desc.param(nm).col + desc.param(nm).size)
+                               for nm in names]).astype(np.int64) if names else np.zeros(0, np.int64)
+        NP = desc.NP
+        fixed = np.ones(NP + 1, dtype=bool)
+        fixed[cols] = False
+        th_fixed = np.where(fixed, desc.theta0, 0.0)
+        keep: list = []
+
+        def split(pid, scale, order, clip):
+            Cm = sp.csr_matrix(desc.maps[pid])
+            base = np.asarray(Cm @ th_fixed).ravel()
+            if clip:
+                base = np.clip(base, -CPG_INF, CPG_INF)
+            Mv = sp.csr_matrix(Cm[:, cols]) if len(cols) else sp.csr_matrix((Cm.shape[0], 0))
+            Mv = sp.diags(scale) @ Mv
+            return np.ascontiguousarray((scale * base)[order]), sp.csr_matrix(Mv)[order]
+
+        qb, Mq = split('q', o.scaling.c * o.scaling.D, p.ordx, False)
+        ub, Mu = split('u', o.scaling.E, p.ordz, True)
+        Cd = sp.csr_matrix(desc.maps['d'])
+        d_base = float((Cd @ th_fixed)[0]) if desc.nonzero_d else 0.0
+        Md = sp.csr_matrix(Cd[:, cols]) if (len(cols) and desc.nonzero_d) else sp.csr_matrix((1, len(cols)))
+        keep += [qb, ub]
+        upd = _Update(np_var=len(cols), q_base=_d(qb), u_base=_d(ub), d_base=d_base,
+                      map_q=_csr_struct(Mq, keep), map_u=_csr_struct(Mu, keep),
+                      map_d=_csr_struct(Md, keep))
+        self.lib.check(self.lib.L.cpg_hip_set_update(self.h, C.byref(upd)), 'cpg_hip_set_update')
+        self._update_key, self._update_keep = key, keep
+        self._var_cols, self.np_var = cols, len(cols)
+        self._updated_names = names
+
+    def theta_var(self, params: Dict[str, np.ndarray], B: Optional[int] = None) -> np.ndarray:
+        """[B, np_var] C-contiguous array of the updated parameters, each flattened as the reference's
+        `get_param_value` does (F-order / diagonal / stored non-zeros), instance-major."""
+        names = self._updated_names
+        blocks = []
+        for nm in names:
+            if nm not in params:
+                raise KeyError(f'value for updated parameter {nm} missing')
+            up = self.desc.param(nm)
+            v = np.asarray(params[nm], dtype=np.float64)
+            Bn = v.shape[0]
+            if B is None:
+                B = Bn
+            if Bn != B:
+                raise ValueError('inconsistent batch sizes')
+            if v.ndim == 2 and v.shape[1] == up.size and (len(up.shape) != 1 or up.kind != 'dense' or True):
+                # already flattened the way the reference stores it (F-order / diagonal / non-zeros)
+                blocks.append(v.reshape(B, up.size))
+            elif up.kind == 'diag' and v.ndim == 3:
+                blocks.append(np.diagonal(v, axis1=1, axis2=2).reshape(B, up.size))
+            elif up.kind == 'sparse' and v.ndim == 3:
+                r, c = up.sparsity
+                blocks.append(v[:, np.asarray(r), np.asarray(c)].reshape(B, up.size))
+            elif up.kind == 'scalar':
+                blocks.append(v.reshape(B, 1))
+            else:
+                blocks.append(v.reshape((B,) + tuple(up.shape)).transpose(
+                    (0,) + tuple(range(len(up.shape), 0, -1))).reshape(B, up.size))
+        if not blocks:
+            return np.zeros((B or 0, 0))
+        return np.ascontiguousarray(np.concatenate(blocks, axis=1))
+
+    # ---- solve ---------------------------------------------------------------------------------------
+    def solve(self, params: Optional[Dict[str, np.ndarray]] = None,
+              updated_params: Optional[Sequence[str]] = None, B: Optional[int] = None,
+              theta_var: Optional[np.ndarray] = None, **kwargs) -> BatchResult:
+        self.set_updated(updated_params)
+        self.apply_settings(**kwargs)
+        if theta_var is None:
+            theta_var = self.theta_var(params or {}, B)
+        theta_var = np.ascontiguousarray(theta_var, dtype=np.float64)
+        Bn = theta_var.shape[0] if theta_var.ndim == 2 and self.np_var else (B or theta_var.shape[0])
+        if self.np_var and theta_var.shape != (Bn, self.np_var):
+            raise ValueError(f'theta_var must have shape (B, {self.np_var})')
+        d = self.desc
+        n_prim, n_dual = len(self.plan.prim_idx), len(self.plan.dual_idx)
+        prim = np.empty((Bn, n_prim)); dual = np.empty((Bn, n_dual))
+        obj = np.empty(Bn); pri = np.empty(Bn); dua = np.empty(Bn)
+        it = np.empty(Bn, dtype=np.int32); st = np.empty(Bn, dtype=np.int32)
+        t0 = time.time()
+        self.lib.check(self.lib.L.cpg_hip_solve_batch(
+            self.h, Bn, _d(theta_var), _d(prim), _d(dual), _d(obj), it.ctypes.data_as(_ip),
+            st.ctypes.data_as(_ip), _d(pri), _d(dua)), 'cpg_hip_solve_batch')
+        t1 = time.time()
+        ms = C.c_float(0)
+        self.lib.L.cpg_hip_last_kernel_ms(self.h, C.byref(ms))
+        return self._result(prim, dual, obj, it, st, pri, dua, t1 - t0, ms.value)
+
+    def _result(self, prim, dual, obj, it, st, pri, dua, dt, ms) -> BatchResult:
+        d = self.desc
+        Bn = prim.shape[0]
+        pd, dd, k = {}, {}, 0
+        for v in d.variables:
+            sz = v.indices.size
+            pd[v.name] = prim[:, k:k + sz].reshape((Bn,) + tuple(v.shape)[::-1]).transpose(
+                (0,) + tuple(range(len(v.shape), 0, -1))) if len(v.shape) > 1 else prim[:, k:k + sz]
+            k += sz
+        k = 0
+        for u in d.duals:
+            sz = u.indices.size
+            if len(u.shape) > 1:
+                dd[u.name] = dual[:, k:k + sz].reshape((Bn,) + tuple(u.shape)[::-1]).transpose(
+                    (0,) + tuple(range(len(u.shape), 0, -1)))
+            elif len(u.shape) == 1:
+                dd[u.name] = dual[:, k:k + sz]
+            else:
+                dd[u.name] = dual[:, k]
+            k += sz
+        # +-1e30 -> +-inf as the reference shim does (templates/cpg_solver.py.jinja2:98-101)
+        obj = np.where(np.abs(obj) >= 1e30, np.sign(obj) * np.inf, obj)
+        return BatchResult(prim=pd, dual=dd, obj_val=obj, iter=it, status=st, pri_res=pri,
+                           dua_res=dua, solve_time=dt, kernel_ms=ms, prim_flat=prim, dual_flat=dual)

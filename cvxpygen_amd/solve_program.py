@@ -40,7 +40,6 @@ import numpy as np
 import scipy.sparse as sp
 
 LANES = 64
-MAX_PENDING = 4          # chunks whose results may be held in registers before the store
 PHASE_COST = 14.0        # fixed cost of a phase, in units of one multiply-add step of a wavefront
 CHUNK_COST = 3.0         # fixed cost of one more chunk inside a phase
 MAX_GROUP_ROWS = 128
@@ -106,8 +105,6 @@ def _chunk_plan(lens: Sequence[int]) -> Tuple[float, int, List[Tuple[int, int, L
 
 def _phase_cost(lens: Sequence[int], intra: bool) -> float:
     cost, nch, _ = _chunk_plan(lens)
-    if intra and nch > MAX_PENDING:
-        return np.inf
     return PHASE_COST + cost
 
 
@@ -118,8 +115,6 @@ def _approx_cost(lens: np.ndarray, intra: bool) -> float:
     steps = max(np.ceil(total / LANES), np.ceil(lens.max() / LANES), 1.0)
     lanes_needed = total / steps
     nch = max(1.0, np.ceil(lanes_needed / LANES))
-    if intra and nch > MAX_PENDING:
-        return np.inf
     split = max(1.0, lens.max() / steps)
     return PHASE_COST + 1.2 * total / LANES + CHUNK_COST * nch + 1.5 * np.log2(split) + 1.0
 
@@ -227,37 +222,28 @@ def _compile_lower(N: int, M: sp.csr_matrix, scale: Optional[np.ndarray], merge:
         a = int(choice[b])
         bounds.append((a, b - 1))
         b = a
-    phases = []
-    for a, b in bounds[::-1]:
-        stack = [(a, b)]
-        while stack:
-            x, y = stack.pop(0)
-            ph = build(x, y)
-            _, nch, _ = _chunk_plan([len(c) for c in ph.cols])
-            if ph.intra and nch > MAX_PENDING and y > x:
-                mid = (x + y) // 2
-                stack = [(x, mid), (mid + 1, y)] + stack
-                continue
-            phases.append(ph)
-    return phases
+    return [build(a, b) for a, b in bounds[::-1]]
 
 
 def compile_ldl(N: int, Lp: np.ndarray, Li: np.ndarray, Lx: np.ndarray, D: np.ndarray,
-                perm: np.ndarray, merge: bool = True) -> List[Phase]:
-    """Phases for  w <- K^-1 w  with K = P' L D L' P, operating on w in NATURAL order (the
-    permutation is folded into the row / column indices)."""
+                perm: np.ndarray, merge: bool = True, devpos: Optional[np.ndarray] = None
+                ) -> List[Phase]:
+    """Phases for  w <- K^-1 w  with K = P' L D L' P.  Row / column indices are LOGICAL entries of
+    w: natural KKT index i, or devpos[i] when a device ordering is given (both the fill-reducing
+    permutation and the device ordering are folded into the indices; nothing is permuted at run
+    time)."""
     L = sp.csc_matrix((Lx, Li, Lp), shape=(N, N))
     fwd = _compile_lower(N, sp.csr_matrix(L), None, merge, 'F')
     # backward: L' x = D^-1 y.  Reverse the index order to obtain a lower-triangular system.
     J = np.arange(N)[::-1]
     Lt_rev = sp.csr_matrix(L.T)[J][:, J]
     bwd = _compile_lower(N, sp.csr_matrix(Lt_rev), (1.0 / D)[J], merge, 'B')
+    mp = perm if devpos is None else devpos[perm]
     out = []
     for ph in fwd:
-        out.append(Phase(perm[ph.rows], [perm[c] for c in ph.cols], ph.vals, ph.intra, ph.name))
+        out.append(Phase(mp[ph.rows], [mp[c] for c in ph.cols], ph.vals, ph.intra, ph.name))
     for ph in bwd:
-        out.append(Phase(perm[J[ph.rows]], [perm[J[c]] for c in ph.cols], ph.vals, ph.intra,
-                         ph.name))
+        out.append(Phase(mp[J[ph.rows]], [mp[J[c]] for c in ph.cols], ph.vals, ph.intra, ph.name))
     return out
 
 
@@ -276,11 +262,11 @@ def spmv_phase(M: sp.spmatrix, col_offset: int, name: str) -> Phase:
 class PackedProgram:
     """Flat arrays consumed by the HIP executor.
 
-    hdr  int32 [n_chunks, 4]: (len, log2 g, flags, value offset in units of 64 entries)
-          flags bit0: store pending results after this chunk (end of a flush group)
-                bit1: last chunk of the program
-    rows uint16 [n_chunks, 64]: output index for the lane (0xFFFF: none)
-    vals float64 [sum(len), 64];  cols uint16 [sum(len), 64]
+    hdr  int32 [n_chunks, 4]: (len, log2 g, flags, first step)
+    rows uint16 [n_chunks, 64]: LDS slot the lane stores its result to (0xFFFF: none)
+    vals float64 [n_steps, 64];  cols uint16 [n_steps, 64]: LDS slot of the operand
+    n_slots: size of the LDS work vector (>= N; merged phases write to fresh slots)
+    final_pos int32 [N]: slot holding logical entry i after the whole program ran
     """
     hdr: np.ndarray
     rows: np.ndarray
@@ -288,6 +274,8 @@ class PackedProgram:
     cols: np.ndarray
     n_phases: int
     nnz: int
+    n_slots: int = 0
+    final_pos: Optional[np.ndarray] = None
 
     @property
     def n_chunks(self) -> int:
@@ -298,18 +286,53 @@ class PackedProgram:
         return int(self.vals.shape[0])
 
 
-FLAG_FLUSH = 1
 FLAG_LAST = 2
 NO_ROW = 0xFFFF
 
 
-def pack(phases: List[Phase], natural: bool = False) -> PackedProgram:
+def assign_slots(phases: List[Phase], N: int):
+    """LDS slot allocation.  Entry i starts in slot i.  A phase whose rows read each other
+    (`intra`) writes its results to free slots and releases the slots its rows occupied, so every
+    chunk can store immediately; other phases update in place.  Returns (per-phase output slots,
+    per-phase column slots, n_slots, final_pos)."""
+    cur = np.arange(N, dtype=np.int64)
+    free: List[int] = []
+    n_slots = N
+    outs, ins = [], []
+    for ph in phases:
+        ins.append([cur[c] for c in ph.cols])
+        if not ph.intra:
+            outs.append(cur[ph.rows].copy())
+            continue
+        new = np.zeros(len(ph.rows), dtype=np.int64)
+        for k in range(len(ph.rows)):
+            if free:
+                new[k] = free.pop()
+            else:
+                new[k] = n_slots
+                n_slots += 1
+        old = cur[ph.rows].copy()
+        cur[ph.rows] = new
+        free.extend(int(v) for v in old[::-1])
+        outs.append(new)
+    return outs, ins, n_slots, cur.copy()
+
+
+def pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None) -> PackedProgram:
     """natural=True: chunk c holds rows 64c .. 64c+63, one row per lane (results are consumed in
     registers by the lane that owns the element; nothing is stored to w)."""
     hdr, rows_out, vals_out, cols_out = [], [], [], []
     off = 0
     nnz = 0
-    for ph in phases:
+    if natural:
+        outs = [ph.rows for ph in phases]
+        ins = [ph.cols for ph in phases]
+        n_slots, final_pos = 0, None
+    else:
+        if N is None:
+            N = int(max(int(ph.rows.max()) for ph in phases)) + 1 if phases else 0
+        outs, ins, n_slots, final_pos = assign_slots(phases, N)
+    for ph, out_slots, col_slots in zip(phases, outs, ins):
         lens = [len(c) for c in ph.cols]
         nnz += sum(lens)
         if natural:
@@ -319,29 +342,20 @@ def pack(phases: List[Phase], natural: bool = False) -> PackedProgram:
                 plan.append((1, max(1, max(lens[k] for k in sel)), sel))
         else:
             _, _, plan = _chunk_plan(lens)
-        npend = 0
         for ci, (g, ln, sel) in enumerate(plan):
             V = np.zeros((ln, LANES))
             Cc = np.zeros((ln, LANES), dtype=np.uint16)
             R = np.full(LANES, NO_ROW, dtype=np.uint16)
             for k, rp in enumerate(sel):
                 base = k * g
-                R[base] = ph.rows[rp] if not natural else ph.rows[rp] % LANES
-                c, v = ph.cols[rp], ph.vals[rp]
+                R[base] = out_slots[rp] if not natural else ph.rows[rp] % LANES
+                c, v = col_slots[rp], ph.vals[rp]
                 seg = -(-len(c) // g) if len(c) else 0
                 for t in range(g):
                     cs, vs = c[t * seg:(t + 1) * seg], v[t * seg:(t + 1) * seg]
                     V[:len(vs), base + t] = vs
                     Cc[:len(cs), base + t] = cs
-            npend += 1
-            last_in_phase = ci == len(plan) - 1
-            flush = last_in_phase or (not ph.intra) or npend == MAX_PENDING
-            if ph.intra and npend == MAX_PENDING and not last_in_phase:
-                raise ValueError('phase with intra-group reads needs more pending slots')
-            flags = FLAG_FLUSH if flush else 0
-            if flush:
-                npend = 0
-            hdr.append([ln, int(np.log2(g)), flags, off])
+            hdr.append([ln, int(np.log2(g)), 0, off])
             rows_out.append(R)
             vals_out.append(V)
             cols_out.append(Cc)
@@ -353,28 +367,25 @@ def pack(phases: List[Phase], natural: bool = False) -> PackedProgram:
         rows=np.asarray(rows_out, dtype=np.uint16).reshape(-1, LANES),
         vals=np.concatenate(vals_out, axis=0) if vals_out else np.zeros((0, LANES)),
         cols=np.concatenate(cols_out, axis=0) if cols_out else np.zeros((0, LANES), dtype=np.uint16),
-        n_phases=len(phases), nnz=nnz)
+        n_phases=len(phases), nnz=nnz, n_slots=n_slots, final_pos=final_pos)
 
 
 def execute_packed(prog: PackedProgram, w: np.ndarray, natural: bool = False):
-    """Host emulation of the HIP executor (tests): applies the program to w in place.  With
-    natural=True returns the per-chunk lane results instead of storing."""
-    pend = []
+    """Host emulation of the HIP executor (tests).  `w` must have prog.n_slots entries; chunk by
+    chunk: multiply-add steps, group reduction, immediate store -- exactly as `run_program` in
+    csrc/cpg_osqp_kernel.h.  With natural=True returns the per-chunk lane results instead."""
     nat = []
     for c in range(prog.n_chunks):
-        ln, lg, flags, off = prog.hdr[c]
+        ln, lg, _, off = prog.hdr[c]
         g = 1 << lg
         acc = np.zeros(LANES)
         for s in range(ln):
             acc += prog.vals[off + s] * w[prog.cols[off + s]]
-        red = acc.reshape(LANES // g, g).sum(axis=1)
         if natural:
-            nat.append(acc.copy())
+            nat.append(acc)
             continue
-        pend.append((prog.rows[c][::g], red))
-        if flags & FLAG_FLUSH:
-            for R, v in pend:
-                ok = R != NO_ROW
-                w[R[ok]] = v[ok]
-            pend = []
+        red = acc.reshape(LANES // g, g).sum(axis=1)
+        R = prog.rows[c][::g]
+        ok = R != NO_ROW
+        w[R[ok]] = red[ok]
     return nat if natural else w

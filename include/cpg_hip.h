@@ -1,0 +1,159 @@
+/*
+ * cpg_hip.h -- C-ABI of the MI355X batched-solve backend for cvxpygen-generated solvers.
+ *
+ * This shared library (libcpg_hip.so, built by hipcc for gfx950) is what a binding loads in place
+ * of the reference's pybind11 extension `cpg_module` (emitted by cvxpygen/utils.py:1163-1412,
+ * declared in cvxpygen/templates/cpg_module.hpp.jinja2:1-102).  Plain pointers and sizes only; no
+ * C++/torch types.  All functions return 0 on success or a negative CPG_E_* code; the message of
+ * the last failure on the calling thread is available from cpg_hip_last_error().
+ *
+ * Mapping to the reference interface (one instance per call there, a batch here):
+ *   cpg_module.solve(upd, par)               utils.py:1194-1270 -> cpg_hip_solve_batch[_device]
+ *     cpg_update_<param>(idx, val)           utils.py:904-935   -> theta_var rows (coalesced load)
+ *     cpg_canonicalize_<p>()                 utils.py:279-294   -> in-kernel CSR product, see
+ *                                                                  cpg_osqp_update_t
+ *     osqp_update_data_vec(q, l, u)          solvers/osqp.py:39-59  -> in-kernel rescale with D,E,c
+ *     osqp_solve(&solver)                    solvers/osqp.py:62     -> ADMM kernel
+ *     cpg_retrieve_prim/dual/info            utils.py:950-985   -> prim / dual / obj / iter / ...
+ *   cpg_module.set_solver_default_settings() utils.py:1070-1076 -> cpg_hip_set_default_settings
+ *   cpg_module.set_solver_<name>(v)          utils.py:1077-1084,1407-1410 -> cpg_hip_set_setting
+ *   static workspace of the extension        utils.py:470-689   -> opaque cpg_handle_t (no globals)
+ *   CPG_Info.status (OSQP string)            utils.py:982       -> int32 code, cpg_hip_status_string
+ */
+#ifndef CPG_HIP_H
+#define CPG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPG_OK 0
+#define CPG_E_BADARG (-1)
+#define CPG_E_HIP (-2)
+#define CPG_E_NOMEM (-3)
+#define CPG_E_UNSUPPORTED (-4)
+
+/* per-instance status codes: OSQP 1.0 numbering, plus one backend-specific code */
+#define CPG_STATUS_SOLVED 1
+#define CPG_STATUS_SOLVED_INACCURATE 2
+#define CPG_STATUS_PRIMAL_INFEASIBLE 3
+#define CPG_STATUS_PRIMAL_INFEASIBLE_INACCURATE 4
+#define CPG_STATUS_DUAL_INFEASIBLE 5
+#define CPG_STATUS_DUAL_INFEASIBLE_INACCURATE 6
+#define CPG_STATUS_MAX_ITER_REACHED 7
+#define CPG_STATUS_NON_CVX 9
+#define CPG_STATUS_UNSOLVED 11
+/* a constraint row changed class (equality <-> inequality <-> free) w.r.t. code generation time:
+ * the shared KKT factor is not valid for this instance (the reference refactors here,
+ * osqp_update_data_vec -> update_rho_vec); the instance must go through the refactor path */
+#define CPG_STATUS_NEEDS_REFACTOR (-2)
+
+typedef struct cpg_solver_s *cpg_handle_t;
+
+/* A "solve program": sequence of sparse phases  w[r] <- sum_k val_k * w[col_k]  cut into chunks
+ * of 64 lane-tasks (see cvxpygen_amd/solve_program.py for the layout). */
+typedef struct {
+    int32_t n_chunks;
+    int32_t n_steps;
+    const int32_t *hdr;   /* [n_chunks][4]: len, log2(lanes per row), flags, first step */
+    const uint16_t *rows; /* [n_chunks][64] */
+    const double *vals;   /* [n_steps][64] */
+    const uint16_t *cols; /* [n_steps][64] */
+} cpg_program_t;
+
+typedef struct {
+    int32_t rows;
+    int32_t nnz;
+    const int32_t *ptr; /* [rows + 1] */
+    const int32_t *idx; /* [nnz] column = position in theta_var */
+    const double *val;  /* [nnz] */
+} cpg_csr_t;
+
+/* Everything fixed at code-generation time for one OSQP problem family (host pointers; copied).
+ * All vectors / index lists are in DEVICE ORDER: the binding permutes the canonical x entries and
+ * constraint rows so that those depending on user parameters come first (cvxpygen_amd/runtime.py). */
+typedef struct {
+    int32_t n;    /* canonical variables */
+    int32_t m;    /* canonical constraints = n_eq + n_ineq */
+    int32_t n_eq;
+    int32_t is_maximization;
+    double sigma, alpha, rho;
+    const double *D; /* [n] Ruiz column scaling at code-generation parameters */
+    const double *E; /* [m] */
+    double c;        /* cost scaling */
+    const int8_t *ctype; /* [m] row class at code-generation time: -1 free, 0 inequality, 1 equality */
+    int32_t n_slots;       /* LDS work-vector length (>= n + m) required by `kkt` */
+    const uint16_t *fpos;  /* [n + m] slot that holds entry i after `kkt` ran */
+    int32_t n_vary_x;      /* entries [0, n_vary_x) of q may depend on user parameters */
+    int32_t n_vary_z;      /* rows [0, n_vary_z) of l / u may depend on user parameters */
+    cpg_program_t kkt;     /* w <- K^-1 w on w = [x-part (n); z-part (m)] */
+    cpg_program_t A_rows;  /* natural layout: (A v)_i,  v = w[0..n)   */
+    cpg_program_t P_rows;  /* natural layout: (P v)_j,  v = w[0..n)   */
+    cpg_program_t At_rows; /* natural layout: (A' v)_j, v = w[n..n+m) */
+    int32_t n_prim;        /* user primal entries */
+    const int32_t *prim_idx; /* [n_prim] indices into x */
+    int32_t n_dual;
+    const int32_t *dual_idx; /* [n_dual] indices into y */
+} cpg_osqp_family_t;
+
+/* Which user parameters vary across the batch and how the canonical VECTORS depend on them
+ * (cpg_update_<param> + cpg_canonicalize_q/l/u/d + osqp_update_data_vec in one description):
+ *     q_scaled = q_base + map_q @ theta_var      (rows pre-multiplied by c * D)
+ *     u_scaled = u_base + map_u @ theta_var      (rows pre-multiplied by E; +1e30 rows included)
+ *     d        = d_base + map_d @ theta_var
+ * The lower bound is implied by the row class: equality rows (ctype 1) have l = u, every other row
+ * has l = -infinity -- the only two kinds of rows the reference's OSQP canonical form contains
+ * (cvxpygen/solvers/_interface.py:62-79); the binding refuses families that violate this. */
+typedef struct {
+    int32_t np_var; /* doubles per instance in theta_var */
+    const double *q_base; /* [n] */
+    const double *u_base; /* [m] */
+    double d_base;
+    cpg_csr_t map_q, map_u, map_d;
+} cpg_osqp_update_t;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int cpg_hip_device_count(int *count);
+int cpg_hip_create_osqp(const cpg_osqp_family_t *family, int device, cpg_handle_t *out);
+int cpg_hip_destroy(cpg_handle_t h);
+const char *cpg_hip_last_error(void);
+const char *cpg_hip_status_string(int32_t status);
+
+/* ---- settings (reference: reset to defaults, then apply kwargs, on every solve) -------------- */
+int cpg_hip_set_default_settings(cpg_handle_t h);
+int cpg_hip_set_setting(cpg_handle_t h, const char *name, double value);
+int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *value);
+
+/* ---- which parameters are updated (sticky until changed) -------------------------------------- */
+int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *upd);
+
+/* ---- solve ---------------------------------------------------------------------------------- */
+/* Host buffers: theta_var [B][np_var]; outputs prim [B][n_prim], dual [B][n_dual], obj/pri_res/
+ * dua_res [B], iter/status [B].  Copies in, solves, copies out, synchronises. */
+int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta_var, double *prim, double *dual,
+                        double *obj, int32_t *iter, int32_t *status, double *pri_res, double *dua_res);
+
+/* Device-resident variant: every pointer is device memory obtained from cpg_hip_malloc on the
+ * handle's device.  Asynchronous on the handle's stream; pair with cpg_hip_synchronize. */
+int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta_var, double *d_prim,
+                               double *d_dual, double *d_obj, int32_t *d_iter, int32_t *d_status,
+                               double *d_pri_res, double *d_dua_res);
+int cpg_hip_synchronize(cpg_handle_t h);
+/* duration of the most recent solve kernel on this handle, from HIP events on its stream */
+int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms);
+/* launch geometry: waves per block (1..16), instances per wave (1, 2 or 4), blocks per CU; 0 = auto */
+int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, int blocks_per_cu);
+
+/* ---- device memory helpers for the device-resident variant ---------------------------------------- */
+int cpg_hip_malloc(cpg_handle_t h, size_t bytes, void **dptr);
+int cpg_hip_free(cpg_handle_t h, void *dptr);
+int cpg_hip_memcpy_h2d(cpg_handle_t h, void *dst, const void *src, size_t bytes);
+int cpg_hip_memcpy_d2h(cpg_handle_t h, void *dst, const void *src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPG_HIP_H */
