@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""
+bench.py -- QP instances solved per second by the MI355X batched-solve backend on the workload
+BASELINE.json's metric is quoted on: config 2, the MPC QP of examples/MPC.ipynb at
+n_x = 12, n_u = 4, horizon 10, OSQP backend, 100 000 instances per GPU, x_init varying per
+instance (tests/test_E2E_QP.py:146: x_init = -2 + 4 * rand), cold start, default OSQP settings
+(cvxpygen/solvers/osqp.py:102-115).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch (theta already resident in HBM): canonicalise ->
+update -> ADMM solve -> retrieve, for every instance of the rank's shard.  Weak scaling: every rank
+solves its own 100 000 instances; no data-path collective (instances are independent); rank 0
+prints ONE JSON line with the whole-job throughput, the roofline object for the solve kernel and
+the CPU baseline (the scalar-C oracle restatement, timed on the host cores of this box).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cvxpygen_amd import families                      # noqa: E402
+from cvxpygen_amd.runtime import BatchSolver, DeviceBatch   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def make_workload(name: str):
+    if name == 'mpc12':
+        desc = families.mpc(12, 4, 10)
+        label = 'MPC QP n_x=12 n_u=4 H=10 (examples/MPC.ipynb shape), OSQP, x_init varies'
+    elif name == 'mpc6':
+        desc = families.mpc(6, 3, 10)
+        label = 'MPC QP n=6 m=3 H=10 (examples/MPC.ipynb), OSQP, x_init varies'
+    else:
+        raise ValueError(name)
+    return desc, label
+
+
+def make_theta(desc, B: int, seed: int) -> np.ndarray:
+    p = desc.param('x_init')
+    rng = np.random.default_rng(seed)
+    return -2.0 + 4.0 * rng.random((B, p.size))
+
+
+def cpu_baseline(desc, target_seconds: float = 12.0):
+    """Oracle (scalar-C restatement of the generated solver, oracle/osqp_oracle.c) on all host cores;
+    bounded sample of the same workload."""
+    from oracle import binding as ob
+    ob.build()
+    cores = ob.lib().oracle_num_threads()
+    p = desc.param('x_init')
+
+    def run(B, seed):
+        th = np.tile(desc.theta0, (B, 1))
+        th[:, p.col:p.col + p.size] = make_theta(desc, B, seed)
+        t0 = time.time()
+        ob.cpg_solve_batch(desc, th, ['x_init'], nthreads=cores)
+        return time.time() - t0
+
+    t_probe = run(8 * cores, 1)
+    per_inst = t_probe / (8 * cores)
+    B = int(max(8 * cores, min(200000, target_seconds / max(per_inst, 1e-9))))
+    t = run(B, 2)
+    return {'value': B / t, 'unit': 'QP instances/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{B} instances of the same workload (same settings, cold start), '
+                      f'OpenMP static over instances, {t:.1f} s wall'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=100000, help='instances per GPU')
+    ap.add_argument('--workload', default='mpc12')
+    ap.add_argument('--lib', default=None, help='alternative libcpg_hip build (experiments)')
+    ap.add_argument('--waves', type=int, default=0)
+    ap.add_argument('--ipw', type=int, default=0, help='instances per wave')
+    ap.add_argument('--blocks-per-cu', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--check', action='store_true', help='compare a sample with the oracle')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    desc, label = make_workload(args.workload)
+    solver = BatchSolver(desc, device=local_rank, lib_path=args.lib)
+    solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)
+    solver.set_updated(['x_init'])
+    solver.apply_settings()                      # reference defaults
+    B = args.batch
+    theta = make_theta(desc, B, seed=1000 + rank)
+    dev = DeviceBatch(solver, B)
+    dev.upload(theta)
+
+    def barrier():
+        solver.synchronize()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        solver.solve_device(dev)
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.solve_device(dev)
+        solver.synchronize()
+        kernel_ms.append(solver.last_kernel_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res = dev.download()
+    iters = res.iter
+    solved = int((res.status == 1).sum())
+    stats = {'mean_iter': float(iters.mean()), 'max_iter': int(iters.max()), 'solved': solved,
+             'not_solved': int(B - solved)}
+    if dist is not None:
+        # the only collective of the job: final gather of the per-instance info (RCCL over xGMI)
+        import torch
+        info = torch.from_numpy(np.stack([res.iter, res.status], axis=1).astype(np.int32)).cuda()
+        outs = [torch.empty_like(info) for _ in range(world)]
+        dist.all_gather(outs, info)
+        alli = torch.cat(outs).cpu().numpy()
+        stats = {'mean_iter': float(alli[:, 0].mean()), 'max_iter': int(alli[:, 0].max()),
+                 'solved': int((alli[:, 1] == 1).sum()), 'not_solved': int((alli[:, 1] != 1).sum())}
+
+    if rank == 0:
+        n_prim, n_dual = len(solver.plan.prim_idx), len(solver.plan.dual_idx)
+        bytes_per_inst = 8 * (solver.np_var + n_prim + n_dual) + 32
+        k_ms = float(np.mean(kernel_ms))
+        achieved = bytes_per_inst * B / (k_ms * 1e-3) / 1e9
+        value = world * B * args.steps / elapsed
+        out = {
+            'metric': 'QP instances solved/sec (batched MPC QP, OSQP)',
+            'value': value, 'unit': 'QP instances/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic (x_init = -2 + 4*U(0,1), default_rng(1000+rank); family parameters of '
+                    'examples/MPC.ipynb cell 3 extended to 12/4)',
+            'config': {'workload': label, 'instances_per_gpu': B, 'kkt_dim': desc.n_var + desc.m,
+                       'n_var': desc.n_var, 'n_constr': desc.m, 'varying_params': ['x_init'],
+                       'settings': 'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
+                                   'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start',
+                       'parallelism': f'shard{world}', **stats,
+                       'plan': {k: (round(v, 3) if isinstance(v, float) else v)
+                                for k, v in solver.plan.stats.items()}},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'osqp_shared_kernel', 'kernel_ms': k_ms,
+                         'algorithmic_bytes_per_instance': bytes_per_inst,
+                         'note': 'compulsory traffic only (theta in, solution out); the iteration '
+                                 'state never leaves registers/LDS, so this path is latency / LDS '
+                                 'bound, not HBM bound (DESIGN.md section 6)'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds)
+        if args.check:
+            from oracle import binding as ob
+            nchk = 256
+            p = desc.param('x_init')
+            th = np.tile(desc.theta0, (nchk, 1))
+            th[:, p.col:p.col + p.size] = theta[:nchk]
+            o = ob.cpg_solve_batch(desc, th, ['x_init'])
+            po = np.concatenate([o['sol_x'][:, v.indices] for v in desc.variables], axis=1)
+            do = np.concatenate([o['sol_y'][:, d.indices] for d in desc.duals], axis=1)
+            out['check'] = {
+                'n': nchk, 'iter_mismatch': int((o['iter'] != res.iter[:nchk]).sum()),
+                'prim_relerr': float(np.abs(po - res.prim_flat[:nchk]).max() / np.abs(po).max()),
+                'dual_relerr': float(np.abs(do - res.dual_flat[:nchk]).max() / np.abs(do).max())}
+        print(json.dumps(out), flush=True)
+    dev.free()
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

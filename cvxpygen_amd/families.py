@@ -236,4 +236,34 @@ def portfolio(n: int = 100, m: int = 10, seed: int = 0, name: str = 'portfolio')
     return cb.build(vals)
 
 
-FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio}
+def toy_box(name: str = 'toy_box') -> FamilyDescriptor:
+    """minimise (x - a)^2 s.t. lb <= x <= ub (test family: primal infeasible when lb > ub).
+    x = [x; t];  eq: x - t = a;  ineq: x <= ub, -x <= -lb."""
+    cb = CanonBuilder(name)
+    a = cb.param('a', ())
+    lb = cb.param('lb', ())
+    ub = cb.param('ub', ())
+    x = cb.var('x', (1,))
+    t = cb.aux(1)
+    cb.sum_squares(t)
+    cb.eq([(x[0], 1.0), (t[0], -1.0)], {a.up.col: 1.0})
+    r1 = cb.ineq([(x[0], 1.0)], {ub.up.col: 1.0})
+    r2 = cb.ineq([(x[0], -1.0)], {lb.up.col: -1.0})
+    cb.dual('d0', [r1], (1,))
+    cb.dual('d1', [r2], (1,))
+    return cb.build({'a': 0.3, 'lb': -1.0, 'ub': 1.0})
+
+
+def toy_lp(name: str = 'toy_lp') -> FamilyDescriptor:
+    """minimise c*x s.t. x >= 0 (test family: dual infeasible / unbounded when c < 0)."""
+    cb = CanonBuilder(name)
+    c = cb.param('c', ())
+    x = cb.var('x', (1,))
+    cb.lin(x[0], {c.up.col: 1.0})
+    r = cb.ineq([(x[0], -1.0)], 0.0)
+    cb.dual('d0', [r], (1,))
+    return cb.build({'c': 1.0})
+
+
+FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio, 'toy_box': toy_box,
+            'toy_lp': toy_lp}

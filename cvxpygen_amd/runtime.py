@@ -386,7 +386,8 @@ class BatchSolver:
     def solve(self, params: Optional[Dict[str, np.ndarray]] = None,
               updated_params: Optional[Sequence[str]] = None, B: Optional[int] = None,
               theta_var: Optional[np.ndarray] = None, **kwargs) -> BatchResult:
-        self.set_updated(updated_params)
+        if not (updated_params is None and theta_var is not None and self._update_key is not None):
+            self.set_updated(updated_params)      # None = every parameter, as in the reference
         self.apply_settings(**kwargs)
         if theta_var is None:
             theta_var = self.theta_var(params or {}, B)
@@ -432,3 +433,65 @@ class BatchSolver:
         obj = np.where(np.abs(obj) >= 1e30, np.sign(obj) * np.inf, obj)
         return BatchResult(prim=pd, dual=dd, obj_val=obj, iter=it, status=st, pri_res=pri,
                            dua_res=dua, solve_time=dt, kernel_ms=ms, prim_flat=prim, dual_flat=dual)
+
+
+class DeviceBatch:
+    """Device-resident buffers for `BatchSolver.solve_device`: theta_var in, results out, all in
+    HBM (cpg_hip_malloc), so that a timed solve contains no PCIe traffic."""
+
+    def __init__(self, solver: BatchSolver, B: int):
+        self.s, self.B = solver, int(B)
+        self.n_prim, self.n_dual = len(solver.plan.prim_idx), len(solver.plan.dual_idx)
+        self._ptrs = {}
+        sizes = dict(theta=B * max(solver.np_var, 1) * 8, prim=B * self.n_prim * 8,
+                     dual=B * self.n_dual * 8, obj=B * 8, pri=B * 8, dua=B * 8, iter=B * 4, status=B * 4)
+        for k, nbytes in sizes.items():
+            p = C.c_void_p()
+            solver.lib.check(solver.lib.L.cpg_hip_malloc(solver.h, nbytes, C.byref(p)), 'cpg_hip_malloc')
+            self._ptrs[k] = p
+
+    def upload(self, theta_var: np.ndarray) -> None:
+        tv = np.ascontiguousarray(theta_var, dtype=np.float64)
+        if tv.size:
+            self.s.lib.check(self.s.lib.L.cpg_hip_memcpy_h2d(self.s.h, self._ptrs['theta'],
+                                                             tv.ctypes.data_as(C.c_void_p), tv.nbytes), 'h2d')
+
+    def download(self) -> BatchResult:
+        s, B = self.s, self.B
+        out = dict(prim=np.empty((B, self.n_prim)), dual=np.empty((B, self.n_dual)), obj=np.empty(B),
+                   pri=np.empty(B), dua=np.empty(B), iter=np.empty(B, dtype=np.int32),
+                   status=np.empty(B, dtype=np.int32))
+        for k, a in out.items():
+            if a.nbytes:
+                s.lib.check(s.lib.L.cpg_hip_memcpy_d2h(s.h, a.ctypes.data_as(C.c_void_p), self._ptrs[k],
+                                                       a.nbytes), 'd2h')
+        return s._result(out['prim'], out['dual'], out['obj'], out['iter'], out['status'], out['pri'],
+                         out['dua'], 0.0, s.last_kernel_ms())
+
+    def free(self) -> None:
+        for p in self._ptrs.values():
+            self.s.lib.L.cpg_hip_free(self.s.h, p)
+        self._ptrs = {}
+
+
+def _solve_device(self, dev: DeviceBatch) -> None:
+    """Asynchronous launch on the solver's stream; pair with synchronize()."""
+    P = dev._ptrs
+    self.lib.check(self.lib.L.cpg_hip_solve_batch_device(
+        self.h, dev.B, P['theta'], P['prim'], P['dual'], P['obj'], P['iter'], P['status'], P['pri'],
+        P['dua']), 'cpg_hip_solve_batch_device')
+
+
+def _synchronize(self) -> None:
+    self.lib.check(self.lib.L.cpg_hip_synchronize(self.h), 'cpg_hip_synchronize')
+
+
+def _last_kernel_ms(self) -> float:
+    ms = C.c_float(0)
+    self.lib.check(self.lib.L.cpg_hip_last_kernel_ms(self.h, C.byref(ms)), 'cpg_hip_last_kernel_ms')
+    return float(ms.value)
+
+
+BatchSolver.solve_device = _solve_device
+BatchSolver.synchronize = _synchronize
+BatchSolver.last_kernel_ms = _last_kernel_ms

@@ -1,0 +1,140 @@
+"""Host logic (CPU): family descriptors, code-generation-time setup, solve-program compiler."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cvxpygen_amd import families, osqp_setup as S, solve_program as SP, ordering as O
+from cvxpygen_amd.canon_builder import canon_lu
+from cvxpygen_amd.descriptor import FamilyDescriptor
+from cvxpygen_amd.runtime import build_family_plan
+from cvxpygen_amd.sharding import shard_bounds
+from oracle.osqp_numpy import ruiz
+
+
+# canonical dimensions of SURVEY.md Appendix B
+@pytest.mark.parametrize('make,dims', [
+    (lambda: families.nonneg_ls(), dict(n_var=5, n_eq=3, n_ineq=2, NP=6, prim=2, dual=2)),
+    (lambda: families.nonneg_ls(10, 5, sparsity=None, seed=0), dict(n_var=15, n_eq=10, n_ineq=5, NP=60, prim=5, dual=5)),
+    (lambda: families.mpc(6, 3, 10), dict(n_var=222, n_eq=162, n_ineq=90, NP=141, prim=96, dual=96)),
+    (lambda: families.mpc(12, 4, 10), dict(n_var=384, n_eq=304, n_ineq=120, NP=508, prim=172, dual=172)),
+    (lambda: families.portfolio(100, 10), dict(n_var=620, n_eq=221, n_ineq=601, NP=1601, prim=210, dual=112)),
+])
+def test_family_dimensions(make, dims):
+    d = make()
+    assert (d.n_var, d.n_eq, d.n_ineq, d.NP, d.n_prim_user, d.n_dual_user) == \
+        (dims['n_var'], dims['n_eq'], dims['n_ineq'], dims['NP'], dims['prim'], dims['dual'])
+    c = d.default_canon()
+    assert np.allclose(c['A'], d.A.data) and np.allclose(c['P'], d.P.data)
+    # P never depends on parameters for these families
+    assert d.changes['P'] is False
+
+
+def test_descriptor_roundtrip_and_dependencies():
+    d = families.mpc(6, 3, 10)
+    dep = d.user_p_name_to_canon_outdated()
+    assert dep['x_init'] == ['l', 'u'] and dep['A'] == ['A'] and dep['Qsqrt'] == ['A']
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'fam.npz')
+        d.save(path)
+        e = FamilyDescriptor.load(path)
+    assert (e.A != d.A).nnz == 0 and np.array_equal(e.theta0, d.theta0)
+    assert [p.name for p in e.params] == [p.name for p in d.params]
+    assert all((e.maps[k] != d.maps[k]).nnz == 0 for k in d.maps)
+    with pytest.raises(AttributeError):
+        d.param('nope')
+
+
+def test_param_flattening_matches_reference_conventions():
+    d = families.mpc(6, 3, 10, sparse_params=True)
+    M = np.arange(36.0).reshape(6, 6)
+    assert np.array_equal(d.flatten_param('Qsqrt', M), np.diag(M))                 # diag=True
+    r, c = d.param('A').sparsity
+    assert np.array_equal(d.flatten_param('A', M), M[np.array(r), np.array(c)])    # sparsity attr
+    d2 = families.mpc(6, 3, 10)
+    assert np.array_equal(d2.flatten_param('A', M), M.flatten(order='F'))          # dense: F-order
+
+
+def test_ruiz_scaling_matches_independent_restatement():
+    d = families.mpc(6, 3, 10)
+    c = d.default_canon()
+    Px, q, Ax, sc = S.ruiz_scale(d.P, c['q'], d.A, 10)
+    Pf = (d.P + sp.triu(d.P, 1).T).toarray()
+    P2, q2, A2, D2, E2, c2 = ruiz(Pf, c['q'], d.A.toarray(), 10)
+    assert np.allclose(sc.D, D2, rtol=1e-13) and np.allclose(sc.E, E2, rtol=1e-13) and abs(sc.c - c2) < 1e-13 * c2
+    As = sp.csc_matrix((Ax, d.A.indices, d.A.indptr), shape=d.A.shape).toarray()
+    assert np.allclose(As, A2, rtol=1e-12, atol=1e-15)
+    # equilibrated: KKT column norms close to one another
+    K = np.block([[P2, A2.T], [A2, np.zeros((d.m, d.m))]])
+    norms = np.abs(K).max(axis=0)
+    assert norms.max() / norms[norms > 0].min() < 50
+
+
+@pytest.mark.parametrize('method', ['mindeg', 'nd'])
+def test_factorisation_solves_kkt(method):
+    d = families.mpc(6, 3, 10)
+    c = d.default_canon(); l, u = canon_lu(d, c)
+    plan = S.setup(d.P, c['q'], d.A, l, u, ordering=method)
+    assert sorted(plan.perm.tolist()) == list(range(plan.N))
+    Kf = (plan.K + sp.triu(plan.K, 1).T).toarray()
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(plan.N)
+    x = S.ldl_solve(plan, b)
+    assert np.abs(Kf @ x - b).max() < 1e-7
+    assert (plan.D[:] != 0).all()
+    # quasi-definite: n positive and m negative pivots
+    assert (plan.D > 0).sum() == d.n_var and (plan.D < 0).sum() == d.m
+
+
+@pytest.mark.parametrize('fam', ['nnls', 'mpc6'])
+@pytest.mark.parametrize('merge', [False, True])
+def test_solve_program_equals_substitution(fam, merge):
+    d = families.nonneg_ls() if fam == 'nnls' else families.mpc(6, 3, 10)
+    c = d.default_canon(); l, u = canon_lu(d, c)
+    plan = S.setup(d.P, c['q'], d.A, l, u, ordering='mindeg')
+    N = plan.N
+    phases = SP.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=merge)
+    prog = SP.pack(phases, N=N)
+    assert prog.n_slots >= N and prog.cols.max() < prog.n_slots
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        b = rng.standard_normal(N)
+        w = np.zeros(prog.n_slots); w[:N] = b
+        SP.execute_packed(prog, w)
+        ref = S.ldl_solve(plan, b)
+        assert np.abs(w[prog.final_pos] - ref).max() <= 1e-11 * np.abs(ref).max()
+    if merge and fam == 'mpc6':
+        unmerged = SP.pack(SP.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=False), N=N)
+        assert prog.n_phases * 8 < unmerged.n_phases      # the point of the transformation
+
+
+def test_family_plan_device_ordering():
+    d = families.mpc(6, 3, 10)
+    p = build_family_plan(d)
+    # the 6 rows X[:,0] == x_init are the only parameter-dependent bounds: they come first
+    assert p.n_vary_z == 6 and p.n_vary_x == 0
+    init_rows = d.duals[2].indices
+    assert sorted(p.ordz[:6].tolist()) == sorted(init_rows.tolist())
+    assert sorted(p.ordx.tolist()) == list(range(d.n_var)) and sorted(p.ordz.tolist()) == list(range(d.m))
+    # natural programs reproduce the scaled products in device order
+    o = p.osqp
+    As = sp.csc_matrix((o.Ax, d.A.indices, d.A.indptr), shape=d.A.shape)
+    rng = np.random.default_rng(2)
+    xv = rng.standard_normal(d.n_var); yv = rng.standard_normal(d.m)
+    w = np.concatenate([xv[p.ordx], yv[p.ordz]])
+    ax = np.concatenate(SP.execute_packed(p.A_rows, w, natural=True))[:d.m]
+    aty = np.concatenate(SP.execute_packed(p.At_rows, w, natural=True))[:d.n_var]
+    assert np.allclose(ax, (As @ xv)[p.ordz], atol=1e-12)
+    assert np.allclose(aty, (As.T @ yv)[p.ordx], atol=1e-12)
+
+
+def test_shard_bounds_cover_batch():
+    for B in (0, 1, 7, 100000, 1000003):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(B, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == B
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

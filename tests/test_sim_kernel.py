@@ -1,0 +1,108 @@
+"""CPU tier for the kernel logic: the product's kernel sources compiled for the lock-step emulator
+(tests/sim/build_sim.py) and driven through the real C-ABI + Python runtime, compared with the C
+oracle.  Small batches only (64 host threads per emulated wavefront)."""
+import numpy as np
+import pytest
+
+from cvxpygen_amd import families
+from cvxpygen_amd.runtime import BatchSolver
+
+
+def _oracle_flat(oracle_lib, desc, theta, upd, **stg):
+    o = oracle_lib.cpg_solve_batch(desc, theta, upd, **stg)
+    prim = np.concatenate([o['sol_x'][:, v.indices] for v in desc.variables], axis=1)
+    dual = np.concatenate([o['sol_y'][:, d.indices] for d in desc.duals], axis=1)
+    return o, prim, dual
+
+
+def _theta(desc, name, values):
+    B = values.shape[0]
+    th = np.tile(desc.theta0, (B, 1))
+    p = desc.param(name)
+    th[:, p.col:p.col + p.size] = values
+    return th
+
+
+def _assert_parity(r, o, prim, dual, tol=1e-9):
+    assert r.iter.tolist() == o['iter'].tolist()
+    assert r.status.tolist() == o['status'].tolist()
+    ok = np.isin(o['status'], (1, 2, 7))
+    if ok.any():
+        assert np.abs(r.prim_flat[ok] - prim[ok]).max() <= tol * max(1.0, np.abs(prim[ok]).max())
+        assert np.abs(r.dual_flat[ok] - dual[ok]).max() <= tol * max(1.0, np.abs(dual[ok]).max())
+        assert np.abs(r.obj_val[ok] - o['obj_val'][ok]).max() <= tol * max(1.0, np.abs(o['obj_val'][ok]).max())
+        assert np.allclose(r.pri_res[ok], o['pri_res'][ok], rtol=1e-6, atol=1e-12)
+        assert np.allclose(r.dua_res[ok], o['dua_res'][ok], rtol=1e-6, atol=1e-12)
+    if (~ok).any():
+        assert np.isnan(r.prim_flat[~ok]).all()
+
+
+@pytest.mark.parametrize('G', [1, 2])
+def test_nonneg_ls_parity(sim_lib, oracle_lib, G):
+    d = families.nonneg_ls()
+    rng = np.random.default_rng(0)
+    B = 5                                  # odd: exercises the padded lane group for G = 2
+    bvals = rng.standard_normal((B, 3))
+    bs = BatchSolver(d, lib_path=sim_lib)
+    bs.set_launch(waves_per_block=2, inst_per_wave=G)
+    for stg in ({}, dict(eps_abs=1e-7, eps_rel=1e-7), dict(max_iter=60), dict(check_termination=10)):
+        r = bs.solve({'b': bvals}, updated_params=['b'], **stg)
+        o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, 'b', bvals), ['b'], **stg)
+        _assert_parity(r, o, prim, dual)
+    assert r.prim['x'].shape == (B, 2) and r.dual['d0'].shape == (B, 2)
+    bs.close()
+
+
+def test_mpc_parity_and_shapes(sim_lib, oracle_lib):
+    d = families.mpc(6, 3, 10)
+    rng = np.random.default_rng(1)
+    x0 = -2 + 4 * rng.random((2, 6))
+    bs = BatchSolver(d, lib_path=sim_lib)
+    bs.set_launch(waves_per_block=2, inst_per_wave=1)
+    r = bs.solve({'x_init': x0}, updated_params=['x_init'])
+    o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, 'x_init', x0), ['x_init'])
+    _assert_parity(r, o, prim, dual)
+    # user-facing arrays are F-order reshapes of the flat vectors (templates/cpg_solver.py.jinja2:78)
+    assert r.prim['U'].shape == (2, 3, 10) and r.prim['X'].shape == (2, 6, 11)
+    Xo = o['sol_x'][0, d.variables[1].indices].reshape(6, 11, order='F')
+    assert np.allclose(r.prim['X'][0], Xo, atol=1e-9)
+    assert np.allclose(r.prim['X'][:, :, 0], x0, atol=1e-3)       # X[:,0] == x_init up to ADMM accuracy
+    bs.close()
+
+
+def test_infeasible_instances_in_a_batch(sim_lib, oracle_lib):
+    d = families.toy_box()
+    B = 4
+    th = np.tile(d.theta0, (B, 1))
+    th[1, d.param('lb').col], th[1, d.param('ub').col] = 2.0, 1.0      # infeasible
+    th[3, d.param('a').col] = 5.0                                      # active upper bound
+    bs = BatchSolver(d, lib_path=sim_lib)
+    bs.set_launch(waves_per_block=1, inst_per_wave=1)
+    vals = {p.name: th[:, p.col:p.col + p.size] for p in d.params}
+    r = bs.solve(vals)
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
+    _assert_parity(r, o, prim, dual)
+    assert r.status[1] == 3 and r.obj_val[1] == np.inf
+    assert abs(r.prim['x'][3, 0] - 1.0) < 1e-2
+    d2 = families.toy_lp()
+    th2 = np.tile(d2.theta0, (2, 1)); th2[1, 0] = -1.0
+    bs2 = BatchSolver(d2, lib_path=sim_lib)
+    bs2.set_launch(waves_per_block=1, inst_per_wave=1)
+    r2 = bs2.solve({'c': th2[:, :1]})
+    o2, prim2, dual2 = _oracle_flat(oracle_lib, d2, th2, None)
+    _assert_parity(r2, o2, prim2, dual2)
+    assert r2.status[1] == 5 and r2.obj_val[1] == -np.inf
+    bs.close(); bs2.close()
+
+
+def test_settings_and_errors(sim_lib):
+    d = families.nonneg_ls()
+    bs = BatchSolver(d, lib_path=sim_lib)
+    with pytest.raises(AttributeError, match='not available'):
+        bs.solve({'b': np.zeros((1, 3))}, updated_params=['b'], polish=True)       # disabled setting
+    with pytest.raises(AttributeError, match='is not a parameter'):
+        bs.solve({'b': np.zeros((1, 3))}, updated_params=['nope'])
+    with pytest.raises(NotImplementedError):
+        bs.set_updated(['A'])                 # matrix parameters need the refactor path
+    bs.solve({'b': np.ones((1, 3))}, updated_params=['b'], warm_start=False)     # cvxpy alias accepted
+    bs.close()
