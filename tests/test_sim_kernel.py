@@ -31,8 +31,8 @@ def _assert_parity(r, o, prim, dual, tol=1e-9):
         assert np.abs(r.prim_flat[ok] - prim[ok]).max() <= tol * max(1.0, np.abs(prim[ok]).max())
         assert np.abs(r.dual_flat[ok] - dual[ok]).max() <= tol * max(1.0, np.abs(dual[ok]).max())
         assert np.abs(r.obj_val[ok] - o['obj_val'][ok]).max() <= tol * max(1.0, np.abs(o['obj_val'][ok]).max())
-        assert np.allclose(r.pri_res[ok], o['pri_res'][ok], rtol=1e-6, atol=1e-12)
-        assert np.allclose(r.dua_res[ok], o['dua_res'][ok], rtol=1e-6, atol=1e-12)
+        assert np.allclose(r.pri_res[ok], o['pri_res'][ok], rtol=1e-6, atol=1e-9)
+        assert np.allclose(r.dua_res[ok], o['dua_res'][ok], rtol=1e-6, atol=1e-9)
     if (~ok).any():
         assert np.isnan(r.prim_flat[~ok]).all()
 
