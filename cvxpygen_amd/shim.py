@@ -1,0 +1,104 @@
+"""
+Runtime behind the generated `cpg_solver.py`: the reference's Python shim
+(`cvxpygen/templates/cpg_solver.py.jinja2`) re-implemented on top of the batched HIP backend.
+
+  cpg_solve(prob, updated_params=None, **kwargs) -> float     same name / signature / side effects
+  cpg_solve_batch(params, updated_params=None, **kwargs)      batched sibling
+"""
+
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .descriptor import FamilyDescriptor
+from .lite import make_solution, make_solver_stats
+from .runtime import STATUS_STRINGS, BatchResult, BatchSolver
+
+
+def squeeze_scalar(val):
+    if isinstance(val, np.ndarray):
+        val = val.squeeze()
+        if val.shape == ():
+            return val.item()
+    return val
+
+
+def get_param_value(param):
+    """`get_param_value` of the reference shim (templates/cpg_solver.py.jinja2:26-34)."""
+    if param.size == 1:
+        return squeeze_scalar(np.asarray(param.value))
+    elif param.attributes["diag"]:
+        v = np.asarray(param.value.toarray() if hasattr(param.value, 'toarray') else param.value)
+        return list(np.diag(v))
+    elif getattr(param, '_has_dim_reducing_attr', False):
+        return list(param.value_sparse.data)
+    else:
+        return list(np.asarray(param.value).flatten(order="F"))
+
+
+class GeneratedSolver:
+    """One generated solver (= one code_dir).  Device resources are created on first use."""
+
+    def __init__(self, code_dir: str, device: int = 0, lib_path: Optional[str] = None):
+        self.code_dir = code_dir
+        self.desc = FamilyDescriptor.load(os.path.join(code_dir, 'descriptor.npz'))
+        self.device = device
+        self.lib_path = lib_path
+        self._bs: Optional[BatchSolver] = None
+
+    @property
+    def batch_solver(self) -> BatchSolver:
+        if self._bs is None:
+            self._bs = BatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
+        return self._bs
+
+    # ---- batched entry point --------------------------------------------------------------------
+    def cpg_solve_batch(self, params: Dict[str, np.ndarray],
+                        updated_params: Optional[Sequence[str]] = None, **kwargs) -> BatchResult:
+        if updated_params is None:
+            updated_params = [p for p in self.desc.param_names if p in params] or None
+        return self.batch_solver.solve(params, updated_params=updated_params, **kwargs)
+
+    # ---- the reference's single-instance entry point -------------------------------------------------
+    def cpg_solve(self, prob, updated_params=None, **kwargs):
+        desc = self.desc
+        if updated_params is None:
+            updated_params = list(desc.param_names)
+        for p in updated_params:
+            if p not in desc.param_names:
+                raise AttributeError(f"{p} is not a parameter.")
+        param_dict = prob.param_dict
+        vals = {}
+        for name in updated_params:
+            v = get_param_value(param_dict[name])
+            vals[name] = np.asarray(v, dtype=np.float64).reshape(1, -1)
+        t0 = time.time()
+        res = self.batch_solver.solve(vals, updated_params=updated_params, **kwargs)
+        t1 = time.time()
+
+        prob._clear_solution()
+        for v in desc.variables:
+            prob.var_dict[v.name].save_value(np.array(res.prim[v.name][0]).reshape(v.shape, order='A'))
+        for i, d in enumerate(desc.duals):
+            dv = res.dual[d.name][0]
+            prob.constraints[i].save_dual_value(np.array(dv).reshape(d.shape) if d.shape else float(dv))
+        status = STATUS_STRINGS.get(int(res.status[0]), 'unknown')
+        prob._status = status
+        obj = float(res.obj_val[0])
+        prob._value = obj                           # +-1e30 already mapped to +-inf by the runtime
+        primal_vars = {var.id: var.value for var in prob.variables()}
+        dual_vars = {c.id: c.dual_value for c in prob.constraints}
+        solver_specific_stats = {'obj_val': obj, 'status': status, 'iter': int(res.iter[0]),
+                                 'pri_res': float(res.pri_res[0]), 'dua_res': float(res.dua_res[0]),
+                                 'time': res.kernel_ms * 1e-3}
+        attr = {'solve_time': t1 - t0, 'solver_specific_stats': solver_specific_stats,
+                'num_iters': int(res.iter[0])}
+        prob._solution = make_solution(prob.status, prob.value, primal_vars, dual_vars, attr)
+        prob._solver_stats = make_solver_stats({'solver_specific_stats': solver_specific_stats,
+                                                'num_iters': int(res.iter[0]),
+                                                'solve_time': t1 - t0}, desc.solver)
+        return prob.value
