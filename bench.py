@@ -86,6 +86,7 @@ def main():
     ap.add_argument('--waves', type=int, default=0)
     ap.add_argument('--ipw', type=int, default=0, help='instances per wave')
     ap.add_argument('--blocks-per-cu', type=int, default=0)
+    ap.add_argument('--placement', type=int, default=-1, help='solve program: -1 auto, 0 L2/HBM stream, 1 LDS resident')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--check', action='store_true', help='compare a sample with the oracle')
@@ -104,6 +105,7 @@ def main():
     desc, label = make_workload(args.workload)
     solver = BatchSolver(desc, device=local_rank, lib_path=args.lib)
     solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)
+    solver.set_program_placement(args.placement)
     solver.set_updated(['x_init'])
     solver.apply_settings()                      # reference defaults
     B = args.batch

@@ -58,7 +58,8 @@ struct cpg_solver_s {
     bool have_update = false;
     cpg::DevSettings S{};
     int warm_starting = 1;              // accepted for API parity; a batch is always cold-started
-    int waves_per_block = 4, inst_per_wave = 1, blocks_per_cu = 0;
+    int waves_per_block = 0, inst_per_wave = 1, blocks_per_cu = 0;
+    int program_in_lds = -1;            // -1 auto, 0 stream from L2/HBM, 1 resident in LDS
     int num_cu = 256;
     size_t lds_limit = 160 * 1024;
     unsigned *d_counter = nullptr;
@@ -159,16 +160,19 @@ static int upload_csr(cpg_handle_t h, std::vector<void *> &own, const cpg_csr_t 
 #endif
 
 #ifndef CPG_HOST_SIM
-template <int NSX, int NSZ, int NV, int G>
-__global__ void __launch_bounds__(256, CPG_MIN_WAVES_PER_SIMD)
+// WMAX = waves per workgroup the kernel may be launched with; it fixes the register budget:
+// streaming kernels run several 4-wave workgroups per CU (CPG_MIN_WAVES_PER_SIMD), LDS-resident
+// kernels run ONE workgroup of up to WMAX waves per CU (WMAX / 4 waves per SIMD).
+template <int NSX, int NSZ, int NV, int G, bool LDSPROG, int WMAX>
+__global__ void __launch_bounds__(WMAX * 64, LDSPROG ? (WMAX + 3) / 4 : CPG_MIN_WAVES_PER_SIMD)
 osqp_shared_kernel(cpg::DevFamily F, cpg::DevUpdate U, cpg::DevSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    cpg::osqp_shared_body<NSX, NSZ, NV, G>(F, U, S, Bt, cpg_lds, wave_global);
+    cpg::osqp_shared_body<NSX, NSZ, NV, G, LDSPROG>(F, U, S, Bt, cpg_lds, wave_global);
 }
-template <int NSX, int NSZ, int NV, int G>
+template <int NSX, int NSZ, int NV, int G, bool LDSPROG, int WMAX>
 static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    auto kern = osqp_shared_kernel<NSX, NSZ, NV, G>;
+    auto kern = osqp_shared_kernel<NSX, NSZ, NV, G, LDSPROG, WMAX>;
     if (lds > 48 * 1024)
         RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->F, h->U, h->S, Bt);
@@ -177,7 +181,7 @@ static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int wav
 }
 #else
 // emulator: every block runs as waves*64 host threads; blocks run one after the other
-template <int NSX, int NSZ, int NV, int G>
+template <int NSX, int NSZ, int NV, int G, bool LDSPROG, int WMAX>
 static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
     for (int b = 0; b < blocks; b++) {
         std::vector<char> ldsbuf(lds + 64);
@@ -191,8 +195,8 @@ static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int wav
                 cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
                 cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
                 cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
-                cpg::osqp_shared_body<NSX, NSZ, NV, G>(h->F, h->U, h->S, Bt, (double *)ldsbuf.data(),
-                                                       b * waves + (t >> 6));
+                cpg::osqp_shared_body<NSX, NSZ, NV, G, LDSPROG>(h->F, h->U, h->S, Bt, (double *)ldsbuf.data(),
+                                                                b * waves + (t >> 6));
             });
         for (auto &t : th) t.join();
         for (auto &w : wv) pthread_barrier_destroy(&w.bar);
@@ -202,25 +206,41 @@ static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int wav
 }
 #endif
 
-// Instantiated kernels: (NSX, NSZ) slot class (NSX = ceil(n/64), NSZ = ceil(m/64)), NV = leading
-// slots with per-instance q / l / u (1: at most 64 parameter-dependent entries; NS: all), G.
+// Instantiated kernels.  (NSX, NSZ): slot class (ceil(n/64), ceil(m/64)); NV: leading slots with
+// per-instance q / u (1: at most 64 parameter-dependent entries; NS: all); G instances per wave.
 // The smallest class that covers the family is used.
+//   streaming kernels  X(NSX, NSZ, NV, G)       4 waves per workgroup, several workgroups per CU
+//   LDS-resident       Y(NSX, NSZ, NV, G, WMAX) one workgroup of <= WMAX waves per CU
 #ifndef CPG_KERNELS
 #define CPG_KERNELS(X)                                                                              \
     X(1, 1, 1, 1) X(1, 1, 1, 2) X(4, 4, 1, 1) X(4, 4, 1, 2) X(4, 4, 4, 1) X(8, 8, 1, 1) X(8, 8, 1, 2)   \
     X(8, 8, 8, 1) X(16, 16, 16, 1)
 #endif
+#ifndef CPG_KERNELS_LDS
+#define CPG_KERNELS_LDS(Y)                                                                          \
+    Y(1, 1, 1, 1, 8) Y(1, 1, 1, 1, 16) Y(1, 1, 1, 2, 8) Y(4, 4, 1, 1, 8) Y(4, 4, 1, 1, 16) Y(4, 4, 1, 2, 8)    \
+    Y(4, 4, 4, 1, 8) Y(8, 8, 1, 1, 8) Y(8, 8, 1, 1, 12) Y(8, 8, 1, 2, 4) Y(8, 8, 1, 2, 8) Y(8, 8, 8, 1, 8) \
+    Y(16, 16, 16, 1, 8)
+#endif
 
-static int launch(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, int G, size_t lds) {
+static int launch(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, int G, size_t lds, bool in_lds) {
     const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
     const int nvx = (h->n_vary_x + 63) / 64, nvz = (h->n_vary_z + 63) / 64;
     const int nv = nvx > nvz ? nvx : nvz;
+    if (!in_lds) {
 #define X(a, b, v, g)                                                                             \
-    if (nsx <= a && nsz <= b && (nv <= v || (v >= a && v >= b)) && G == g)                        \
-        return launch_t<a, b, v, g>(h, Bt, blocks, waves, lds);
-    CPG_KERNELS(X)
+        if (nsx <= a && nsz <= b && (nv <= v || (v >= a && v >= b)) && G == g && waves <= 4)      \
+            return launch_t<a, b, v, g, false, 4>(h, Bt, blocks, waves, lds);
+        CPG_KERNELS(X)
 #undef X
-    set_error("no compiled kernel for this family size / instances-per-wave combination");
+    } else {
+#define Y(a, b, v, g, wm)                                                                         \
+        if (nsx <= a && nsz <= b && (nv <= v || (v >= a && v >= b)) && G == g && waves <= wm)     \
+            return launch_t<a, b, v, g, true, wm>(h, Bt, blocks, waves, lds);
+        CPG_KERNELS_LDS(Y)
+#undef Y
+    }
+    set_error("no compiled kernel for this family size / launch geometry");
     return CPG_E_UNSUPPORTED;
 }
 
@@ -332,6 +352,13 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     TRY(upload_program(h, f->A_rows, &F.A_rows));
     TRY(upload_program(h, f->P_rows, &F.P_rows));
     TRY(upload_program(h, f->At_rows, &F.At_rows));
+    F.kkt_ragged.n_chunks = f->kkt_ragged.n_chunks; F.kkt_ragged.nnz = f->kkt_ragged.nnz;
+    if (f->kkt_ragged.n_chunks > 0) {
+        TRY(upload<int>(h, h->owned, f->kkt_ragged.ctab, (size_t)f->kkt_ragged.n_chunks * 4, &F.kkt_ragged.ctab));
+        TRY(upload<unsigned>(h, h->owned, f->kkt_ragged.desc, (size_t)f->kkt_ragged.n_chunks * 64, &F.kkt_ragged.desc));
+        TRY(upload<double>(h, h->owned, f->kkt_ragged.vals, (size_t)f->kkt_ragged.nnz, &F.kkt_ragged.vals));
+        TRY(upload<unsigned short>(h, h->owned, f->kkt_ragged.cols, (size_t)f->kkt_ragged.nnz, &F.kkt_ragged.cols));
+    }
     F.n_slots = f->n_slots;
     if (f->n_slots < f->n + f->m || f->n_slots >= 0xFFFF) { set_error("bad n_slots"); cpg_hip_destroy(h); return CPG_E_BADARG; }
     TRY(upload<unsigned short>(h, h->owned, f->fpos, (size_t)f->n + f->m, &F.fpos));
@@ -398,7 +425,7 @@ int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, i
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
     if (waves_per_block < 0 || waves_per_block > 16 || (inst_per_wave != 0 && inst_per_wave != 1 && inst_per_wave != 2)) {
         set_error("waves_per_block in 0..16, inst_per_wave in {0,1,2}"); return CPG_E_BADARG; }
-    h->waves_per_block = waves_per_block ? waves_per_block : 4;
+    h->waves_per_block = waves_per_block;
     h->inst_per_wave = inst_per_wave ? inst_per_wave : 1;
     h->blocks_per_cu = blocks_per_cu;
     return CPG_OK;
@@ -414,6 +441,12 @@ static int ensure(DevBuf &b, size_t bytes) {
     return CPG_OK;
 }
 
+int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds) {
+    if (!h || in_lds < -1 || in_lds > 1) { set_error("in_lds must be -1, 0 or 1"); return CPG_E_BADARG; }
+    h->program_in_lds = in_lds;
+    return CPG_OK;
+}
+
 int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta, double *d_prim, double *d_dual,
                                double *d_obj, int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
@@ -423,12 +456,35 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     if (B == 0) return CPG_OK;
     int rc = rt_set_device(h->device);
     if (rc) return rc;
-    const int G = h->inst_per_wave, W = h->waves_per_block;
-    const size_t lds = ((size_t)(h->F.n + h->F.m) + (size_t)W * G * h->F.n_slots) * sizeof(double);
+    const int G = h->inst_per_wave;
+    const size_t N = (size_t)(h->F.n + h->F.m);
+    const size_t per_wave = (size_t)G * h->F.n_slots * sizeof(double);
+    // LDS-resident program: one workgroup per CU, as many waves as fit next to the program
+    const cpg::DevRagged &R = h->F.kkt_ragged;
+    const size_t prog_bytes = R.n_chunks > 0 ? ((size_t)R.nnz + (size_t)((R.nnz + 3) / 4) + (size_t)R.n_chunks * 34) * 8 : 0;
+    bool in_lds = false;
+    int W = h->waves_per_block;
+    if (h->program_in_lds != 0 && R.n_chunks > 0) {
+        const size_t fixed = N * 8 + prog_bytes;
+        int wfit = fixed < h->lds_limit ? (int)((h->lds_limit - fixed) / per_wave) : 0;
+        // every slot class has an LDS kernel for <= 8 waves (<= 4 for G = 2 on the larger classes);
+        // more waves only on explicit request (cpg_hip_set_launch) where such a kernel exists
+        const int wcap = h->waves_per_block > 0 ? 16 : (G == 2 ? 4 : 8);
+        if (wfit > wcap) wfit = wcap;
+        if (wfit >= 4 || (h->program_in_lds == 1 && wfit >= 1)) {
+            in_lds = true;
+            if (W <= 0 || W > wfit) W = wfit;
+        } else if (h->program_in_lds == 1) {
+            set_error("solve program does not fit into LDS next to the work vectors"); return CPG_E_UNSUPPORTED;
+        }
+    }
+    if (!in_lds && (W <= 0 || W > 4)) W = 4;
+    const size_t lds = N * 8 + (in_lds ? prog_bytes : 0) + (size_t)W * per_wave;
     if (lds > h->lds_limit) { set_error("work vectors do not fit the 160 KiB LDS; lower waves_per_block / inst_per_wave"); return CPG_E_UNSUPPORTED; }
     const long long ngroups = (B + G - 1) / G;
     int per_cu = h->blocks_per_cu;
-    if (per_cu <= 0) {   // as many blocks as LDS and the register budget (CPG_MIN_WAVES_PER_SIMD) admit
+    if (in_lds) per_cu = 1;
+    else if (per_cu <= 0) {   // as many blocks as LDS and the register budget (CPG_MIN_WAVES_PER_SIMD) admit
         per_cu = (int)(h->lds_limit / (lds ? lds : 1));
         const int by_regs = (CPG_MIN_WAVES_PER_SIMD * 4) / W;
         if (per_cu > by_regs) per_cu = by_regs;
@@ -448,7 +504,7 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
 #else
     *h->d_counter = 0;
 #endif
-    rc = launch(h, Bt, (int)blocks, W, G, lds);
+    rc = launch(h, Bt, (int)blocks, W, G, lds, in_lds);
     if (rc) return rc;
 #ifndef CPG_HOST_SIM
     RT_CHECK(hipEventRecord(h->ev1, h->stream));

@@ -31,6 +31,9 @@ namespace cpg {
 #define CPG_ILP 2   // unrolled slot iterations the scheduler may interleave in the hot loops
 #endif
 #define CPG_FENCE_EVERY(s) do { if (((s) + 1) % CPG_ILP == 0) cpgw::sched_fence(); } while (0)
+#ifndef CPG_LDS_UNROLL
+#define CPG_LDS_UNROLL 4
+#endif
 #ifndef CPG_CHUNK_UNROLL
 #define CPG_CHUNK_UNROLL 4
 #endif
@@ -41,6 +44,14 @@ struct DevProgram {
     const double *vals;
     const unsigned short *cols;
     int n_chunks;
+};
+// compact program (solve_program.RaggedProgram); staged into LDS once per block
+struct DevRagged {
+    const int *ctab;            // [n_chunks][4]: max len, log2 g, first entry, 0
+    const unsigned *desc;       // [n_chunks][64]: out slot | len << 16
+    const double *vals;         // [nnz]
+    const unsigned short *cols; // [nnz]
+    int n_chunks, nnz;
 };
 struct DevCsr {
     const int *ptr;
@@ -56,6 +67,7 @@ struct DevFamily {
     const signed char *ctype;
     const unsigned short *fpos;   // [n + m] LDS slot holding entry i after the KKT program
     DevProgram kkt, A_rows, P_rows, At_rows;
+    DevRagged kkt_ragged;
     int n_prim, n_dual;
     const int *prim_idx, *dual_idx;
 };
@@ -120,6 +132,89 @@ CPG_DEV void run_program(const DevProgram &P, double *w, int ldw, int lane) {
         double r[G];
         do_chunk<G, true>(P, c, w, ldw, lane, r);
         const unsigned row = cpgw::gld(P.rows, (unsigned)c * 64u + (unsigned)lane);
+        cpgw::lds_order();
+        if (row != CPG_NO_ROW) {
+#pragma unroll
+            for (int g = 0; g < G; g++) w[(unsigned)(g * ldw) + row] = r[g];
+        }
+        cpgw::lds_order();
+    }
+}
+
+// Same, with the program resident in LDS in its compact form (solve_program.RaggedProgram): lanes
+// of a chunk are ordered by non-increasing entry count, so at step s the lanes that still have an
+// entry are a prefix and lane t's entry sits at  first + (entries of earlier steps) + t.
+struct LdsProg {
+    const int *ctab;
+    const unsigned *desc;
+    const double *vals;
+    const unsigned short *cols;   // BYTE offsets into the work vector
+    int n_chunks;
+    unsigned dummy;               // index of the trailing zero entry
+};
+template <int G>
+CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
+    const char *wb = (const char *)w;
+    const unsigned ldwb = (unsigned)ldw * 8u;
+    // descriptors of chunk c + 1 are fetched while chunk c runs
+    int t0 = P.ctab[0], t1 = P.ctab[1], t2 = P.ctab[2];
+    unsigned dn = P.desc[(unsigned)lane];
+#pragma nounroll
+    for (int c = 0; c < P.n_chunks; c++) {
+        const int L = cpgw::read_first_lane(t0);
+        const int lg = cpgw::read_first_lane(t1);
+        unsigned base = (unsigned)cpgw::read_first_lane(t2);
+        const unsigned d = dn;
+        if (c + 1 < P.n_chunks) {
+            t0 = P.ctab[4 * c + 4]; t1 = P.ctab[4 * c + 5]; t2 = P.ctab[4 * c + 6];
+            dn = P.desc[(unsigned)(c + 1) * 64u + (unsigned)lane];
+        }
+        const unsigned row = d & 0xFFFFu;
+        const int len = (int)(d >> 16);
+        double acc[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = 0.0;
+        // lanes without an entry at step s read the trailing dummy entry (0 * w[0]) instead of being
+        // masked off: no exec-mask traffic, and the loads of CPG_LDS_UNROLL steps are issued
+        // back to back before the first multiply-add needs them
+        int s = 0;
+#pragma nounroll
+        for (; s + CPG_LDS_UNROLL <= L; s += CPG_LDS_UNROLL) {
+            unsigned e[CPG_LDS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CPG_LDS_UNROLL; u++) {
+                const bool act = s + u < len;
+                e[u] = act ? base + (unsigned)lane : P.dummy;
+                base += cpgw::popc64(cpgw::ballot(act));
+            }
+            double v[CPG_LDS_UNROLL];
+            unsigned co[CPG_LDS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CPG_LDS_UNROLL; u++) { v[u] = P.vals[e[u]]; co[u] = P.cols[e[u]]; }
+            double x[CPG_LDS_UNROLL][G];
+#pragma unroll
+            for (int u = 0; u < CPG_LDS_UNROLL; u++)
+#pragma unroll
+                for (int g = 0; g < G; g++) x[u][g] = *(const double *)(wb + (unsigned)g * ldwb + co[u]);
+#pragma unroll
+            for (int u = 0; u < CPG_LDS_UNROLL; u++)
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = fma(v[u], x[u][g], acc[g]);
+        }
+#pragma nounroll
+        for (; s < L; s++) {
+            const bool act = s < len;
+            const unsigned e = act ? base + (unsigned)lane : P.dummy;
+            base += cpgw::popc64(cpgw::ballot(act));
+            const double v = P.vals[e];
+            const unsigned co = P.cols[e];
+#pragma unroll
+            for (int g = 0; g < G; g++)
+                acc[g] = fma(v, *(const double *)(wb + (unsigned)g * ldwb + co), acc[g]);
+        }
+        double r[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) r[g] = cpgw::group_sum_first_dyn(acc[g], lg);
         cpgw::lds_order();
         if (row != CPG_NO_ROW) {
 #pragma unroll
@@ -385,7 +480,7 @@ CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, Inst<NSX, NSZ, NV>
 }
 
 // ------------------------------------------------------------------------------------ the kernel body
-template <int NSX, int NSZ, int NV, int G>
+template <int NSX, int NSZ, int NV, int G, bool LDSPROG>
 CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevSettings &S,
                               const DevBatch &Bt, double *lds, int wave_global) {
     typedef Inst<NSX, NSZ, NV> InstT;
@@ -396,8 +491,24 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
     double *sh = lds;
     for (unsigned t = cpgw::thread_in_block(); t < (unsigned)N; t += cpgw::block_threads())
         sh[t] = t < (unsigned)F.n ? cpgw::gld(U.q_base, t) : cpgw::gld(U.u_base, t - (unsigned)F.n);
+    // LDS-resident program: [vals | cols | desc | ctab] right after the base vectors
+    LdsProg LP;
+    size_t lds_off = (size_t)N;
+    if (LDSPROG) {
+        const DevRagged &R = F.kkt_ragged;
+        double *lv = lds + lds_off;                         lds_off += (size_t)R.nnz;
+        unsigned short *lc = (unsigned short *)(lds + lds_off); lds_off += (size_t)((R.nnz + 3) / 4);
+        unsigned *ld = (unsigned *)(lds + lds_off);         lds_off += (size_t)R.n_chunks * 32;
+        int *lt = (int *)(lds + lds_off);                   lds_off += (size_t)R.n_chunks * 2;
+        const unsigned nt = cpgw::block_threads(), t0 = cpgw::thread_in_block();
+        for (unsigned t = t0; t < (unsigned)R.nnz; t += nt) { lv[t] = cpgw::gld(R.vals, t); lc[t] = cpgw::gld(R.cols, t); }
+        for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) ld[t] = cpgw::gld(R.desc, t);
+        for (unsigned t = t0; t < (unsigned)R.n_chunks * 4u; t += nt) lt[t] = cpgw::gld(R.ctab, t);
+        LP.ctab = lt; LP.desc = ld; LP.vals = lv; LP.cols = lc; LP.n_chunks = R.n_chunks;
+        LP.dummy = (unsigned)R.nnz - 1u;
+    }
     cpgw::block_sync();
-    double *w = lds + (size_t)N + (size_t)cpgw::wave_in_block() * G * ldw;
+    double *w = lds + lds_off + (size_t)cpgw::wave_in_block() * G * ldw;
     double *scr = Bt.scratch + (size_t)wave_global * G * N;
     const long long ngroups = (Bt.B + G - 1) / G;
     const double rho_eq = 1e3 * F.rho, rho_in = F.rho, rho_fr = 1e-6;
@@ -467,7 +578,8 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                     }
                 }
                 cpgw::lds_order();
-                run_program<G>(F.kkt, w, ldw, lane);
+                if (LDSPROG) run_program_lds<G>(LP, w, ldw, lane);
+                else run_program<G>(F.kkt, w, ldw, lane);
                 // ---- relaxation, projection on [l, u], dual update
 #pragma unroll
                 for (int g = 0; g < G; g++) {

@@ -51,6 +51,12 @@ CPG_DEV double read_lane(double v, int lane) {   // `lane` must be wave-uniform
 CPG_DEV double shfl_down(double v, int delta) { return __shfl_down(v, delta, 64); }
 CPG_DEV int read_first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 CPG_DEV bool wave_any(bool p) { return __any(p) != 0; }
+CPG_DEV unsigned long long ballot(bool p) { return __ballot(p); }
+// number of set bits of `mask` below this lane
+CPG_DEV unsigned mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+CPG_DEV unsigned popc64(unsigned long long m) { return (unsigned)__popcll(m); }
 
 CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
 // keeps the instruction scheduler from interleaving unrolled loop bodies (register pressure)
@@ -144,6 +150,19 @@ inline bool wave_any(bool p) {
 inline unsigned atomic_next(unsigned *ctr) {
     return __atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED);
 }
+inline unsigned long long ballot(bool p) {
+    SimWave *w = tls.wv;
+    w->ixch[tls.lane] = p ? 1 : 0;
+    wave_sync();
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) if (w->ixch[i]) m |= 1ULL << i;
+    wave_sync();
+    return m;
+}
+inline unsigned mbcnt(unsigned long long mask) {
+    return (unsigned)__builtin_popcountll(mask & ((1ULL << tls.lane) - 1ULL));
+}
+inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
 

@@ -50,6 +50,11 @@ class _Program(C.Structure):
                 ('vals', _dp), ('cols', _u16p)]
 
 
+class _Ragged(C.Structure):
+    _fields_ = [('n_chunks', C.c_int32), ('nnz', C.c_int32), ('ctab', _ip),
+                ('desc', C.POINTER(C.c_uint32)), ('vals', _dp), ('cols', _u16p)]
+
+
 class _Csr(C.Structure):
     _fields_ = [('rows', C.c_int32), ('nnz', C.c_int32), ('ptr', _ip), ('idx', _ip), ('val', _dp)]
 
@@ -60,6 +65,7 @@ class _Family(C.Structure):
                 ('D', _dp), ('E', _dp), ('c', C.c_double), ('ctype', _i8p),
                 ('n_slots', C.c_int32), ('fpos', _u16p), ('n_vary_x', C.c_int32), ('n_vary_z', C.c_int32),
                 ('kkt', _Program), ('A_rows', _Program), ('P_rows', _Program), ('At_rows', _Program),
+                ('kkt_ragged', _Ragged),
                 ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip)]
 
 
@@ -79,7 +85,7 @@ class CpgLibrary:
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
                'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_solve_batch',
                'cpg_hip_solve_batch_device', 'cpg_hip_synchronize', 'cpg_hip_last_kernel_ms',
-               'cpg_hip_set_launch', 'cpg_hip_malloc', 'cpg_hip_free', 'cpg_hip_memcpy_h2d',
+               'cpg_hip_set_launch', 'cpg_hip_set_program_placement', 'cpg_hip_malloc', 'cpg_hip_free', 'cpg_hip_memcpy_h2d',
                'cpg_hip_memcpy_d2h']
 
     def __init__(self, path: Optional[str] = None):
@@ -106,6 +112,7 @@ class CpgLibrary:
         L.cpg_hip_synchronize.argtypes = [C.c_void_p]
         L.cpg_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.cpg_hip_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.cpg_hip_set_program_placement.argtypes = [C.c_void_p, C.c_int]
         L.cpg_hip_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.cpg_hip_free.argtypes = [C.c_void_p, C.c_void_p]
         L.cpg_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -160,6 +167,7 @@ class FamilyPlan:
     n_vary_x: int
     n_vary_z: int
     kkt: _sp.PackedProgram
+    kkt_ragged: _sp.RaggedProgram
     A_rows: _sp.PackedProgram
     P_rows: _sp.PackedProgram
     At_rows: _sp.PackedProgram
@@ -193,6 +201,8 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
     phases = _sp.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=merge,
                              devpos=devpos)
     kkt = _sp.pack(phases, N=N)
+    kkt_ragged = _sp.pack_ragged(phases, N)
+    assert kkt_ragged.n_slots == kkt.n_slots and np.array_equal(kkt_ragged.final_pos, kkt.final_pos)
     if kkt.n_slots >= 0xFFFF:
         raise NotImplementedError('problem family too large for 16-bit LDS slot indices')
     As = sp.csc_matrix((plan.Ax, desc.A.indices, desc.A.indptr), shape=desc.A.shape)
@@ -208,9 +218,11 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
     dual_idx = np.concatenate([posz[d.indices] for d in desc.duals]).astype(np.int32) \
         if desc.duals else np.zeros(0, dtype=np.int32)
     stats = dict(nnzL=len(plan.Li), phases=kkt.n_phases, chunks=kkt.n_chunks, steps=kkt.steps,
-                 nnz_program=kkt.nnz, n_slots=kkt.n_slots, compile_s=time.time() - t0)
+                 nnz_program=kkt.nnz, n_slots=kkt.n_slots, lds_program_bytes=kkt_ragged.lds_bytes(),
+                 compile_s=time.time() - t0)
     return FamilyPlan(desc=desc, osqp=plan, ordx=ordx, ordz=ordz, posx=posx, posz=posz,
-                      n_vary_x=int(vary_q.sum()), n_vary_z=int(vary_u.sum()), kkt=kkt, A_rows=A_rows,
+                      n_vary_x=int(vary_q.sum()), n_vary_z=int(vary_u.sum()), kkt=kkt,
+                      kkt_ragged=kkt_ragged, A_rows=A_rows,
                       P_rows=P_rows, At_rows=At_rows, prim_idx=prim_idx, dual_idx=dual_idx,
                       stats=stats)
 
@@ -256,6 +268,15 @@ class BatchSolver:
         prim_idx = np.ascontiguousarray(p.prim_idx, dtype=np.int32)
         dual_idx = np.ascontiguousarray(p.dual_idx, dtype=np.int32)
         keep += [D, E, ctype, fpos, prim_idx, dual_idx]
+        rg = p.kkt_ragged
+        rg_ctab = np.ascontiguousarray(rg.ctab, dtype=np.int32)
+        rg_desc = np.ascontiguousarray(rg.desc, dtype=np.uint32)
+        rg_vals = np.ascontiguousarray(rg.vals, dtype=np.float64)
+        rg_cols = np.ascontiguousarray(rg.cols, dtype=np.uint16)
+        keep += [rg_ctab, rg_desc, rg_vals, rg_cols]
+        ragged = _Ragged(rg.n_chunks, rg.nnz, rg_ctab.ctypes.data_as(_ip),
+                         rg_desc.ctypes.data_as(C.POINTER(C.c_uint32)), _d(rg_vals),
+                         rg_cols.ctypes.data_as(_u16p))
         fam = _Family(
             n=desc.n_var, m=desc.m, n_eq=desc.n_eq, is_maximization=int(desc.is_maximization),
             sigma=o.settings['sigma'], alpha=o.settings['alpha'], rho=o.settings['rho'],
@@ -264,6 +285,7 @@ class BatchSolver:
             n_vary_x=p.n_vary_x, n_vary_z=p.n_vary_z,
             kkt=_program_struct(p.kkt, keep), A_rows=_program_struct(p.A_rows, keep),
             P_rows=_program_struct(p.P_rows, keep), At_rows=_program_struct(p.At_rows, keep),
+            kkt_ragged=ragged,
             n_prim=len(prim_idx), prim_idx=prim_idx.ctypes.data_as(_ip),
             n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip))
         self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), device, C.byref(self.h)),
@@ -296,6 +318,10 @@ class BatchSolver:
     def set_launch(self, waves_per_block=0, inst_per_wave=0, blocks_per_cu=0):
         self.lib.check(self.lib.L.cpg_hip_set_launch(self.h, waves_per_block, inst_per_wave,
                                                     blocks_per_cu), 'set_launch')
+
+    def set_program_placement(self, in_lds: int = -1):
+        """-1 automatic, 0 stream the solve program from L2/HBM, 1 keep it resident in LDS"""
+        self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h, in_lds), 'set_program_placement')
 
     # ---- which parameters vary ----------------------------------------------------------------------
     def set_updated(self, updated_params: Optional[Sequence[str]] = None) -> None:

@@ -389,3 +389,109 @@ def execute_packed(prog: PackedProgram, w: np.ndarray, natural: bool = False):
         ok = R != NO_ROW
         w[R[ok]] = red[ok]
     return nat if natural else w
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class RaggedProgram:
+    """Compact (padding-free) form of a solve program, small enough to stay resident in LDS.
+
+    ctab int32 [n_chunks, 4]: (max len, log2 g, first entry, 0)
+    desc uint32 [n_chunks, 64]: output slot (low 16 bits, 0xFFFF none) | number of entries << 16
+    vals float64 [nnz + 1]; cols uint16 [nnz + 1]: entries step-major.  Inside a chunk the lanes are
+    ordered by non-increasing number of entries, so the lanes that still have an entry at step s
+    are a prefix [0, cnt_s) and lane t finds its entry at  first + sum_{s' < s} cnt_s' + t.
+    `cols` holds BYTE offsets into the work vector (slot * 8).  The last entry (index nnz) is a
+    zero coefficient on slot 0: lanes without an entry read it instead of being masked off.
+    """
+    ctab: np.ndarray
+    desc: np.ndarray
+    vals: np.ndarray
+    cols: np.ndarray
+    n_phases: int
+    n_slots: int
+    final_pos: np.ndarray
+
+    @property
+    def n_chunks(self) -> int:
+        return int(self.ctab.shape[0])
+
+    @property
+    def nnz(self) -> int:
+        return int(self.vals.shape[0])          # including the trailing dummy entry
+
+    def lds_bytes(self) -> int:
+        """bytes the program occupies in LDS (values, indices, descriptors, chunk table)"""
+        return 8 * self.nnz + 8 * (-(-self.nnz // 4)) + 4 * 64 * self.n_chunks + 16 * self.n_chunks
+
+
+def pack_ragged(phases: List[Phase], N: int) -> RaggedProgram:
+    outs, ins, n_slots, final_pos = assign_slots(phases, N)
+    if n_slots * 8 > 0xFFFF:
+        raise NotImplementedError('work vector too large for 16-bit byte offsets')
+    ctab, desc, vals, cols = [], [], [], []
+    first = 0
+    for ph, out_slots, col_slots in zip(phases, outs, ins):
+        lens = [len(c) for c in ph.cols]
+        _, _, plan = _chunk_plan(lens)
+        for g, ln, sel in plan:
+            # rows of a chunk in order of non-increasing segment length; every lane of a row gets
+            # the same number of entries (short segments are padded with zero coefficients)
+            segs = [(-(-len(col_slots[rp]) // g) if len(col_slots[rp]) else 0) for rp in sel]
+            order = np.argsort(-np.asarray(segs), kind='stable')
+            lane_c = [np.zeros(0, dtype=np.int64)] * LANES
+            lane_v = [np.zeros(0)] * LANES
+            D = np.full(LANES, NO_ROW, dtype=np.uint32)
+            for k, oi in enumerate(order):
+                rp, seg = sel[oi], segs[oi]
+                base = k * g
+                D[base] = out_slots[rp]
+                c, v = np.asarray(col_slots[rp], dtype=np.int64), np.asarray(ph.vals[rp], dtype=np.float64)
+                for t in range(g):
+                    cs, vs = c[t * seg:(t + 1) * seg], v[t * seg:(t + 1) * seg]
+                    pad = seg - len(cs)
+                    lane_c[base + t] = np.concatenate([cs, np.zeros(pad, dtype=np.int64)])
+                    lane_v[base + t] = np.concatenate([vs, np.zeros(pad)])
+            ll = np.array([len(x) for x in lane_c], dtype=np.int64)
+            assert np.all(np.diff(ll) <= 0), 'lane lengths must be non-increasing'
+            L = int(ll.max()) if len(ll) else 0
+            D = D | (ll.astype(np.uint32) << 16)
+            n_ent = 0
+            for s in range(L):
+                cnt = int((ll > s).sum())
+                vals.append(np.array([lane_v[t][s] for t in range(cnt)]))
+                cols.append(np.array([8 * lane_c[t][s] for t in range(cnt)], dtype=np.uint16))
+                n_ent += cnt
+            ctab.append([L, int(np.log2(g)), first, 0])
+            desc.append(D)
+            first += n_ent
+    vals.append(np.zeros(1))
+    cols.append(np.zeros(1, dtype=np.uint16))
+    return RaggedProgram(
+        ctab=np.asarray(ctab, dtype=np.int32).reshape(-1, 4),
+        desc=np.asarray(desc, dtype=np.uint32).reshape(-1, LANES),
+        vals=np.concatenate(vals), cols=np.concatenate(cols).astype(np.uint16),
+        n_phases=len(phases), n_slots=n_slots, final_pos=final_pos)
+
+
+def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
+    """Host emulation of `run_program_lds` (tests)."""
+    lane = np.arange(LANES)
+    dummy = prog.nnz - 1
+    for c in range(prog.n_chunks):
+        L, lg, first, _ = prog.ctab[c]
+        d = prog.desc[c]
+        row, ln = d & 0xFFFF, d >> 16
+        g = 1 << lg
+        acc = np.zeros(LANES)
+        base = first
+        for s in range(L):
+            act = ln > s
+            e = np.where(act, base + lane, dummy)
+            acc += prog.vals[e] * w[prog.cols[e] // 8]
+            base += int(act.sum())
+        red = acc.reshape(LANES // g, g).sum(axis=1)
+        R = row[::g]
+        ok = R != NO_ROW
+        w[R[ok]] = red[ok]
+    return w

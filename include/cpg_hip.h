@@ -64,6 +64,17 @@ typedef struct {
     const uint16_t *cols; /* [n_steps][64] */
 } cpg_program_t;
 
+/* The same program without padding (cvxpygen_amd/solve_program.py::RaggedProgram): small enough
+ * to be kept resident in LDS, one copy per workgroup.  Optional (n_chunks == 0: not provided). */
+typedef struct {
+    int32_t n_chunks;
+    int32_t nnz;
+    const int32_t *ctab;  /* [n_chunks][4]: max len, log2(lanes per row), first entry, 0 */
+    const uint32_t *desc; /* [n_chunks][64]: output slot | (entries of the lane << 16) */
+    const double *vals;   /* [nnz] */
+    const uint16_t *cols; /* [nnz] */
+} cpg_ragged_t;
+
 typedef struct {
     int32_t rows;
     int32_t nnz;
@@ -93,6 +104,7 @@ typedef struct {
     cpg_program_t A_rows;  /* natural layout: (A v)_i,  v = w[0..n)   */
     cpg_program_t P_rows;  /* natural layout: (P v)_j,  v = w[0..n)   */
     cpg_program_t At_rows; /* natural layout: (A' v)_j, v = w[n..n+m) */
+    cpg_ragged_t kkt_ragged; /* compact form of `kkt` for the LDS-resident path (optional) */
     int32_t n_prim;        /* user primal entries */
     const int32_t *prim_idx; /* [n_prim] indices into x */
     int32_t n_dual;
@@ -144,8 +156,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta_
 int cpg_hip_synchronize(cpg_handle_t h);
 /* duration of the most recent solve kernel on this handle, from HIP events on its stream */
 int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms);
-/* launch geometry: waves per block (1..16), instances per wave (1, 2 or 4), blocks per CU; 0 = auto */
+/* launch geometry: waves per block (1..16), instances per wave (1 or 2), blocks per CU; 0 = auto */
 int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, int blocks_per_cu);
+/* where the solve program lives: 0 = streamed from L2/HBM, 1 = resident in LDS (one workgroup per
+ * CU; fails if it does not fit), -1 = automatic (LDS when it fits) */
+int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds);
 
 /* ---- device memory helpers for the device-resident variant ---------------------------------------- */
 int cpg_hip_malloc(cpg_handle_t h, size_t bytes, void **dptr);
