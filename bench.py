@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--batch', type=int, default=100000, help='instances per GPU')
     ap.add_argument('--workload', default='mpc12')
     ap.add_argument('--lib', default=None, help='alternative libcpg_hip build (experiments)')
+    ap.add_argument('--generic', action='store_true', help='table-driven kernels instead of the family-specialised library')
     ap.add_argument('--waves', type=int, default=0)
     ap.add_argument('--ipw', type=int, default=0, help='instances per wave')
     ap.add_argument('--blocks-per-cu', type=int, default=0)
@@ -103,7 +104,11 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     desc, label = make_workload(args.workload)
-    solver = BatchSolver(desc, device=local_rank, lib_path=args.lib)
+    lib_path = args.lib
+    gen = os.path.join(ROOT, 'cvxpygen_amd', 'generated', args.workload, f'libcpg_{args.workload}.so')
+    if lib_path is None and not args.generic and os.path.exists(gen):
+        lib_path = gen          # what generate_code() builds: executor specialised for this family
+    solver = BatchSolver(desc, device=local_rank, lib_path=lib_path)
     solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)
     solver.set_program_placement(args.placement)
     solver.set_updated(['x_init'])
@@ -170,6 +175,7 @@ def main():
                        'settings': 'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
                                    'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start',
                        'parallelism': f'shard{world}', **stats,
+                       'library': os.path.relpath(solver.lib.path, ROOT),
                        'plan': {k: (round(v, 3) if isinstance(v, float) else v)
                                 for k, v in solver.plan.stats.items()}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -359,6 +359,19 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
         TRY(upload<double>(h, h->owned, f->kkt_ragged.vals, (size_t)f->kkt_ragged.nnz, &F.kkt_ragged.vals));
         TRY(upload<unsigned short>(h, h->owned, f->kkt_ragged.cols, (size_t)f->kkt_ragged.nnz, &F.kkt_ragged.cols));
     }
+#ifdef CPG_GEN_HEADER
+    {   // this build contains an executor generated for one specific family: refuse any other
+        unsigned hsh = 0x811C9DC5u;
+        auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = (const unsigned char *)p;
+            for (size_t i = 0; i < nbytes; i++) hsh = (hsh ^ b[i]) * 0x01000193u; };
+        const cpg_ragged_t &rg = f->kkt_ragged;
+        if (rg.n_chunks > 0) { mix(rg.ctab, (size_t)rg.n_chunks * 16); mix(rg.desc, (size_t)rg.n_chunks * 256); mix(rg.cols, (size_t)rg.nnz * 2); }
+        if (rg.n_chunks != CPG_GEN_NCHUNKS || rg.nnz != CPG_GEN_NNZ || hsh != CPG_GEN_FINGERPRINT) {
+            set_error("this library was generated for a different problem family (solve-program fingerprint mismatch)");
+            cpg_hip_destroy(h); return CPG_E_BADARG; }
+        h->program_in_lds = 1;
+    }
+#endif
     F.n_slots = f->n_slots;
     if (f->n_slots < f->n + f->m || f->n_slots >= 0xFFFF) { set_error("bad n_slots"); cpg_hip_destroy(h); return CPG_E_BADARG; }
     TRY(upload<unsigned short>(h, h->owned, f->fpos, (size_t)f->n + f->m, &F.fpos));
@@ -461,7 +474,12 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     const size_t per_wave = (size_t)G * h->F.n_slots * sizeof(double);
     // LDS-resident program: one workgroup per CU, as many waves as fit next to the program
     const cpg::DevRagged &R = h->F.kkt_ragged;
-    const size_t prog_bytes = R.n_chunks > 0 ? ((size_t)R.nnz + (size_t)((R.nnz + 3) / 4) + (size_t)R.n_chunks * 34) * 8 : 0;
+#ifdef CPG_GEN_HEADER
+    const size_t tab_doubles = (size_t)R.n_chunks * 16;     // 16-bit output-slot table
+#else
+    const size_t tab_doubles = (size_t)R.n_chunks * 34;     // desc (u32 x 64) + ctab (int x 4)
+#endif
+    const size_t prog_bytes = R.n_chunks > 0 ? ((size_t)R.nnz + (size_t)((R.nnz + 3) / 4) + tab_doubles) * 8 : 0;
     bool in_lds = false;
     int W = h->waves_per_block;
     if (h->program_in_lds != 0 && R.n_chunks > 0) {

@@ -151,6 +151,7 @@ struct LdsProg {
     const unsigned short *cols;   // BYTE offsets into the work vector
     int n_chunks;
     unsigned dummy;               // index of the trailing zero entry
+    const unsigned short *rows16; // generated executor: output slot per (chunk, lane)
 };
 template <int G>
 CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
@@ -223,6 +224,40 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
         cpgw::lds_order();
     }
 }
+
+#ifdef CPG_GEN_HEADER
+// ---- family-specialised executor generated by cvxpygen_amd/codegen.py ---------------------------
+#define CPG_GEN_ZERO(A) _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = 0.0
+// all 64 lanes have an entry: constant offsets only
+#define CPG_GEN_STEP_FULL(A, E)                                                                    \
+    {                                                                                              \
+        const double v_ = *(const double *)(vb + (E) * 8u);                                        \
+        const unsigned co_ = *(const unsigned short *)(cb + (E) * 2u);                             \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
+            A[g_] = fma(v_, *(const double *)(wb + (unsigned)g_ * ldwb + co_), A[g_]);             \
+    }
+// lanes >= CNT read the trailing dummy entry (zero coefficient)
+#define CPG_GEN_STEP_PART(A, E, CNT)                                                               \
+    {                                                                                              \
+        const bool a_ = lane < (CNT);                                                              \
+        const double v_ = *(const double *)(a_ ? vb + (E) * 8u : vdum);                            \
+        const unsigned co_ = *(const unsigned short *)(a_ ? cb + (E) * 2u : cdum);                 \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
+            A[g_] = fma(v_, *(const double *)(wb + (unsigned)g_ * ldwb + co_), A[g_]);             \
+    }
+#define CPG_GEN_REDUCE_STORE(A, LG, C)                                                             \
+    {                                                                                              \
+        const unsigned row_ = rows[(C) * 64u + (unsigned)lane];                                    \
+        double r_[G];                                                                              \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) r_[g_] = cpgw::group_sum_first<LG>(A[g_]); \
+        if (row_ != CPG_NO_ROW) {                                                                  \
+            _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) w[(unsigned)(g_ * ldw) + row_] = r_[g_]; \
+        }                                                                                          \
+    }
+}  // namespace cpg
+#include CPG_GEN_HEADER
+namespace cpg {
+#endif
 
 // natural-layout product: chunk s delivers element lane + 64 s of the result to this lane
 CPG_DEV double natural_chunk(const DevProgram &P, int s, const double *w, int lane) {
@@ -498,14 +533,22 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
         const DevRagged &R = F.kkt_ragged;
         double *lv = lds + lds_off;                         lds_off += (size_t)R.nnz;
         unsigned short *lc = (unsigned short *)(lds + lds_off); lds_off += (size_t)((R.nnz + 3) / 4);
-        unsigned *ld = (unsigned *)(lds + lds_off);         lds_off += (size_t)R.n_chunks * 32;
-        int *lt = (int *)(lds + lds_off);                   lds_off += (size_t)R.n_chunks * 2;
         const unsigned nt = cpgw::block_threads(), t0 = cpgw::thread_in_block();
         for (unsigned t = t0; t < (unsigned)R.nnz; t += nt) { lv[t] = cpgw::gld(R.vals, t); lc[t] = cpgw::gld(R.cols, t); }
+        LP.vals = lv; LP.cols = lc; LP.n_chunks = R.n_chunks; LP.dummy = (unsigned)R.nnz - 1u;
+#ifdef CPG_GEN_HEADER
+        // the generated executor has every count / offset baked in; it only needs the per-lane
+        // output slots as a 16-bit table
+        unsigned short *lr = (unsigned short *)(lds + lds_off); lds_off += (size_t)R.n_chunks * 16;
+        for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) lr[t] = (unsigned short)(cpgw::gld(R.desc, t) & 0xFFFFu);
+        LP.rows16 = lr; LP.ctab = nullptr; LP.desc = nullptr;
+#else
+        unsigned *ld = (unsigned *)(lds + lds_off);         lds_off += (size_t)R.n_chunks * 32;
+        int *lt = (int *)(lds + lds_off);                   lds_off += (size_t)R.n_chunks * 2;
         for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) ld[t] = cpgw::gld(R.desc, t);
         for (unsigned t = t0; t < (unsigned)R.n_chunks * 4u; t += nt) lt[t] = cpgw::gld(R.ctab, t);
-        LP.ctab = lt; LP.desc = ld; LP.vals = lv; LP.cols = lc; LP.n_chunks = R.n_chunks;
-        LP.dummy = (unsigned)R.nnz - 1u;
+        LP.ctab = lt; LP.desc = ld; LP.rows16 = nullptr;
+#endif
     }
     cpgw::block_sync();
     double *w = lds + lds_off + (size_t)cpgw::wave_in_block() * G * ldw;
@@ -578,7 +621,11 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                     }
                 }
                 cpgw::lds_order();
+#ifdef CPG_GEN_HEADER
+                if (LDSPROG) run_program_gen<G>(LP.vals, LP.cols, LP.rows16, w, ldw, lane);
+#else
                 if (LDSPROG) run_program_lds<G>(LP, w, ldw, lane);
+#endif
                 else run_program<G>(F.kkt, w, ldw, lane);
                 // ---- relaxation, projection on [l, u], dual update
 #pragma unroll

@@ -47,6 +47,11 @@ class GeneratedSolver:
         self.code_dir = code_dir
         self.desc = FamilyDescriptor.load(os.path.join(code_dir, 'descriptor.npz'))
         self.device = device
+        if lib_path is None:
+            # the library generate_code compiled for this family, else the generic table-driven one
+            tag = ''.join(ch if ch.isalnum() else '_' for ch in self.desc.name)
+            cand = os.path.join(code_dir, f'libcpg_{tag}.so')
+            lib_path = cand if os.path.exists(cand) else None
         self.lib_path = lib_path
         self._bs: Optional[BatchSolver] = None
 

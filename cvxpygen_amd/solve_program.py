@@ -411,6 +411,7 @@ class RaggedProgram:
     n_phases: int
     n_slots: int
     final_pos: np.ndarray
+    chunk_phase: Optional[np.ndarray] = None    # phase index of every chunk
 
     @property
     def n_chunks(self) -> int:
@@ -419,6 +420,14 @@ class RaggedProgram:
     @property
     def nnz(self) -> int:
         return int(self.vals.shape[0])          # including the trailing dummy entry
+
+    def fingerprint(self) -> int:
+        """32-bit FNV-1a over the structural tables; ties a generated library to its family"""
+        h = 0x811C9DC5
+        for arr in (self.ctab.astype(np.int32), self.desc.astype(np.uint32), self.cols.astype(np.uint16)):
+            for b in arr.tobytes():
+                h = ((h ^ b) * 0x01000193) & 0xFFFFFFFF
+        return h
 
     def lds_bytes(self) -> int:
         """bytes the program occupies in LDS (values, indices, descriptors, chunk table)"""
@@ -429,12 +438,13 @@ def pack_ragged(phases: List[Phase], N: int) -> RaggedProgram:
     outs, ins, n_slots, final_pos = assign_slots(phases, N)
     if n_slots * 8 > 0xFFFF:
         raise NotImplementedError('work vector too large for 16-bit byte offsets')
-    ctab, desc, vals, cols = [], [], [], []
+    ctab, desc, vals, cols, chunk_phase = [], [], [], [], []
     first = 0
-    for ph, out_slots, col_slots in zip(phases, outs, ins):
+    for pi, (ph, out_slots, col_slots) in enumerate(zip(phases, outs, ins)):
         lens = [len(c) for c in ph.cols]
         _, _, plan = _chunk_plan(lens)
         for g, ln, sel in plan:
+            chunk_phase.append(pi)
             # rows of a chunk in order of non-increasing segment length; every lane of a row gets
             # the same number of entries (short segments are padded with zero coefficients)
             segs = [(-(-len(col_slots[rp]) // g) if len(col_slots[rp]) else 0) for rp in sel]
@@ -471,7 +481,8 @@ def pack_ragged(phases: List[Phase], N: int) -> RaggedProgram:
         ctab=np.asarray(ctab, dtype=np.int32).reshape(-1, 4),
         desc=np.asarray(desc, dtype=np.uint32).reshape(-1, LANES),
         vals=np.concatenate(vals), cols=np.concatenate(cols).astype(np.uint16),
-        n_phases=len(phases), n_slots=n_slots, final_pos=final_pos)
+        n_phases=len(phases), n_slots=n_slots, final_pos=final_pos,
+        chunk_phase=np.asarray(chunk_phase, dtype=np.int32))
 
 
 def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:

@@ -129,3 +129,22 @@ def test_full_size_properties():
     rd = dev.download()
     assert np.array_equal(rd.prim_flat, r.prim_flat[:4096]) and np.array_equal(rd.iter, r.iter[:4096])
     dev.free(); bs.close()
+
+
+def test_generated_family_library_vs_oracle(oracle_lib, tmp_path):
+    """what generate_code() compiles: executor specialised for the family (cvxpygen_amd/codegen.py)"""
+    from cvxpygen_amd import codegen
+    from cvxpygen_amd.runtime import build_family_plan
+    d = families.mpc(12, 4, 10)
+    plan = build_family_plan(d)
+    pre = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'cvxpygen_amd',
+                       'generated', 'mpc12', 'libcpg_mpc12.so')
+    lib = pre if os.path.exists(pre) else codegen.build_family_library(plan, str(tmp_path), 'mpc12')
+    rng = np.random.default_rng(21)
+    x0 = -2 + 4 * rng.random((777, 12))
+    for G in (1, 2):
+        bs = BatchSolver(d, lib_path=lib, plan=plan)
+        bs.set_launch(0, G, 0)
+        r = bs.solve({'x_init': x0}, updated_params=['x_init'])
+        _check(r, oracle_lib.cpg_solve_batch(d, _theta(d, 'x_init', x0), ['x_init']), d)
+        bs.close()

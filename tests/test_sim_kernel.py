@@ -106,3 +106,26 @@ def test_settings_and_errors(sim_lib):
         bs.set_updated(['A'])                 # matrix parameters need the refactor path
     bs.solve({'b': np.ones((1, 3))}, updated_params=['b'], warm_start=False)     # cvxpy alias accepted
     bs.close()
+
+
+@pytest.mark.parametrize('fam,G', [('nnls', 1), ('nnls', 2), ('mpc6', 1)])
+def test_generated_executor_parity(oracle_lib, tmp_path, fam, G):
+    """cvxpygen_amd.codegen: the family-specialised straight-line executor (emulator build of the
+    generated source) gives the oracle's results; a library generated for one family refuses another."""
+    from cvxpygen_amd import codegen
+    from cvxpygen_amd.runtime import build_family_plan
+    if fam == 'nnls':
+        d, name, vals = families.nonneg_ls(), 'b', np.random.default_rng(0).standard_normal((5, 3))
+    else:
+        d, name, vals = families.mpc(6, 3, 10), 'x_init', -2 + 4 * np.random.default_rng(1).random((3, 6))
+    plan = build_family_plan(d)
+    lib = codegen.build_family_library(plan, str(tmp_path), fam, sim=True)
+    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    bs.set_launch(waves_per_block=2, inst_per_wave=G)
+    r = bs.solve({name: vals}, updated_params=[name])
+    o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, name, vals), [name])
+    _assert_parity(r, o, prim, dual)
+    bs.close()
+    other = families.toy_box()
+    with pytest.raises(RuntimeError, match='different problem family'):
+        BatchSolver(other, lib_path=lib)
