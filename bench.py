@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--check', action='store_true', help='compare a sample with the oracle')
+    ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -111,10 +112,18 @@ def main():
     solver = BatchSolver(desc, device=local_rank, lib_path=lib_path)
     solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)
     solver.set_program_placement(args.placement)
-    solver.set_updated(['x_init'])
-    solver.apply_settings()                      # reference defaults
     B = args.batch
-    theta = make_theta(desc, B, seed=1000 + rank)
+    if args.all_params:
+        solver.set_updated(None)
+        rng = np.random.default_rng(1000 + rank)
+        full = np.tile(desc.theta0[:-1], (B, 1)) * (1 + 0.05 * rng.standard_normal((B, desc.NP)))
+        p = desc.param('x_init')
+        full[:, p.col:p.col + p.size] = make_theta(desc, B, seed=1000 + rank)
+        theta = full[:, solver._var_cols]
+    else:
+        solver.set_updated(['x_init'])
+        theta = make_theta(desc, B, seed=1000 + rank)
+    solver.apply_settings()                      # reference defaults
     dev = DeviceBatch(solver, B)
     dev.upload(theta)
 
@@ -171,7 +180,7 @@ def main():
             'data': 'synthetic (x_init = -2 + 4*U(0,1), default_rng(1000+rank); family parameters of '
                     'examples/MPC.ipynb cell 3 extended to 12/4)',
             'config': {'workload': label, 'instances_per_gpu': B, 'kkt_dim': desc.n_var + desc.m,
-                       'n_var': desc.n_var, 'n_constr': desc.m, 'varying_params': ['x_init'],
+                       'n_var': desc.n_var, 'n_constr': desc.m, 'varying_params': 'all (matrix parameters: per-instance refactorisation)' if args.all_params else ['x_init'],
                        'settings': 'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
                                    'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start',
                        'parallelism': f'shard{world}', **stats,

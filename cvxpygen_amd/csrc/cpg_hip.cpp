@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "cpg_osqp_kernel.h"
+#include "cpg_osqp_refactor.h"
 
 // ------------------------------------------------------------------------------------ runtime layer
 #ifndef CPG_HOST_SIM
@@ -56,6 +57,9 @@ struct cpg_solver_s {
     cpg::DevFamily F{};
     cpg::DevUpdate U{};
     bool have_update = false;
+    cpg::DevRefactor R{};
+    bool refactor_mode = false;
+    std::vector<void *> refactor_owned;
     cpg::DevSettings S{};
     int warm_starting = 1;              // accepted for API parity; a batch is always cold-started
     int waves_per_block = 0, inst_per_wave = 1, blocks_per_cu = 0;
@@ -205,6 +209,59 @@ static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int wav
     return CPG_OK;
 }
 #endif
+
+#ifndef CPG_HOST_SIM
+template <int NSX, int NSZ>
+__global__ void __launch_bounds__(256, 2)
+osqp_refactor_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cpg::osqp_refactor_body<NSX, NSZ>(F, R, S, Bt, cpg_lds, wave_global);
+}
+template <int NSX, int NSZ>
+static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = osqp_refactor_kernel<NSX, NSZ>;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->F, h->R, h->S, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#else
+template <int NSX, int NSZ>
+static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    for (int b = 0; b < blocks; b++) {
+        std::vector<char> ldsbuf(lds + 64);
+        std::vector<cpgw::SimWave> wv(waves);
+        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
+        pthread_barrier_t block_bar;
+        pthread_barrier_init(&block_bar, nullptr, waves * 64);
+        std::vector<std::thread> th;
+        for (int t = 0; t < waves * 64; t++)
+            th.emplace_back([&, t]() {
+                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
+                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
+                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
+                cpg::osqp_refactor_body<NSX, NSZ>(h->F, h->R, h->S, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
+            });
+        for (auto &t : th) t.join();
+        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
+        pthread_barrier_destroy(&block_bar);
+    }
+    return CPG_OK;
+}
+#endif
+#ifndef CPG_KERNELS_REFACTOR
+#define CPG_KERNELS_REFACTOR(Z) Z(1, 1) Z(4, 4) Z(8, 8) Z(16, 16)
+#endif
+static int launch_refactor(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
+#define Z(a, b) if (nsx <= a && nsz <= b) return launch_refactor_t<a, b>(h, Bt, blocks, waves, lds);
+    CPG_KERNELS_REFACTOR(Z)
+#undef Z
+    set_error("problem family larger than the largest compiled slot class");
+    return CPG_E_UNSUPPORTED;
+}
 
 // Instantiated kernels.  (NSX, NSZ): slot class (ceil(n/64), ceil(m/64)); NV: leading slots with
 // per-instance q / u (1: at most 64 parameter-dependent entries; NS: all); G instances per wave.
@@ -394,7 +451,7 @@ int cpg_hip_destroy(cpg_handle_t h) {
     if (!h) return CPG_OK;
     rt_set_device(h->device);
     rt_sync(h);
-    free_list(h->owned); free_list(h->update_owned);
+    free_list(h->owned); free_list(h->update_owned); free_list(h->refactor_owned);
     if (h->d_counter) rt_free(h->d_counter);
     free_buf(h->scratch);
     free_buf(h->s_theta); free_buf(h->s_prim); free_buf(h->s_dual); free_buf(h->s_obj);
@@ -431,6 +488,44 @@ int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *u) {
     if ((rc = upload_csr(h, h->update_owned, u->map_d, &U.map_d))) return rc;
     if ((rc = rt_sync(h))) return rc;
     h->have_update = true;
+    h->refactor_mode = false;
+    return CPG_OK;
+}
+
+int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
+    if (!h || !r) { set_error("null argument"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    if ((rc = rt_sync(h))) return rc;
+    free_list(h->refactor_owned);
+    std::vector<void *> &own = h->refactor_owned;
+    cpg::DevRefactor &R = h->R;
+    const size_t n = h->F.n, m = h->F.m, N = n + m;
+    R.nnzP = r->nnzP; R.nnzA = r->nnzA; R.nnzL = r->nnzL; R.n_eq = h->F.n_eq; R.np_var = r->np_var;
+    R.scaling_iters = r->scaling_iters; R.d_base = r->d_base;
+    R.fac_chunks = r->fac_chunks; R.sol_chunks = r->sol_chunks; R.sol_nnz = r->sol_nnz; R.sol_slots = r->sol_slots;
+#define UP(T, field, count) if ((rc = upload<T>(h, own, (const T *)r->field, (size_t)(count), (const T **)&R.field))) return rc
+    UP(int, Ap, n + 1); UP(int, Ai, r->nnzA); UP(int, Arp, m + 1); UP(int, Aent, r->nnzA); UP(int, Acol, r->nnzA);
+    UP(int, Pp, n + 1); UP(int, Pi, r->nnzP); UP(int, Prp, n + 1);
+    { const int npf = r->Prp[n]; UP(int, Pent, npf); UP(int, Pcol, npf); }
+    UP(int, Lcol, r->nnzL); UP(int, ksrc_kind, r->nnzL + N); UP(int, ksrc_idx, r->nnzL + N);
+    UP(int, fac_ctab, (size_t)r->fac_chunks * 4); UP(unsigned, fac_task, (size_t)r->fac_chunks * 64);
+    UP(unsigned, fac_len, (size_t)r->fac_chunks * 64);
+    UP(unsigned, fac_a, r->fac_triples); UP(unsigned, fac_b, r->fac_triples); UP(unsigned, fac_k, r->fac_triples);
+    UP(int, sol_ctab, (size_t)r->sol_chunks * 4); UP(unsigned, sol_desc, (size_t)r->sol_chunks * 64);
+    UP(unsigned short, sol_cols, r->sol_nnz); UP(int, sol_kind, r->sol_nnz); UP(int, sol_idx, r->sol_nnz);
+    UP(unsigned short, sol_fpos, N);
+    UP(double, P_base, r->nnzP); UP(double, A_base, r->nnzA); UP(double, q_base, n); UP(double, u_base, m);
+#undef UP
+    if ((rc = upload_csr(h, own, r->map_P, &R.map_P))) return rc;
+    if ((rc = upload_csr(h, own, r->map_A, &R.map_A))) return rc;
+    if ((rc = upload_csr(h, own, r->map_q, &R.map_q))) return rc;
+    if ((rc = upload_csr(h, own, r->map_u, &R.map_u))) return rc;
+    if ((rc = upload_csr(h, own, r->map_d, &R.map_d))) return rc;
+    R.buf_doubles = (long long)(r->nnzP + r->nnzA + 4 * n + 5 * m + r->nnzL + 2 * N + r->sol_nnz + 64);   // see carve()
+    if ((rc = rt_sync(h))) return rc;
+    h->refactor_mode = true;
+    h->have_update = true;
     return CPG_OK;
 }
 
@@ -464,11 +559,38 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
                                double *d_obj, int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
     if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
-    if (B < 0 || !d_prim || !d_dual || !d_obj || !d_iter || !d_status || !d_pri || !d_dua || (h->U.np_var > 0 && !d_theta)) {
+    if (B < 0 || !d_prim || !d_dual || !d_obj || !d_iter || !d_status || !d_pri || !d_dua || ((h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !d_theta)) {
         set_error("null buffer"); return CPG_E_BADARG; }
     if (B == 0) return CPG_OK;
     int rc = rt_set_device(h->device);
     if (rc) return rc;
+    if (h->refactor_mode) {
+        const int W = 4;
+        const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
+        if (lds > h->lds_limit) { set_error("work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
+        long long blocks = (B + W - 1) / W;
+        int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : 2;
+        if ((long long)per_cu * (long long)lds > (long long)h->lds_limit) per_cu = (int)(h->lds_limit / lds);
+        const long long cap = (long long)h->num_cu * per_cu;
+        if (blocks > cap) blocks = cap;
+        if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
+        cpg::DevBatch Bt;
+        Bt.scratch = (double *)h->scratch.p;
+        Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
+        Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
+#ifndef CPG_HOST_SIM
+        RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
+        RT_CHECK(hipEventRecord(h->ev0, h->stream));
+#else
+        *h->d_counter = 0;
+#endif
+        rc = launch_refactor(h, Bt, (int)blocks, W, lds);
+        if (rc) return rc;
+#ifndef CPG_HOST_SIM
+        RT_CHECK(hipEventRecord(h->ev1, h->stream));
+#endif
+        return CPG_OK;
+    }
     const int G = h->inst_per_wave;
     const size_t N = (size_t)(h->F.n + h->F.m);
     const size_t per_wave = (size_t)G * h->F.n_slots * sizeof(double);
@@ -552,13 +674,14 @@ int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta, double *
                         int32_t *iter, int32_t *status, double *pri_res, double *dua_res) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
     if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
-    if (B < 0 || !prim || !dual || !obj || !iter || !status || !pri_res || !dua_res || (h->U.np_var > 0 && !theta)) {
+    if (B < 0 || !prim || !dual || !obj || !iter || !status || !pri_res || !dua_res || ((h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !theta)) {
         set_error("null buffer"); return CPG_E_BADARG; }
     if (B == 0) return CPG_OK;
     int rc = rt_set_device(h->device);
     if (rc) return rc;
     const size_t b = (size_t)B;
-    if ((rc = ensure(h->s_theta, b * h->U.np_var * sizeof(double)))) return rc;
+    const size_t npv = (size_t)(h->refactor_mode ? h->R.np_var : h->U.np_var);
+    if ((rc = ensure(h->s_theta, b * npv * sizeof(double)))) return rc;
     if ((rc = ensure(h->s_prim, b * h->F.n_prim * sizeof(double)))) return rc;
     if ((rc = ensure(h->s_dual, b * h->F.n_dual * sizeof(double)))) return rc;
     if ((rc = ensure(h->s_obj, b * sizeof(double)))) return rc;
@@ -566,7 +689,7 @@ int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta, double *
     if ((rc = ensure(h->s_dua, b * sizeof(double)))) return rc;
     if ((rc = ensure(h->s_iter, b * sizeof(int32_t)))) return rc;
     if ((rc = ensure(h->s_status, b * sizeof(int32_t)))) return rc;
-    if ((rc = rt_h2d(h, h->s_theta.p, theta, b * h->U.np_var * sizeof(double)))) return rc;
+    if ((rc = rt_h2d(h, h->s_theta.p, theta, b * npv * sizeof(double)))) return rc;
     rc = cpg_hip_solve_batch_device(h, B, (const double *)h->s_theta.p, (double *)h->s_prim.p, (double *)h->s_dual.p,
                                     (double *)h->s_obj.p, (int32_t *)h->s_iter.p, (int32_t *)h->s_status.p,
                                     (double *)h->s_pri.p, (double *)h->s_dua.p);

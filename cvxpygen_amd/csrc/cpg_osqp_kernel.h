@@ -291,10 +291,27 @@ CPG_DEV double csr_row(const DevCsr &mp, unsigned row, const double *theta, doub
     return v;
 }
 
-// q / u of entry i (slot s): per-instance register for the leading NV slots, otherwise the family's
-// base vectors staged in LDS (`sh` = [q_base (n) | u_base (m)], shared by the block)
-#define CPG_Q(I, sh, s, i) ((s) < Inst<NSX, NSZ, NV>::NVX ? (I).qv[(s) < Inst<NSX, NSZ, NV>::NVX ? (s) : 0] : (sh)[i])
-#define CPG_U(I, sh, s, i) ((s) < Inst<NSX, NSZ, NV>::NVZ ? (I).uv[(s) < Inst<NSX, NSZ, NV>::NVZ ? (s) : 0] : (sh)[(unsigned)F.n + (i)])
+// How the termination test obtains the instance's q / u and the sparse row products of the
+// staged vector w.  Shared-factor kernel: q / u of entry i (slot s) = per-instance register for the
+// leading NV slots, otherwise the family's base vectors staged in LDS (`sh` = [q_base | u_base]);
+// products through the family's natural-layout row programs.
+template <int NSX, int NSZ, int NV>
+struct SharedCtx {
+    const DevFamily &F;
+    const double *sh;
+    const Inst<NSX, NSZ, NV> &I;
+    const double *w;
+    int lane;
+    CPG_DEV double q(int s, unsigned i) const {
+        return s < Inst<NSX, NSZ, NV>::NVX ? I.qv[s < Inst<NSX, NSZ, NV>::NVX ? s : 0] : sh[i];
+    }
+    CPG_DEV double u(int s, unsigned i) const {
+        return s < Inst<NSX, NSZ, NV>::NVZ ? I.uv[s < Inst<NSX, NSZ, NV>::NVZ ? s : 0] : sh[(unsigned)F.n + i];
+    }
+    CPG_DEV double ax(int s) const { return natural_chunk(F.A_rows, s, w, lane); }     // (A v)_i, v = w[0..n)
+    CPG_DEV double px(int s) const { return natural_chunk(F.P_rows, s, w, lane); }     // (P v)_j
+    CPG_DEV double atx(int s) const { return natural_chunk(F.At_rows, s, w, lane); }   // (A' v)_j, v = w[n..)
+};
 
 // cpg_canonicalize_q/l/u/d + osqp_update_data_vec for the parameter-dependent entries; returns
 // (wave-uniform) whether a row changed class w.r.t. the family's factor.
@@ -328,16 +345,15 @@ CPG_DEV bool canonicalise(const DevFamily &F, const DevUpdate &U, const double *
 }
 
 // is_primal_infeasible on delta_y (OSQP paper sec. 3.4); wave-uniform result
-template <int NSX, int NSZ, int NV>
-CPG_DEV bool primal_infeasible(const DevFamily &F, const double *sh, const signed char (&ct)[NSZ],
-                               bool unsc, double eps, Inst<NSX, NSZ, NV> &I, double *w, double *sdy,
-                               int lane) {
+template <int NSX, int NSZ, typename Ctx>
+CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
+                               bool unsc, double eps, double *w, double *sdy, int lane) {
     double nrm = 0.0, lhs = 0.0;
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         if (i < (unsigned)F.m) {
-            const double uu = CPG_U(I, sh, s, i);
+            const double uu = cx.u(s, i);
             const bool eq = ct[s] == 1;
             const double ll = eq ? uu : -CPG_INFTY;
             const bool iu = uu > CPG_INFTY * CPG_MIN_SCALING, il = !eq;
@@ -360,7 +376,7 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const double *sh, const signe
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-        const double t = natural_chunk(F.At_rows, s, w, lane);
+        const double t = cx.atx(s);
         if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cpgw::gld(F.Dinv, i) * t : t));
         cpgw::sched_fence();
     }
@@ -370,10 +386,9 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const double *sh, const signe
 }
 
 // is_dual_infeasible on delta_x; wave-uniform result
-template <int NSX, int NSZ, int NV>
-CPG_DEV bool dual_infeasible(const DevFamily &F, const double *sh, const signed char (&ct)[NSZ],
-                             bool unsc, double eps, Inst<NSX, NSZ, NV> &I, double *w, const double *sdx,
-                             int lane) {
+template <int NSX, int NSZ, typename Ctx>
+CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
+                             bool unsc, double eps, double *w, const double *sdx, int lane) {
     double nrm = 0.0, qdx = 0.0;
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
@@ -381,7 +396,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const double *sh, const signed 
         if (i < (unsigned)F.n) {
             const double d = cpgw::gld(sdx, i);
             nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.D, i) * d : d));
-            qdx += CPG_Q(I, sh, s, i) * d;
+            qdx += cx.q(s, i) * d;
         }
     }
     nrm = cpgw::wave_max_nonneg(nrm);
@@ -396,7 +411,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const double *sh, const signed 
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-        const double t = natural_chunk(F.P_rows, s, w, lane);
+        const double t = cx.px(s);
         if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cpgw::gld(F.Dinv, i) * t : t));
         cpgw::sched_fence();
     }
@@ -407,10 +422,10 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const double *sh, const signed 
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-            const double a = natural_chunk(F.A_rows, s, w, lane);
+            const double a = cx.ax(s);
             if (i < (unsigned)F.m) {
                 const double av = unsc ? cpgw::gld(F.Einv, i) * a : a;
-                if ((CPG_U(I, sh, s, i) < CPG_INFTY * CPG_MIN_SCALING && av > eps * nrm) ||
+                if ((cx.u(s, i) < CPG_INFTY * CPG_MIN_SCALING && av > eps * nrm) ||
                     (ct[s] == 1 && av < -eps * nrm)) viol = true;
             }
             cpgw::sched_fence();
@@ -423,26 +438,27 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const double *sh, const signed 
 
 // update_info + check_termination: residuals in the unscaled space (scaled_termination = 0),
 // optimality / infeasibility decisions.  status stays 11 (unsolved) when nothing triggers.
-template <int NSX, int NSZ, int NV>
-CPG_DEV CheckOut check(const DevFamily &F, const double *sh, const signed char (&ct)[NSZ],
-                       const DevSettings &S, Inst<NSX, NSZ, NV> &I, double *w, double *sdx, double *sdy,
-                       int lane, bool approximate) {
+template <int NSX, int NSZ, typename Ctx>
+CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
+                       const DevSettings &S, const double (&Ix)[NSX], const double (&Iz)[NSZ],
+                       const double (&Iy)[NSZ], double *w, double *sdx, double *sdy, int lane,
+                       bool approximate) {
     const bool unsc = !S.scaled_termination;
     CheckOut o;
 #pragma unroll
-    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = I.x[s]; }
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = Ix[s]; }
 #pragma unroll
-    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = I.y[s]; }
+    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = Iy[s]; }
     cpgw::lds_order();
     double rp = 0.0, nz = 0.0, na = 0.0;
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-        const double ax = natural_chunk(F.A_rows, s, w, lane);
+        const double ax = cx.ax(s);
         if (i < (unsigned)F.m) {
             const double ei = unsc ? cpgw::gld(F.Einv, i) : 1.0;
-            rp = cpgw::dmax2(rp, fabs(ei * (ax - I.z[s])));
-            nz = cpgw::dmax2(nz, fabs(ei * I.z[s]));
+            rp = cpgw::dmax2(rp, fabs(ei * (ax - Iz[s])));
+            nz = cpgw::dmax2(nz, fabs(ei * Iz[s]));
             na = cpgw::dmax2(na, fabs(ei * ax));
         }
         cpgw::sched_fence();
@@ -451,17 +467,17 @@ CPG_DEV CheckOut check(const DevFamily &F, const double *sh, const signed char (
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-        const double px = natural_chunk(F.P_rows, s, w, lane);
-        const double aty = natural_chunk(F.At_rows, s, w, lane);
+        const double px = cx.px(s);
+        const double aty = cx.atx(s);
         if (i < (unsigned)F.n) {
             const double di = unsc ? cpgw::gld(F.Dinv, i) : 1.0;
-            const double qq = CPG_Q(I, sh, s, i);
+            const double qq = cx.q(s, i);
             rd = cpgw::dmax2(rd, fabs(di * (qq + px + aty)));
             nq = cpgw::dmax2(nq, fabs(di * qq));
             nat = cpgw::dmax2(nat, fabs(di * aty));
             npx = cpgw::dmax2(npx, fabs(di * px));
-            quad += I.x[s] * px;
-            lin += qq * I.x[s];
+            quad += Ix[s] * px;
+            lin += qq * Ix[s];
         }
         cpgw::sched_fence();
     }
@@ -482,9 +498,9 @@ CPG_DEV CheckOut check(const DevFamily &F, const double *sh, const signed char (
     bool pc = false, dc = false, pic = false, dic = false;
     if (F.m == 0) pc = true;
     else if (rp < ea + er * cpgw::dmax2(nz, na)) pc = true;
-    else pic = primal_infeasible<NSX, NSZ, NV>(F, sh, ct, unsc, epi, I, w, sdy, lane);
+    else pic = primal_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, epi, w, sdy, lane);
     if (rd < ea + er * dn) dc = true;
-    else dic = dual_infeasible<NSX, NSZ, NV>(F, sh, ct, unsc, edi, I, w, sdx, lane);
+    else dic = dual_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, edi, w, sdx, lane);
     if (pc && dc) o.status = approximate ? 2 : 1;
     else if (pic) { o.status = approximate ? 4 : 3; o.obj = CPG_INFTY; }
     else if (dic) { o.status = approximate ? 6 : 5; o.obj = -CPG_INFTY; }
@@ -492,26 +508,26 @@ CPG_DEV CheckOut check(const DevFamily &F, const double *sh, const signed char (
 }
 
 // store_solution + cpg_retrieve_*: unscale, gather the user-facing entries, write the info scalars
-template <int NSX, int NSZ, int NV>
-CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, Inst<NSX, NSZ, NV> &I, double *w,
-                      int lane, int iter, const CheckOut &o) {
+template <int NSX, int NSZ>
+CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)[NSX],
+                      const double (&Iy)[NSZ], double dconst, long long b, double *w, int lane, int iter,
+                      const CheckOut &o) {
     const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
 #pragma unroll
-    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = has_sol ? cpgw::gld(F.D, i) * I.x[s] : NAN; }
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = has_sol ? cpgw::gld(F.D, i) * Ix[s] : NAN; }
 #pragma unroll
-    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = has_sol ? F.cinv * cpgw::gld(F.E, i) * I.y[s] : NAN; }
+    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = has_sol ? F.cinv * cpgw::gld(F.E, i) * Iy[s] : NAN; }
     cpgw::lds_order();
-    double *pp = Bt.prim + (size_t)I.b * F.n_prim, *dp = Bt.dual + (size_t)I.b * F.n_dual;
+    double *pp = Bt.prim + (size_t)b * F.n_prim, *dp = Bt.dual + (size_t)b * F.n_dual;
     for (unsigned k = (unsigned)lane; k < (unsigned)F.n_prim; k += 64u) cpgw::gst(pp, k, w[(unsigned)cpgw::gld(F.prim_idx, k)]);
     for (unsigned k = (unsigned)lane; k < (unsigned)F.n_dual; k += 64u) cpgw::gst(dp, k, w[(unsigned)F.n + (unsigned)cpgw::gld(F.dual_idx, k)]);
     if (lane == 0) {
-        double ov = o.obj + I.dconst;
+        double ov = o.obj + dconst;
         if (F.is_max) ov = -ov;
-        Bt.obj[I.b] = ov; Bt.iter[I.b] = iter; Bt.status[I.b] = o.status;
-        Bt.pri_res[I.b] = o.prim_res; Bt.dua_res[I.b] = o.dual_res;
+        Bt.obj[b] = ov; Bt.iter[b] = iter; Bt.status[b] = o.status;
+        Bt.pri_res[b] = o.prim_res; Bt.dua_res[b] = o.dual_res;
     }
     cpgw::lds_order();
-    I.done = 1;
 }
 
 // ------------------------------------------------------------------------------------ the kernel body
@@ -609,7 +625,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma unroll
                     for (int s = 0; s < NSX; s++) {
                         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < (unsigned)F.n) wg[i] = F.sigma * I[g].x[s] - CPG_Q(I[g], sh, s, i);
+                        if (i < (unsigned)F.n) wg[i] = F.sigma * I[g].x[s] - SharedCtx<NSX, NSZ, NV>{F, sh, I[g], wg, lane}.q(s, i);
                         CPG_FENCE_EVERY(s);
                     }
 #pragma unroll
@@ -652,7 +668,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                             const double zt = (zp - ri * yp) + ri * wg[fpz[s]];
                             const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
                             // projection on [l, u]: equality rows have l = u, all others l = -inf
-                            const double uu = CPG_U(I[g], sh, s, i);
+                            const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, I[g], wg, lane}.u(s, i);
                             const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
                             const double dyv = rv * (zr - zn);
                             I[g].z[s] = zn; I[g].y[s] = yp + dyv;
@@ -675,13 +691,17 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma nounroll
                     for (int pass = 0; pass < 2; pass++) {
                         if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                        o = check<NSX, NSZ, NV>(F, sh, ct, S, I[g], wg, sdx, sdy, lane, pass == 1);
+                        o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(F, SharedCtx<NSX, NSZ, NV>{F, sh, I[g], wg, lane}, ct, S,
+                                                                    I[g].x, I[g].z, I[g].y, wg, sdx, sdy, lane, pass == 1);
                     }
                     if (o.status == 11 && iter >= S.max_iter) o.status = 7;
                 }
                 if (o.status == 11 && iter >= S.max_iter) o.status = 7;   // max_iter == 0
                 co[g] = o;
-                if (__builtin_expect(o.status != 11, 0)) { finalize<NSX, NSZ, NV>(F, Bt, I[g], wg, lane, iter, o); n_open--; }
+                if (__builtin_expect(o.status != 11, 0)) {
+                    finalize<NSX, NSZ>(F, Bt, I[g].x, I[g].y, I[g].dconst, I[g].b, wg, lane, iter, o);
+                    I[g].done = 1; n_open--;
+                }
             }
         }
     }

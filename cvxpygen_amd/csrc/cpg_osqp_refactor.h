@@ -1,0 +1,360 @@
+// Per-instance refactorisation path of the batched OSQP backend: what the reference's generated
+// cpg_solve() does when a parameter enters P or A --
+//   cpg_canonicalize_P / _A            (cvxpygen/utils.py:279-294)
+//   osqp_update_data_mat(...)          (cvxpygen/solvers/osqp.py:20-33; third-party OSQP: unscale,
+//                                       overwrite values, Ruiz-equilibrate from scratch, numeric
+//                                       LDL' on the fixed symbolic pattern)
+//   osqp_update_data_vec, osqp_solve, cpg_retrieve_*   as in cpg_osqp_kernel.h
+// -- for every instance of a batch, one wavefront per instance.  All structure (row / column views,
+// KKT value sources, LDL' dot-product schedule, level-scheduled substitution program) is shared and
+// prepared on the host (cvxpygen_amd/refactor_plan.py); per-instance numbers (scaled matrices,
+// factor, substitution coefficients) live in a per-wavefront buffer in HBM / L2.
+//
+// This path favours generality over speed: every coefficient of the per-instance factor is
+// streamed from memory in every ADMM iteration, and the substitution is level-scheduled without
+// the partitioned-inverse merging of the shared-factor path.
+#pragma once
+
+#include "cpg_osqp_kernel.h"
+
+namespace cpg {
+
+struct DevRefactor {
+    int nnzP, nnzA, nnzL, n_eq, np_var, scaling_iters;
+    // equilibration views
+    const int *Ap, *Ai, *Arp, *Aent, *Acol, *Pp, *Pi, *Prp, *Pent, *Pcol;
+    // factor
+    const int *Lcol, *ksrc_kind, *ksrc_idx;
+    const int *fac_ctab;
+    const unsigned *fac_task, *fac_len, *fac_a, *fac_b, *fac_k;
+    int fac_chunks;
+    // substitution program (ragged layout, tables shared, values per instance)
+    const int *sol_ctab;
+    const unsigned *sol_desc;
+    const unsigned short *sol_cols;
+    const int *sol_kind, *sol_idx;
+    const unsigned short *sol_fpos;
+    int sol_chunks, sol_nnz, sol_slots;
+    // canonicalisation of everything (UNSCALED): p = base + map @ theta_var
+    const double *P_base, *A_base, *q_base, *u_base;
+    double d_base;
+    DevCsr map_P, map_A, map_q, map_u, map_d;
+    long long buf_doubles;   // per-wavefront buffer length
+};
+
+#define CPG_K_NONE 0
+#define CPG_K_P 1
+#define CPG_K_A 2
+#define CPG_K_SIGMA 3
+#define CPG_K_RHO 4
+
+CPG_DEV double lim_scaling(double v) { v = v < 1e-4 ? 1.0 : v; return v > 1e4 ? 1e4 : v; }
+
+// per-wavefront buffer layout (doubles)
+struct InstBuf {
+    double *P, *A, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *Lx, *Dg, *Dginv, *sv, *sdx, *sdy;
+};
+CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
+    InstBuf o;
+    const size_t n = (size_t)F.n, m = (size_t)F.m, N = n + m;
+    o.P = b; b += R.nnzP; o.A = b; b += R.nnzA;
+    o.D = b; b += n; o.Dinv = b; b += n; o.E = b; b += m; o.Einv = b; b += m;
+    o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
+    o.Lx = b; b += R.nnzL; o.Dg = b; b += N; o.Dginv = b; b += N;
+    o.sv = b; b += R.sol_nnz; o.sdx = b; b += n; o.sdy = b; b += m;
+    return o;
+}
+
+// row products with the instance's own scaled matrices (values gathered from the buffer)
+template <int NSX, int NSZ>
+struct InstCtx {
+    const DevFamily &F;
+    const DevRefactor &R;
+    const InstBuf &B;
+    const double *w;
+    int lane;
+    CPG_DEV double q(int, unsigned i) const { return cpgw::gld((const double *)B.q, i); }
+    CPG_DEV double u(int, unsigned i) const { return cpgw::gld((const double *)B.u, i); }
+    CPG_DEV double ax(int s) const {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        double acc = 0.0;
+        if (i < (unsigned)F.m) {
+            const unsigned a = (unsigned)cpgw::gld(R.Arp, i), e = (unsigned)cpgw::gld(R.Arp, i + 1u);
+            for (unsigned k = a; k < e; k++)
+                acc = fma(cpgw::gld((const double *)B.A, (unsigned)cpgw::gld(R.Aent, k)), w[(unsigned)cpgw::gld(R.Acol, k)], acc);
+        }
+        return acc;
+    }
+    CPG_DEV double px(int s) const {
+        const unsigned j = (unsigned)lane + 64u * (unsigned)s;
+        double acc = 0.0;
+        if (j < (unsigned)F.n) {
+            const unsigned a = (unsigned)cpgw::gld(R.Prp, j), e = (unsigned)cpgw::gld(R.Prp, j + 1u);
+            for (unsigned k = a; k < e; k++)
+                acc = fma(cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)), w[(unsigned)cpgw::gld(R.Pcol, k)], acc);
+        }
+        return acc;
+    }
+    CPG_DEV double atx(int s) const {
+        const unsigned j = (unsigned)lane + 64u * (unsigned)s;
+        double acc = 0.0;
+        if (j < (unsigned)F.n) {
+            const unsigned a = (unsigned)cpgw::gld(R.Ap, j), e = (unsigned)cpgw::gld(R.Ap, j + 1u);
+            for (unsigned k = a; k < e; k++)
+                acc = fma(cpgw::gld((const double *)B.A, k), w[(unsigned)F.n + (unsigned)cpgw::gld(R.Ai, k)], acc);
+        }
+        return acc;
+    }
+};
+
+template <int NSX, int NSZ>
+CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const DevSettings &S,
+                                const DevBatch &Bt, double *lds, int wave_global) {
+    const int lane = cpgw::lane_id();
+    const unsigned n = (unsigned)F0.n, m = (unsigned)F0.m, N = n + m;
+    const int ldw = R.sol_slots;
+    double *w = lds + (size_t)cpgw::wave_in_block() * ldw;
+    const InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F0, R);
+    const double rho_eq = 1e3 * F0.rho, rho_in = F0.rho, rho_fr = 1e-6;
+    const double ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in, ri_fr = 1.0 / rho_fr;
+    unsigned short fpx[NSX], fpz[NSZ];
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; fpx[s] = i < n ? cpgw::gld(R.sol_fpos, i) : 0; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; fpz[s] = i < m ? cpgw::gld(R.sol_fpos, n + i) : 0; }
+
+    for (;;) {
+        unsigned ig = 0;
+        if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
+        ig = (unsigned)cpgw::read_first_lane((int)ig);
+        if ((long long)ig >= Bt.B) break;
+        const long long b = (long long)ig;
+        const double *theta = Bt.theta + (size_t)b * R.np_var;
+
+        // ---- 1. canonicalise (unscaled): P, A values, q, u, d
+        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) cpgw::gst(B.A, k, csr_row(R.map_A, k, theta, cpgw::gld(R.A_base, k)));
+        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) cpgw::gst(B.P, k, csr_row(R.map_P, k, theta, cpgw::gld(R.P_base, k)));
+        for (unsigned i = (unsigned)lane; i < n; i += 64u) cpgw::gst(B.q, i, csr_row(R.map_q, i, theta, cpgw::gld(R.q_base, i)));
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) cpgw::gst(B.u, i, csr_row(R.map_u, i, theta, cpgw::gld(R.u_base, i)));
+        const double dconst = csr_row(R.map_d, 0, theta, R.d_base);
+        cpgw::mem_order();
+
+        // ---- 2. Ruiz equilibration from scratch (D in w[0..n), E in w[n..N), cumulative form)
+        double cs = 1.0;
+        for (unsigned i = (unsigned)lane; i < N; i += 64u) w[i] = 1.0;
+        cpgw::lds_order();
+#pragma nounroll
+        for (int it = 0; it < R.scaling_iters; it++) {
+            double dn[NSX], en[NSZ];
+#pragma unroll
+            for (int s = 0; s < NSX; s++) {
+                const unsigned j = (unsigned)lane + 64u * (unsigned)s;
+                double acc = 0.0;
+                if (j < n) {
+                    const double dj = w[j];
+                    unsigned a = (unsigned)cpgw::gld(R.Prp, j), e = (unsigned)cpgw::gld(R.Prp, j + 1u);
+                    for (unsigned k = a; k < e; k++)
+                        acc = cpgw::dmax2(acc, fabs(cs * dj * cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)) * w[(unsigned)cpgw::gld(R.Pcol, k)]));
+                    a = (unsigned)cpgw::gld(R.Ap, j); e = (unsigned)cpgw::gld(R.Ap, j + 1u);
+                    for (unsigned k = a; k < e; k++)
+                        acc = cpgw::dmax2(acc, fabs(w[n + (unsigned)cpgw::gld(R.Ai, k)] * cpgw::gld((const double *)B.A, k) * dj));
+                }
+                dn[s] = acc;
+            }
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) {
+                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                double acc = 0.0;
+                if (i < m) {
+                    const double ei = w[n + i];
+                    const unsigned a = (unsigned)cpgw::gld(R.Arp, i), e = (unsigned)cpgw::gld(R.Arp, i + 1u);
+                    for (unsigned k = a; k < e; k++)
+                        acc = cpgw::dmax2(acc, fabs(ei * cpgw::gld((const double *)B.A, (unsigned)cpgw::gld(R.Aent, k)) * w[(unsigned)cpgw::gld(R.Acol, k)]));
+                }
+                en[s] = acc;
+            }
+            cpgw::lds_order();
+#pragma unroll
+            for (int s = 0; s < NSX; s++) { const unsigned j = (unsigned)lane + 64u * (unsigned)s; if (j < n) w[j] = w[j] * (1.0 / sqrt(lim_scaling(dn[s]))); }
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < m) w[n + i] = w[n + i] * (1.0 / sqrt(lim_scaling(en[s]))); }
+            cpgw::lds_order();
+            // cost scaling: mean column norm of the scaled P against ||q||_inf
+            double psum = 0.0, qn = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSX; s++) {
+                const unsigned j = (unsigned)lane + 64u * (unsigned)s;
+                if (j < n) {
+                    const double dj = w[j];
+                    double acc = 0.0;
+                    const unsigned a = (unsigned)cpgw::gld(R.Prp, j), e = (unsigned)cpgw::gld(R.Prp, j + 1u);
+                    for (unsigned k = a; k < e; k++)
+                        acc = cpgw::dmax2(acc, fabs(cs * dj * cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)) * w[(unsigned)cpgw::gld(R.Pcol, k)]));
+                    psum += acc;
+                    qn = cpgw::dmax2(qn, fabs(cs * dj * cpgw::gld((const double *)B.q, j)));
+                }
+            }
+            psum = cpgw::wave_sum(psum);
+            qn = lim_scaling(cpgw::wave_max_nonneg(qn));
+            const double cm = n ? psum / (double)n : 0.0;
+            cs = cs * (1.0 / lim_scaling(cpgw::dmax2(cm, qn)));
+        }
+        // ---- 3. scaled data, row classes, step sizes
+        for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+            const double dj = w[j];
+            cpgw::gst(B.D, j, dj); cpgw::gst(B.Dinv, j, 1.0 / dj);
+            cpgw::gst(B.q, j, cs * dj * cpgw::gld((const double *)B.q, j));
+            unsigned a = (unsigned)cpgw::gld(R.Ap, j), e = (unsigned)cpgw::gld(R.Ap, j + 1u);
+            for (unsigned k = a; k < e; k++) cpgw::gst(B.A, k, w[n + (unsigned)cpgw::gld(R.Ai, k)] * cpgw::gld((const double *)B.A, k) * dj);
+            a = (unsigned)cpgw::gld(R.Pp, j); e = (unsigned)cpgw::gld(R.Pp, j + 1u);
+            for (unsigned k = a; k < e; k++) cpgw::gst(B.P, k, cs * w[(unsigned)cpgw::gld(R.Pi, k)] * cpgw::gld((const double *)B.P, k) * dj);
+        }
+        signed char ct[NSZ];
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            ct[s] = 0;
+            if (i < m) {
+                const double ei = w[n + i];
+                const double uu = ei * cpgw::gld((const double *)B.u, i);
+                cpgw::gst(B.E, i, ei); cpgw::gst(B.Einv, i, 1.0 / ei); cpgw::gst(B.u, i, uu);
+                // equality rows (l = u) are the first n_eq rows of the canonical form
+                ct[s] = i < (unsigned)R.n_eq ? 1 : (uu > CPG_INFTY * CPG_MIN_SCALING ? -1 : 0);
+                cpgw::gst(B.rinv, i, ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr));
+            }
+        }
+        cpgw::lds_order();
+        cpgw::mem_order();
+
+        // ---- 4. numeric LDL' through the dot-product schedule (levels of the elimination tree)
+        {
+            int level_start = 0;
+#pragma nounroll
+            for (int c = 0; c < R.fac_chunks; c++) {
+                const int L = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c));
+                const int last = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 1u));
+                unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 2u));
+                const unsigned task = cpgw::gld(R.fac_task, (unsigned)c * 64u + (unsigned)lane);
+                const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
+                double acc = 0.0;
+#pragma nounroll
+                for (int s = 0; s < L; s++) {
+                    const bool act = s < len;
+                    if (act) {
+                        const unsigned e = base + (unsigned)lane;
+                        const double la = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_a, e));
+                        const double lb = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_b, e));
+                        const double dk = cpgw::gld((const double *)B.Dg, cpgw::gld(R.fac_k, e));
+                        acc = fma(la * dk, lb, acc);
+                    }
+                    base += cpgw::popc64(cpgw::ballot(act));
+                }
+                if (task != 0xFFFFFFFFu) {
+                    const int kind = cpgw::gld(R.ksrc_kind, task);
+                    const unsigned idx = (unsigned)cpgw::gld(R.ksrc_idx, task);
+                    const bool piv = task >= (unsigned)R.nnzL;
+                    double kv = 0.0;
+                    if (kind == CPG_K_P) kv = cpgw::gld((const double *)B.P, idx) + (piv ? F0.sigma : 0.0);
+                    else if (kind == CPG_K_A) kv = cpgw::gld((const double *)B.A, idx);
+                    else if (kind == CPG_K_SIGMA) kv = F0.sigma;
+                    else if (kind == CPG_K_RHO) kv = -cpgw::gld((const double *)B.rinv, idx);
+                    const double v = kv - acc;
+                    if (piv) { cpgw::gst(B.Dg, task - (unsigned)R.nnzL, v); cpgw::gst(B.Dginv, task - (unsigned)R.nnzL, 1.0 / v); }
+                    else cpgw::gst(B.Lx, task, v);
+                }
+                if (last) {   // level complete: divide the new columns by their pivots
+                    cpgw::mem_order();
+#pragma nounroll
+                    for (int c2 = level_start; c2 <= c; c2++) {
+                        const unsigned t2 = cpgw::gld(R.fac_task, (unsigned)c2 * 64u + (unsigned)lane);
+                        if (t2 < (unsigned)R.nnzL)
+                            cpgw::gst(B.Lx, t2, cpgw::gld((const double *)B.Lx, t2) * cpgw::gld((const double *)B.Dginv, (unsigned)cpgw::gld(R.Lcol, t2)));
+                    }
+                    cpgw::mem_order();
+                    level_start = c + 1;
+                }
+            }
+        }
+        // ---- 5. coefficients of the substitution program
+        for (unsigned e = (unsigned)lane; e < (unsigned)R.sol_nnz; e += 64u) {
+            const int kind = cpgw::gld(R.sol_kind, e);
+            const unsigned idx = (unsigned)cpgw::gld(R.sol_idx, e);
+            double v = 0.0;
+            if (kind == 1) v = 1.0;
+            else if (kind == 2) v = -cpgw::gld((const double *)B.Lx, idx);
+            else if (kind == 3) v = cpgw::gld((const double *)B.Dginv, idx);
+            cpgw::gst(B.sv, e, v);
+        }
+        cpgw::mem_order();
+
+        // ---- 6. ADMM from cold start with the instance's own factor
+        DevFamily F = F0;
+        F.D = B.D; F.Dinv = B.Dinv; F.E = B.E; F.Einv = B.Einv; F.c = cs; F.cinv = 1.0 / cs;
+        LdsProg SP;
+        SP.ctab = R.sol_ctab; SP.desc = R.sol_desc; SP.vals = B.sv; SP.cols = R.sol_cols;
+        SP.n_chunks = R.sol_chunks; SP.dummy = (unsigned)R.sol_nnz - 1u; SP.rows16 = nullptr;
+        const InstCtx<NSX, NSZ> cx{F, R, B, w, lane};
+        double x[NSX], z[NSZ], y[NSZ];
+#pragma unroll
+        for (int s = 0; s < NSX; s++) x[s] = 0.0;
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) { z[s] = 0.0; y[s] = 0.0; }
+        CheckOut o;
+        o.prim_res = 0; o.dual_res = 0; o.obj = 0; o.status = 11;
+        int iter = 0;
+#pragma nounroll
+        while (o.status == 11) {
+            if (iter >= S.max_iter) { o.status = 7; break; }
+            iter++;
+            const bool chk = (S.check_termination > 0 && iter % S.check_termination == 0) || iter >= S.max_iter;
+#pragma unroll
+            for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < n) w[i] = F.sigma * x[s] - cx.q(s, i); }
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) {
+                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+                if (i < m) w[n + i] = z[s] - ri * y[s];
+            }
+            cpgw::lds_order();
+            run_program_lds<1>(SP, w, ldw, lane);
+#pragma unroll
+            for (int s = 0; s < NSX; s++) {
+                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                if (i < n) {
+                    const double xn = F.alpha * w[fpx[s]] + (1.0 - F.alpha) * x[s];
+                    if (chk) cpgw::gst(B.sdx, i, xn - x[s]);
+                    x[s] = xn;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) {
+                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                if (i < m) {
+                    const double rv = ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr);
+                    const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+                    const double zp = z[s], yp = y[s];
+                    const double zt = (zp - ri * yp) + ri * w[fpz[s]];
+                    const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
+                    const double uu = cx.u(s, i);
+                    const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
+                    const double dyv = rv * (zr - zn);
+                    z[s] = zn; y[s] = yp + dyv;
+                    if (chk) cpgw::gst(B.sdy, i, dyv);
+                }
+            }
+            cpgw::lds_order();
+            if (chk) {
+                cpgw::mem_order();
+#pragma nounroll
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
+                    o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, w, B.sdx, B.sdy, lane, pass == 1);
+                }
+                if (o.status == 11 && iter >= S.max_iter) o.status = 7;
+            }
+        }
+        finalize<NSX, NSZ>(F, Bt, x, y, dconst, b, w, lane, iter, o);
+    }
+}
+
+}  // namespace cpg

@@ -51,6 +51,12 @@ CPG_DEV double read_lane(double v, int lane) {   // `lane` must be wave-uniform
 CPG_DEV double shfl_down(double v, int delta) { return __shfl_down(v, delta, 64); }
 CPG_DEV int read_first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 CPG_DEV bool wave_any(bool p) { return __any(p) != 0; }
+// orders GLOBAL stores and loads of one wavefront among its own lanes (per-wavefront buffers:
+// written by some lanes, read by others later); the CU's L1 is coherent for its own traffic
+CPG_DEV void mem_order() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 CPG_DEV unsigned long long ballot(bool p) { return __ballot(p); }
 // number of set bits of `mask` below this lane
 CPG_DEV unsigned mbcnt(unsigned long long mask) {
@@ -150,6 +156,7 @@ inline bool wave_any(bool p) {
 inline unsigned atomic_next(unsigned *ctr) {
     return __atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED);
 }
+inline void mem_order() { wave_sync(); }
 inline unsigned long long ballot(bool p) {
     SimWave *w = tls.wv;
     w->ixch[tls.lane] = p ? 1 : 0;

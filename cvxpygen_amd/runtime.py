@@ -69,6 +69,22 @@ class _Family(C.Structure):
                 ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip)]
 
 
+class _Refactor(C.Structure):
+    _fields_ = [('nnzP', C.c_int32), ('nnzA', C.c_int32), ('nnzL', C.c_int32), ('scaling_iters', C.c_int32),
+                ('Ap', _ip), ('Ai', _ip), ('Arp', _ip), ('Aent', _ip), ('Acol', _ip),
+                ('Pp', _ip), ('Pi', _ip), ('Prp', _ip), ('Pent', _ip), ('Pcol', _ip),
+                ('Lcol', _ip), ('ksrc_kind', _ip), ('ksrc_idx', _ip),
+                ('fac_chunks', C.c_int32), ('fac_triples', C.c_int32), ('fac_ctab', _ip),
+                ('fac_task', C.POINTER(C.c_uint32)), ('fac_len', C.POINTER(C.c_uint32)),
+                ('fac_a', C.POINTER(C.c_uint32)), ('fac_b', C.POINTER(C.c_uint32)), ('fac_k', C.POINTER(C.c_uint32)),
+                ('sol_chunks', C.c_int32), ('sol_nnz', C.c_int32), ('sol_slots', C.c_int32),
+                ('sol_ctab', _ip), ('sol_desc', C.POINTER(C.c_uint32)), ('sol_cols', _u16p),
+                ('sol_kind', _ip), ('sol_idx', _ip), ('sol_fpos', _u16p),
+                ('np_var', C.c_int32), ('P_base', _dp), ('A_base', _dp), ('q_base', _dp), ('u_base', _dp),
+                ('d_base', C.c_double),
+                ('map_P', _Csr), ('map_A', _Csr), ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr)]
+
+
 class _Update(C.Structure):
     _fields_ = [('np_var', C.c_int32), ('q_base', _dp), ('u_base', _dp), ('d_base', C.c_double),
                 ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr)]
@@ -83,7 +99,7 @@ class CpgLibrary:
 
     SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_destroy', 'cpg_hip_last_error',
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
-               'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_solve_batch',
+               'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_solve_batch',
                'cpg_hip_solve_batch_device', 'cpg_hip_synchronize', 'cpg_hip_last_kernel_ms',
                'cpg_hip_set_launch', 'cpg_hip_set_program_placement', 'cpg_hip_malloc', 'cpg_hip_free', 'cpg_hip_memcpy_h2d',
                'cpg_hip_memcpy_d2h']
@@ -107,6 +123,7 @@ class CpgLibrary:
         L.cpg_hip_set_setting.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.cpg_hip_get_setting.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.cpg_hip_set_update.argtypes = [C.c_void_p, C.POINTER(_Update)]
+        L.cpg_hip_set_refactor.argtypes = [C.c_void_p, C.POINTER(_Refactor)]
         L.cpg_hip_solve_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
         L.cpg_hip_solve_batch_device.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
         L.cpg_hip_synchronize.argtypes = [C.c_void_p]
@@ -290,13 +307,95 @@ class BatchSolver:
             n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip))
         self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), device, C.byref(self.h)),
                        'cpg_hip_create_osqp')
+        self.device = device
+        self.h_shared = self.h
+        self.h_ref = C.c_void_p()          # canonical-order handle of the refactorisation path
+        self._rplan = None
         self.np_var = 0
         self._var_cols = np.zeros(0, dtype=np.int64)
 
     def close(self):
-        if getattr(self, 'h', None) and self.h.value:
-            self.lib.L.cpg_hip_destroy(self.h)
-            self.h = C.c_void_p()
+        for name in ('h_shared', 'h_ref'):
+            hh = getattr(self, name, None)
+            if hh is not None and hh.value:
+                self.lib.L.cpg_hip_destroy(hh)
+                setattr(self, name, C.c_void_p())
+        self.h = C.c_void_p()
+
+    def _ensure_refactor_handle(self):
+        """second handle in canonical ordering (no device permutation) carrying the structural
+        tables of the per-instance refactorisation path"""
+        if self.h_ref.value:
+            return
+        from . import refactor_plan as _rp
+        desc, o = self.desc, self.plan.osqp
+        self._rplan = _rp.build_refactor_plan(desc.P, desc.A, o)
+        keep = self._keep
+        n, m = desc.n_var, desc.m
+        ones_n, ones_m = np.ones(n), np.ones(m)
+        ctype = np.ascontiguousarray(o.constr_type, dtype=np.int8)
+        fpos = np.ascontiguousarray(self._rplan.sol.final_pos, dtype=np.uint16)
+        prim_idx = np.ascontiguousarray(np.concatenate([v.indices for v in desc.variables]), dtype=np.int32) \
+            if desc.variables else np.zeros(0, dtype=np.int32)
+        dual_idx = np.ascontiguousarray(np.concatenate([d.indices for d in desc.duals]), dtype=np.int32) \
+            if desc.duals else np.zeros(0, dtype=np.int32)
+        keep += [ones_n, ones_m, ctype, fpos, prim_idx, dual_idx]
+        empty = _Program(0, 0, None, None, None, None)
+        fam = _Family(
+            n=n, m=m, n_eq=desc.n_eq, is_maximization=int(desc.is_maximization),
+            sigma=o.settings['sigma'], alpha=o.settings['alpha'], rho=o.settings['rho'],
+            D=_d(ones_n), E=_d(ones_m), c=1.0, ctype=ctype.ctypes.data_as(_i8p),
+            n_slots=self._rplan.sol.n_slots, fpos=fpos.ctypes.data_as(_u16p), n_vary_x=n, n_vary_z=m,
+            kkt=empty, A_rows=empty, P_rows=empty, At_rows=empty,
+            kkt_ragged=_Ragged(0, 0, None, None, None, None),
+            n_prim=len(prim_idx), prim_idx=prim_idx.ctypes.data_as(_ip),
+            n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip))
+        self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), self.device, C.byref(self.h_ref)),
+                       'cpg_hip_create_osqp (refactor handle)')
+
+    def _set_refactor(self, cols: np.ndarray, th_fixed: np.ndarray):
+        self._ensure_refactor_handle()
+        desc, rp, o = self.desc, self._rplan, self.plan.osqp
+        keep: list = []
+
+        def split(pid, clip=False):
+            Cm = sp.csr_matrix(desc.maps[pid])
+            base = np.asarray(Cm @ th_fixed).ravel()
+            if clip:
+                base = np.clip(base, -CPG_INF, CPG_INF)
+            Mv = sp.csr_matrix(Cm[:, cols]) if len(cols) else sp.csr_matrix((Cm.shape[0], 0))
+            base = np.ascontiguousarray(base)
+            keep.append(base)
+            return base, _csr_struct(Mv, keep)
+
+        Pb, MP = split('P'); Ab, MA = split('A'); qb, Mq = split('q'); ub, Mu = split('u', clip=True)
+        Cd = sp.csr_matrix(desc.maps['d'])
+        d_base = float((Cd @ th_fixed)[0]) if desc.nonzero_d else 0.0
+        Md = _csr_struct(sp.csr_matrix(Cd[:, cols]) if (len(cols) and desc.nonzero_d)
+                         else sp.csr_matrix((1, len(cols))), keep)
+
+        def i32(a):
+            a = np.ascontiguousarray(a, dtype=np.int32); keep.append(a); return a.ctypes.data_as(_ip)
+
+        def u32(a):
+            a = np.ascontiguousarray(a, dtype=np.uint32); keep.append(a); return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+        def u16(a):
+            a = np.ascontiguousarray(a, dtype=np.uint16); keep.append(a); return a.ctypes.data_as(_u16p)
+        rf = _Refactor(
+            nnzP=rp.nnzP, nnzA=rp.nnzA, nnzL=rp.nnzL, scaling_iters=int(o.settings['scaling']),
+            Ap=i32(rp.Ap), Ai=i32(rp.Ai), Arp=i32(rp.Arp), Aent=i32(rp.Aent), Acol=i32(rp.Acol),
+            Pp=i32(rp.Pp), Pi=i32(rp.Pi), Prp=i32(rp.Prp), Pent=i32(rp.Pent), Pcol=i32(rp.Pcol),
+            Lcol=i32(rp.Lcol), ksrc_kind=i32(rp.ksrc_kind), ksrc_idx=i32(rp.ksrc_idx),
+            fac_chunks=rp.fac.n_chunks, fac_triples=len(rp.fac_a), fac_ctab=i32(rp.fac.ctab),
+            fac_task=u32(rp.fac.task), fac_len=u32(rp.fac.tlen), fac_a=u32(rp.fac_a), fac_b=u32(rp.fac_b),
+            fac_k=u32(rp.fac_k), sol_chunks=rp.sol.n_chunks, sol_nnz=rp.sol.nnz, sol_slots=rp.sol.n_slots,
+            sol_ctab=i32(rp.sol.ctab), sol_desc=u32(rp.sol.desc), sol_cols=u16(rp.sol.cols),
+            sol_kind=i32(rp.sol_kind), sol_idx=i32(rp.sol_idx), sol_fpos=u16(rp.sol.final_pos),
+            np_var=len(cols), P_base=_d(Pb), A_base=_d(Ab), q_base=_d(qb), u_base=_d(ub), d_base=d_base,
+            map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md)
+        self.lib.check(self.lib.L.cpg_hip_set_refactor(self.h_ref, C.byref(rf)), 'cpg_hip_set_refactor')
+        self._refactor_keep = keep
 
     def __del__(self):
         try:
@@ -341,16 +440,21 @@ class BatchSolver:
         touched = set()
         for nm in names:
             touched.update(dep[nm])
-        if touched & {'P', 'A'}:
-            raise NotImplementedError(
-                'parameters entering P or A need the per-instance refactorisation path '
-                f'(updated: {sorted(touched & {"P", "A"})})')
         cols = np.concatenate([np.arange(desc.param(nm).col, desc.param(nm).col + desc.param(nm).size)
                                for nm in names]).astype(np.int64) if names else np.zeros(0, np.int64)
         NP = desc.NP
         fixed = np.ones(NP + 1, dtype=bool)
         fixed[cols] = False
         th_fixed = np.where(fixed, desc.theta0, 0.0)
+        if touched & {'P', 'A'}:
+            # a parameter enters P or A: per-instance equilibration + refactorisation path
+            self._set_refactor(cols, th_fixed)
+            self.h = self.h_ref
+            self._update_key, self._update_keep = key, []
+            self._var_cols, self.np_var = cols, len(cols)
+            self._updated_names = names
+            return
+        self.h = self.h_shared
         keep: list = []
 
         def split(pid, scale, order, clip):

@@ -127,6 +127,36 @@ typedef struct {
     cpg_csr_t map_q, map_u, map_d;
 } cpg_osqp_update_t;
 
+/* Per-instance refactorisation path (parameters entering P or A): shared structural tables built by
+ * cvxpygen_amd/refactor_plan.py + the UNSCALED canonicalisation of every canonical parameter over
+ * the updated user parameters.  Replaces, for a batch, the reference's
+ * cpg_canonicalize_P/_A + osqp_update_data_mat + osqp_update_data_vec (solvers/osqp.py:20-61).
+ * Canonical (not device) ordering throughout. */
+typedef struct {
+    int32_t nnzP, nnzA, nnzL, scaling_iters;
+    /* equilibration views */
+    const int32_t *Ap, *Ai;             /* A in CSC */
+    const int32_t *Arp, *Aent, *Acol;   /* row view of A: entry index into CSC order, column */
+    const int32_t *Pp, *Pi;             /* upper-triangular P in CSC */
+    const int32_t *Prp, *Pent, *Pcol;   /* full symmetric row view of P */
+    /* factor */
+    const int32_t *Lcol;                /* [nnzL] column of every entry of L */
+    const int32_t *ksrc_kind, *ksrc_idx;/* [nnzL + n + m] where the KKT value of a destination comes from */
+    int32_t fac_chunks, fac_triples;
+    const int32_t *fac_ctab;            /* [fac_chunks][4]: max len, last-of-level, first triple, #tasks */
+    const uint32_t *fac_task, *fac_len; /* [fac_chunks][64] */
+    const uint32_t *fac_a, *fac_b, *fac_k; /* [fac_triples]: positions of L_ik, L_jk and column k */
+    /* substitution program (ragged layout), value sources instead of values */
+    int32_t sol_chunks, sol_nnz, sol_slots;
+    const int32_t *sol_ctab; const uint32_t *sol_desc; const uint16_t *sol_cols;
+    const int32_t *sol_kind, *sol_idx;  /* [sol_nnz]: 0 zero, 1 one, 2 -L[idx], 3 1/d[idx] */
+    const uint16_t *sol_fpos;           /* [n + m] */
+    /* canonicalisation over theta_var (unscaled) */
+    int32_t np_var;
+    const double *P_base, *A_base, *q_base, *u_base; double d_base;
+    cpg_csr_t map_P, map_A, map_q, map_u, map_d;
+} cpg_osqp_refactor_t;
+
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 int cpg_hip_device_count(int *count);
 int cpg_hip_create_osqp(const cpg_osqp_family_t *family, int device, cpg_handle_t *out);
@@ -141,6 +171,10 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *value);
 
 /* ---- which parameters are updated (sticky until changed) -------------------------------------- */
 int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *upd);
+
+/* per-instance refactorisation path; after this call solves go through it until cpg_hip_set_update
+ * is called again */
+int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *rf);
 
 /* ---- solve ---------------------------------------------------------------------------------- */
 /* Host buffers: theta_var [B][np_var]; outputs prim [B][n_prim], dual [B][n_dual], obj/pri_res/

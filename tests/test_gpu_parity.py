@@ -148,3 +148,23 @@ def test_generated_family_library_vs_oracle(oracle_lib, tmp_path):
         r = bs.solve({'x_init': x0}, updated_params=['x_init'])
         _check(r, oracle_lib.cpg_solve_batch(d, _theta(d, 'x_init', x0), ['x_init']), d)
         bs.close()
+
+
+@pytest.mark.parametrize('make,B', [(lambda: families.nonneg_ls(10, 5, sparsity=None, seed=0), 200),
+                                    (lambda: families.mpc(6, 3, 10, sparse_params=True, terminal_index=9, const=1.0), 96),
+                                    (lambda: families.mpc(6, 3, 10), 64),
+                                    (lambda: families.mpc(12, 4, 10), 48)])
+def test_refactor_path_vs_oracle(oracle_lib, make, B):
+    """every parameter varies per instance (matrices included): reference osqp_update_data_mat path"""
+    d = make()
+    rng = np.random.default_rng(17)
+    th = np.tile(d.theta0, (B, 1))
+    th[:, :d.NP] *= 1 + 0.1 * rng.standard_normal((B, d.NP))
+    if 'x_init' in d.param_names:
+        p = d.param('x_init')
+        th[:, p.col:p.col + p.size] = -2 + 4 * rng.random((B, p.size))
+    bs = BatchSolver(d)
+    vals = {p.name: th[:, p.col:p.col + p.size] for p in d.params}
+    r = bs.solve(vals)
+    _check(r, oracle_lib.cpg_solve_batch(d, th, None), d)
+    bs.close()

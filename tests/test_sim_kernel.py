@@ -102,8 +102,6 @@ def test_settings_and_errors(sim_lib):
         bs.solve({'b': np.zeros((1, 3))}, updated_params=['b'], polish=True)       # disabled setting
     with pytest.raises(AttributeError, match='is not a parameter'):
         bs.solve({'b': np.zeros((1, 3))}, updated_params=['nope'])
-    with pytest.raises(NotImplementedError):
-        bs.set_updated(['A'])                 # matrix parameters need the refactor path
     bs.solve({'b': np.ones((1, 3))}, updated_params=['b'], warm_start=False)     # cvxpy alias accepted
     bs.close()
 
@@ -129,3 +127,23 @@ def test_generated_executor_parity(oracle_lib, tmp_path, fam, G):
     other = families.toy_box()
     with pytest.raises(RuntimeError, match='different problem family'):
         BatchSolver(other, lib_path=lib)
+
+
+def test_refactor_path_all_parameters(sim_lib, oracle_lib):
+    """parameters entering A: per-instance canonicalisation, Ruiz equilibration from scratch, numeric
+    LDL' and ADMM with the instance's own factor (reference: osqp_update_data_mat)"""
+    d = families.nonneg_ls()
+    rng = np.random.default_rng(0)
+    B = 3
+    th = np.tile(d.theta0, (B, 1))
+    th[:, :d.NP] *= 1 + 0.1 * rng.standard_normal((B, d.NP))
+    bs = BatchSolver(d, lib_path=sim_lib)
+    vals = {p.name: th[:, p.col:p.col + p.size] for p in d.params}
+    r = bs.solve(vals)                                  # updated_params=None: every parameter
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
+    _assert_parity(r, o, prim, dual)
+    # switching back to a vector-only update uses the shared factor again
+    r2 = bs.solve({'b': th[:, 3:6]}, updated_params=['b'])
+    o2, prim2, dual2 = _oracle_flat(oracle_lib, d, _theta(d, 'b', th[:, 3:6]), ['b'])
+    _assert_parity(r2, o2, prim2, dual2)
+    bs.close()
