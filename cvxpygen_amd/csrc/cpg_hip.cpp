@@ -60,6 +60,10 @@ struct cpg_solver_s {
     cpg::DevRefactor R{};
     bool refactor_mode = false;
     std::vector<void *> refactor_owned;
+    cpg::DevGradient Gd{};
+    bool have_gradient = false;
+    std::vector<void *> gradient_owned;
+    DevBuf g_theta, g_x, g_y, g_dprim, g_dtheta;
     cpg::DevSettings S{};
     int warm_starting = 1;              // accepted for API parity; a batch is always cold-started
     int waves_per_block = 0, inst_per_wave = 1, blocks_per_cu = 0;
@@ -254,6 +258,55 @@ static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks
 #ifndef CPG_KERNELS_REFACTOR
 #define CPG_KERNELS_REFACTOR(Z) Z(1, 1) Z(4, 4) Z(8, 8) Z(16, 16)
 #endif
+#ifndef CPG_HOST_SIM
+template <int NSX, int NSZ>
+__global__ void __launch_bounds__(256, 2)
+osqp_gradient_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevGradient Gd, cpg::DevGradBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cpg::osqp_gradient_body<NSX, NSZ>(F, R, Gd, Bt, cpg_lds, wave_global);
+}
+template <int NSX, int NSZ>
+static int launch_gradient_t(cpg_handle_t h, const cpg::DevGradBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = osqp_gradient_kernel<NSX, NSZ>;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->F, h->R, h->Gd, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#else
+template <int NSX, int NSZ>
+static int launch_gradient_t(cpg_handle_t h, const cpg::DevGradBatch &Bt, int blocks, int waves, size_t lds) {
+    for (int b = 0; b < blocks; b++) {
+        std::vector<char> ldsbuf(lds + 64);
+        std::vector<cpgw::SimWave> wv(waves);
+        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
+        pthread_barrier_t block_bar;
+        pthread_barrier_init(&block_bar, nullptr, waves * 64);
+        std::vector<std::thread> th;
+        for (int t = 0; t < waves * 64; t++)
+            th.emplace_back([&, t]() {
+                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
+                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
+                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
+                cpg::osqp_gradient_body<NSX, NSZ>(h->F, h->R, h->Gd, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
+            });
+        for (auto &t : th) t.join();
+        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
+        pthread_barrier_destroy(&block_bar);
+    }
+    return CPG_OK;
+}
+#endif
+static int launch_gradient(cpg_handle_t h, const cpg::DevGradBatch &Bt, int blocks, int waves, size_t lds) {
+    const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
+#define Z(a, b) if (nsx <= a && nsz <= b) return launch_gradient_t<a, b>(h, Bt, blocks, waves, lds);
+    CPG_KERNELS_REFACTOR(Z)
+#undef Z
+    set_error("problem family larger than the largest compiled slot class");
+    return CPG_E_UNSUPPORTED;
+}
 static int launch_refactor(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
     const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
 #define Z(a, b) if (nsx <= a && nsz <= b) return launch_refactor_t<a, b>(h, Bt, blocks, waves, lds);
@@ -444,6 +497,7 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     return CPG_OK;
 }
 
+static int ensure(DevBuf &b, size_t bytes);
 static void free_list(std::vector<void *> &v) { for (void *p : v) rt_free(p); v.clear(); }
 static void free_buf(DevBuf &b) { if (b.p) rt_free(b.p); b.p = nullptr; b.bytes = 0; }
 
@@ -451,7 +505,8 @@ int cpg_hip_destroy(cpg_handle_t h) {
     if (!h) return CPG_OK;
     rt_set_device(h->device);
     rt_sync(h);
-    free_list(h->owned); free_list(h->update_owned); free_list(h->refactor_owned);
+    free_list(h->owned); free_list(h->update_owned); free_list(h->refactor_owned); free_list(h->gradient_owned);
+    free_buf(h->g_theta); free_buf(h->g_x); free_buf(h->g_y); free_buf(h->g_dprim); free_buf(h->g_dtheta);
     if (h->d_counter) rt_free(h->d_counter);
     free_buf(h->scratch);
     free_buf(h->s_theta); free_buf(h->s_prim); free_buf(h->s_dual); free_buf(h->s_obj);
@@ -527,6 +582,72 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     h->refactor_mode = true;
     h->have_update = true;
     return CPG_OK;
+}
+
+int cpg_hip_set_gradient(cpg_handle_t h, const cpg_osqp_gradient_t *g) {
+    if (!h || !g) { set_error("null argument"); return CPG_E_BADARG; }
+    if (!h->refactor_mode && h->refactor_owned.empty()) { set_error("cpg_hip_set_refactor must be called first"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    if ((rc = rt_sync(h))) return rc;
+    free_list(h->gradient_owned);
+    std::vector<void *> &own = h->gradient_owned;
+    h->Gd.NP = g->NP;
+    const size_t nt = (size_t)g->tptr[g->NP];
+    if ((rc = upload<int>(h, own, g->Pcolidx, h->R.nnzP, &h->Gd.Pcolidx))) return rc;
+    if ((rc = upload<int>(h, own, g->Acolidx, h->R.nnzA, &h->Gd.Acolidx))) return rc;
+    if ((rc = upload<int>(h, own, g->tptr, (size_t)g->NP + 1, &h->Gd.tptr))) return rc;
+    if ((rc = upload<int>(h, own, g->tkind, nt, &h->Gd.tkind))) return rc;
+    if ((rc = upload<int>(h, own, g->tidx, nt, &h->Gd.tidx))) return rc;
+    if ((rc = upload<double>(h, own, g->tcoef, nt, &h->Gd.tcoef))) return rc;
+    if ((rc = rt_sync(h))) return rc;
+    h->have_gradient = true;
+    return CPG_OK;
+}
+
+int cpg_hip_gradient_batch(cpg_handle_t h, int64_t B, const double *theta, const double *sol_x, const double *sol_y,
+                           const double *dx, double *dtheta) {
+    if (!h || !h->have_gradient) { set_error("cpg_hip_set_gradient has not been called"); return CPG_E_BADARG; }
+    if (B < 0 || !sol_x || !sol_y || !dx || !dtheta || (h->R.np_var > 0 && !theta)) { set_error("null buffer"); return CPG_E_BADARG; }
+    if (B == 0) return CPG_OK;
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    const size_t b = (size_t)B, n = h->F.n, m = h->F.m, N = n + m;
+    if ((rc = ensure(h->g_theta, b * h->R.np_var * sizeof(double)))) return rc;
+    if ((rc = ensure(h->g_x, b * n * sizeof(double)))) return rc;
+    if ((rc = ensure(h->g_y, b * m * sizeof(double)))) return rc;
+    if ((rc = ensure(h->g_dprim, b * n * sizeof(double)))) return rc;
+    if ((rc = ensure(h->g_dtheta, b * h->Gd.NP * sizeof(double)))) return rc;
+    if ((rc = rt_h2d(h, h->g_theta.p, theta, b * h->R.np_var * sizeof(double)))) return rc;
+    if ((rc = rt_h2d(h, h->g_x.p, sol_x, b * n * sizeof(double)))) return rc;
+    if ((rc = rt_h2d(h, h->g_y.p, sol_y, b * m * sizeof(double)))) return rc;
+    if ((rc = rt_h2d(h, h->g_dprim.p, dx, b * n * sizeof(double)))) return rc;
+    const int W = 4;
+    const size_t per_wave = (size_t)h->R.sol_slots + N + n + m + n + m;
+    const size_t lds = (size_t)W * per_wave * sizeof(double);
+    if (lds > h->lds_limit) { set_error("adjoint work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
+    long long blocks = (B + W - 1) / W;
+    int per_cu = (int)(h->lds_limit / lds); if (per_cu > 2) per_cu = 2; if (per_cu < 1) per_cu = 1;
+    const long long cap = (long long)h->num_cu * per_cu;
+    if (blocks > cap) blocks = cap;
+    if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
+    cpg::DevGradBatch Bt;
+    Bt.B = B; Bt.theta = (const double *)h->g_theta.p; Bt.sol_x = (const double *)h->g_x.p;
+    Bt.sol_y = (const double *)h->g_y.p; Bt.dx = (const double *)h->g_dprim.p; Bt.dtheta = (double *)h->g_dtheta.p;
+    Bt.counter = h->d_counter; Bt.scratch = (double *)h->scratch.p;
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
+    RT_CHECK(hipEventRecord(h->ev0, h->stream));
+#else
+    *h->d_counter = 0;
+#endif
+    rc = launch_gradient(h, Bt, (int)blocks, W, lds);
+    if (rc) return rc;
+#ifndef CPG_HOST_SIM
+    RT_CHECK(hipEventRecord(h->ev1, h->stream));
+#endif
+    if ((rc = rt_d2h(h, dtheta, h->g_dtheta.p, b * h->Gd.NP * sizeof(double)))) return rc;
+    return rt_sync(h);
 }
 
 int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, int blocks_per_cu) {

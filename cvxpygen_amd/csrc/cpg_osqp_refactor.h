@@ -358,3 +358,200 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 }
 
 }  // namespace cpg
+
+// =================================================================================================
+// QP adjoint for a batch: cpg_update_d<var> + cpg_gradient() + cpg_osqp_gradient()
+// (cvxpygen/writer.py:222-312, cvxpygen/templates/cpg_osqp_grad_compute.c.jinja2:432-531).
+//
+// The reference keeps one factor of K = [[P + 1e-6 I, A'], [A, -1e-6 I]] and switches constraint
+// rows on / off with rank-one up / down-dates (template :157-324) -- a sequential-reuse trick.  An
+// inactive row leaves exactly "row and column zero, -1 on the diagonal" (template :196-214), so for
+// independent instances the masked matrix is factored directly: its pattern is the pattern of the
+// OSQP KKT matrix, hence the LDL' schedule and substitution program of the refactorisation path are
+// reused with other value sources (1e-6 instead of sigma, -1e-6 / -1 instead of -1/rho, A masked).
+namespace cpg {
+
+struct DevGradient {
+    const int *Pcolidx, *Acolidx;    // column of every stored entry of P / A
+    // transposed canonical maps: for user-parameter column c the contributions (kind, index, coef)
+    const int *tptr, *tkind, *tidx;
+    const double *tcoef;
+    int NP;
+};
+struct DevGradBatch {
+    long long B;
+    const double *theta, *sol_x, *sol_y, *dx;    // dx: upstream gradient scattered to canonical x [B][n]
+    double *dtheta;
+    unsigned *counter;
+    double *scratch;
+};
+#define CPG_G_Q 0
+#define CPG_G_L 1
+#define CPG_G_U 2
+#define CPG_G_P 3
+#define CPG_G_A 4
+
+template <int NSX, int NSZ>
+CPG_DEV void osqp_gradient_body(const DevFamily &F, const DevRefactor &R, const DevGradient &Gd,
+                                const DevGradBatch &Bt, double *lds, int wave_global) {
+    const int lane = cpgw::lane_id();
+    const unsigned n = (unsigned)F.n, m = (unsigned)F.m, N = n + m;
+    const int ldw = R.sol_slots;
+    // LDS per wavefront: w | r (N) | x (n) | y (m) | dx (n) | active flags (m)
+    const size_t per_wave = (size_t)ldw + N + n + m + n + m;
+    double *w = lds + (size_t)cpgw::wave_in_block() * per_wave;
+    double *rr = w + ldw, *xs = rr + N, *ys = xs + n, *dxs = ys + m, *act = dxs + n;
+    const InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F, R);
+    const double eps = 1e-6;
+    LdsProg SP;
+    SP.ctab = R.sol_ctab; SP.desc = R.sol_desc; SP.vals = B.sv; SP.cols = R.sol_cols;
+    SP.n_chunks = R.sol_chunks; SP.dummy = (unsigned)R.sol_nnz - 1u; SP.rows16 = nullptr;
+
+    for (;;) {
+        unsigned ig = 0;
+        if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
+        ig = (unsigned)cpgw::read_first_lane((int)ig);
+        if ((long long)ig >= Bt.B) break;
+        const size_t b = (size_t)ig;
+        const double *theta = Bt.theta + b * (size_t)R.np_var;
+        // ---- solution, active set, upstream gradient (cpg_update_d<var>: scatter to canonical x)
+        for (unsigned i = (unsigned)lane; i < n; i += 64u) { xs[i] = cpgw::gld(Bt.sol_x + b * n, i); dxs[i] = cpgw::gld(Bt.dx + b * n, i); }
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+            const double yi = cpgw::gld(Bt.sol_y + b * m, i);
+            ys[i] = yi;
+            const double a = yi < -1e-12 ? -1.0 : (yi > 1e-12 ? 1.0 : 0.0);
+            act[i] = a;
+            cpgw::gst(B.rinv, i, a != 0.0 ? eps : 1.0);
+        }
+        cpgw::lds_order();
+        // ---- canonical P, A of this instance (unscaled); inactive rows of A removed
+        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) {
+            const double v = csr_row(R.map_A, k, theta, cpgw::gld(R.A_base, k));
+            cpgw::gst(B.A, k, act[(unsigned)cpgw::gld(R.Ai, k)] != 0.0 ? v : 0.0);
+        }
+        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) cpgw::gst(B.P, k, csr_row(R.map_P, k, theta, cpgw::gld(R.P_base, k)));
+        cpgw::lds_order();
+        cpgw::mem_order();
+        // ---- numeric LDL' of the masked, regularised KKT matrix
+        {
+            int level_start = 0;
+#pragma nounroll
+            for (int c = 0; c < R.fac_chunks; c++) {
+                const int L = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c));
+                const int last = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 1u));
+                unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 2u));
+                const unsigned task = cpgw::gld(R.fac_task, (unsigned)c * 64u + (unsigned)lane);
+                const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
+                double acc = 0.0;
+#pragma nounroll
+                for (int s = 0; s < L; s++) {
+                    const bool on = s < len;
+                    if (on) {
+                        const unsigned e = base + (unsigned)lane;
+                        const double la = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_a, e));
+                        const double lb = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_b, e));
+                        const double dk = cpgw::gld((const double *)B.Dg, cpgw::gld(R.fac_k, e));
+                        acc = fma(la * dk, lb, acc);
+                    }
+                    base += cpgw::popc64(cpgw::ballot(on));
+                }
+                if (task != 0xFFFFFFFFu) {
+                    const int kind = cpgw::gld(R.ksrc_kind, task);
+                    const unsigned idx = (unsigned)cpgw::gld(R.ksrc_idx, task);
+                    const bool piv = task >= (unsigned)R.nnzL;
+                    double kv = 0.0;
+                    if (kind == CPG_K_P) kv = cpgw::gld((const double *)B.P, idx) + (piv ? eps : 0.0);
+                    else if (kind == CPG_K_A) kv = cpgw::gld((const double *)B.A, idx);
+                    else if (kind == CPG_K_SIGMA) kv = eps;
+                    else if (kind == CPG_K_RHO) kv = -cpgw::gld((const double *)B.rinv, idx);
+                    const double v = kv - acc;
+                    if (piv) { cpgw::gst(B.Dg, task - (unsigned)R.nnzL, v); cpgw::gst(B.Dginv, task - (unsigned)R.nnzL, 1.0 / v); }
+                    else cpgw::gst(B.Lx, task, v);
+                }
+                if (last) {
+                    cpgw::mem_order();
+#pragma nounroll
+                    for (int c2 = level_start; c2 <= c; c2++) {
+                        const unsigned t2 = cpgw::gld(R.fac_task, (unsigned)c2 * 64u + (unsigned)lane);
+                        if (t2 < (unsigned)R.nnzL)
+                            cpgw::gst(B.Lx, t2, cpgw::gld((const double *)B.Lx, t2) * cpgw::gld((const double *)B.Dginv, (unsigned)cpgw::gld(R.Lcol, t2)));
+                    }
+                    cpgw::mem_order();
+                    level_start = c + 1;
+                }
+            }
+        }
+        for (unsigned e = (unsigned)lane; e < (unsigned)R.sol_nnz; e += 64u) {
+            const int kind = cpgw::gld(R.sol_kind, e);
+            const unsigned idx = (unsigned)cpgw::gld(R.sol_idx, e);
+            double v = 0.0;
+            if (kind == 1) v = 1.0;
+            else if (kind == 2) v = -cpgw::gld((const double *)B.Lx, idx);
+            else if (kind == 3) v = cpgw::gld((const double *)B.Dginv, idx);
+            cpgw::gst(B.sv, e, v);
+        }
+        cpgw::mem_order();
+        // ---- r = K^-1 [dx; 0] and three sweeps of refinement against the exact masked KKT matrix
+#pragma nounroll
+        for (int sweep = 0; sweep < 4; sweep++) {
+            if (sweep == 0) {
+                for (unsigned i = (unsigned)lane; i < n; i += 64u) w[i] = dxs[i];
+                for (unsigned i = (unsigned)lane; i < m; i += 64u) w[n + i] = 0.0;
+            } else {
+                // delta = rhs - K_true r, inactive rows / columns skipped (template :460-476)
+                for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                    double d = dxs[j];
+                    unsigned a0 = (unsigned)cpgw::gld(R.Prp, j), e0 = (unsigned)cpgw::gld(R.Prp, j + 1u);
+                    for (unsigned k = a0; k < e0; k++)
+                        d -= cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)) * rr[(unsigned)cpgw::gld(R.Pcol, k)];
+                    a0 = (unsigned)cpgw::gld(R.Ap, j); e0 = (unsigned)cpgw::gld(R.Ap, j + 1u);
+                    for (unsigned k = a0; k < e0; k++)
+                        d -= cpgw::gld((const double *)B.A, k) * rr[n + (unsigned)cpgw::gld(R.Ai, k)];
+                    w[j] = d;
+                }
+                for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+                    double d = 0.0;
+                    if (act[i] != 0.0) {
+                        const unsigned a0 = (unsigned)cpgw::gld(R.Arp, i), e0 = (unsigned)cpgw::gld(R.Arp, i + 1u);
+                        for (unsigned k = a0; k < e0; k++)
+                            d -= cpgw::gld((const double *)B.A, (unsigned)cpgw::gld(R.Aent, k)) * rr[(unsigned)cpgw::gld(R.Acol, k)];
+                    }
+                    w[n + i] = d;
+                }
+            }
+            cpgw::lds_order();
+            run_program_lds<1>(SP, w, ldw, lane);
+            for (unsigned i = (unsigned)lane; i < N; i += 64u) {
+                const double v = w[(unsigned)cpgw::gld(R.sol_fpos, i)];
+                rr[i] = sweep == 0 ? v : rr[i] + v;
+            }
+            cpgw::lds_order();
+        }
+        // ---- canonical gradients and pull-back through the transposed maps (writer.py:268-311)
+        double *out = Bt.dtheta + b * (size_t)Gd.NP;
+        for (unsigned c = (unsigned)lane; c < (unsigned)Gd.NP; c += 64u) {
+            const unsigned a0 = (unsigned)cpgw::gld(Gd.tptr, c), e0 = (unsigned)cpgw::gld(Gd.tptr, c + 1u);
+            double acc = 0.0;
+            for (unsigned t = a0; t < e0; t++) {
+                const int kind = cpgw::gld(Gd.tkind, t);
+                const unsigned idx = (unsigned)cpgw::gld(Gd.tidx, t);
+                double d = 0.0;
+                if (kind == CPG_G_Q) d = -rr[idx];
+                else if (kind == CPG_G_L) d = act[idx] == -1.0 ? rr[n + idx] : 0.0;
+                else if (kind == CPG_G_U) d = act[idx] == 1.0 ? rr[n + idx] : 0.0;
+                else if (kind == CPG_G_P) {
+                    const unsigned i = (unsigned)cpgw::gld(R.Pi, idx), j = (unsigned)cpgw::gld(Gd.Pcolidx, idx);
+                    d = -0.5 * (rr[i] * xs[j] + xs[i] * rr[j]);
+                } else {
+                    const unsigned i = (unsigned)cpgw::gld(R.Ai, idx), j = (unsigned)cpgw::gld(Gd.Acolidx, idx);
+                    d = act[i] != 0.0 ? -(rr[n + i] * xs[j] + ys[i] * rr[j]) : 0.0;
+                }
+                acc = fma(cpgw::gld(Gd.tcoef, t), d, acc);
+            }
+            cpgw::gst(out, c, acc);
+        }
+        cpgw::lds_order();
+    }
+}
+
+}  // namespace cpg

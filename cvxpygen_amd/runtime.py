@@ -85,6 +85,11 @@ class _Refactor(C.Structure):
                 ('map_P', _Csr), ('map_A', _Csr), ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr)]
 
 
+class _Gradient(C.Structure):
+    _fields_ = [('NP', C.c_int32), ('Pcolidx', _ip), ('Acolidx', _ip), ('tptr', _ip), ('tkind', _ip),
+                ('tidx', _ip), ('tcoef', _dp)]
+
+
 class _Update(C.Structure):
     _fields_ = [('np_var', C.c_int32), ('q_base', _dp), ('u_base', _dp), ('d_base', C.c_double),
                 ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr)]
@@ -99,7 +104,8 @@ class CpgLibrary:
 
     SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_destroy', 'cpg_hip_last_error',
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
-               'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_solve_batch',
+               'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
+               'cpg_hip_solve_batch',
                'cpg_hip_solve_batch_device', 'cpg_hip_synchronize', 'cpg_hip_last_kernel_ms',
                'cpg_hip_set_launch', 'cpg_hip_set_program_placement', 'cpg_hip_malloc', 'cpg_hip_free', 'cpg_hip_memcpy_h2d',
                'cpg_hip_memcpy_d2h']
@@ -124,6 +130,8 @@ class CpgLibrary:
         L.cpg_hip_get_setting.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.cpg_hip_set_update.argtypes = [C.c_void_p, C.POINTER(_Update)]
         L.cpg_hip_set_refactor.argtypes = [C.c_void_p, C.POINTER(_Refactor)]
+        L.cpg_hip_set_gradient.argtypes = [C.c_void_p, C.POINTER(_Gradient)]
+        L.cpg_hip_gradient_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp]
         L.cpg_hip_solve_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
         L.cpg_hip_solve_batch_device.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
         L.cpg_hip_synchronize.argtypes = [C.c_void_p]
@@ -257,6 +265,8 @@ class BatchResult:
     kernel_ms: float = 0.0
     prim_flat: Optional[np.ndarray] = None
     dual_flat: Optional[np.ndarray] = None
+    sol_x: Optional[np.ndarray] = None      # canonical solution (full_output solvers only)
+    sol_y: Optional[np.ndarray] = None
 
     def status_str(self) -> List[str]:
         return [STATUS_STRINGS.get(int(s), 'unknown') for s in self.status]
@@ -267,7 +277,10 @@ class BatchSolver:
     `cpg_solve(prob, updated_params, **kwargs)` for B instances at once."""
 
     def __init__(self, desc: FamilyDescriptor, device: int = 0, lib_path: Optional[str] = None,
-                 plan: Optional[FamilyPlan] = None, ordering: str = 'mindeg'):
+                 plan: Optional[FamilyPlan] = None, ordering: str = 'mindeg', full_output: bool = False):
+        """full_output: return the complete canonical solution (sol_x, sol_y) -- what the reference's
+        `cpg_solve_and_gradient_info` hands to `cpg_gradient` (templates/cpg_solver.py.jinja2:122-173)"""
+        self.full_output = full_output
         if desc.solver != 'OSQP':
             raise ValueError(f'BatchSolver handles OSQP families, not {desc.solver}')
         self.desc = desc
@@ -282,8 +295,8 @@ class BatchSolver:
         D = np.ascontiguousarray(o.scaling.D[p.ordx]); E = np.ascontiguousarray(o.scaling.E[p.ordz])
         ctype = np.ascontiguousarray(o.constr_type[p.ordz], dtype=np.int8)
         fpos = np.ascontiguousarray(p.kkt.final_pos, dtype=np.uint16)
-        prim_idx = np.ascontiguousarray(p.prim_idx, dtype=np.int32)
-        dual_idx = np.ascontiguousarray(p.dual_idx, dtype=np.int32)
+        prim_idx = np.ascontiguousarray(p.posx if full_output else p.prim_idx, dtype=np.int32)
+        dual_idx = np.ascontiguousarray(p.posz if full_output else p.dual_idx, dtype=np.int32)
         keep += [D, E, ctype, fpos, prim_idx, dual_idx]
         rg = p.kkt_ragged
         rg_ctab = np.ascontiguousarray(rg.ctab, dtype=np.int32)
@@ -339,6 +352,8 @@ class BatchSolver:
             if desc.variables else np.zeros(0, dtype=np.int32)
         dual_idx = np.ascontiguousarray(np.concatenate([d.indices for d in desc.duals]), dtype=np.int32) \
             if desc.duals else np.zeros(0, dtype=np.int32)
+        if self.full_output:
+            prim_idx, dual_idx = np.arange(n, dtype=np.int32), np.arange(m, dtype=np.int32)
         keep += [ones_n, ones_m, ctype, fpos, prim_idx, dual_idx]
         empty = _Program(0, 0, None, None, None, None)
         fam = _Family(
@@ -480,6 +495,81 @@ class BatchSolver:
         self._var_cols, self.np_var = cols, len(cols)
         self._updated_names = names
 
+    # ---- adjoint ---------------------------------------------------------------------------------------
+    def _set_gradient(self):
+        desc, rp = self.desc, self._rplan
+        NP = desc.NP
+        blocks, kinds = [], []
+        sizes = {'q': desc.n_var, 'l': desc.n_eq, 'u': desc.m, 'P': desc.P.nnz, 'A': desc.A.nnz}
+        for kind, pid in enumerate(('q', 'l', 'u', 'P', 'A')):
+            Cm = sp.csr_matrix(desc.maps[pid])[:, :NP]
+            if not desc.changes.get(pid, False):
+                Cm = sp.csr_matrix((sizes[pid], NP))
+            blocks.append(Cm)
+            kinds.append(np.full(Cm.shape[0], kind, dtype=np.int32))
+        S = sp.vstack(blocks).tocsc()
+        S.sort_indices()
+        kind_of_row = np.concatenate(kinds)
+        off = np.concatenate([[0], np.cumsum([b.shape[0] for b in blocks])])
+        rows = S.indices
+        tkind = kind_of_row[rows]
+        tidx = (rows - off[tkind]).astype(np.int32)
+        keep = []
+
+        def i32(a):
+            a = np.ascontiguousarray(a, dtype=np.int32); keep.append(a); return a.ctypes.data_as(_ip)
+        tcoef = np.ascontiguousarray(S.data, dtype=np.float64); keep.append(tcoef)
+        Pcol = np.repeat(np.arange(desc.n_var), np.diff(desc.P.indptr))
+        Acol = np.repeat(np.arange(desc.n_var), np.diff(desc.A.indptr))
+        g = _Gradient(NP=NP, Pcolidx=i32(Pcol), Acolidx=i32(Acol), tptr=i32(S.indptr), tkind=i32(tkind),
+                      tidx=i32(tidx), tcoef=_d(tcoef))
+        self.lib.check(self.lib.L.cpg_hip_set_gradient(self.h_ref, C.byref(g)), 'cpg_hip_set_gradient')
+        self._gradient_keep = keep
+
+    def gradient(self, params: Dict[str, np.ndarray], sol_x: np.ndarray, sol_y: np.ndarray,
+                 dvars: Dict[str, np.ndarray], updated_params: Optional[Sequence[str]] = None
+                 ) -> Dict[str, np.ndarray]:
+        """Batched `cpg_gradient` (templates/cpg_solver.py.jinja2:135-173): given the canonical solution of
+        the forward solve and the gradient of a scalar loss w.r.t. the user variables, returns the
+        gradient w.r.t. every user parameter (F-order reshaped like the reference's `param.gradient`)."""
+        desc = self.desc
+        if updated_params is None:
+            updated_params = [q.name for q in desc.params if q.name in params]
+        names = [q.name for q in desc.params if q.name in updated_params]
+        cols = np.concatenate([np.arange(desc.param(nm).col, desc.param(nm).col + desc.param(nm).size)
+                               for nm in names]).astype(np.int64) if names else np.zeros(0, np.int64)
+        fixed = np.ones(desc.NP + 1, dtype=bool)
+        fixed[cols] = False
+        key = ('grad',) + tuple(names)
+        if getattr(self, '_grad_key', None) != key:
+            self._set_refactor(cols, np.where(fixed, desc.theta0, 0.0))
+            self._set_gradient()
+            self._grad_key = key
+            self._update_key = None          # the refactor tables were re-uploaded for this set
+        self._updated_names, self._var_cols, self.np_var = names, cols, len(cols)
+        tv = self.theta_var(params)
+        B = sol_x.shape[0]
+        dx = np.zeros((B, desc.n_var))
+        for v in desc.variables:
+            if v.name in dvars:
+                g = np.asarray(dvars[v.name], dtype=np.float64).reshape((B,) + tuple(v.shape))
+                dx[:, v.indices] = g.transpose((0,) + tuple(range(len(v.shape), 0, -1))).reshape(B, -1) \
+                    if len(v.shape) > 1 else g.reshape(B, -1)
+        dth = np.empty((B, desc.NP))
+        sx = np.ascontiguousarray(sol_x, dtype=np.float64); sy = np.ascontiguousarray(sol_y, dtype=np.float64)
+        tv = np.ascontiguousarray(tv, dtype=np.float64)
+        self.lib.check(self.lib.L.cpg_hip_gradient_batch(self.h_ref, B, _d(tv), _d(sx), _d(sy), _d(dx), _d(dth)),
+                       'cpg_hip_gradient_batch')
+        out = {'_flat': dth}
+        for q in desc.params:
+            blk = dth[:, q.col:q.col + q.size]
+            if q.kind == 'dense' and len(q.shape) > 1:
+                blk = blk.reshape((B,) + tuple(q.shape)[::-1]).transpose((0,) + tuple(range(len(q.shape), 0, -1)))
+            elif q.kind == 'scalar':
+                blk = blk[:, 0]
+            out[q.name] = blk
+        return out
+
     def theta_var(self, params: Dict[str, np.ndarray], B: Optional[int] = None) -> np.ndarray:
         """[B, np_var] C-contiguous array of the updated parameters, each flattened as the reference's
         `get_param_value` does (F-order / diagonal / stored non-zeros), instance-major."""
@@ -526,7 +616,7 @@ class BatchSolver:
         if self.np_var and theta_var.shape != (Bn, self.np_var):
             raise ValueError(f'theta_var must have shape (B, {self.np_var})')
         d = self.desc
-        n_prim, n_dual = len(self.plan.prim_idx), len(self.plan.dual_idx)
+        n_prim, n_dual = self.n_out_prim, self.n_out_dual
         prim = np.empty((Bn, n_prim)); dual = np.empty((Bn, n_dual))
         obj = np.empty(Bn); pri = np.empty(Bn); dua = np.empty(Bn)
         it = np.empty(Bn, dtype=np.int32); st = np.empty(Bn, dtype=np.int32)
@@ -539,9 +629,22 @@ class BatchSolver:
         self.lib.L.cpg_hip_last_kernel_ms(self.h, C.byref(ms))
         return self._result(prim, dual, obj, it, st, pri, dua, t1 - t0, ms.value)
 
+    @property
+    def n_out_prim(self) -> int:
+        return self.desc.n_var if self.full_output else len(self.plan.prim_idx)
+
+    @property
+    def n_out_dual(self) -> int:
+        return self.desc.m if self.full_output else len(self.plan.dual_idx)
+
     def _result(self, prim, dual, obj, it, st, pri, dua, dt, ms) -> BatchResult:
         d = self.desc
         Bn = prim.shape[0]
+        sol_x = sol_y = None
+        if self.full_output:
+            sol_x, sol_y = prim, dual
+            prim = np.concatenate([sol_x[:, v.indices] for v in d.variables], axis=1) if d.variables else np.zeros((Bn, 0))
+            dual = np.concatenate([sol_y[:, u.indices] for u in d.duals], axis=1) if d.duals else np.zeros((Bn, 0))
         pd, dd, k = {}, {}, 0
         for v in d.variables:
             sz = v.indices.size
@@ -561,8 +664,10 @@ class BatchSolver:
             k += sz
         # +-1e30 -> +-inf as the reference shim does (templates/cpg_solver.py.jinja2:98-101)
         obj = np.where(np.abs(obj) >= 1e30, np.sign(obj) * np.inf, obj)
-        return BatchResult(prim=pd, dual=dd, obj_val=obj, iter=it, status=st, pri_res=pri,
-                           dua_res=dua, solve_time=dt, kernel_ms=ms, prim_flat=prim, dual_flat=dual)
+        res = BatchResult(prim=pd, dual=dd, obj_val=obj, iter=it, status=st, pri_res=pri,
+                          dua_res=dua, solve_time=dt, kernel_ms=ms, prim_flat=prim, dual_flat=dual)
+        res.sol_x, res.sol_y = sol_x, sol_y
+        return res
 
 
 class DeviceBatch:
@@ -571,7 +676,7 @@ class DeviceBatch:
 
     def __init__(self, solver: BatchSolver, B: int):
         self.s, self.B = solver, int(B)
-        self.n_prim, self.n_dual = len(solver.plan.prim_idx), len(solver.plan.dual_idx)
+        self.n_prim, self.n_dual = solver.n_out_prim, solver.n_out_dual
         self._ptrs = {}
         sizes = dict(theta=B * max(solver.np_var, 1) * 8, prim=B * self.n_prim * 8,
                      dual=B * self.n_dual * 8, obj=B * 8, pri=B * 8, dua=B * 8, iter=B * 4, status=B * 4)

@@ -43,9 +43,13 @@ def get_param_value(param):
 class GeneratedSolver:
     """One generated solver (= one code_dir).  Device resources are created on first use."""
 
-    def __init__(self, code_dir: str, device: int = 0, lib_path: Optional[str] = None):
+    def __init__(self, code_dir: str, device: int = 0, lib_path: Optional[str] = None,
+                 gradient: Optional[bool] = None):
         self.code_dir = code_dir
         self.desc = FamilyDescriptor.load(os.path.join(code_dir, 'descriptor.npz'))
+        if gradient is None:
+            gradient = os.path.exists(os.path.join(code_dir, 'GRADIENT'))
+        self.gradient = bool(gradient)
         self.device = device
         if lib_path is None:
             # the library generate_code compiled for this family, else the generic table-driven one
@@ -58,7 +62,8 @@ class GeneratedSolver:
     @property
     def batch_solver(self) -> BatchSolver:
         if self._bs is None:
-            self._bs = BatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
+            self._bs = BatchSolver(self.desc, device=self.device, lib_path=self.lib_path,
+                                   full_output=self.gradient)
         return self._bs
 
     # ---- batched entry point --------------------------------------------------------------------
@@ -106,4 +111,64 @@ class GeneratedSolver:
         prob._solver_stats = make_solver_stats({'solver_specific_stats': solver_specific_stats,
                                                 'num_iters': int(res.iter[0]),
                                                 'solve_time': t1 - t0}, desc.solver)
+        self._last = (res.sol_x[0].copy(), res.sol_y[0].copy()) if res.sol_x is not None else None
         return prob.value
+
+    # ---- gradient=True surface (templates/cpg_solver.py.jinja2:122-212) ---------------------------------
+    def cpg_solve_and_gradient_info(self, prob, updated_params=None, **kwargs):
+        if not self.gradient:
+            raise AttributeError('code was generated with gradient=False')
+        val = self.cpg_solve(prob, updated_params, **kwargs)
+        gp, gd = self._last
+        return val, list(gp), list(gd)
+
+    def cpg_gradient(self, prob, gradient_sol_primal=None, gradient_sol_dual=None):
+        """reads `var.gradient` of every variable, writes `param.gradient` of every parameter"""
+        if not self.gradient:
+            raise AttributeError('code was generated with gradient=False')
+        desc = self.desc
+        if gradient_sol_primal is not None and gradient_sol_dual is not None:
+            sx, sy = np.asarray(gradient_sol_primal, dtype=np.float64), np.asarray(gradient_sol_dual, dtype=np.float64)
+        else:
+            sx, sy = self._last
+        dvars = {}
+        for v in desc.variables:
+            g = prob.var_dict[v.name].gradient
+            dvars[v.name] = np.asarray(0.0 if g is None else g, dtype=np.float64).reshape((1,) + tuple(v.shape))
+        vals = {name: np.asarray(get_param_value(prob.param_dict[name]), dtype=np.float64).reshape(1, -1)
+                for name in desc.param_names}
+        out = self.batch_solver.gradient(vals, sx[None, :], sy[None, :], dvars, updated_params=desc.param_names)
+        for q in desc.params:
+            g = out[q.name][0]
+            prob.param_dict[q.name].gradient = float(g) if q.kind == 'scalar' else np.array(g)
+
+    def forward(self, params, context):
+        """cvxpylayers `custom_method` forward (templates/cpg_solver.py.jinja2:176-193)"""
+        info = {}
+        kwargs = context.solver_args.copy()
+        prob = kwargs.pop("problem")
+        parameters = prob.parameters()
+        for pid, val in zip(context.param_ids, params):
+            next(p for p in parameters if p.id == pid).value = val
+        updated_params = kwargs.pop("updated_params", None)
+        _, info["gradient_primal"], info["gradient_dual"] = self.cpg_solve_and_gradient_info(prob, updated_params, **kwargs)
+        info["prob"] = prob
+        vars_ = prob.variables()
+        return [next(v for v in vars_ if v.id == variable.id).value for variable in context.variables], info
+
+    def backward(self, dvars, context):
+        prob = context.info["prob"]
+        vars_ = prob.variables()
+        for variable, dv in zip(context.variables, dvars):
+            next(v for v in vars_ if v.id == variable.id).gradient = dv
+        self.cpg_gradient(prob, context.info["gradient_primal"], context.info["gradient_dual"])
+        params = prob.parameters()
+        return [next(p for p in params if p.id == pid).gradient for pid in context.param_ids], {}
+
+    # batched siblings
+    def cpg_solve_and_gradient_info_batch(self, params, updated_params=None, **kwargs):
+        res = self.cpg_solve_batch(params, updated_params, **kwargs)
+        return res, res.sol_x, res.sol_y
+
+    def cpg_gradient_batch(self, params, sol_x, sol_y, dvars, updated_params=None):
+        return self.batch_solver.gradient(params, sol_x, sol_y, dvars, updated_params)

@@ -157,6 +157,19 @@ typedef struct {
     cpg_csr_t map_P, map_A, map_q, map_u, map_d;
 } cpg_osqp_refactor_t;
 
+/* QP adjoint (gradient=True in the reference): transposed canonical maps over ALL user parameters.
+ * For parameter column c, entries tptr[c] .. tptr[c+1]: kind 0 q[idx], 1 l[idx], 2 u[idx],
+ * 3 P entry idx, 4 A entry idx, with coefficient tcoef (rows of the reference's canon_<p>_map,
+ * cvxpygen/writer.py:268-311). */
+typedef struct {
+    int32_t NP;
+    const int32_t *Pcolidx;  /* [nnzP] column of every stored P entry */
+    const int32_t *Acolidx;  /* [nnzA] */
+    const int32_t *tptr;     /* [NP + 1] */
+    const int32_t *tkind, *tidx;
+    const double *tcoef;
+} cpg_osqp_gradient_t;
+
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 int cpg_hip_device_count(int *count);
 int cpg_hip_create_osqp(const cpg_osqp_family_t *family, int device, cpg_handle_t *out);
@@ -175,6 +188,15 @@ int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *upd);
 /* per-instance refactorisation path; after this call solves go through it until cpg_hip_set_update
  * is called again */
 int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *rf);
+
+/* adjoint tables; requires cpg_hip_set_refactor on the same handle (canonical ordering) */
+int cpg_hip_set_gradient(cpg_handle_t h, const cpg_osqp_gradient_t *g);
+/* Batched cpg_gradient(): for every instance, canonical solution sol_x [B][n], sol_y [B][m] of the
+ * forward solve, upstream gradient dx [B][n] on the canonical variables (the user-variable gradients
+ * scattered to their canonical positions, the reference's cpg_update_d<var>) -> dtheta [B][NP],
+ * gradient w.r.t. every user parameter.  Host buffers. */
+int cpg_hip_gradient_batch(cpg_handle_t h, int64_t B, const double *theta_var, const double *sol_x,
+                           const double *sol_y, const double *dx, double *dtheta);
 
 /* ---- solve ---------------------------------------------------------------------------------- */
 /* Host buffers: theta_var [B][np_var]; outputs prim [B][n_prim], dual [B][n_dual], obj/pri_res/

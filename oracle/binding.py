@@ -194,3 +194,30 @@ def cpg_solve_batch(desc, theta, updated_params=None, nthreads=0, oracle=None, *
     out['prim'] = {v.name: sol_x[:, v.indices] for v in desc.variables}
     out['dual'] = {d.name: sol_y[:, d.indices] for d in desc.duals}
     return out
+
+
+def qp_adjoint(desc, canon, x, y, dx):
+    """C restatement of cpg_osqp_gradient for one instance; canon = desc.canon_at(theta).
+    Returns dict(r, dq, dl, du, dP (nnzP), dA (nnzA), dtheta (NP))."""
+    import scipy.sparse as sp
+    L = lib()
+    L.oracle_qp_adjoint.restype = C.c_int
+    L.oracle_qp_adjoint.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp, _dp, _dp, _dp,
+                                    _dp, _dp, _dp, _dp, _dp, _dp]
+    n, m = desc.n_var, desc.m
+    Pp = np.ascontiguousarray(desc.P.indptr, dtype=np.int32); Pi = np.ascontiguousarray(desc.P.indices, dtype=np.int32)
+    Ap = np.ascontiguousarray(desc.A.indptr, dtype=np.int32); Ai = np.ascontiguousarray(desc.A.indices, dtype=np.int32)
+    Px = np.ascontiguousarray(canon['P'], dtype=np.float64); Ax = np.ascontiguousarray(canon['A'], dtype=np.float64)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    x, y, dx = f(x), f(y), f(dx)
+    r, dq, dl, du = np.zeros(n + m), np.zeros(n), np.zeros(m), np.zeros(m)
+    dP, dA = np.zeros(len(Px)), np.zeros(len(Ax))
+    rc = L.oracle_qp_adjoint(n, m, _i(Pp), _i(Pi), _d(Px), _i(Ap), _i(Ai), _d(Ax), _d(x), _d(y), _d(dx),
+                             _d(r), _d(dq), _d(dl), _d(du), _d(dP), _d(dA))
+    if rc:
+        raise RuntimeError('oracle_qp_adjoint failed')
+    dth = np.zeros(desc.NP + 1)
+    for pid, vec in (('q', dq), ('l', dl[:desc.n_eq]), ('u', du), ('P', dP), ('A', dA)):
+        if desc.changes.get(pid, False):
+            dth += sp.csr_matrix(desc.maps[pid]).T @ vec
+    return dict(r=r, dq=dq, dl=dl, du=du, dP=dP, dA=dA, dtheta=dth[:desc.NP])

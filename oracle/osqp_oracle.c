@@ -622,3 +622,62 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------ QP adjoint (gradient) */
+/*
+ * Restatement of cpg_osqp_gradient() (cvxpygen/templates/cpg_osqp_grad_compute.c.jinja2:432-531)
+ * for one instance; see oracle/osqp_grad_numpy.py for the line-by-line map.  The masked,
+ * eps-regularised KKT matrix is factored densely (LDL' without pivoting, natural order as in the
+ * reference, template :326-347) -- the rank-one add / delete machinery of the reference
+ * (template :157-324) produces exactly this factor.
+ *   P upper CSC (Pp, Pi, Px), A CSC (Ap, Ai, Ax), x[n], y[m], dx[n]
+ *   out: r[n+m], dq[n], dl[m], du[m], dP[nnzP], dA[nnzA]
+ */
+int oracle_qp_adjoint(int n, int m, const int *Pp, const int *Pi, const double *Px, const int *Ap,
+                      const int *Ai, const double *Ax, const double *x, const double *y, const double *dx,
+                      double *r, double *dq, double *dl, double *du, double *dP, double *dA) {
+    int N = n + m;
+    double *K = dvec(N * N), *L = dvec(N * N), *D = dvec(N), *rhs = dvec(N), *delta = dvec(N), *t = dvec(N);
+    int *a = ivec(m);
+    for (int i = 0; i < m; i++) a[i] = y[i] < -1e-12 ? -1 : (y[i] > 1e-12 ? 1 : 0);
+    for (int j = 0; j < n; j++) for (int k = Pp[j]; k < Pp[j + 1]; k++) { int i = Pi[k];
+        K[i * N + j] = Px[k]; K[j * N + i] = Px[k]; }
+    for (int j = 0; j < n; j++) K[j * N + j] += 1e-6;
+    for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) { int i = Ai[k];
+        if (a[i]) { K[(n + i) * N + j] = Ax[k]; K[j * N + n + i] = Ax[k]; } }
+    for (int i = 0; i < m; i++) K[(n + i) * N + n + i] = a[i] ? -1e-6 : -1.0;
+    /* dense LDL', no pivoting */
+    for (int j = 0; j < N; j++) { double d = K[j * N + j];
+        for (int k = 0; k < j; k++) d -= L[j * N + k] * L[j * N + k] * D[k];
+        if (d == 0.0) { free(K); free(L); free(D); free(rhs); free(delta); free(t); free(a); return -1; }
+        D[j] = d; L[j * N + j] = 1.0;
+        for (int i = j + 1; i < N; i++) { double v = K[i * N + j];
+            for (int k = 0; k < j; k++) v -= L[i * N + k] * L[j * N + k] * D[k];
+            L[i * N + j] = v / d; } }
+#define ADJ_SOLVE(v)                                                                     \
+    do { for (int i_ = 0; i_ < N; i_++) { double s_ = v[i_]; for (int k_ = 0; k_ < i_; k_++) s_ -= L[i_ * N + k_] * v[k_]; v[i_] = s_; } \
+         for (int i_ = 0; i_ < N; i_++) v[i_] /= D[i_];                                  \
+         for (int i_ = N - 1; i_ >= 0; i_--) { double s_ = v[i_]; for (int k_ = i_ + 1; k_ < N; k_++) s_ -= L[k_ * N + i_] * v[k_]; v[i_] = s_; } } while (0)
+    for (int i = 0; i < n; i++) { r[i] = dx[i]; rhs[i] = dx[i]; }
+    for (int i = n; i < N; i++) { r[i] = 0; rhs[i] = 0; }
+    ADJ_SOLVE(r);
+    for (int l = 0; l < 3; l++) {
+        /* delta = rhs - K_true r with inactive rows / columns skipped */
+        for (int i = 0; i < N; i++) delta[i] = rhs[i];
+        symv_triu(n, Pp, Pi, Px, r, t);
+        for (int i = 0; i < n; i++) delta[i] -= t[i];
+        for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) { int i = Ai[k];
+            if (a[i]) { delta[j] -= Ax[k] * r[n + i]; delta[n + i] -= Ax[k] * r[j]; } }
+        for (int i = 0; i < m; i++) if (!a[i]) delta[n + i] = 0.0;
+        ADJ_SOLVE(delta);
+        for (int i = 0; i < N; i++) r[i] += delta[i];
+    }
+    for (int i = 0; i < n; i++) dq[i] = -r[i];
+    for (int i = 0; i < m; i++) { dl[i] = a[i] == -1 ? r[n + i] : 0.0; du[i] = a[i] == 1 ? r[n + i] : 0.0; }
+    for (int j = 0; j < n; j++) for (int k = Pp[j]; k < Pp[j + 1]; k++) { int i = Pi[k];
+        dP[k] = -0.5 * (r[i] * x[j] + x[i] * r[j]); }
+    for (int j = 0; j < n; j++) for (int k = Ap[j]; k < Ap[j + 1]; k++) { int i = Ai[k];
+        dA[k] = a[i] ? -(r[n + i] * x[j] + y[i] * r[j]) : 0.0; }
+    free(K); free(L); free(D); free(rhs); free(delta); free(t); free(a);
+    return 0;
+}

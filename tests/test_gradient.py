@@ -1,0 +1,94 @@
+"""QP adjoint (gradient=True), SURVEY.md section 8 rows G1-G6.  The reference tests it against
+cvxpylayers / finite differences on nonneg least squares (tests/test_diff.py:14-69, 147-164); here:
+restated adjoint (numpy + C) vs finite differences of the forward oracle, emulator build of the HIP
+adjoint kernel vs the oracle, and the reference-facing cpg_gradient / forward / backward surface."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cvxpygen_amd import cpg, families
+from cvxpygen_amd.lite import LiteProblem
+from cvxpygen_amd.runtime import BatchSolver
+from oracle.osqp_grad_numpy import dtheta_from_canonical, qp_adjoint
+
+
+def _tight_solve(oracle_lib, d, th):
+    o = oracle_lib.cpg_solve_batch(d, th[None, :], None, eps_abs=1e-11, eps_rel=1e-11, max_iter=300000)
+    assert o['status'][0] == 1
+    return o['sol_x'][0], o['sol_y'][0]
+
+
+@pytest.mark.parametrize('make', [lambda: families.nonneg_ls(10, 5, sparsity=None, seed=0),
+                                  lambda: families.nonneg_ls(),
+                                  lambda: families.mpc(4, 2, 3)])
+def test_adjoint_oracles_match_finite_differences(oracle_lib, make):
+    d = make()
+    rng = np.random.default_rng(1)
+    th = np.append(d.theta0[:-1] * (1 + 0.05 * rng.standard_normal(d.NP)), 1.0)
+    x, y = _tight_solve(oracle_lib, d, th)
+    wts = np.zeros(d.n_var)
+    for v in d.variables:
+        wts[v.indices] = 0.1                          # loss = 0.1 * sum(variables), tests/test_diff.py:38
+    c = d.canon_at(th)
+    Pd = sp.csc_matrix((c['P'], d.P.indices, d.P.indptr), shape=d.P.shape).toarray()
+    Ad = sp.csc_matrix((c['A'], d.A.indices, d.A.indptr), shape=d.A.shape).toarray()
+    dth = dtheta_from_canonical(d, qp_adjoint(Pd, Ad, x, y, wts))
+    gc = oracle_lib.qp_adjoint(d, c, x, y, wts)
+    assert np.abs(gc['dtheta'] - dth).max() <= 1e-12 * max(1.0, np.abs(dth).max())
+    for k in rng.choice(d.NP, size=min(6, d.NP), replace=False):
+        h = 1e-6 * max(1.0, abs(th[k]))
+        tp, tm = th.copy(), th.copy()
+        tp[k] += h; tm[k] -= h
+        fd = (wts @ _tight_solve(oracle_lib, d, tp)[0] - wts @ _tight_solve(oracle_lib, d, tm)[0]) / (2 * h)
+        assert abs(fd - dth[k]) <= 1e-6 * max(1.0, abs(fd))
+
+
+def test_adjoint_kernel_vs_oracle_emulator(sim_lib, oracle_lib):
+    d = families.nonneg_ls(10, 5, sparsity=None, seed=0)
+    B = 2
+    rng = np.random.default_rng(1)
+    th = np.tile(d.theta0, (B, 1))
+    th[:, :d.NP] *= 1 + 0.05 * rng.standard_normal((B, d.NP))
+    bs = BatchSolver(d, lib_path=sim_lib, full_output=True)
+    vals = {p.name: th[:, p.col:p.col + p.size] for p in d.params}
+    r = bs.solve(vals, eps_abs=1e-5, eps_rel=1e-5, max_iter=300)
+    assert r.sol_x.shape == (B, d.n_var) and r.prim['x'].shape == (B, 5)
+    g = bs.gradient(vals, r.sol_x, r.sol_y, {'x': 0.1 * np.ones((B, 5))})
+    assert g['A'].shape == (B, 10, 5) and g['b'].shape == (B, 10)
+    for k in range(B):
+        wts = np.zeros(d.n_var); wts[d.variables[0].indices] = 0.1
+        go = oracle_lib.qp_adjoint(d, d.canon_at(th[k]), r.sol_x[k], r.sol_y[k], wts)
+        assert np.abs(g['_flat'][k] - go['dtheta']).max() <= 1e-10 * np.abs(go['dtheta']).max()
+        pA = d.param('A')
+        assert np.allclose(g['A'][k].flatten(order='F'), go['dtheta'][pA.col:pA.col + pA.size], rtol=1e-9, atol=1e-14)
+    bs.close()
+
+
+def test_reference_gradient_surface(sim_lib, oracle_lib, tmp_path):
+    """generate_code(gradient=True) -> cpg_solve_and_gradient_info / cpg_gradient / forward / backward"""
+    d = families.nonneg_ls()                                      # examples/main.py family
+    prob = LiteProblem.from_descriptor(d)
+    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'grad_code'), solver='OSQP', gradient=True, wrapper=True)
+    mod._SOLVER.lib_path = sim_lib
+    val, gp, gd = mod.cpg_solve_and_gradient_info(prob, eps_abs=1e-9, eps_rel=1e-9)
+    assert len(gp) == d.n_var and len(gd) == d.m and prob.status == 'solved'
+    prob.var_dict['x'].gradient = np.array([0.1, 0.1])
+    mod.cpg_gradient(prob, gp, gd)
+    wts = np.zeros(d.n_var); wts[d.variables[0].indices] = 0.1
+    go = oracle_lib.qp_adjoint(d, d.default_canon(), np.array(gp), np.array(gd), wts)
+    pA, pb = d.param('A'), d.param('b')
+    assert np.allclose(np.ravel(prob.param_dict['b'].gradient), go['dtheta'][pb.col:pb.col + pb.size], rtol=1e-8, atol=1e-12)
+    assert np.allclose(np.ravel(prob.param_dict['A'].gradient), go['dtheta'][pA.col:pA.col + pA.size], rtol=1e-8, atol=1e-12)
+    assert np.abs(go['dtheta']).max() > 1e-3
+    # cvxpylayers custom_method protocol
+    ctx = SimpleNamespace(solver_args={'problem': prob}, param_ids=[id(p) for p in prob.parameters()],
+                          variables=prob.variables(), info=None)
+    for p in prob.parameters():
+        p.id = id(p)
+    sol, info = mod.forward([p.value for p in prob.parameters()], ctx)
+    ctx.info = info
+    grads, _ = mod.backward([np.array([0.1, 0.1])], ctx)
+    assert len(grads) == 2 and all(g is not None for g in grads)
