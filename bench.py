@@ -40,9 +40,22 @@ def make_workload(name: str):
     elif name == 'mpc6':
         desc = families.mpc(6, 3, 10)
         label = 'MPC QP n=6 m=3 H=10 (examples/MPC.ipynb), OSQP, x_init varies'
+    elif name == 'portfolio':
+        desc = families.portfolio(100, 10)
+        label = 'portfolio QP n=100 m=10 (examples/portfolio.ipynb), OSQP, a/F/Sig_f_sqrt/d_sqrt/w_prev per instance'
     else:
         raise ValueError(name)
     return desc, label
+
+
+def portfolio_params(desc, B: int, seed: int):
+    """per-instance values of examples/portfolio.ipynb cell 7"""
+    rng = np.random.default_rng(seed)
+    n, m = 100, 10
+    sig = np.zeros((B, m, m))
+    sig[:, np.arange(m), np.arange(m)] = rng.random((B, m))
+    return {'a': rng.standard_normal((B, n)), 'F': np.round(rng.standard_normal((B, n, m))),
+            'Sig_f_sqrt': sig, 'd_sqrt': rng.random((B, n)), 'w_prev': np.zeros((B, n))}
 
 
 def make_theta(desc, B: int, seed: int) -> np.ndarray:
@@ -113,7 +126,11 @@ def main():
     solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)
     solver.set_program_placement(args.placement)
     B = args.batch
-    if args.all_params:
+    if args.workload == 'portfolio':
+        pv = portfolio_params(desc, B, 1000 + rank)
+        solver.set_updated(list(pv.keys()))
+        theta = solver.theta_var(pv)
+    elif args.all_params:
         solver.set_updated(None)
         rng = np.random.default_rng(1000 + rank)
         full = np.tile(desc.theta0[:-1], (B, 1)) * (1 + 0.05 * rng.standard_normal((B, desc.NP)))
@@ -169,6 +186,8 @@ def main():
     if rank == 0:
         n_prim, n_dual = len(solver.plan.prim_idx), len(solver.plan.dual_idx)
         bytes_per_inst = 8 * (solver.np_var + n_prim + n_dual) + 32
+        if args.workload == 'portfolio':
+            bytes_per_inst = 15416                                      # config 3 figure of SURVEY.md 8(d)
         k_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_inst * B / (k_ms * 1e-3) / 1e9
         value = world * B * args.steps / elapsed
@@ -177,10 +196,13 @@ def main():
             'value': value, 'unit': 'QP instances/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-            'data': 'synthetic (x_init = -2 + 4*U(0,1), default_rng(1000+rank); family parameters of '
-                    'examples/MPC.ipynb cell 3 extended to 12/4)',
+            'data': ('synthetic (examples/portfolio.ipynb cell 7 draws, default_rng(1000+rank))'
+                     if args.workload == 'portfolio' else
+                     'synthetic (x_init = -2 + 4*U(0,1), default_rng(1000+rank); family parameters of '
+                     'examples/MPC.ipynb cell 3 extended to 12/4)'),
             'config': {'workload': label, 'instances_per_gpu': B, 'kkt_dim': desc.n_var + desc.m,
-                       'n_var': desc.n_var, 'n_constr': desc.m, 'varying_params': 'all (matrix parameters: per-instance refactorisation)' if args.all_params else ['x_init'],
+                       'n_var': desc.n_var, 'n_constr': desc.m, 'varying_params': (['a', 'F', 'Sig_f_sqrt', 'd_sqrt', 'w_prev'] if args.workload == 'portfolio' else
+                                          'all (matrix parameters: per-instance refactorisation)' if args.all_params else ['x_init']),
                        'settings': 'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
                                    'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start',
                        'parallelism': f'shard{world}', **stats,
@@ -189,13 +211,14 @@ def main():
                                 for k, v in solver.plan.stats.items()}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'osqp_shared_kernel', 'kernel_ms': k_ms,
+                         'kernel': ('osqp_refactor_kernel' if (args.all_params or args.workload == 'portfolio')
+                                    else 'osqp_shared_kernel'), 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_instance': bytes_per_inst,
                          'note': 'compulsory traffic only (theta in, solution out); the iteration '
                                  'state never leaves registers/LDS, so this path is latency / LDS '
                                  'bound, not HBM bound (DESIGN.md section 6)'},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != 'portfolio' and not args.all_params:
             out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds)
         if args.check:
             from oracle import binding as ob

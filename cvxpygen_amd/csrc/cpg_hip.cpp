@@ -571,6 +571,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     UP(unsigned short, sol_cols, r->sol_nnz); UP(int, sol_kind, r->sol_nnz); UP(int, sol_idx, r->sol_nnz);
     UP(unsigned short, sol_fpos, N);
     UP(double, P_base, r->nnzP); UP(double, A_base, r->nnzA); UP(double, q_base, n); UP(double, u_base, m);
+    UP(double, q_setup, n);
 #undef UP
     if ((rc = upload_csr(h, own, r->map_P, &R.map_P))) return rc;
     if ((rc = upload_csr(h, own, r->map_A, &R.map_A))) return rc;

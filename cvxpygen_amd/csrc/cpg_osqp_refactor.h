@@ -37,6 +37,7 @@ struct DevRefactor {
     int sol_chunks, sol_nnz, sol_slots;
     // canonicalisation of everything (UNSCALED): p = base + map @ theta_var
     const double *P_base, *A_base, *q_base, *u_base;
+    const double *q_setup;   // unscaled q of the code-generation-time workspace (cost scaling sees this one)
     double d_base;
     DevCsr map_P, map_A, map_q, map_u, map_d;
     long long buf_doubles;   // per-wavefront buffer length
@@ -191,7 +192,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                     for (unsigned k = a; k < e; k++)
                         acc = cpgw::dmax2(acc, fabs(cs * dj * cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)) * w[(unsigned)cpgw::gld(R.Pcol, k)]));
                     psum += acc;
-                    qn = cpgw::dmax2(qn, fabs(cs * dj * cpgw::gld((const double *)B.q, j)));
+                    qn = cpgw::dmax2(qn, fabs(cs * dj * cpgw::gld(R.q_setup, j)));   // update_mat runs before update_vec
                 }
             }
             psum = cpgw::wave_sum(psum);

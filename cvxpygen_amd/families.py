@@ -265,5 +265,28 @@ def toy_lp(name: str = 'toy_lp') -> FamilyDescriptor:
     return cb.build({'c': 1.0})
 
 
+def toy_qa(n: int = 3, name: str = 'toy_qa') -> FamilyDescriptor:
+    """minimise ||G x - h||^2 + c'x  s.t. 0 <= x <= 1 (test family: q AND A parameter-dependent, so
+    osqp_update_data_mat and osqp_update_data_vec both fire; cvxpygen/solvers/osqp.py:20-59)"""
+    cb = CanonBuilder(name)
+    G = cb.param('G', (n, n))
+    h = cb.param('h', (n,))
+    c = cb.param('c', (n,))
+    x = cb.var('x', (n,))
+    t = cb.aux(n)
+    cb.sum_squares(t)
+    for j in range(n):
+        cb.lin(x[j], {c.idx(j): 1.0})
+    for i in range(n):
+        cb.eq([(x[j], {G.idx(i, j): 1.0}) for j in range(n)] + [(t[i], -1.0)], {h.idx(i): 1.0})
+    r1 = [cb.ineq([(x[j], 1.0)], 1.0) for j in range(n)]
+    r2 = [cb.ineq([(x[j], -1.0)], 0.0) for j in range(n)]
+    cb.dual('d0', r1, (n,))
+    cb.dual('d1', r2, (n,))
+    rng = np.random.default_rng(5)
+    return cb.build({'G': np.eye(n) + 0.3 * rng.standard_normal((n, n)), 'h': rng.standard_normal(n),
+                     'c': 0.5 * rng.standard_normal(n)})
+
+
 FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio, 'toy_box': toy_box,
-            'toy_lp': toy_lp}
+            'toy_lp': toy_lp, 'toy_qa': toy_qa}

@@ -82,7 +82,8 @@ class _Refactor(C.Structure):
                 ('sol_kind', _ip), ('sol_idx', _ip), ('sol_fpos', _u16p),
                 ('np_var', C.c_int32), ('P_base', _dp), ('A_base', _dp), ('q_base', _dp), ('u_base', _dp),
                 ('d_base', C.c_double),
-                ('map_P', _Csr), ('map_A', _Csr), ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr)]
+                ('map_P', _Csr), ('map_A', _Csr), ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr),
+                ('q_setup', _dp)]
 
 
 class _Gradient(C.Structure):
@@ -384,6 +385,8 @@ class BatchSolver:
             return base, _csr_struct(Mv, keep)
 
         Pb, MP = split('P'); Ab, MA = split('A'); qb, Mq = split('q'); ub, Mu = split('u', clip=True)
+        q_setup = np.ascontiguousarray(desc.default_canon()['q'], dtype=np.float64)
+        keep.append(q_setup)
         Cd = sp.csr_matrix(desc.maps['d'])
         d_base = float((Cd @ th_fixed)[0]) if desc.nonzero_d else 0.0
         Md = _csr_struct(sp.csr_matrix(Cd[:, cols]) if (len(cols) and desc.nonzero_d)
@@ -408,7 +411,7 @@ class BatchSolver:
             sol_ctab=i32(rp.sol.ctab), sol_desc=u32(rp.sol.desc), sol_cols=u16(rp.sol.cols),
             sol_kind=i32(rp.sol_kind), sol_idx=i32(rp.sol_idx), sol_fpos=u16(rp.sol.final_pos),
             np_var=len(cols), P_base=_d(Pb), A_base=_d(Ab), q_base=_d(qb), u_base=_d(ub), d_base=d_base,
-            map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md)
+            map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md, q_setup=_d(q_setup))
         self.lib.check(self.lib.L.cpg_hip_set_refactor(self.h_ref, C.byref(rf)), 'cpg_hip_set_refactor')
         self._refactor_keep = keep
 

@@ -155,6 +155,10 @@ typedef struct {
     int32_t np_var;
     const double *P_base, *A_base, *q_base, *u_base; double d_base;
     cpg_csr_t map_P, map_A, map_q, map_u, map_d;
+    /* [n] unscaled q of the code-generation-time workspace: the reference applies
+     * osqp_update_data_mat BEFORE osqp_update_data_vec (cvxpygen/solvers/osqp.py:20-59), so the
+     * cost scaling of the re-equilibration sees the old q, never the instance's new one */
+    const double *q_setup;
 } cpg_osqp_refactor_t;
 
 /* QP adjoint (gradient=True in the reference): transposed canonical maps over ALL user parameters.

@@ -201,3 +201,24 @@ def test_adjoint_vs_oracle(oracle_lib, make, B, upd):
         # instances whose gradient vanishes identically (solution at a vertex) need an absolute floor
         assert np.abs(g['_flat'][k] - go['dtheta']).max() <= 1e-6 * np.abs(go['dtheta']).max() + 1e-10
     bs.close()
+
+
+def test_portfolio_config3_vs_oracle(oracle_lib):
+    """BASELINE config 3 (examples/portfolio.ipynb, n=100, m=10): a, F, Sig_f_sqrt, d_sqrt, w_prev per
+    instance -> matrix parameters -> per-instance refactorisation path; maximisation problem"""
+    d = families.portfolio(100, 10)
+    B = 48
+    rng = np.random.default_rng(31)
+    sig = np.zeros((B, 10, 10)); sig[:, np.arange(10), np.arange(10)] = rng.random((B, 10))
+    pv = {'a': rng.standard_normal((B, 100)), 'F': np.round(rng.standard_normal((B, 100, 10))),
+          'Sig_f_sqrt': sig, 'd_sqrt': rng.random((B, 100)), 'w_prev': np.zeros((B, 100))}
+    th = np.tile(d.theta0, (B, 1))
+    for k in range(B):
+        th[k] = d.theta_from_values({nm: v[k] for nm, v in pv.items()})
+    bs = BatchSolver(d)
+    r = bs.solve(pv, updated_params=list(pv.keys()))
+    o = oracle_lib.cpg_solve_batch(d, th, list(pv.keys()))
+    _check(r, o, d)
+    assert r.prim['w'].shape == (B, 100) and r.dual['d3'].shape == (B, 100)
+    assert np.abs(r.prim['w'].sum(axis=1) - 1).max() < 1e-2          # 1'w == 1
+    bs.close()

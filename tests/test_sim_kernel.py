@@ -147,3 +147,19 @@ def test_refactor_path_all_parameters(sim_lib, oracle_lib):
     o2, prim2, dual2 = _oracle_flat(oracle_lib, d, _theta(d, 'b', th[:, 3:6]), ['b'])
     _assert_parity(r2, o2, prim2, dual2)
     bs.close()
+
+
+def test_refactor_path_matrix_and_vector_update_order(sim_lib, oracle_lib):
+    """q and A both outdated: the reference calls osqp_update_data_mat first (re-equilibration, cost
+    scaling sees the OLD q) and osqp_update_data_vec second (cvxpygen/solvers/osqp.py:20-59)"""
+    d = families.toy_qa()
+    rng = np.random.default_rng(3)
+    B = 3
+    th = np.tile(d.theta0, (B, 1))
+    th[:, :d.NP] += 0.5 * rng.standard_normal((B, d.NP))
+    th[:, d.param('c').col:d.param('c').col + 3] *= 40.0      # make ||q|| decide the cost scaling
+    bs = BatchSolver(d, lib_path=sim_lib)
+    r = bs.solve({p.name: th[:, p.col:p.col + p.size] for p in d.params})
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
+    _assert_parity(r, o, prim, dual)
+    bs.close()
