@@ -90,6 +90,7 @@ class CanonBuilder:
         self._q: Dict[int, Dict[int, float]] = {}
         self._d: Dict[int, float] = {}
         self._duals: List[Tuple[str, List[Tuple[str, int]], Tuple[int, ...]]] = []
+        self._soc: List[List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]] = []
         self.is_maximization = False
 
     # ---- declarations -------------------------------------------------------------------------
@@ -133,6 +134,12 @@ class CanonBuilder:
         self._ineq.append(([(int(c), _as_coef(v)) for c, v in entries], _as_coef(rhs)))
         return ('ineq', len(self._ineq) - 1)
 
+    def soc(self, rows: Sequence[Tuple[Iterable[Tuple[int, Coef]], Coef]]) -> Tuple[str, int]:
+        """second-order cone over len(rows) slack entries: s_k = rhs_k - sum_j entries_kj * x_j and
+        s_0 >= ||s_1:||  (conic families only; `cvxpygen/solvers/clarabel.py:133-155`)"""
+        self._soc.append([([(int(c), _as_coef(v)) for c, v in entries], _as_coef(rhs)) for entries, rhs in rows])
+        return ('soc', len(self._soc) - 1)
+
     def quad(self, i: int, j: int, coef: Coef) -> None:
         """objective += 1/2 * coef * x_i x_j * (2 if i != j else 1), i.e. P[i, j] += coef (upper)."""
         i, j = (int(i), int(j)) if i <= j else (int(j), int(i))
@@ -165,8 +172,12 @@ class CanonBuilder:
                     r.append(i); c.append(k); v.append(w)
         return sp.csr_matrix((v, (r, c)), shape=(len(rows), self.NP + 1))
 
-    def build(self, values: Dict[str, np.ndarray]) -> FamilyDescriptor:
-        n, n_eq, n_ineq = self.n_var, len(self._eq), len(self._ineq)
+    def build(self, values: Dict[str, np.ndarray], solver: str = 'OSQP') -> FamilyDescriptor:
+        conic = solver != 'OSQP'
+        if self._soc and not conic:
+            raise ValueError('second-order cones need a conic solver')
+        soc_rows = [row for cone in self._soc for row in cone]
+        n, n_eq, n_ineq = self.n_var, len(self._eq), len(self._ineq) + len(soc_rows)
         m = n_eq + n_ineq
 
         # theta0
@@ -181,7 +192,7 @@ class CanonBuilder:
 
         # A: gather entries, CSC order (column-major, rows ascending)
         ent: Dict[Tuple[int, int], Dict[int, float]] = {}
-        for r, (entries, _) in enumerate(self._eq + self._ineq):
+        for r, (entries, _) in enumerate(self._eq + self._ineq + soc_rows):
             for c, coef in entries:
                 if coef:
                     ent[(r, c)] = cadd(ent.get((r, c), {}), coef)
@@ -216,9 +227,13 @@ class CanonBuilder:
 
         # l (n_eq rows, padded later with -inf), u (m rows)
         map_l = self._map_from_rows([rhs for _, rhs in self._eq])
-        map_u = self._map_from_rows([rhs for _, rhs in self._eq + self._ineq])
+        map_u = self._map_from_rows([rhs for _, rhs in self._eq + self._ineq + soc_rows])
 
         maps = {'P': map_P, 'q': map_q, 'd': map_d, 'A': map_A, 'l': map_l, 'u': map_u}
+        cones = None
+        if conic:       # Ax + s = b, s in K: the same rows, one right-hand side b (clarabel.py:19-46)
+            maps = {'P': map_P, 'q': map_q, 'd': map_d, 'A': map_A, 'b': map_u}
+            cones = {'zero': n_eq, 'nonneg': len(self._ineq), 'soc': [len(c) for c in self._soc]}
         # p_id_to_changes: depends on any non-constant theta column
         # (`cvxpygen/canonicalizer.py:324`)
         changes = {}
@@ -228,13 +243,14 @@ class CanonBuilder:
         duals = []
         for name, rows, shape in self._duals:
             idx = np.array([r if kind == 'eq' else n_eq + r for kind, r in rows], dtype=np.int32)
-            duals.append(UserDual(name, idx, shape))
+            duals.append(UserDual(name, idx, shape, 'z' if conic else 'y'))
 
         nonzero_d = bool(map_d.nnz > 0)
         return FamilyDescriptor(
             name=self.name, n_var=n, n_eq=n_eq, n_ineq=n_ineq, P=P, A=A, maps=maps,
             changes=changes, theta0=theta0, params=self.params, variables=self.variables,
-            duals=duals, is_maximization=self.is_maximization, nonzero_d=nonzero_d, solver='OSQP')
+            duals=duals, is_maximization=self.is_maximization, nonzero_d=nonzero_d, solver=solver,
+            cones=cones)
 
 
 def canon_lu(desc: FamilyDescriptor, canon: Dict[str, np.ndarray]):

@@ -1,0 +1,734 @@
+// Conic interior-point kernel: what the reference does per solve on
+// its Clarabel path -- cpg_copy_* of the canonical parameters, clarabel_DefaultSolver_new
+// (equilibration, KKT assembly, factorisation), clarabel_DefaultSolver_solve, _solution
+// (cvxpygen/solvers/clarabel.py:172-204) -- for every instance of a batch.
+//
+// Mapping: ONE wavefront per instance, instances handed out through a global atomic counter.
+// The whole interior-point state of an instance (scaled P / A values, iterates, step, NT scaling,
+// the numeric factor L, D and the coefficients of the substitution program) lives in the
+// wavefront's slice of LDS; HBM is touched for theta on the way in, the solution on the way out
+// and the read-only family tables (patterns, schedules), which stay in L2.  Vectors are strided
+// over the 64 lanes; second-order cones are handled one cone per lane.
+//
+// Algorithm (restated from Goulart & Chen 2024, "Clarabel"; defaults cvxpygen/solvers/clarabel.py:
+// 63-119): homogeneous embedding (tau, kappa); Ruiz equilibration; Nesterov-Todd scaling;
+// K = [[P + eps I, A'], [A, -W'W - eps I]] factored as LDL' (fixed pattern, level-scheduled
+// dot-product form) with dynamic pivot regularisation and iterative refinement against the
+// unregularised K; Mehrotra predictor-corrector with sigma = (1 - alpha)^3.
+#pragma once
+#include "cpg_osqp_kernel.h"
+
+namespace cpg {
+
+#define CPG_CK_P 1
+#define CPG_CK_A 2
+#define CPG_CK_DIAGX 3
+#define CPG_CK_HDIAG 5
+#define CPG_CK_HSOC 6
+
+// Clarabel's SolverStatus numbering (the reference hands the integer through: clarabel.py:37-46)
+#define CPG_CL_UNSOLVED 0
+#define CPG_CL_SOLVED 1
+#define CPG_CL_PRIMAL_INFEASIBLE 2
+#define CPG_CL_DUAL_INFEASIBLE 3
+#define CPG_CL_MAX_ITERATIONS 7
+#define CPG_CL_NUMERICAL_ERROR 9
+#define CPG_CL_INSUFFICIENT_PROGRESS 10
+
+struct DevConicSettings {
+    int max_iter, equilibrate_enable, equilibrate_max_iter, static_reg_enable, dynamic_reg_enable, ir_enable,
+        ir_max_iter;
+    double max_step_fraction, tol_gap_abs, tol_gap_rel, tol_feas, tol_infeas_abs, tol_infeas_rel, eq_min, eq_max,
+        static_const, static_prop, dyn_eps, dyn_delta, ir_reltol, ir_abstol, ir_stop_ratio, min_terminate_step;
+};
+
+struct DevConic {
+    int n, m, nnzP, nnzA, nnzL, n_zero, n_nonneg, n_soc, is_max, p_is_zero;
+    const int *soc_start, *soc_dim;          // [n_soc]
+    const int *row_cone;                     // [m] first row of the row's second-order cone, -1 otherwise
+    const int *Ap, *Ai, *Arp, *Aent, *Acol, *Pp, *Pi, *Prp, *Pent, *Pcol;
+    const int *Lcol, *ksrc_kind, *ksrc_idx;
+    const int *fac_ctab;
+    const unsigned *fac_task, *fac_len, *fac_a, *fac_b, *fac_k;
+    int fac_chunks;
+    const int *sol_ctab;
+    const unsigned *sol_desc;
+    const unsigned short *sol_cols;
+    const int *sol_kind, *sol_idx;
+    const unsigned short *sol_fpos;
+    int sol_chunks, sol_nnz, sol_slots;
+    int np_var;
+    const double *P_base, *A_base, *q_base, *b_base;
+    double d_base;
+    DevCsr map_P, map_A, map_q, map_b, map_d;
+    int n_prim, n_dual;
+    const int *prim_idx, *dual_idx;
+    int lds_doubles;                         // per wavefront
+};
+
+struct ConicBuf {
+    double *P, *A, *q, *b, *D, *E, *x, *z, *s, *dx, *dz, *ds, *x2, *z2, *rx, *rz, *tx, *tz, *lam, *wv, *hd, *et,
+        *dsc, *rb, *sol, *er, *cand, *Lx, *Dg, *Dginv, *sv, *w;
+};
+// per-wavefront LDS: nnzP + nnzA + 7n + 14m + 6(n+m) + nnzL + sol_nnz + sol_slots doubles (host: cpg_hip.cpp)
+CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
+    ConicBuf o;
+    const int n = C.n, m = C.m, N = n + m;
+    o.P = p; p += C.nnzP; o.A = p; p += C.nnzA;
+    o.q = p; p += n; o.D = p; p += n; o.x = p; p += n; o.dx = p; p += n; o.x2 = p; p += n; o.rx = p; p += n; o.tx = p; p += n;
+    o.b = p; p += m; o.E = p; p += m; o.z = p; p += m; o.s = p; p += m; o.dz = p; p += m; o.ds = p; p += m;
+    o.z2 = p; p += m; o.rz = p; p += m; o.tz = p; p += m; o.lam = p; p += m; o.wv = p; p += m; o.hd = p; p += m;
+    o.et = p; p += m; o.dsc = p; p += m;
+    o.rb = p; p += N; o.sol = p; p += N; o.er = p; p += N; o.cand = p; p += N; o.Dg = p; p += N; o.Dginv = p; p += N;
+    o.Lx = p; p += C.nnzL; o.sv = p; p += C.sol_nnz; o.w = p;
+    return o;
+}
+
+struct ConicCtx {
+    const DevConic &C;
+    const DevConicSettings &S;
+    ConicBuf B;
+    int lane;
+    unsigned n, m, N;
+
+    // ---- sparse products with the instance's scaled matrices ------------------------------------
+    CPG_DEV double row_P(unsigned j, const double *v) const {
+        double acc = 0.0;
+        const unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
+        for (unsigned k = a; k < e; k++) acc = fma(B.P[(unsigned)cpgw::gld(C.Pent, k)], v[(unsigned)cpgw::gld(C.Pcol, k)], acc);
+        return acc;
+    }
+    CPG_DEV double row_A(unsigned i, const double *v) const {
+        double acc = 0.0;
+        const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
+        for (unsigned k = a; k < e; k++) acc = fma(B.A[(unsigned)cpgw::gld(C.Aent, k)], v[(unsigned)cpgw::gld(C.Acol, k)], acc);
+        return acc;
+    }
+    CPG_DEV double col_At(unsigned j, const double *v) const {
+        double acc = 0.0;
+        const unsigned a = (unsigned)cpgw::gld(C.Ap, j), e = (unsigned)cpgw::gld(C.Ap, j + 1u);
+        for (unsigned k = a; k < e; k++) acc = fma(B.A[k], v[(unsigned)cpgw::gld(C.Ai, k)], acc);
+        return acc;
+    }
+    CPG_DEV double dot_n(const double *a, const double *b) const {
+        double acc = 0.0;
+        for (unsigned i = (unsigned)lane; i < n; i += 64u) acc = fma(a[i], b[i], acc);
+        return cpgw::wave_sum(acc);
+    }
+    CPG_DEV double dot_m(const double *a, const double *b) const {
+        double acc = 0.0;
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) acc = fma(a[i], b[i], acc);
+        return cpgw::wave_sum(acc);
+    }
+    // per-cone dot products  sum_r wv[r] v[r] * eta  are written to tmp[first row of the cone]
+    CPG_DEV void soc_dots(const double *v, double *tmp) const {
+        for (int k = lane; k < C.n_soc; k += 64) {
+            const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
+            double acc = 0.0;
+            for (unsigned r = 0; r < dm; r++) acc += B.wv[st + r] * v[st + r];
+            tmp[st] = acc;
+        }
+        cpgw::lds_order();
+    }
+    // (W'W v)_i for row i; `dots` from soc_dots(v)
+    CPG_DEV double hs_row(unsigned i, const double *v, const double *dots) const {
+        if (i < (unsigned)C.n_zero) return 0.0;
+        const int st = cpgw::gld(C.row_cone, i);
+        if (st < 0) return B.hd[i] * v[i];
+        const double eta = B.et[i];
+        const double t = 2.0 * dots[(unsigned)st];
+        const double o = t * B.wv[i] + ((unsigned)st == i ? -v[i] : v[i]);
+        return (eta * eta) * o;
+    }
+    // er = rb - K v (K without regularisation); returns ||er||_inf
+    CPG_DEV double kkt_residual(const double *v) const {
+        soc_dots(v + n, B.tz);
+        double nrm = 0.0;
+        for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+            const double r = B.rb[j] - (row_P(j, v) + col_At(j, v + n));
+            B.er[j] = r;
+            nrm = cpgw::dmax2(nrm, fabs(r));
+        }
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+            const double r = B.rb[n + i] - (row_A(i, v) - hs_row(i, v + n, B.tz));
+            B.er[n + i] = r;
+            nrm = cpgw::dmax2(nrm, fabs(r));
+        }
+        cpgw::lds_order();
+        return cpgw::wave_max_nonneg(nrm);
+    }
+    // out = (LDL')^{-1} in  (+ add, if given)
+    CPG_DEV void ldl_apply(const LdsProg &SP, const double *in, double *out, const double *add) const {
+        for (unsigned i = (unsigned)lane; i < N; i += 64u) B.w[i] = in[i];
+        cpgw::lds_order();
+        run_program_lds<1>(SP, B.w, C.sol_slots, lane);
+        for (unsigned i = (unsigned)lane; i < N; i += 64u) {
+            const double r = B.w[(unsigned)cpgw::gld(C.sol_fpos, i)];
+            out[i] = add ? add[i] + r : r;
+        }
+        cpgw::lds_order();
+    }
+    // sol = K^{-1} rb with iterative refinement
+    CPG_DEV void kkt_solve(const LdsProg &SP) const {
+        ldl_apply(SP, B.rb, B.sol, nullptr);
+        if (!S.ir_enable) return;
+        double nb = 0.0;
+        for (unsigned i = (unsigned)lane; i < N; i += 64u) nb = cpgw::dmax2(nb, fabs(B.rb[i]));
+        nb = cpgw::wave_max_nonneg(nb);
+        double norme = kkt_residual(B.sol);
+#pragma nounroll
+        for (int it = 0; it < S.ir_max_iter; it++) {
+            if (norme <= S.ir_abstol + S.ir_reltol * nb) break;
+            const double last = norme;
+            ldl_apply(SP, B.er, B.cand, B.sol);
+            const double nn = kkt_residual(B.cand);
+            const double ratio = nn > 0.0 ? last / nn : CPG_INFTY;
+            const bool stop = ratio < S.ir_stop_ratio;
+            if (!stop || ratio > 1.0) {
+                for (unsigned i = (unsigned)lane; i < N; i += 64u) B.sol[i] = B.cand[i];
+                cpgw::lds_order();
+            }
+            if (stop) break;
+            norme = nn;
+        }
+    }
+
+    // ---- numeric factorisation -------------------------------------------------------------------
+    CPG_DEV void factor() const {
+        // static regularisation from the largest diagonal entry of K
+        double eps = 0.0;
+        if (S.static_reg_enable) {
+            double md = 0.0;
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                const unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
+                for (unsigned k = a; k < e; k++)
+                    if ((unsigned)cpgw::gld(C.Pcol, k) == j) md = cpgw::dmax2(md, fabs(B.P[(unsigned)cpgw::gld(C.Pent, k)]));
+            }
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) md = cpgw::dmax2(md, fabs(B.hd[i]));
+            md = cpgw::wave_max_nonneg(md);
+            eps = S.static_const + S.static_prop * md;
+        }
+        int level_start = 0;
+#pragma nounroll
+        for (int c = 0; c < C.fac_chunks; c++) {
+            const int L = cpgw::read_first_lane(cpgw::gld(C.fac_ctab, 4u * (unsigned)c));
+            const int last = cpgw::read_first_lane(cpgw::gld(C.fac_ctab, 4u * (unsigned)c + 1u));
+            unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(C.fac_ctab, 4u * (unsigned)c + 2u));
+            const unsigned task = cpgw::gld(C.fac_task, (unsigned)c * 64u + (unsigned)lane);
+            const int len = (int)cpgw::gld(C.fac_len, (unsigned)c * 64u + (unsigned)lane);
+            double acc = 0.0;
+#pragma nounroll
+            for (int s = 0; s < L; s++) {
+                const bool act = s < len;
+                if (act) {
+                    const unsigned e = base + (unsigned)lane;
+                    const double la = B.Lx[cpgw::gld(C.fac_a, e)];
+                    const double lb = B.Lx[cpgw::gld(C.fac_b, e)];
+                    const double dk = B.Dg[cpgw::gld(C.fac_k, e)];
+                    acc = fma(la * dk, lb, acc);
+                }
+                base += cpgw::popc64(cpgw::ballot(act));
+            }
+            if (task != 0xFFFFFFFFu) {
+                const int kind = cpgw::gld(C.ksrc_kind, task);
+                const unsigned idx = (unsigned)cpgw::gld(C.ksrc_idx, task);
+                const bool piv = task >= (unsigned)C.nnzL;
+                double kv = 0.0, sign = 1.0;
+                if (kind == CPG_CK_P) kv = B.P[idx] + (piv ? eps : 0.0);
+                else if (kind == CPG_CK_A) kv = B.A[idx];
+                else if (kind == CPG_CK_DIAGX) kv = eps;
+                else if (kind == CPG_CK_HDIAG) { kv = -B.hd[idx] - eps; sign = -1.0; }
+                else if (kind == CPG_CK_HSOC) {
+                    const unsigned i = idx & 0xFFFFu, j = idx >> 16;
+                    kv = -((B.et[i] * B.et[i]) * (2.0 * (B.wv[i] * B.wv[j])));
+                }
+                double v = kv - acc;
+                if (piv) {
+                    if (S.dynamic_reg_enable && v * sign < S.dyn_eps) v = S.dyn_delta * sign;
+                    B.Dg[task - (unsigned)C.nnzL] = v;
+                    B.Dginv[task - (unsigned)C.nnzL] = 1.0 / v;
+                } else B.Lx[task] = v;
+            }
+            if (last) {   // level complete: divide the new columns by their pivots
+                cpgw::lds_order();
+#pragma nounroll
+                for (int c2 = level_start; c2 <= c; c2++) {
+                    const unsigned t2 = cpgw::gld(C.fac_task, (unsigned)c2 * 64u + (unsigned)lane);
+                    if (t2 < (unsigned)C.nnzL) B.Lx[t2] = B.Lx[t2] * B.Dginv[(unsigned)cpgw::gld(C.Lcol, t2)];
+                }
+                cpgw::lds_order();
+                level_start = c + 1;
+            }
+        }
+        for (unsigned e = (unsigned)lane; e < (unsigned)C.sol_nnz; e += 64u) {
+            const int kind = cpgw::gld(C.sol_kind, e);
+            const unsigned idx = (unsigned)cpgw::gld(C.sol_idx, e);
+            double v = 0.0;
+            if (kind == 1) v = 1.0;
+            else if (kind == 2) v = -B.Lx[idx];
+            else if (kind == 3) v = B.Dginv[idx];
+            B.sv[e] = v;
+        }
+        cpgw::lds_order();
+    }
+
+    // ---- cone operations -------------------------------------------------------------------------
+    CPG_DEV void identity_scaling() const {
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+            const int st = cpgw::gld(C.row_cone, i);
+            B.et[i] = 1.0;
+            B.wv[i] = (st < 0 || (unsigned)st == i) ? 1.0 : 0.0;
+            B.lam[i] = 1.0;
+            B.hd[i] = i < (unsigned)C.n_zero ? 0.0 : 1.0;
+        }
+        cpgw::lds_order();
+    }
+    // (min margin, sum of positive margins) of v over the nonnegative and second-order cones
+    CPG_DEV void margins(const double *v, double &mn, double &pos) const {
+        double a = CPG_INFTY, bsum = 0.0;
+        for (unsigned i = (unsigned)C.n_zero + (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {
+            a = cpgw::dmin2(a, v[i]);
+            bsum += cpgw::dmax2(v[i], 0.0);
+        }
+        for (int k = lane; k < C.n_soc; k += 64) {
+            const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
+            double ss = 0.0;
+            for (unsigned r = 1; r < dm; r++) ss += v[st + r] * v[st + r];
+            const double mg = v[st] - sqrt(ss);
+            a = cpgw::dmin2(a, mg);
+            bsum += cpgw::dmax2(0.0, mg);
+        }
+        mn = cpgw::wave_min(a);
+        pos = cpgw::wave_sum(bsum);
+    }
+    CPG_DEV void unit_shift(double *v, double a, bool primal) const {
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+            if (i < (unsigned)C.n_zero) { if (primal) v[i] = 0.0; continue; }
+            const int st = cpgw::gld(C.row_cone, i);
+            if (st < 0 || (unsigned)st == i) v[i] += a;
+        }
+        cpgw::lds_order();
+    }
+    CPG_DEV void shift_to_cone(double *v, bool primal) const {
+        const int degree = C.n_nonneg + C.n_soc;
+        if (degree == 0) { unit_shift(v, 0.0, primal); return; }
+        double mn, pos;
+        margins(v, mn, pos);
+        const double target = cpgw::dmax2(1.0, 0.1 * pos / (double)degree);
+        if (mn <= 0.0) { unit_shift(v, -mn, primal); unit_shift(v, target, primal); }
+        else if (mn < target) unit_shift(v, target - mn, primal);
+        else unit_shift(v, 0.0, primal);
+    }
+    // Nesterov-Todd scaling from (s, z); false if a second-order cone iterate left the cone
+    CPG_DEV bool update_scaling() const {
+        bool ok = true;
+        for (unsigned i = (unsigned)C.n_zero + (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {
+            const double w = sqrt(B.s[i] / B.z[i]);
+            B.wv[i] = w; B.et[i] = 1.0;
+            B.lam[i] = sqrt(B.s[i] * B.z[i]);
+            B.hd[i] = w * w;
+        }
+        for (int k = lane; k < C.n_soc; k += 64) {
+            const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
+            const double s0 = B.s[st], z0 = B.z[st];
+            double ss = 0.0, zz = 0.0, sz = s0 * z0;
+            for (unsigned r = 1; r < dm; r++) {
+                ss += B.s[st + r] * B.s[st + r]; zz += B.z[st + r] * B.z[st + r]; sz += B.s[st + r] * B.z[st + r];
+            }
+            const double rs = s0 * s0 - ss, rz = z0 * z0 - zz;
+            if (!(rs > 0.0 && rz > 0.0)) { ok = false; continue; }
+            const double sscale = sqrt(rs), zscale = sqrt(rz);
+            const double gamma = sqrt(0.5 * (1.0 + sz / (sscale * zscale)));
+            const double fs = 2.0 * sscale * gamma, fz = 2.0 * zscale * gamma;
+            double w1sq = 0.0;
+            for (unsigned r = 1; r < dm; r++) {
+                const double w = B.s[st + r] / fs - B.z[st + r] / fz;
+                B.wv[st + r] = w;
+                w1sq += w * w;
+            }
+            const double w0 = sqrt(1.0 + w1sq);
+            B.wv[st] = w0;
+            const double eta = sqrt(sscale / zscale);
+            double zeta = 0.0;
+            for (unsigned r = 1; r < dm; r++) zeta += B.wv[st + r] * B.z[st + r];
+            B.lam[st] = eta * (w0 * z0 + zeta);
+            const double f = z0 + zeta / (1.0 + w0);
+            for (unsigned r = 1; r < dm; r++) B.lam[st + r] = eta * (B.z[st + r] + f * B.wv[st + r]);
+            const double e2 = eta * eta;
+            for (unsigned r = 0; r < dm; r++) {
+                B.et[st + r] = eta;
+                const double w = B.wv[st + r];
+                B.hd[st + r] = e2 * (2.0 * (w * w) - (r == 0 ? 1.0 : -1.0));
+            }
+        }
+        cpgw::lds_order();
+        return !cpgw::wave_any(!ok);
+    }
+    // largest a in [0, amax] with v + a dv in the cone
+    CPG_DEV double step_length(const double *v, const double *dv, double amax) const {
+        double a = amax;
+        for (unsigned i = (unsigned)C.n_zero + (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u)
+            if (dv[i] < 0.0) a = cpgw::dmin2(a, -v[i] / dv[i]);
+        for (int k = lane; k < C.n_soc; k += 64) {
+            const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
+            double yy = 0.0, xy = 0.0, xx = 0.0;
+            for (unsigned r = 1; r < dm; r++) { yy += dv[st + r] * dv[st + r]; xy += v[st + r] * dv[st + r]; xx += v[st + r] * v[st + r]; }
+            const double qa = dv[st] * dv[st] - yy;
+            const double qb = 2.0 * (v[st] * dv[st] - xy);
+            const double qc = cpgw::dmax2(0.0, v[st] * v[st] - xx);
+            const double disc = qb * qb - 4.0 * qa * qc;
+            double r = CPG_INFTY;
+            if (!((qa > 0.0 && qb > 0.0) || disc < 0.0) && qa != 0.0) {
+                const double t = qb >= 0.0 ? (-qb - sqrt(disc)) : (-qb + sqrt(disc));
+                double r1 = t != 0.0 ? (2.0 * qc) / t : CPG_INFTY;
+                double r2 = t / (2.0 * qa);
+                if (r1 < 0.0) r1 = CPG_INFTY;
+                if (r2 < 0.0) r2 = CPG_INFTY;
+                r = cpgw::dmin2(r1, r2);
+            }
+            a = cpgw::dmin2(a, r);
+        }
+        return cpgw::wave_min(a);
+    }
+    // dsc = W'(lambda \ (lambda o lambda + (W^-1 ds) o (W dz) - sigma mu e)), zero-cone rows 0
+    CPG_DEV void combined_ds_offset(double sigmamu) const {
+        for (unsigned i = (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {
+            if (i < (unsigned)C.n_zero) { B.dsc[i] = 0.0; continue; }
+            const double w = B.wv[i], lm = B.lam[i];
+            const double d = lm * lm + (B.ds[i] / w) * (B.dz[i] * w) - sigmamu;
+            B.dsc[i] = (d / lm) * w;
+        }
+        for (int k = lane; k < C.n_soc; k += 64) {
+            const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
+            const double eta = B.et[st], w0 = B.wv[st];
+            double *a = B.tz + st, *bb = B.dsc + st;
+            const double *lm = B.lam + st, *w = B.wv + st;
+            // a = W^-1 ds, bb = W dz
+            double zs = 0.0, zz = 0.0;
+            for (unsigned r = 1; r < dm; r++) { zs += w[r] * B.ds[st + r]; zz += w[r] * B.dz[st + r]; }
+            const double ds0 = B.ds[st], dz0 = B.dz[st];
+            a[0] = (w0 * ds0 - zs) / eta;
+            bb[0] = eta * (w0 * dz0 + zz);
+            const double fa = -ds0 + zs / (1.0 + w0), fb = dz0 + zz / (1.0 + w0);
+            for (unsigned r = 1; r < dm; r++) {
+                a[r] = (B.ds[st + r] + fa * w[r]) / eta;
+                bb[r] = eta * (B.dz[st + r] + fb * w[r]);
+            }
+            // d = lam o lam + a o bb - sigma mu e   (into a)
+            double ll = 0.0, ab = 0.0;
+            for (unsigned r = 0; r < dm; r++) { ll += lm[r] * lm[r]; ab += a[r] * bb[r]; }
+            const double a0 = a[0], b0 = bb[0];
+            for (unsigned r = 1; r < dm; r++) a[r] = (lm[0] * lm[r] + lm[0] * lm[r]) + (a0 * bb[r] + b0 * a[r]);
+            a[0] = ll + ab - sigmamu;
+            // u = lam \ d   (into a)
+            double l1 = 0.0, ld = 0.0;
+            for (unsigned r = 1; r < dm; r++) { l1 += lm[r] * lm[r]; ld += lm[r] * a[r]; }
+            const double p = lm[0] * lm[0] - l1;
+            const double u0 = (lm[0] * a[0] - ld) / p;
+            for (unsigned r = 1; r < dm; r++) a[r] = (a[r] - u0 * lm[r]) / lm[0];
+            a[0] = u0;
+            // out = W u   (into dsc)
+            double zu = 0.0;
+            for (unsigned r = 1; r < dm; r++) zu += w[r] * a[r];
+            bb[0] = eta * (w0 * u0 + zu);
+            const double fu = u0 + zu / (1.0 + w0);
+            for (unsigned r = 1; r < dm; r++) bb[r] = eta * (a[r] + fu * w[r]);
+        }
+        cpgw::lds_order();
+    }
+};
+
+// Solves rb = (rhs_x, dsc - rhs_z) and assembles the step (dx, dz, ds, dtau, dkappa) of the
+// homogeneous embedding; x2 / z2 is the constant part K^{-1}(-q, b), `den` its denominator.
+CPG_DEV void conic_step(const ConicCtx &cx, const LdsProg &SP, double rhs_tau, double rhs_kap, double tau, double kap,
+                        double den, double &dtau, double &dkap) {
+    const ConicBuf &B = cx.B;
+    const unsigned n = cx.n, m = cx.m;
+    const int lane = cx.lane;
+    cx.kkt_solve(SP);                          // sol = (x1, z1)
+    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.tx[j] = cx.row_P(j, B.sol);
+    cpgw::lds_order();
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (unsigned j = (unsigned)lane; j < n; j += 64u) { a1 = fma(B.q[j], B.sol[j], a1); a3 = fma(B.x[j] / tau, B.tx[j], a3); }
+    for (unsigned i = (unsigned)lane; i < m; i += 64u) a2 = fma(B.b[i], B.sol[n + i], a2);
+    a1 = cpgw::wave_sum(a1); a2 = cpgw::wave_sum(a2); a3 = cpgw::wave_sum(a3);
+    const double num = rhs_tau - rhs_kap / tau + a1 + a2 + 2.0 * a3;
+    dtau = num / den;
+    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.dx[j] = B.sol[j] + dtau * B.x2[j];
+    for (unsigned i = (unsigned)lane; i < m; i += 64u) B.dz[i] = B.sol[n + i] + dtau * B.z2[i];
+    cpgw::lds_order();
+    cx.soc_dots(B.dz, B.tz);
+    for (unsigned i = (unsigned)lane; i < m; i += 64u) B.ds[i] = -(cx.hs_row(i, B.dz, B.tz) + B.dsc[i]);
+    cpgw::lds_order();
+    dkap = -(rhs_kap + kap * dtau) / tau;
+}
+
+CPG_DEV void clarabel_body(const DevConic &C, const DevConicSettings &S, const DevBatch &Bt, double *lds, int /*wave_global*/) {
+    const int lane = cpgw::lane_id();
+    const unsigned n = (unsigned)C.n, m = (unsigned)C.m, N = n + m;
+    const ConicBuf B = conic_carve(lds + (size_t)cpgw::wave_in_block() * (size_t)C.lds_doubles, C);
+    const ConicCtx cx{C, S, B, lane, n, m, N};
+    LdsProg SP;
+    SP.ctab = C.sol_ctab; SP.desc = C.sol_desc; SP.vals = B.sv; SP.cols = C.sol_cols;
+    SP.n_chunks = C.sol_chunks; SP.dummy = (unsigned)C.sol_nnz - 1u; SP.rows16 = nullptr;
+    const int degree = C.n_nonneg + C.n_soc;
+
+    for (;;) {
+        unsigned ig = 0;
+        if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
+        ig = (unsigned)cpgw::read_first_lane((int)ig);
+        if ((long long)ig >= Bt.B) break;
+        const long long bi = (long long)ig;
+        const double *theta = Bt.theta + (size_t)bi * C.np_var;
+
+        // ---- 1. canonicalise: cpg_canonicalize_* + cpg_copy_* (utils.py:279-294, 987-1006)
+        for (unsigned k = (unsigned)lane; k < (unsigned)C.nnzA; k += 64u) B.A[k] = csr_row(C.map_A, k, theta, cpgw::gld(C.A_base, k));
+        for (unsigned k = (unsigned)lane; k < (unsigned)C.nnzP; k += 64u) B.P[k] = csr_row(C.map_P, k, theta, cpgw::gld(C.P_base, k));
+        double normq = 0.0, normb = 0.0;
+        for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+            const double v = csr_row(C.map_q, j, theta, cpgw::gld(C.q_base, j));
+            B.q[j] = v; B.D[j] = 1.0; normq = cpgw::dmax2(normq, fabs(v));
+        }
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+            const double v = csr_row(C.map_b, i, theta, cpgw::gld(C.b_base, i));
+            B.b[i] = v; B.E[i] = 1.0; normb = cpgw::dmax2(normb, fabs(v));
+        }
+        const double dconst = csr_row(C.map_d, 0, theta, C.d_base);
+        normq = cpgw::wave_max_nonneg(normq); normb = cpgw::wave_max_nonneg(normb);
+        cpgw::lds_order();
+
+        // ---- 2. equilibration (in place; D, E cumulative, c the cost scaling)
+        double cs = 1.0;
+        if (S.equilibrate_enable) {
+#pragma nounroll
+            for (int it = 0; it < S.equilibrate_max_iter; it++) {
+                for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                    double acc = 0.0;
+                    unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
+                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.P[(unsigned)cpgw::gld(C.Pent, k)]));
+                    a = (unsigned)cpgw::gld(C.Ap, j); e = (unsigned)cpgw::gld(C.Ap, j + 1u);
+                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.A[k]));
+                    acc = acc == 0.0 ? 1.0 : acc;
+                    acc = acc < S.eq_min ? S.eq_min : (acc > S.eq_max ? S.eq_max : acc);
+                    B.tx[j] = 1.0 / sqrt(acc);
+                }
+                for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+                    double acc = 0.0;
+                    const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
+                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.A[(unsigned)cpgw::gld(C.Aent, k)]));
+                    acc = acc == 0.0 ? 1.0 : acc;
+                    acc = acc < S.eq_min ? S.eq_min : (acc > S.eq_max ? S.eq_max : acc);
+                    B.tz[i] = 1.0 / sqrt(acc);
+                }
+                cpgw::lds_order();
+                for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                    const double dj = B.tx[j];
+                    unsigned a = (unsigned)cpgw::gld(C.Pp, j), e = (unsigned)cpgw::gld(C.Pp, j + 1u);
+                    for (unsigned k = a; k < e; k++) B.P[k] = (B.tx[(unsigned)cpgw::gld(C.Pi, k)] * B.P[k]) * dj;
+                    a = (unsigned)cpgw::gld(C.Ap, j); e = (unsigned)cpgw::gld(C.Ap, j + 1u);
+                    for (unsigned k = a; k < e; k++) B.A[k] = (B.tz[(unsigned)cpgw::gld(C.Ai, k)] * B.A[k]) * dj;
+                    B.q[j] = dj * B.q[j];
+                    B.D[j] *= dj;
+                }
+                for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.b[i] = B.tz[i] * B.b[i]; B.E[i] *= B.tz[i]; }
+                cpgw::lds_order();
+                double psum = 0.0, qn = 0.0;
+                for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                    double acc = 0.0;
+                    const unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
+                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.P[(unsigned)cpgw::gld(C.Pent, k)]));
+                    psum += acc;
+                    qn = cpgw::dmax2(qn, fabs(B.q[j]));
+                }
+                psum = cpgw::wave_sum(psum); qn = cpgw::wave_max_nonneg(qn);
+                const double pn = n ? psum / (double)n : 0.0;
+                if (pn != 0.0 && qn != 0.0) {
+                    double ct = 1.0 / cpgw::dmax2(pn, qn);
+                    ct = ct < S.eq_min ? S.eq_min : (ct > S.eq_max ? S.eq_max : ct);
+                    for (unsigned k = (unsigned)lane; k < (unsigned)C.nnzP; k += 64u) B.P[k] *= ct;
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.q[j] *= ct;
+                    cs *= ct;
+                    cpgw::lds_order();
+                }
+            }
+            // second-order cone rows must share one scale: mean of the cone
+            for (int k = lane; k < C.n_soc; k += 64) {
+                const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
+                double sum = 0.0;
+                for (unsigned r = 0; r < dm; r++) sum += B.E[st + r];
+                const double mean = sum / (double)dm;
+                for (unsigned r = 0; r < dm; r++) B.tz[st + r] = mean / B.E[st + r];
+            }
+            cpgw::lds_order();
+            if (C.n_soc > 0) {
+                const unsigned first = (unsigned)(C.n_zero + C.n_nonneg);
+                for (unsigned i = first + (unsigned)lane; i < m; i += 64u) {
+                    const double ew = B.tz[i];
+                    const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
+                    for (unsigned k = a; k < e; k++) B.A[(unsigned)cpgw::gld(C.Aent, k)] *= ew;
+                    B.b[i] *= ew; B.E[i] *= ew;
+                }
+                cpgw::lds_order();
+            }
+        }
+        const double cinv = 1.0 / cs;
+
+        // ---- 3. initial point: identity scaling, one factorisation, shift into the cones
+        cx.identity_scaling();
+        cx.factor();
+        if (!C.p_is_zero) {
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = -B.q[j];
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.b[i];
+            cpgw::lds_order();
+            cx.kkt_solve(SP);
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = B.sol[j];
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) { const double zv = B.sol[n + i]; B.z[i] = zv; B.s[i] = -zv; }
+        } else {
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = 0.0;
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.b[i];
+            cpgw::lds_order();
+            cx.kkt_solve(SP);
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) { B.x[j] = B.sol[j]; B.rb[j] = -B.q[j]; }
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.s[i] = -B.sol[n + i]; B.rb[n + i] = 0.0; }
+            cpgw::lds_order();
+            cx.kkt_solve(SP);
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.z[i] = B.sol[n + i];
+        }
+        cpgw::lds_order();
+        cx.shift_to_cone(B.s, true);
+        cx.shift_to_cone(B.z, false);
+        double tau = 1.0, kap = 1.0;
+
+        // ---- 4. interior-point iterations
+        int status = CPG_CL_UNSOLVED, iter = 0;
+        double cost_p = 0.0, res_p = 0.0, res_d = 0.0;
+#pragma nounroll
+        for (;;) {
+            // residuals: tx = P x, rx = -P x - A'z - q tau, rz = A x + s - b tau
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.tx[j] = cx.row_P(j, B.x);
+            cpgw::lds_order();
+            double dqx = 0.0, dbz = 0.0, dsz = 0.0, xPx = 0.0;
+            double n_x = 0.0, n_z = 0.0, n_s = 0.0, n_rxinf = 0.0, n_px = 0.0, n_rzinf = 0.0, n_rz = 0.0, n_rx = 0.0;
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                const double xj = B.x[j], px = B.tx[j], di = 1.0 / B.D[j];
+                const double rinf = -cx.col_At(j, B.z);
+                const double r = rinf - px - B.q[j] * tau;
+                B.rx[j] = r;
+                dqx = fma(B.q[j], xj, dqx); xPx = fma(xj, px, xPx);
+                n_x = cpgw::dmax2(n_x, fabs(B.D[j] * xj)); n_rxinf = cpgw::dmax2(n_rxinf, fabs(di * rinf));
+                n_px = cpgw::dmax2(n_px, fabs(di * px)); n_rx = cpgw::dmax2(n_rx, fabs(di * r));
+            }
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+                const double zi = B.z[i], si = B.s[i], ei = 1.0 / B.E[i];
+                const double rinf = cx.row_A(i, B.x) + si;
+                const double r = rinf - B.b[i] * tau;
+                B.rz[i] = r;
+                dbz = fma(B.b[i], zi, dbz); dsz = fma(si, zi, dsz);
+                n_z = cpgw::dmax2(n_z, fabs(B.E[i] * zi)); n_s = cpgw::dmax2(n_s, fabs(ei * si));
+                n_rzinf = cpgw::dmax2(n_rzinf, fabs(ei * rinf)); n_rz = cpgw::dmax2(n_rz, fabs(ei * r));
+            }
+            cpgw::lds_order();
+            dqx = cpgw::wave_sum(dqx); dbz = cpgw::wave_sum(dbz); dsz = cpgw::wave_sum(dsz); xPx = cpgw::wave_sum(xPx);
+            n_x = cpgw::wave_max_nonneg(n_x); n_z = cpgw::wave_max_nonneg(n_z) * cinv; n_s = cpgw::wave_max_nonneg(n_s);
+            n_rxinf = cpgw::wave_max_nonneg(n_rxinf); n_px = cpgw::wave_max_nonneg(n_px);
+            n_rzinf = cpgw::wave_max_nonneg(n_rzinf); n_rz = cpgw::wave_max_nonneg(n_rz); n_rx = cpgw::wave_max_nonneg(n_rx);
+            const double rtau = dqx + dbz + kap + xPx / tau;
+            const double mu = (dsz + tau * kap) / (double)(degree + 1);
+            // termination quantities on the unscaled problem
+            const double tinv = 1.0 / tau;
+            cost_p = (dqx * tinv + 0.5 * xPx * tinv * tinv) * cinv;
+            const double cost_d = (-dbz * tinv - 0.5 * xPx * tinv * tinv) * cinv;
+            const double res_pinf = n_rxinf / cpgw::dmax2(1.0, n_z);
+            const double res_dinf = cpgw::dmax2(n_px / cpgw::dmax2(1.0, n_x), n_rzinf / cpgw::dmax2(1.0, n_x + n_s));
+            const double nx = n_x * tinv, nz = n_z * tinv, ns = n_s * tinv;
+            res_p = n_rz * tinv / cpgw::dmax2(1.0, normb + nx + ns);
+            res_d = n_rx * tinv * cinv / cpgw::dmax2(1.0, normq + nx + nz);
+            const double gap_abs = fabs(cost_p - cost_d);
+            const double gap_rel = gap_abs / cpgw::dmax2(1.0, cpgw::dmin2(fabs(cost_p), fabs(cost_d)));
+            const double ktratio = kap / tau;
+            if (ktratio <= 1.0 && (gap_abs < S.tol_gap_abs || gap_rel < S.tol_gap_rel) && res_p < S.tol_feas && res_d < S.tol_feas)
+                status = CPG_CL_SOLVED;
+            else if (ktratio > 1000.0) {
+                const double bz = dbz * cinv, qx = dqx * cinv;
+                if (bz < -S.tol_infeas_abs && res_pinf < -S.tol_infeas_rel * bz) status = CPG_CL_PRIMAL_INFEASIBLE;
+                else if (qx < -S.tol_infeas_abs && res_dinf < -S.tol_infeas_rel * qx) status = CPG_CL_DUAL_INFEASIBLE;
+            }
+            if (status == CPG_CL_UNSOLVED && iter >= S.max_iter) status = CPG_CL_MAX_ITERATIONS;
+            if (status != CPG_CL_UNSOLVED) break;
+            iter++;
+
+            // scaling, factorisation, constant part (x2, z2) = K^{-1}(-q, b)
+            if (!cx.update_scaling()) { status = CPG_CL_NUMERICAL_ERROR; break; }
+            cx.factor();
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = -B.q[j];
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.b[i];
+            cpgw::lds_order();
+            cx.kkt_solve(SP);
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) { B.x2[j] = B.sol[j]; B.cand[j] = B.x[j] / tau - B.sol[j]; }
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.z2[i] = B.sol[n + i];
+            cpgw::lds_order();
+            double den;
+            {
+                double qx2 = 0.0, bz2 = 0.0, vPv = 0.0, x2Px2 = 0.0;
+                for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                    qx2 = fma(B.q[j], B.x2[j], qx2);
+                    vPv = fma(B.cand[j], cx.row_P(j, B.cand), vPv);
+                    x2Px2 = fma(B.x2[j], cx.row_P(j, B.x2), x2Px2);
+                }
+                for (unsigned i = (unsigned)lane; i < m; i += 64u) bz2 = fma(B.b[i], B.z2[i], bz2);
+                qx2 = cpgw::wave_sum(qx2); bz2 = cpgw::wave_sum(bz2); vPv = cpgw::wave_sum(vPv); x2Px2 = cpgw::wave_sum(x2Px2);
+                den = kap / tau - qx2 - bz2 + vPv - x2Px2;
+            }
+            // affine step: rhs (rx, rz, rtau, tau kappa), ds offset = s
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = B.rx[j];
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.dsc[i] = B.s[i]; B.rb[n + i] = B.s[i] - B.rz[i]; }
+            cpgw::lds_order();
+            double dtau, dkap;
+            conic_step(cx, SP, rtau, tau * kap, tau, kap, den, dtau, dkap);
+            double alpha = 1.0;
+            if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
+            if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
+            alpha = cx.step_length(B.z, B.dz, alpha);
+            alpha = cx.step_length(B.s, B.ds, alpha);
+            const double sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
+            // combined step
+            cx.combined_ds_offset(sigma * mu);
+            const double rk = -sigma * mu + dtau * dkap + tau * kap;
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = (1.0 - sigma) * B.rx[j];
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.dsc[i] - (1.0 - sigma) * B.rz[i];
+            cpgw::lds_order();
+            conic_step(cx, SP, (1.0 - sigma) * rtau, rk, tau, kap, den, dtau, dkap);
+            alpha = 1.0;
+            if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
+            if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
+            alpha = cx.step_length(B.z, B.dz, alpha);
+            alpha = cx.step_length(B.s, B.ds, alpha);
+            alpha *= S.max_step_fraction;
+            if (alpha < S.min_terminate_step) { status = CPG_CL_INSUFFICIENT_PROGRESS; break; }
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] += alpha * B.dx[j];
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.s[i] += alpha * B.ds[i]; B.z[i] += alpha * B.dz[i]; }
+            tau += alpha * dtau; kap += alpha * dkap;
+            cpgw::lds_order();
+        }
+
+        // ---- 5. retrieve: cpg_retrieve_prim / _dual / _info (utils.py:1040-1046; clarabel.py:37-46)
+        const bool infeasible = status == CPG_CL_PRIMAL_INFEASIBLE || status == CPG_CL_DUAL_INFEASIBLE;
+        const double scale = infeasible ? 1.0 : 1.0 / tau;
+        for (unsigned k = (unsigned)lane; k < (unsigned)C.n_prim; k += 64u) {
+            const unsigned j = (unsigned)cpgw::gld(C.prim_idx, k);
+            Bt.prim[(size_t)bi * C.n_prim + k] = B.D[j] * B.x[j] * scale;
+        }
+        for (unsigned k = (unsigned)lane; k < (unsigned)C.n_dual; k += 64u) {
+            const unsigned i = (unsigned)cpgw::gld(C.dual_idx, k);
+            Bt.dual[(size_t)bi * C.n_dual + k] = B.E[i] * B.z[i] * scale / cs;
+        }
+        if (lane == 0) {
+            double ov = infeasible ? NAN : cost_p + dconst;
+            if (C.is_max) ov = -ov;
+            Bt.obj[bi] = ov; Bt.iter[bi] = iter; Bt.status[bi] = status; Bt.pri_res[bi] = res_p; Bt.dua_res[bi] = res_d;
+        }
+        cpgw::lds_order();
+    }
+}
+
+}  // namespace cpg

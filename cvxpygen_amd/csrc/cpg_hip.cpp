@@ -15,6 +15,7 @@
 
 #include "cpg_osqp_kernel.h"
 #include "cpg_osqp_refactor.h"
+#include "cpg_clarabel_kernel.h"
 
 // ------------------------------------------------------------------------------------ runtime layer
 #ifndef CPG_HOST_SIM
@@ -72,6 +73,12 @@ struct cpg_solver_s {
     size_t lds_limit = 160 * 1024;
     unsigned *d_counter = nullptr;
     int n_vary_x = 0, n_vary_z = 0;
+    bool conic = false;                 // interior-point handle (cpg_hip_create_clarabel)
+    cpg::DevConic C{};
+    cpg::DevConicSettings CS{};
+    double time_limit = 1e10; int verbose = 1, direct_kkt_solver = 1, presolve_enable = 1;   // accepted, unused
+    double reduced[6] = {5e-5, 5e-5, 1e-4, 5e-5, 5e-5, 1e-4}, tol_ktratio = 1e-6, linesearch_backtrack_step = 0.8,
+           min_switch_step_length = 0.1;
     DevBuf scratch;                     // delta_x / delta_y stash, [waves][G][n + m]
     // staging for the host-pointer entry point
     DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status;
@@ -316,6 +323,46 @@ static int launch_refactor(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, 
     return CPG_E_UNSUPPORTED;
 }
 
+// ---- conic interior-point kernel: no slot classes, every vector lives in LDS ---------------------
+#ifndef CPG_HOST_SIM
+__global__ void __launch_bounds__(512, 1)
+clarabel_kernel(cpg::DevConic C, cpg::DevConicSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cpg::clarabel_body(C, S, Bt, cpg_lds, wave_global);
+}
+static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = clarabel_kernel;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->C, h->CS, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#else
+static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    for (int b = 0; b < blocks; b++) {
+        std::vector<char> ldsbuf(lds + 64);
+        std::vector<cpgw::SimWave> wv(waves);
+        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
+        pthread_barrier_t block_bar;
+        pthread_barrier_init(&block_bar, nullptr, waves * 64);
+        std::vector<std::thread> th;
+        for (int t = 0; t < waves * 64; t++)
+            th.emplace_back([&, t]() {
+                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
+                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
+                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
+                cpg::clarabel_body(h->C, h->CS, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
+            });
+        for (auto &t : th) t.join();
+        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
+        pthread_barrier_destroy(&block_bar);
+    }
+    return CPG_OK;
+}
+#endif
+
 // Instantiated kernels.  (NSX, NSZ): slot class (ceil(n/64), ceil(m/64)); NV: leading slots with
 // per-instance q / u (1: at most 64 parameter-dependent entries; NS: all); G instances per wave.
 // The smallest class that covers the family is used.
@@ -385,8 +432,68 @@ int cpg_hip_device_count(int *count) {
     return CPG_OK;
 }
 
+// conic settings by name (cvxpygen/solvers/clarabel.py:63-119); returns the slot or nullptr
+static double *conic_double_setting(cpg_handle_t h, const std::string &s) {
+    cpg::DevConicSettings &c = h->CS;
+    if (s == "max_step_fraction") return &c.max_step_fraction;
+    if (s == "tol_gap_abs") return &c.tol_gap_abs;
+    if (s == "tol_gap_rel") return &c.tol_gap_rel;
+    if (s == "tol_feas") return &c.tol_feas;
+    if (s == "tol_infeas_abs") return &c.tol_infeas_abs;
+    if (s == "tol_infeas_rel") return &c.tol_infeas_rel;
+    if (s == "tol_ktratio") return &h->tol_ktratio;
+    if (s == "reduced_tol_gap_abs") return &h->reduced[0];
+    if (s == "reduced_tol_gap_rel") return &h->reduced[1];
+    if (s == "reduced_tol_feas") return &h->reduced[2];
+    if (s == "reduced_tol_infeas_abs") return &h->reduced[3];
+    if (s == "reduced_tol_infeas_rel") return &h->reduced[4];
+    if (s == "reduced_tol_ktratio") return &h->reduced[5];
+    if (s == "equilibrate_min_scaling") return &c.eq_min;
+    if (s == "equilibrate_max_scaling") return &c.eq_max;
+    if (s == "linesearch_backtrack_step") return &h->linesearch_backtrack_step;
+    if (s == "min_switch_step_length") return &h->min_switch_step_length;
+    if (s == "min_terminate_step_length") return &c.min_terminate_step;
+    if (s == "static_regularization_constant") return &c.static_const;
+    if (s == "static_regularization_proportional") return &c.static_prop;
+    if (s == "dynamic_regularization_eps") return &c.dyn_eps;
+    if (s == "dynamic_regularization_delta") return &c.dyn_delta;
+    if (s == "iterative_refinement_reltol") return &c.ir_reltol;
+    if (s == "iterative_refinement_abstol") return &c.ir_abstol;
+    if (s == "iterative_refinement_stop_ratio") return &c.ir_stop_ratio;
+    if (s == "time_limit") return &h->time_limit;
+    return nullptr;
+}
+static int *conic_int_setting(cpg_handle_t h, const std::string &s) {
+    cpg::DevConicSettings &c = h->CS;
+    if (s == "max_iter") return &c.max_iter;
+    if (s == "equilibrate_enable") return &c.equilibrate_enable;
+    if (s == "equilibrate_max_iter") return &c.equilibrate_max_iter;
+    if (s == "static_regularization_enable") return &c.static_reg_enable;
+    if (s == "dynamic_regularization_enable") return &c.dynamic_reg_enable;
+    if (s == "iterative_refinement_enable") return &c.ir_enable;
+    if (s == "iterative_refinement_max_iter") return &c.ir_max_iter;
+    if (s == "verbose") return &h->verbose;
+    if (s == "direct_kkt_solver") return &h->direct_kkt_solver;
+    if (s == "presolve_enable") return &h->presolve_enable;
+    return nullptr;
+}
+
 int cpg_hip_set_default_settings(cpg_handle_t h) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    if (h->conic) {   // cvxpygen/solvers/clarabel.py:63-119
+        cpg::DevConicSettings &c = h->CS;
+        c.max_iter = 200; c.max_step_fraction = 0.99;
+        c.tol_gap_abs = 1e-8; c.tol_gap_rel = 1e-8; c.tol_feas = 1e-8; c.tol_infeas_abs = 1e-8; c.tol_infeas_rel = 1e-8;
+        c.equilibrate_enable = 1; c.equilibrate_max_iter = 10; c.eq_min = 1e-4; c.eq_max = 1e4;
+        c.min_terminate_step = 1e-4;
+        c.static_reg_enable = 1; c.static_const = 1e-8; c.static_prop = 2.2e-16;
+        c.dynamic_reg_enable = 1; c.dyn_eps = 1e-13; c.dyn_delta = 2e-7;
+        c.ir_enable = 1; c.ir_reltol = 1e-13; c.ir_abstol = 1e-12; c.ir_max_iter = 10; c.ir_stop_ratio = 5.0;
+        h->time_limit = 1e10; h->verbose = 1; h->direct_kkt_solver = 1; h->presolve_enable = 1;
+        h->reduced[0] = 5e-5; h->reduced[1] = 5e-5; h->reduced[2] = 1e-4; h->reduced[3] = 5e-5; h->reduced[4] = 5e-5;
+        h->reduced[5] = 1e-4; h->tol_ktratio = 1e-6; h->linesearch_backtrack_step = 0.8; h->min_switch_step_length = 0.1;
+        return CPG_OK;
+    }
     // defaults of the generated solver, cvxpygen/solvers/osqp.py:102-115
     h->S.max_iter = 4000; h->S.eps_abs = 1e-3; h->S.eps_rel = 1e-3; h->S.eps_prim_inf = 1e-4;
     h->S.eps_dual_inf = 1e-4; h->S.scaled_termination = 0; h->S.check_termination = 25;
@@ -397,6 +504,11 @@ int cpg_hip_set_default_settings(cpg_handle_t h) {
 int cpg_hip_set_setting(cpg_handle_t h, const char *name, double v) {
     if (!h || !name) { set_error("null argument"); return CPG_E_BADARG; }
     std::string s(name);
+    if (h->conic) {
+        if (double *d = conic_double_setting(h, s)) { *d = v; return CPG_OK; }
+        if (int *i = conic_int_setting(h, s)) { *i = (int)v; return CPG_OK; }
+        set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG;
+    }
     if (s == "max_iter") h->S.max_iter = (int)v;
     else if (s == "eps_abs") h->S.eps_abs = v;
     else if (s == "eps_rel") h->S.eps_rel = v;
@@ -412,6 +524,11 @@ int cpg_hip_set_setting(cpg_handle_t h, const char *name, double v) {
 int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     if (!h || !name || !v) { set_error("null argument"); return CPG_E_BADARG; }
     std::string s(name);
+    if (h->conic) {
+        if (double *d = conic_double_setting(h, s)) { *v = *d; return CPG_OK; }
+        if (int *i = conic_int_setting(h, s)) { *v = *i; return CPG_OK; }
+        set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG;
+    }
     if (s == "max_iter") *v = h->S.max_iter;
     else if (s == "eps_abs") *v = h->S.eps_abs;
     else if (s == "eps_rel") *v = h->S.eps_rel;
@@ -497,6 +614,87 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     return CPG_OK;
 }
 
+int cpg_hip_destroy(cpg_handle_t h);
+static int open_device(cpg_handle_t h, int device) {
+    h->device = device;
+#ifndef CPG_HOST_SIM
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { set_error(std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)); return CPG_E_HIP; }
+    h->num_cu = prop.multiProcessorCount;
+    h->lds_limit = prop.sharedMemPerBlock;
+    if (h->lds_limit < 160 * 1024 && strstr(prop.gcnArchName, "gfx950")) h->lds_limit = 160 * 1024;
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); return CPG_E_HIP; }
+    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); h->have_events = true;
+#else
+    h->num_cu = 2;
+#endif
+    return CPG_OK;
+}
+
+int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_t *out) {
+    if (!f || !out) { set_error("null argument"); return CPG_E_BADARG; }
+    if (f->n <= 0 || f->m < 0 || f->n + f->m >= 0xFFFF) { set_error("bad family dimensions"); return CPG_E_BADARG; }
+    long long rows = (long long)f->n_zero + f->n_nonneg;
+    for (int k = 0; k < f->n_soc; k++) { if (f->soc_dims[k] < 1) { set_error("second-order cone of dimension < 1"); return CPG_E_BADARG; } rows += f->soc_dims[k]; }
+    if (rows != f->m) { set_error("cone dimensions do not add up to m"); return CPG_E_BADARG; }
+    if (f->sol_slots < f->n + f->m || f->sol_slots > 8191) { set_error("bad sol_slots"); return CPG_E_BADARG; }
+    int rc = rt_set_device(device);
+    if (rc) return rc;
+    cpg_handle_t h = new cpg_solver_s();
+    h->conic = true;
+    if ((rc = open_device(h, device))) { delete h; return rc; }
+    cpg::DevConic &C = h->C;
+    const int n = f->n, m = f->m, N = n + m;
+    C.n = n; C.m = m; C.nnzP = f->nnzP; C.nnzA = f->nnzA; C.nnzL = f->nnzL; C.n_zero = f->n_zero;
+    C.n_nonneg = f->n_nonneg; C.n_soc = f->n_soc; C.is_max = f->is_maximization; C.p_is_zero = f->nnzP == 0;
+    C.fac_chunks = f->fac_chunks; C.sol_chunks = f->sol_chunks; C.sol_nnz = f->sol_nnz; C.sol_slots = f->sol_slots;
+    C.np_var = f->np_var; C.d_base = f->d_base; C.n_prim = f->n_prim; C.n_dual = f->n_dual;
+    h->F.n = n; h->F.m = m; h->F.n_prim = f->n_prim; h->F.n_dual = f->n_dual;   // staging sizes of the host entry point
+    std::vector<int> soc_start(f->n_soc > 0 ? f->n_soc : 1), row_cone(m > 0 ? m : 1, -1);
+    {
+        int o = f->n_zero + f->n_nonneg;
+        for (int k = 0; k < f->n_soc; k++) { soc_start[k] = o; for (int r = 0; r < f->soc_dims[k]; r++) row_cone[o + r] = o; o += f->soc_dims[k]; }
+    }
+    std::vector<void *> &own = h->owned;
+#define TRY(x) do { rc = (x); if (rc) { cpg_hip_destroy(h); return rc; } } while (0)
+#define UP(T, field, count) TRY(upload<T>(h, own, (const T *)f->field, (size_t)(count), (const T **)&C.field))
+    TRY(upload<int>(h, own, soc_start.data(), (size_t)f->n_soc, &C.soc_start));
+    TRY(upload<int>(h, own, f->soc_dims, (size_t)f->n_soc, &C.soc_dim));
+    TRY(upload<int>(h, own, row_cone.data(), (size_t)m, &C.row_cone));
+    UP(int, Ap, n + 1); UP(int, Ai, f->nnzA); UP(int, Arp, m + 1); UP(int, Aent, f->nnzA); UP(int, Acol, f->nnzA);
+    UP(int, Pp, n + 1); UP(int, Pi, f->nnzP); UP(int, Prp, n + 1);
+    { const int npf = f->Prp[n]; UP(int, Pent, npf); UP(int, Pcol, npf); }
+    UP(int, Lcol, f->nnzL); UP(int, ksrc_kind, f->nnzL + N); UP(int, ksrc_idx, f->nnzL + N);
+    UP(int, fac_ctab, (size_t)f->fac_chunks * 4); UP(unsigned, fac_task, (size_t)f->fac_chunks * 64);
+    UP(unsigned, fac_len, (size_t)f->fac_chunks * 64);
+    UP(unsigned, fac_a, f->fac_triples); UP(unsigned, fac_b, f->fac_triples); UP(unsigned, fac_k, f->fac_triples);
+    UP(int, sol_ctab, (size_t)f->sol_chunks * 4); UP(unsigned, sol_desc, (size_t)f->sol_chunks * 64);
+    UP(unsigned short, sol_cols, f->sol_nnz); UP(int, sol_kind, f->sol_nnz); UP(int, sol_idx, f->sol_nnz);
+    UP(unsigned short, sol_fpos, N);
+    UP(double, P_base, f->nnzP); UP(double, A_base, f->nnzA); UP(double, q_base, n); UP(double, b_base, m);
+    UP(int, prim_idx, f->n_prim); UP(int, dual_idx, f->n_dual);
+#undef UP
+    TRY(upload_csr(h, own, f->map_P, &C.map_P)); TRY(upload_csr(h, own, f->map_A, &C.map_A));
+    TRY(upload_csr(h, own, f->map_q, &C.map_q)); TRY(upload_csr(h, own, f->map_b, &C.map_b));
+    TRY(upload_csr(h, own, f->map_d, &C.map_d));
+    {   // per-wavefront LDS slice, see conic_carve()
+        const long long d = (long long)f->nnzP + f->nnzA + 7LL * n + 14LL * m + 6LL * N + f->nnzL + f->sol_nnz + f->sol_slots;
+        C.lds_doubles = (int)((d + 1) & ~1LL);
+        if ((size_t)C.lds_doubles * 8 > h->lds_limit) {
+            set_error("conic family too large: the interior-point state of one instance does not fit the LDS");
+            cpg_hip_destroy(h); return CPG_E_UNSUPPORTED; }
+    }
+    { void *p = nullptr; TRY(rt_malloc(&p, 64)); h->d_counter = (unsigned *)p; }
+    TRY(rt_sync(h));
+#undef TRY
+    h->have_update = true;
+    cpg_hip_set_default_settings(h);
+    *out = h;
+    return CPG_OK;
+}
+
 static int ensure(DevBuf &b, size_t bytes);
 static void free_list(std::vector<void *> &v) { for (void *p : v) rt_free(p); v.clear(); }
 static void free_buf(DevBuf &b) { if (b.p) rt_free(b.p); b.p = nullptr; b.bytes = 0; }
@@ -521,6 +719,7 @@ int cpg_hip_destroy(cpg_handle_t h) {
 
 int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *u) {
     if (!h || !u) { set_error("null argument"); return CPG_E_BADARG; }
+    if (h && h->conic) { set_error("not available for a conic (interior-point) handle"); return CPG_E_BADARG; }
     if (u->map_q.nnz && u->map_q.rows != h->F.n) { set_error("map_q rows != n"); return CPG_E_BADARG; }
     if (u->map_u.nnz && u->map_u.rows != h->F.m) { set_error("map_u rows != m"); return CPG_E_BADARG; }
     {   // parameter-dependent entries must sit inside the leading "varying" prefix
@@ -548,6 +747,7 @@ int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *u) {
 }
 
 int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
+    if (h && h->conic) { set_error("not available for a conic (interior-point) handle"); return CPG_E_BADARG; }
     if (!h || !r) { set_error("null argument"); return CPG_E_BADARG; }
     int rc = rt_set_device(h->device);
     if (rc) return rc;
@@ -586,6 +786,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
 }
 
 int cpg_hip_set_gradient(cpg_handle_t h, const cpg_osqp_gradient_t *g) {
+    if (h && h->conic) { set_error("not available for a conic (interior-point) handle"); return CPG_E_BADARG; }
     if (!h || !g) { set_error("null argument"); return CPG_E_BADARG; }
     if (!h->refactor_mode && h->refactor_owned.empty()) { set_error("cpg_hip_set_refactor must be called first"); return CPG_E_BADARG; }
     int rc = rt_set_device(h->device);
@@ -681,11 +882,47 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
                                double *d_obj, int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
     if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
-    if (B < 0 || !d_prim || !d_dual || !d_obj || !d_iter || !d_status || !d_pri || !d_dua || ((h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !d_theta)) {
+    if (B < 0 || !d_prim || !d_dual || !d_obj || !d_iter || !d_status || !d_pri || !d_dua || ((h->conic ? h->C.np_var : h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !d_theta)) {
         set_error("null buffer"); return CPG_E_BADARG; }
     if (B == 0) return CPG_OK;
     int rc = rt_set_device(h->device);
     if (rc) return rc;
+    if (h->conic) {
+        const size_t per_wave = (size_t)h->C.lds_doubles * sizeof(double);
+        int W = h->waves_per_block > 0 ? (h->waves_per_block > 8 ? 8 : h->waves_per_block) : 0;
+        if (W == 0) {   // workgroup size that packs the most wavefronts into one CU's LDS (<= 32 per CU)
+            int best = 0;
+            for (int w = 8; w >= 1; w--) {
+                int tot = (int)(h->lds_limit / ((size_t)w * per_wave)) * w;
+                if (tot > 32) tot = 32;
+                if (tot > best) { best = tot; W = w; }
+            }
+            if (W == 0) W = 1;
+        }
+        const size_t lds = (size_t)W * per_wave;
+        long long blocks = (B + W - 1) / W;
+        int per_cu = (int)(h->lds_limit / lds); if (per_cu < 1) per_cu = 1;
+        if (h->blocks_per_cu > 0 && per_cu > h->blocks_per_cu) per_cu = h->blocks_per_cu;
+        if (per_cu * W > 32) per_cu = 32 / W;
+        const long long cap = (long long)h->num_cu * per_cu;
+        if (blocks > cap) blocks = cap;
+        cpg::DevBatch Bt;
+        Bt.scratch = nullptr;
+        Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
+        Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
+#ifndef CPG_HOST_SIM
+        RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
+        RT_CHECK(hipEventRecord(h->ev0, h->stream));
+#else
+        *h->d_counter = 0;
+#endif
+        rc = launch_conic(h, Bt, (int)blocks, W, lds);
+        if (rc) return rc;
+#ifndef CPG_HOST_SIM
+        RT_CHECK(hipEventRecord(h->ev1, h->stream));
+#endif
+        return CPG_OK;
+    }
     if (h->refactor_mode) {
         const int W = 4;
         const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
@@ -796,13 +1033,13 @@ int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta, double *
                         int32_t *iter, int32_t *status, double *pri_res, double *dua_res) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
     if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
-    if (B < 0 || !prim || !dual || !obj || !iter || !status || !pri_res || !dua_res || ((h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !theta)) {
+    if (B < 0 || !prim || !dual || !obj || !iter || !status || !pri_res || !dua_res || ((h->conic ? h->C.np_var : h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !theta)) {
         set_error("null buffer"); return CPG_E_BADARG; }
     if (B == 0) return CPG_OK;
     int rc = rt_set_device(h->device);
     if (rc) return rc;
     const size_t b = (size_t)B;
-    const size_t npv = (size_t)(h->refactor_mode ? h->R.np_var : h->U.np_var);
+    const size_t npv = (size_t)(h->conic ? h->C.np_var : h->refactor_mode ? h->R.np_var : h->U.np_var);
     if ((rc = ensure(h->s_theta, b * npv * sizeof(double)))) return rc;
     if ((rc = ensure(h->s_prim, b * h->F.n_prim * sizeof(double)))) return rc;
     if ((rc = ensure(h->s_dual, b * h->F.n_dual * sizeof(double)))) return rc;

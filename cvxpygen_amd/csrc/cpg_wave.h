@@ -229,4 +229,16 @@ CPG_DEV double wave_max_nonneg(double v) {   // v >= 0 on every lane (0 is the n
     return dmax2(dmax2(read_lane(v, 0), read_lane(v, 16)), dmax2(read_lane(v, 32), read_lane(v, 48)));
 }
 
+// general wave-wide min / max (any sign), wave-uniform result
+CPG_DEV double wave_min(double v) {
+    v = dmin2(v, shfl_down(v, 1)); v = dmin2(v, shfl_down(v, 2)); v = dmin2(v, shfl_down(v, 4));
+    v = dmin2(v, shfl_down(v, 8)); v = dmin2(v, shfl_down(v, 16)); v = dmin2(v, shfl_down(v, 32));
+    return read_lane(v, 0);
+}
+CPG_DEV double wave_max(double v) {
+    v = dmax2(v, shfl_down(v, 1)); v = dmax2(v, shfl_down(v, 2)); v = dmax2(v, shfl_down(v, 4));
+    v = dmax2(v, shfl_down(v, 8)); v = dmax2(v, shfl_down(v, 16)); v = dmax2(v, shfl_down(v, 32));
+    return read_lane(v, 0);
+}
+
 }  // namespace cpgw

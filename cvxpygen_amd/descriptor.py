@@ -20,6 +20,11 @@ Conventions kept from the reference:
     equalities first (l = u) then inequalities with l = -inf
     (`cvxpygen/solvers/_interface.py:39-79`); P upper-triangular CSC, A CSC.
   * +-inf is stored as +-1e30 (`cvxpygen/utils.py:213-228`).
+  * conic families (solver 'CLARABEL'; `cvxpygen/solvers/clarabel.py:19-46, 133-155`): canonical
+    parameters {P, q, d, A, b} for  minimise 1/2 x'Px + q'x + d  s.t.  Ax + s = b, s in K, with the
+    rows ordered zero cone, nonnegative cone, second-order cones; `cones` holds
+    {'zero': int, 'nonneg': int, 'soc': [dims]}; n_eq = zero-cone rows, n_ineq = all other rows;
+    the dual vector is called 'z' (`cvxpygen/solvers/clarabel.py:33-35`).
 """
 
 from __future__ import annotations
@@ -35,6 +40,8 @@ import scipy.sparse as sp
 CPG_INF = 1e30
 
 CANON_IDS_QP = ('P', 'q', 'd', 'A', 'l', 'u')
+CANON_IDS_CONIC = ('P', 'q', 'd', 'A', 'b')
+CANON_IDS_ALL = ('P', 'q', 'd', 'A', 'l', 'u', 'b')
 
 
 @dataclass
@@ -85,6 +92,7 @@ class FamilyDescriptor:
     is_maximization: bool = False
     nonzero_d: bool = True
     solver: str = 'OSQP'
+    cones: Dict[str, object] = None      # conic families only
 
     # ---- derived --------------------------------------------------------------------------
     @property
@@ -119,7 +127,7 @@ class FamilyDescriptor:
         out = {}
         for p in self.params:
             deps = []
-            for pid in CANON_IDS_QP:
+            for pid in CANON_IDS_ALL:
                 if pid not in self.maps:
                     continue
                 Cm = self.maps[pid].tocsc()
@@ -170,7 +178,7 @@ class FamilyDescriptor:
         meta = {
             'name': self.name, 'n_var': self.n_var, 'n_eq': self.n_eq, 'n_ineq': self.n_ineq,
             'is_maximization': self.is_maximization, 'nonzero_d': self.nonzero_d,
-            'solver': self.solver, 'changes': self.changes,
+            'solver': self.solver, 'changes': self.changes, 'cones': self.cones,
             'params': [dict(name=p.name, col=p.col, size=p.size, shape=list(p.shape), kind=p.kind,
                             sparsity=[list(map(int, s)) for s in p.sparsity] if p.sparsity else None)
                        for p in self.params],
@@ -219,4 +227,4 @@ class FamilyDescriptor:
             name=meta['name'], n_var=n_var, n_eq=meta['n_eq'], n_ineq=meta['n_ineq'], P=P, A=A,
             maps=maps, changes=meta['changes'], theta0=z['theta0'], params=params,
             variables=variables, duals=duals, is_maximization=meta['is_maximization'],
-            nonzero_d=meta['nonzero_d'], solver=meta['solver'])
+            nonzero_d=meta['nonzero_d'], solver=meta['solver'], cones=meta.get('cones'))

@@ -236,7 +236,7 @@ def portfolio(n: int = 100, m: int = 10, seed: int = 0, name: str = 'portfolio')
     return cb.build(vals)
 
 
-def toy_box(name: str = 'toy_box') -> FamilyDescriptor:
+def toy_box(name: str = 'toy_box', solver: str = 'OSQP') -> FamilyDescriptor:
     """minimise (x - a)^2 s.t. lb <= x <= ub (test family: primal infeasible when lb > ub).
     x = [x; t];  eq: x - t = a;  ineq: x <= ub, -x <= -lb."""
     cb = CanonBuilder(name)
@@ -251,10 +251,10 @@ def toy_box(name: str = 'toy_box') -> FamilyDescriptor:
     r2 = cb.ineq([(x[0], -1.0)], {lb.up.col: -1.0})
     cb.dual('d0', [r1], (1,))
     cb.dual('d1', [r2], (1,))
-    return cb.build({'a': 0.3, 'lb': -1.0, 'ub': 1.0})
+    return cb.build({'a': 0.3, 'lb': -1.0, 'ub': 1.0}, solver=solver)
 
 
-def toy_lp(name: str = 'toy_lp') -> FamilyDescriptor:
+def toy_lp(name: str = 'toy_lp', solver: str = 'OSQP') -> FamilyDescriptor:
     """minimise c*x s.t. x >= 0 (test family: dual infeasible / unbounded when c < 0)."""
     cb = CanonBuilder(name)
     c = cb.param('c', ())
@@ -262,7 +262,49 @@ def toy_lp(name: str = 'toy_lp') -> FamilyDescriptor:
     cb.lin(x[0], {c.up.col: 1.0})
     r = cb.ineq([(x[0], -1.0)], 0.0)
     cb.dual('d0', [r], (1,))
-    return cb.build({'c': 1.0})
+    return cb.build({'c': 1.0}, solver=solver)
+
+
+def adp_dynamics(state: np.ndarray):
+    """discrete-time dynamics of `tests/test_E2E_SOCP.py:42-55` (td = 0.1, unit mass)"""
+    A_cont = np.zeros((6, 6))
+    A_cont[0, 3] = A_cont[1, 4] = A_cont[2, 5] = 1.0
+    A_cont[3, 3], A_cont[4, 4], A_cont[5, 5] = -state[3], -state[4], -state[5]
+    B_cont = np.vstack([np.zeros((3, 3)), np.diag(state[3:])])
+    return np.eye(6) + 0.1 * A_cont, 0.1 * B_cont
+
+
+def adp_values(state: np.ndarray) -> Dict[str, np.ndarray]:
+    """parameter values of `tests/test_E2E_SOCP.py:57-62` for one state"""
+    A, B = adp_dynamics(state)
+    return {'Rsqrt': np.sqrt(0.1) * np.eye(3), 'f': A @ state, 'G': B}
+
+
+def adp(name: str = 'ADP') -> FamilyDescriptor:
+    """BASELINE config 4: the ADP problem of `tests/test_E2E_SOCP.py:15-35` (norm form) in conic form
+    the way cvxpy hands it to a quadratic-objective conic solver: sum_squares(affine) -> t == affine
+    with objective t't (P = 2I on t), norm(u_i) <= 0.1 -> (tn_i, u_i) in SOC(4), tn_i <= 0.1.
+    x = [u (2x3, F-order); t1 (6); t2 (3); tn (2)], rows: zero 9, nonneg 2, SOC [4, 4] (SURVEY.md
+    Appendix B); theta = [diag(Rsqrt) 3, f 6, G 18 (F-order)]."""
+    cb = CanonBuilder(name)
+    n, m = 6, 3
+    Rsqrt = cb.param('Rsqrt', (m, m), kind='diag')
+    f = cb.param('f', (n,))
+    G = cb.param('G', (n, m))
+    u = cb.var('u', (2, m))
+    t1, t2, tn = cb.aux(n), cb.aux(m), cb.aux(2)
+    cb.sum_squares(t1)
+    cb.sum_squares(t2)
+    for i in range(n):
+        cb.eq([(t1[i], 1.0)] + [(u[0, j], cmul(G[i, j], -1.0)) for j in range(m)], f[i])
+    for i in range(m):
+        cb.eq([(t2[i], 1.0), (u[0, i], cmul(Rsqrt[i, i], -1.0))], 0.0)
+    rows = [cb.ineq([(tn[i], 1.0)], 0.1) for i in range(2)]
+    for i in range(2):
+        cb.soc([([(tn[i], -1.0)], 0.0)] + [([(u[i, j], -1.0)], 0.0) for j in range(m)])
+    cb.dual('d0', rows, (2,))
+    state = -2.0 + 4.0 * np.random.RandomState(0).rand(6)          # np.random.seed(0) of the test
+    return cb.build(adp_values(state), solver='CLARABEL')
 
 
 def toy_qa(n: int = 3, name: str = 'toy_qa') -> FamilyDescriptor:
@@ -289,4 +331,4 @@ def toy_qa(n: int = 3, name: str = 'toy_qa') -> FamilyDescriptor:
 
 
 FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio, 'toy_box': toy_box,
-            'toy_lp': toy_lp, 'toy_qa': toy_qa}
+            'toy_lp': toy_lp, 'toy_qa': toy_qa, 'ADP': adp}

@@ -102,55 +102,16 @@ class RefactorPlan:
     stats: Dict[str, float]
 
 
-def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPlan) -> RefactorPlan:
-    n, m = P.shape[0], A.shape[0]
-    N = n + m
-    P, A = sp.csc_matrix(P), sp.csc_matrix(A)
-    nnzP, nnzA = P.nnz, A.nnz
-    # ---- A row view
-    Ac = sp.coo_matrix((np.arange(nnzA) + 1, (A.indices, np.repeat(np.arange(n), np.diff(A.indptr)))),
-                       shape=(m, n)).tocsr()
-    Ac.sort_indices()
-    Arp, Aent, Acol = Ac.indptr.astype(np.int32), (Ac.data - 1).astype(np.int32), Ac.indices.astype(np.int32)
-    # ---- P symmetric row view (entry k of the upper triangle appears in row i and, if i != j, row j)
-    pr = P.indices
-    pc = np.repeat(np.arange(n), np.diff(P.indptr))
-    rows = np.concatenate([pr, pc[pr != pc]])
-    cols = np.concatenate([pc, pr[pr != pc]])
-    ent = np.concatenate([np.arange(nnzP), np.arange(nnzP)[pr != pc]])
-    o = np.lexsort((cols, rows))
-    Prp = np.zeros(n + 1, dtype=np.int32)
-    np.add.at(Prp, rows + 1, 1)
-    Prp = np.cumsum(Prp).astype(np.int32)
-    Pent, Pcol = ent[o].astype(np.int32), cols[o].astype(np.int32)
-
-    # ---- factor pattern (same permutation / symbolic analysis as the shared-factor plan)
-    perm, Lp, Li = osqp.perm, osqp.Lp.astype(np.int64), osqp.Li.astype(np.int64)
+def build_schedules(N: int, perm: np.ndarray, Lp: np.ndarray, Li: np.ndarray, src: Dict[tuple, tuple]):
+    """Everything that only depends on the pattern of the permuted factor: for a symmetric
+    quasi-definite matrix whose permuted upper-triangle entries (r <= c) have the value sources
+    `src[(r, c)] = (kind, idx)`, returns (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol,
+    sol_kind, sol_idx, stats): the KKT source of every destination (L entries, then the N pivots),
+    the level-scheduled dot-product schedule of the numeric LDL' and the ragged substitution
+    program with value sources."""
+    Lp, Li = np.asarray(Lp, dtype=np.int64), np.asarray(Li, dtype=np.int64)
     nnzL = len(Li)
     Lcol = np.repeat(np.arange(N), np.diff(Lp)).astype(np.int64)
-    pinv = np.empty(N, dtype=np.int64); pinv[perm] = np.arange(N)
-    # KKT sources keyed by permuted (row <= col)
-    src: Dict[tuple, tuple] = {}
-
-    def put(r, c, kind, idx):
-        r, c = (pinv[r], pinv[c])
-        key = (min(r, c), max(r, c))
-        if key in src:                       # P diagonal entry + sigma
-            k0, i0 = src[key]
-            assert {k0, kind} == {K_P, K_SIGMA}
-            src[key] = (K_P, i0 if k0 == K_P else idx)
-        else:
-            src[key] = (kind, idx)
-    for k in range(nnzP):
-        put(pr[k], pc[k], K_P, k)
-    for j in range(n):
-        put(j, j, K_SIGMA, j)
-    Ar = A.indices
-    Acn = np.repeat(np.arange(n), np.diff(A.indptr))
-    for k in range(nnzA):
-        put(n + Ar[k], Acn[k], K_A, k)
-    for i in range(m):
-        put(n + i, n + i, K_RHO, i)
     # diagonal P entries carry "+ sigma": flag by kind K_P with idx and diag -> handled in kernel:
     ksrc_kind = np.zeros(nnzL + N, dtype=np.int32)
     ksrc_idx = np.zeros(nnzL + N, dtype=np.int32)
@@ -233,6 +194,60 @@ def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPla
     sol_idx = (codes & 0xFFFFFFFF).astype(np.int32)
     stats = dict(nnzL=nnzL, fac_chunks=fac.n_chunks, fac_triples=len(fac_a), fac_steps=int(fac.ctab[:, 0].sum()),
                  sol_chunks=sol.n_chunks, sol_steps=int(sol.ctab[:, 0].sum()), sol_nnz=sol.nnz, levels=nlev)
+    return (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol, sol_kind, sol_idx, stats)
+
+
+def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPlan) -> RefactorPlan:
+    n, m = P.shape[0], A.shape[0]
+    N = n + m
+    P, A = sp.csc_matrix(P), sp.csc_matrix(A)
+    nnzP, nnzA = P.nnz, A.nnz
+    # ---- A row view
+    Ac = sp.coo_matrix((np.arange(nnzA) + 1, (A.indices, np.repeat(np.arange(n), np.diff(A.indptr)))),
+                       shape=(m, n)).tocsr()
+    Ac.sort_indices()
+    Arp, Aent, Acol = Ac.indptr.astype(np.int32), (Ac.data - 1).astype(np.int32), Ac.indices.astype(np.int32)
+    # ---- P symmetric row view (entry k of the upper triangle appears in row i and, if i != j, row j)
+    pr = P.indices
+    pc = np.repeat(np.arange(n), np.diff(P.indptr))
+    rows = np.concatenate([pr, pc[pr != pc]])
+    cols = np.concatenate([pc, pr[pr != pc]])
+    ent = np.concatenate([np.arange(nnzP), np.arange(nnzP)[pr != pc]])
+    o = np.lexsort((cols, rows))
+    Prp = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(Prp, rows + 1, 1)
+    Prp = np.cumsum(Prp).astype(np.int32)
+    Pent, Pcol = ent[o].astype(np.int32), cols[o].astype(np.int32)
+
+    # ---- factor pattern (same permutation / symbolic analysis as the shared-factor plan)
+    perm, Lp, Li = osqp.perm, osqp.Lp.astype(np.int64), osqp.Li.astype(np.int64)
+    nnzL = len(Li)
+    Lcol = np.repeat(np.arange(N), np.diff(Lp)).astype(np.int64)
+    pinv = np.empty(N, dtype=np.int64); pinv[perm] = np.arange(N)
+    # KKT sources keyed by permuted (row <= col)
+    src: Dict[tuple, tuple] = {}
+
+    def put(r, c, kind, idx):
+        r, c = (pinv[r], pinv[c])
+        key = (min(r, c), max(r, c))
+        if key in src:                       # P diagonal entry + sigma
+            k0, i0 = src[key]
+            assert {k0, kind} == {K_P, K_SIGMA}
+            src[key] = (K_P, i0 if k0 == K_P else idx)
+        else:
+            src[key] = (kind, idx)
+    for k in range(nnzP):
+        put(pr[k], pc[k], K_P, k)
+    for j in range(n):
+        put(j, j, K_SIGMA, j)
+    Ar = A.indices
+    Acn = np.repeat(np.arange(n), np.diff(A.indptr))
+    for k in range(nnzA):
+        put(n + Ar[k], Acn[k], K_A, k)
+    for i in range(m):
+        put(n + i, n + i, K_RHO, i)
+    (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol, sol_kind, sol_idx, stats) = \
+        build_schedules(N, perm, Lp, Li, src)
     return RefactorPlan(n=n, m=m, nnzP=nnzP, nnzA=nnzA, nnzL=nnzL, Ap=A.indptr.astype(np.int32),
                         Ai=A.indices.astype(np.int32), Arp=Arp, Aent=Aent, Acol=Acol, Prp=Prp, Pent=Pent,
                         Pcol=Pcol, Pp=P.indptr.astype(np.int32), Pi=P.indices.astype(np.int32),

@@ -103,7 +103,7 @@ def default_lib_path() -> str:
 class CpgLibrary:
     """ctypes view of the C-ABI declared in include/cpg_hip.h."""
 
-    SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_destroy', 'cpg_hip_last_error',
+    SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_create_clarabel', 'cpg_hip_destroy', 'cpg_hip_last_error',
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
                'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
                'cpg_hip_solve_batch',

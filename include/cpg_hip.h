@@ -174,9 +174,50 @@ typedef struct {
     const double *tcoef;
 } cpg_osqp_gradient_t;
 
+/* Everything fixed at code-generation time for one CONIC problem family solved by the
+ * interior-point kernel (reference: the Clarabel path, cvxpygen/solvers/clarabel.py:19-46, 133-204):
+ *   minimise 1/2 x'Px + q'x + d   s.t.   Ax + s = b,  s in K,
+ * rows ordered zero cone, nonnegative cone, second-order cones -- the `cones` array the reference
+ * emits (clarabel.py:308-323).  The reference builds a new solver per solve
+ * (clarabel_DefaultSolver_new, clarabel.py:201-204), so canonicalisation, equilibration and every
+ * factorisation happen per instance inside the kernel; the tables below are the family's fixed
+ * patterns and schedules (cvxpygen_amd/conic_plan.py).  Natural order (no device permutation). */
+typedef struct {
+    int32_t n, m, is_maximization;
+    int32_t n_zero, n_nonneg, n_soc;
+    const int32_t *soc_dims;            /* [n_soc] */
+    int32_t nnzP, nnzA, nnzL;
+    const int32_t *Ap, *Ai;             /* A in CSC (row indices) */
+    const int32_t *Arp, *Aent, *Acol;   /* A by rows: entry number in CSC order, column */
+    const int32_t *Pp, *Pi;             /* upper-triangular P in CSC */
+    const int32_t *Prp, *Pent, *Pcol;   /* full symmetric row view of P */
+    /* factor of K = [[P + eps I, A'], [A, -W'W - eps I]] (same table layout as cpg_osqp_refactor_t);
+     * ksrc_kind: 1 P entry idx, 2 A entry idx, 3 eps only, 5 -(W'W)_ii - eps of row idx,
+     * 6 off-diagonal entry of a second-order-cone block, idx = row_i | row_j << 16 */
+    const int32_t *Lcol, *ksrc_kind, *ksrc_idx;
+    int32_t fac_chunks, fac_triples;
+    const int32_t *fac_ctab;
+    const uint32_t *fac_task, *fac_len, *fac_a, *fac_b, *fac_k;
+    int32_t sol_chunks, sol_nnz, sol_slots;
+    const int32_t *sol_ctab; const uint32_t *sol_desc; const uint16_t *sol_cols;
+    const int32_t *sol_kind, *sol_idx;
+    const uint16_t *sol_fpos;
+    /* canonicalisation over theta_var: p = base + map @ theta_var  (cpg_canonicalize_<p>, utils.py:279-294) */
+    int32_t np_var;
+    const double *P_base, *A_base, *q_base, *b_base; double d_base;
+    cpg_csr_t map_P, map_A, map_q, map_b, map_d;
+    int32_t n_prim; const int32_t *prim_idx;   /* user primal entries: indices into x */
+    int32_t n_dual; const int32_t *dual_idx;   /* user dual entries: indices into z */
+} cpg_conic_family_t;
+
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 int cpg_hip_device_count(int *count);
 int cpg_hip_create_osqp(const cpg_osqp_family_t *family, int device, cpg_handle_t *out);
+/* conic interior-point handle; solve with cpg_hip_solve_batch[_device]; `status` then carries
+ * Clarabel's SolverStatus integers (1 solved, 2 primal infeasible, 3 dual infeasible, 7 maximum
+ * iterations, 9 numerical error, 10 insufficient progress) and the setting names are those of
+ * cvxpygen/solvers/clarabel.py:63-119 */
+int cpg_hip_create_clarabel(const cpg_conic_family_t *family, int device, cpg_handle_t *out);
 int cpg_hip_destroy(cpg_handle_t h);
 const char *cpg_hip_last_error(void);
 const char *cpg_hip_status_string(int32_t status);

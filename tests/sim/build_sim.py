@@ -19,7 +19,7 @@ def lib_path():
 
 def build(force=False):
     out = lib_path()
-    deps = [os.path.join(SRC, f) for f in ('cpg_hip.cpp', 'cpg_osqp_kernel.h', 'cpg_wave.h')]
+    deps = [os.path.join(SRC, f) for f in ('cpg_hip.cpp', 'cpg_osqp_kernel.h', 'cpg_osqp_refactor.h', 'cpg_clarabel_kernel.h', 'cpg_wave.h')]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) < os.path.getmtime(out) for d in deps):
         return out
     cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-DCPG_HOST_SIM', '-x', 'c++',

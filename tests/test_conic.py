@@ -1,0 +1,265 @@
+"""Row C1: the conic interior-point path (reference: Clarabel,
+cvxpygen/solvers/clarabel.py) -- oracle against independent known answers, the kernel logic in the
+lock-step emulator against the oracle (CPU tier), and the HIP kernel on the GPU against the oracle
+and through size-independent properties (-m gpu)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from cvxpygen_amd import families
+from cvxpygen_amd.conic_plan import build_conic_plan
+from cvxpygen_amd.conic_runtime import ConicBatchSolver
+from oracle import clarabel_numpy as cl
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'known_answers.json')))
+REL_TOL = 1e-6
+
+
+def _adp_batch(B, seed):
+    rs = np.random.RandomState(seed)
+    vals = [families.adp_values(-2 + 4 * rs.rand(6)) for _ in range(B)]     # tests/test_E2E_SOCP.py:57
+    return {k: np.stack([v[k] for v in vals]) for k in vals[0]}
+
+
+def _theta(desc, pv):
+    B = next(iter(pv.values())).shape[0]
+    return np.stack([desc.theta_from_values({k: v[i] for k, v in pv.items()}) for i in range(B)])
+
+
+def _assert_parity(r, o, tol=REL_TOL):
+    assert r.iter.tolist() == o['iter'].tolist()
+    assert r.status.tolist() == o['status'].tolist()
+    ok = o['status'] == 1
+    assert np.abs(r.sol_x[ok] - o['sol_x'][ok]).max() <= tol * max(1.0, np.abs(o['sol_x'][ok]).max())
+    assert np.abs(r.sol_y[ok] - o['sol_z'][ok]).max() <= tol * max(1.0, np.abs(o['sol_z'][ok]).max())
+    assert np.abs(r.obj_val[ok] - o['obj_val'][ok]).max() <= tol * max(1.0, np.abs(o['obj_val'][ok]).max())
+    assert np.isnan(r.obj_val[~ok]).all()
+
+
+# ------------------------------------------------------------------------------------ oracle / host
+def test_oracle_matches_exact_adp_solutions():
+    """the restatement against the exact trust-region solution of the reference's ADP inputs
+    (tests/golden/make_golden.py); the reference's own bar is 10 % (tests/test_E2E_SOCP.py:96-109)"""
+    d = families.adp()
+    for seed, g in GOLD['ADP'].items():
+        th = d.theta_from_values({'Rsqrt': np.diag(g['Rsqrt_diag']), 'f': np.array(g['f']), 'G': np.array(g['G'])})
+        o = cl.cpg_solve_batch(d, th[None])
+        assert o['status'][0] == cl.SOLVED and o['iter'][0] <= 12
+        u = o['prim']['u'][0].reshape((2, 3), order='F')
+        assert abs(o['obj_val'][0] - g['obj']) <= 1e-7 * g['obj']
+        assert np.abs(u[0] - g['u0']).max() <= 1e-5
+        assert np.abs(u[1]).max() <= 1e-6                      # only has to stay in its ball: centre
+        assert abs(o['dual']['d0'][0][0] - g['dual_norm_u0']) <= 1e-6
+        assert o['pri_res'][0] < 1e-8 and o['dua_res'][0] < 1e-8
+
+
+def test_adp_descriptor_matches_survey_dimensions():
+    d = families.adp()
+    assert (d.n_var, d.n_eq, d.n_ineq, d.NP) == (17, 9, 10, 27)
+    assert d.cones == {'zero': 9, 'nonneg': 2, 'soc': [4, 4]}
+    assert d.user_p_name_to_canon_outdated() == {'Rsqrt': ['A'], 'f': ['b'], 'G': ['A']}
+    # theta0 = the values of np.random.seed(0) in tests/test_E2E_SOCP.py:38-62
+    g = GOLD['ADP']['0']
+    assert np.allclose(d.theta0[3:9], g['f']) and np.allclose(d.theta0[9:27], np.array(g['G']).flatten(order='F'))
+
+
+def test_conic_plan_factor_replay():
+    """the LDL' schedule + substitution program of the plan, replayed in numpy with random
+    quasi-definite values, solve K x = b"""
+    from cvxpygen_amd import conic_plan as cp_
+    d = families.adp()
+    cp = build_conic_plan(d)
+    rng = np.random.default_rng(0)
+    n, m, N = d.n_var, d.m, d.n_var + d.m
+    Pv, Av = np.abs(d.P.data) + 0.1, rng.standard_normal(d.A.nnz)
+    hd = rng.random(m) + 0.5
+    hd[:cp.n_zero] = 0.0
+    wv = rng.random(m)
+    o = cp.n_zero + cp.n_nonneg
+    for dm in cp.soc_dims:                              # a valid NT scaling: w0^2 - |w1|^2 = 1
+        wv[o] = np.sqrt(1.0 + wv[o + 1:o + dm] @ wv[o + 1:o + dm])
+        hd[o:o + dm] = 2.0 * wv[o:o + dm] ** 2 + 1.0
+        hd[o] -= 2.0
+        o += dm
+    eps = 1e-2                                          # schedule test, not a conditioning test
+    # dense K from the sources
+    K = np.zeros((N, N))
+    pc = np.repeat(np.arange(n), np.diff(d.P.indptr))
+    K[d.P.indices, pc] = Pv
+    K[np.arange(n), np.arange(n)] += eps
+    ac = np.repeat(np.arange(n), np.diff(d.A.indptr))
+    K[ac, n + d.A.indices] = Av
+    K[n + np.arange(m), n + np.arange(m)] = -hd - eps
+    o = cp.n_zero + cp.n_nonneg
+    for dm in cp.soc_dims:
+        for a in range(dm):
+            for b in range(a + 1, dm):
+                K[n + o + a, n + o + b] = -2.0 * wv[o + a] * wv[o + b]
+        o += dm
+    K = np.triu(K) + np.triu(K, 1).T
+    # numeric factor through the schedule
+    nnzL = cp.nnzL
+    Lx, Dg = np.zeros(nnzL), np.zeros(N)
+
+    def kval(t):
+        kind, idx = cp.ksrc_kind[t], cp.ksrc_idx[t]
+        piv = t >= nnzL
+        if kind == cp_.K_P: return Pv[idx] + (eps if piv else 0.0)
+        if kind == cp_.K_A: return Av[idx]
+        if kind == cp_.K_DIAGX: return eps
+        if kind == cp_.K_HDIAG: return -hd[idx] - eps
+        if kind == cp_.K_HSOC: return -2.0 * wv[idx & 0xFFFF] * wv[idx >> 16]
+        return 0.0
+    level_start = 0
+    for c in range(cp.fac.n_chunks):
+        L, last, base, _ = cp.fac.ctab[c]
+        acc = np.zeros(64)
+        for s in range(L):
+            act = np.nonzero(cp.fac.tlen[c] > s)[0]
+            e = base + np.arange(len(act))
+            acc[act] += Lx[cp.fac_a[e]] * Dg[cp.fac_k[e]] * Lx[cp.fac_b[e]]
+            base += len(act)
+        for ln in range(64):
+            t = int(cp.fac.task[c, ln])
+            if t == 0xFFFFFFFF:
+                continue
+            v = kval(t) - acc[ln]
+            if t >= nnzL: Dg[t - nnzL] = v
+            else: Lx[t] = v
+        if last:
+            for c2 in range(level_start, c + 1):
+                for t in cp.fac.task[c2]:
+                    if t < nnzL:
+                        Lx[t] /= Dg[cp.Lcol[t]]
+            level_start = c + 1
+    Lm = np.eye(N)
+    Lm[cp.Li, cp.Lcol] = Lx
+    Kp = K[np.ix_(cp.perm, cp.perm)]
+    assert np.abs(Lm @ np.diag(Dg) @ Lm.T - Kp).max() < 1e-9 * np.abs(Kp).max()
+    assert (np.sign(Dg) == np.where(cp.perm < n, 1, -1)).all()          # quasi-definite pivots
+
+
+# ------------------------------------------------------------------------------------ emulator tier
+def test_adp_in_emulator_vs_oracle(sim_lib):
+    d = families.adp()
+    pv = _adp_batch(3, 1)
+    bs = ConicBatchSolver(d, lib_path=sim_lib, full_output=True)
+    r = bs.solve(pv)
+    _assert_parity(r, cl.cpg_solve_batch(d, _theta(d, pv)), tol=1e-9)
+    assert r.prim['u'].shape == (3, 2, 3) and r.dual['d0'].shape == (3, 2)
+    # tighter / looser settings change the iteration count the same way on both sides
+    r2 = bs.solve(pv, tol_gap_abs=1e-4, tol_gap_rel=1e-4, tol_feas=1e-4)
+    o2 = cl.cpg_solve_batch(d, _theta(d, pv), tol_gap_abs=1e-4, tol_gap_rel=1e-4, tol_feas=1e-4)
+    _assert_parity(r2, o2, tol=1e-9)
+    assert (r2.iter < r.iter).any()
+    r3 = bs.solve(pv, max_iters=2)                      # cvxpy name of max_iter (clarabel.py:65)
+    assert (r3.status == 7).all() and (r3.iter == 2).all()
+    with pytest.raises(AttributeError, match='not available'):
+        bs.solve(pv, eps_abs=1e-3)                      # an OSQP setting
+    bs.close()
+
+
+def test_infeasible_and_lp_instances_in_emulator(sim_lib):
+    """status integers of the conic path (Clarabel numbering) and the P == 0 initialisation"""
+    d = families.toy_box(solver='CLARABEL')
+    th = np.tile(d.theta0, (3, 1))
+    th[1, :3] = [0.3, 1.0, -1.0]                        # lb > ub
+    th[2, :3] = [5.0, -1.0, 1.0]
+    bs = ConicBatchSolver(d, lib_path=sim_lib, full_output=True)
+    r = bs.solve({'a': th[:, 0], 'lb': th[:, 1], 'ub': th[:, 2]})
+    o = cl.cpg_solve_batch(d, th)
+    assert o['status'].tolist() == [1, 2, 1]
+    _assert_parity(r, o, tol=1e-9)
+    bs.close()
+    d = families.toy_lp(solver='CLARABEL')
+    th = np.tile(d.theta0, (3, 1)); th[1, 0] = -1.0; th[2, 0] = 0.7
+    bs = ConicBatchSolver(d, lib_path=sim_lib, full_output=True)
+    r = bs.solve({'c': th[:, 0]})
+    o = cl.cpg_solve_batch(d, th)
+    assert o['status'].tolist() == [1, 3, 1]            # c < 0: unbounded below
+    _assert_parity(r, o, tol=1e-9)
+    bs.close()
+
+
+def test_conic_solver_rejects_wrong_family(sim_lib):
+    with pytest.raises(ValueError, match='conic'):
+        ConicBatchSolver(families.nonneg_ls(), lib_path=sim_lib)
+
+
+# ------------------------------------------------------------------------------------ GPU tier
+@pytest.mark.gpu
+def test_adp_on_gpu_vs_oracle():
+    d = families.adp()
+    B = 500
+    pv = _adp_batch(B, 7)
+    bs = ConicBatchSolver(d, full_output=True)
+    r = bs.solve(pv)
+    o = cl.cpg_solve_batch(d, _theta(d, pv))
+    assert (o['status'] == 1).all()
+    _assert_parity(r, o)
+    # only f varies: A stays at its code-generation-time values
+    r2 = bs.solve({'f': pv['f']}, updated_params=['f'])
+    th = np.tile(d.theta0, (B, 1)); th[:, 3:9] = pv['f']
+    _assert_parity(r2, cl.cpg_solve_batch(d, th))
+    bs.close()
+
+
+@pytest.mark.gpu
+def test_adp_known_answers_on_gpu():
+    d = families.adp()
+    bs = ConicBatchSolver(d)
+    for seed, g in GOLD['ADP'].items():
+        r = bs.solve({'Rsqrt': np.array([g['Rsqrt_diag']]), 'f': np.array([g['f']]), 'G': np.array([g['G']])})
+        assert r.status[0] == 1
+        assert abs(r.obj_val[0] - g['obj']) <= 1e-7 * g['obj']
+        assert np.abs(r.prim['u'][0][0] - g['u0']).max() <= 1e-5
+        assert abs(r.dual['d0'][0][0] - g['dual_norm_u0']) <= 1e-6
+    bs.close()
+
+
+@pytest.mark.gpu
+def test_conic_statuses_on_gpu():
+    d = families.toy_box(solver='CLARABEL')
+    B = 300
+    rng = np.random.default_rng(3)
+    a, lb, ub = rng.standard_normal(B) * 2, -1 + 0.5 * rng.standard_normal(B), 1 + 0.5 * rng.standard_normal(B)
+    swap = rng.random(B) < 0.3
+    lb[swap], ub[swap] = ub[swap] + 0.5, lb[swap] - 0.5       # infeasible boxes
+    th = np.tile(d.theta0, (B, 1)); th[:, 0], th[:, 1], th[:, 2] = a, lb, ub
+    bs = ConicBatchSolver(d, full_output=True)
+    r = bs.solve({'a': a, 'lb': lb, 'ub': ub})
+    o = cl.cpg_solve_batch(d, th)
+    assert set(o['status'].tolist()) == {1, 2}
+    _assert_parity(r, o)
+    assert np.allclose(r.prim['x'][o['status'] == 1, 0], np.clip(a, lb, ub)[o['status'] == 1], atol=1e-6)
+    bs.close()
+
+
+@pytest.mark.gpu
+def test_adp_full_batch_properties():
+    """BASELINE config 4 size (B = 100 000): every instance solved; objective equals the user's
+    objective evaluated at the returned u; ||u_i|| <= 0.1; batch-order invariance; duplicates"""
+    d = families.adp()
+    B = 100_000
+    rs = np.random.RandomState(11)
+    states = -2 + 4 * rs.rand(B, 6)
+    f = np.empty((B, 6)); G = np.zeros((B, 6, 3))
+    f[:, :3] = states[:, :3] + 0.1 * states[:, 3:]
+    f[:, 3:] = states[:, 3:] * (1 - 0.1 * states[:, 3:])
+    G[:, 3, 0], G[:, 4, 1], G[:, 5, 2] = 0.1 * states[:, 3], 0.1 * states[:, 4], 0.1 * states[:, 5]
+    chk = families.adp_values(states[0])
+    assert np.allclose(f[0], chk['f']) and np.allclose(G[0], chk['G'])
+    pv = {'f': f, 'G': G}
+    bs = ConicBatchSolver(d)
+    r = bs.solve(pv, updated_params=['f', 'G'])
+    assert (r.status == 1).all() and r.iter.max() <= 15
+    u0 = r.prim['u'][:, 0, :]
+    obj = ((f + np.einsum('bij,bj->bi', G, u0)) ** 2).sum(axis=1) + 0.1 * (u0 ** 2).sum(axis=1)
+    assert np.abs(obj - r.obj_val).max() <= 1e-6 * np.abs(obj).max()
+    assert (np.linalg.norm(r.prim['u'], axis=2) <= 0.1 + 1e-7).all()
+    perm = np.random.default_rng(0).permutation(B)
+    r2 = bs.solve({'f': f[perm], 'G': G[perm]}, updated_params=['f', 'G'])
+    assert (r2.iter == r.iter[perm]).all() and np.array_equal(r2.prim_flat, r.prim_flat[perm])
+    bs.close()
