@@ -43,9 +43,24 @@ def make_workload(name: str):
     elif name == 'portfolio':
         desc = families.portfolio(100, 10)
         label = 'portfolio QP n=100 m=10 (examples/portfolio.ipynb), OSQP, a/F/Sig_f_sqrt/d_sqrt/w_prev per instance'
+    elif name == 'adp':
+        desc = families.adp()
+        label = 'ADP SOCP (tests/test_E2E_SOCP.py:15-64, norm form), conic interior point (Clarabel path), f/G per instance'
     else:
         raise ValueError(name)
     return desc, label
+
+
+def adp_params(B: int, seed: int):
+    """per-instance values of tests/test_E2E_SOCP.py:38-62: state = -2 + 4 rand(6), f = A(state) state,
+    G = B(state); Rsqrt stays sqrt(0.1) I"""
+    st = -2.0 + 4.0 * np.random.default_rng(seed).random((B, 6))
+    f = np.empty((B, 6)); G = np.zeros((B, 6, 3))
+    f[:, :3] = st[:, :3] + 0.1 * st[:, 3:]
+    f[:, 3:] = st[:, 3:] * (1.0 - 0.1 * st[:, 3:])
+    for k in range(3):
+        G[:, 3 + k, k] = 0.1 * st[:, 3 + k]
+    return {'f': f, 'G': G}
 
 
 def portfolio_params(desc, B: int, seed: int):
@@ -122,12 +137,16 @@ def main():
     gen = os.path.join(ROOT, 'cvxpygen_amd', 'generated', args.workload, f'libcpg_{args.workload}.so')
     if lib_path is None and not args.generic and os.path.exists(gen):
         lib_path = gen          # what generate_code() builds: executor specialised for this family
-    solver = BatchSolver(desc, device=local_rank, lib_path=lib_path)
+    if desc.solver == 'CLARABEL':
+        from cvxpygen_amd.conic_runtime import ConicBatchSolver
+        solver = ConicBatchSolver(desc, device=local_rank, lib_path=args.lib)
+    else:
+        solver = BatchSolver(desc, device=local_rank, lib_path=lib_path)
     solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)
     solver.set_program_placement(args.placement)
     B = args.batch
-    if args.workload == 'portfolio':
-        pv = portfolio_params(desc, B, 1000 + rank)
+    if args.workload in ('portfolio', 'adp'):
+        pv = portfolio_params(desc, B, 1000 + rank) if args.workload == 'portfolio' else adp_params(B, 1000 + rank)
         solver.set_updated(list(pv.keys()))
         theta = solver.theta_var(pv)
     elif args.all_params:
@@ -188,37 +207,46 @@ def main():
         bytes_per_inst = 8 * (solver.np_var + n_prim + n_dual) + 32
         if args.workload == 'portfolio':
             bytes_per_inst = 15416                                      # config 3 figure of SURVEY.md 8(d)
+        if args.workload == 'adp':
+            bytes_per_inst = 8 * (27 + 6 + 2) + 32                      # config 4: theta 27, u 6, dual 2, info
         k_ms = float(np.mean(kernel_ms))
         achieved = bytes_per_inst * B / (k_ms * 1e-3) / 1e9
         value = world * B * args.steps / elapsed
         out = {
-            'metric': 'QP instances solved/sec (batched MPC QP, OSQP)',
-            'value': value, 'unit': 'QP instances/s', 'n_gpus': world, 'steps': args.steps,
+            'metric': ('SOCP instances solved/sec (batched ADP, conic interior point)' if args.workload == 'adp'
+                       else 'QP instances solved/sec (batched MPC QP, OSQP)'),
+            'value': value, 'unit': ('SOCP instances/s' if args.workload == 'adp' else 'QP instances/s'), 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': ('synthetic (examples/portfolio.ipynb cell 7 draws, default_rng(1000+rank))'
                      if args.workload == 'portfolio' else
+                     'synthetic (state = -2 + 4*U(0,1), default_rng(1000+rank); tests/test_E2E_SOCP.py:38-62)'
+                     if args.workload == 'adp' else
                      'synthetic (x_init = -2 + 4*U(0,1), default_rng(1000+rank); family parameters of '
                      'examples/MPC.ipynb cell 3 extended to 12/4)'),
             'config': {'workload': label, 'instances_per_gpu': B, 'kkt_dim': desc.n_var + desc.m,
                        'n_var': desc.n_var, 'n_constr': desc.m, 'varying_params': (['a', 'F', 'Sig_f_sqrt', 'd_sqrt', 'w_prev'] if args.workload == 'portfolio' else
+                                          ['f', 'G'] if args.workload == 'adp' else
                                           'all (matrix parameters: per-instance refactorisation)' if args.all_params else ['x_init']),
-                       'settings': 'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
-                                   'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start',
+                       'settings': ('Clarabel defaults of the generated solver (cvxpygen/solvers/clarabel.py:63-119): '
+                                    'tol_gap/feas 1e-8, max_iter 200, new solver per instance' if args.workload == 'adp' else
+                                    'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
+                                    'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start'),
                        'parallelism': f'shard{world}', **stats,
                        'library': os.path.relpath(solver.lib.path, ROOT),
                        'plan': {k: (round(v, 3) if isinstance(v, float) else v)
                                 for k, v in solver.plan.stats.items()}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': ('osqp_refactor_kernel' if (args.all_params or args.workload == 'portfolio')
+                         'kernel': ('clarabel_kernel' if args.workload == 'adp' else
+                                    'osqp_refactor_kernel' if (args.all_params or args.workload == 'portfolio')
                                     else 'osqp_shared_kernel'), 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_instance': bytes_per_inst,
                          'note': 'compulsory traffic only (theta in, solution out); the iteration '
                                  'state never leaves registers/LDS, so this path is latency / LDS '
                                  'bound, not HBM bound (DESIGN.md section 6)'},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload != 'portfolio' and not args.all_params:
+        if world == 1 and not args.no_cpu_baseline and args.workload not in ('portfolio', 'adp') and not args.all_params:
             out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds)
         if args.check:
             from oracle import binding as ob

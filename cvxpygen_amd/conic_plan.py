@@ -78,6 +78,10 @@ def matrix_views(P: sp.csc_matrix, A: sp.csc_matrix):
 def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
     if not desc.cones:
         raise ValueError('not a conic family')
+    for key, val in desc.cones.items():
+        if key not in ('zero', 'nonneg', 'soc') and val:
+            # exponential / PSD / power cones (clarabel.py:140-155) have no kernel support yet
+            raise NotImplementedError(f'cone type "{key}" is not supported by the interior-point kernel')
     P, A = sp.csc_matrix(desc.P), sp.csc_matrix(desc.A)
     n, m = desc.n_var, desc.m
     N = n + m

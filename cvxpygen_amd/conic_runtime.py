@@ -108,7 +108,7 @@ class ConicBatchSolver(BatchSolver):
 
     def gradient(self, *a, **k):
         raise NotImplementedError('differentiation is available for OSQP families only '
-                                  '(the reference: cvxpygen/cpg.py:93-96)')
+                                  '(the reference needs a second, OSQP-form canonicalisation: cvxpygen/generator.py:76-80)')
 
     def set_updated(self, updated_params: Optional[Sequence[str]] = None) -> None:
         """(Re)creates the device handle for this set of per-instance parameters: every other

@@ -324,8 +324,11 @@ static int launch_refactor(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, 
 }
 
 // ---- conic interior-point kernel: no slot classes, every vector lives in LDS ---------------------
+#ifndef CPG_CONIC_WAVES_PER_SIMD
+#define CPG_CONIC_WAVES_PER_SIMD 4   // <= 128 VGPRs
+#endif
 #ifndef CPG_HOST_SIM
-__global__ void __launch_bounds__(512, 1)
+__global__ void __launch_bounds__(512, CPG_CONIC_WAVES_PER_SIMD)
 clarabel_kernel(cpg::DevConic C, cpg::DevConicSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -889,21 +892,16 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     if (rc) return rc;
     if (h->conic) {
         const size_t per_wave = (size_t)h->C.lds_doubles * sizeof(double);
-        int W = h->waves_per_block > 0 ? (h->waves_per_block > 8 ? 8 : h->waves_per_block) : 0;
-        if (W == 0) {   // workgroup size that packs the most wavefronts into one CU's LDS (<= 32 per CU)
-            int best = 0;
-            for (int w = 8; w >= 1; w--) {
-                int tot = (int)(h->lds_limit / ((size_t)w * per_wave)) * w;
-                if (tot > 32) tot = 32;
-                if (tot > best) { best = tot; W = w; }
-            }
-            if (W == 0) W = 1;
-        }
+        // the kernel is compiled for CPG_CONIC_WAVES_PER_SIMD waves per SIMD (register budget); measured
+        // best on MI355X: workgroups of 4 waves, as many per CU as LDS and that budget admit
+        int W = h->waves_per_block > 0 ? (h->waves_per_block > 8 ? 8 : h->waves_per_block) : 4;
+        while (W > 1 && (size_t)W * per_wave > h->lds_limit) W--;
         const size_t lds = (size_t)W * per_wave;
         long long blocks = (B + W - 1) / W;
         int per_cu = (int)(h->lds_limit / lds); if (per_cu < 1) per_cu = 1;
         if (h->blocks_per_cu > 0 && per_cu > h->blocks_per_cu) per_cu = h->blocks_per_cu;
-        if (per_cu * W > 32) per_cu = 32 / W;
+        if (per_cu * W > 4 * CPG_CONIC_WAVES_PER_SIMD) per_cu = (4 * CPG_CONIC_WAVES_PER_SIMD) / W;
+        if (per_cu < 1) per_cu = 1;
         const long long cap = (long long)h->num_cu * per_cu;
         if (blocks > cap) blocks = cap;
         cpg::DevBatch Bt;

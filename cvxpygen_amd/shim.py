@@ -62,8 +62,12 @@ class GeneratedSolver:
     @property
     def batch_solver(self) -> BatchSolver:
         if self._bs is None:
-            self._bs = BatchSolver(self.desc, device=self.device, lib_path=self.lib_path,
-                                   full_output=self.gradient)
+            if self.desc.solver == 'CLARABEL':
+                from .conic_runtime import ConicBatchSolver
+                self._bs = ConicBatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
+            else:
+                self._bs = BatchSolver(self.desc, device=self.device, lib_path=self.lib_path,
+                                       full_output=self.gradient)
         return self._bs
 
     # ---- batched entry point --------------------------------------------------------------------
@@ -96,7 +100,11 @@ class GeneratedSolver:
         for i, d in enumerate(desc.duals):
             dv = res.dual[d.name][0]
             prob.constraints[i].save_dual_value(np.array(dv).reshape(d.shape) if d.shape else float(dv))
-        status = STATUS_STRINGS.get(int(res.status[0]), 'unknown')
+        if desc.solver == 'CLARABEL':
+            # integer status, formatted as the reference does (cvxpygen/utils.py:1598-1601)
+            status = '%d (for description visit https://oxfordcontrol.github.io/ClarabelDocs/)' % int(res.status[0])
+        else:
+            status = STATUS_STRINGS.get(int(res.status[0]), 'unknown')
         prob._status = status
         obj = float(res.obj_val[0])
         prob._value = obj                           # +-1e30 already mapped to +-inf by the runtime

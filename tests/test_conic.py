@@ -183,6 +183,33 @@ def test_infeasible_and_lp_instances_in_emulator(sim_lib):
     bs.close()
 
 
+def test_generate_code_drop_in_for_conic_family(sim_lib, tmp_path):
+    """tests/test_E2E_SOCP.py:119-121 shape: generate_code(prob, solver='CLARABEL') -> prob.solve(method='CPG')"""
+    from cvxpygen_amd import cpg
+    from cvxpygen_amd.lite import LiteProblem
+    d = families.adp()
+    prob = LiteProblem.from_descriptor(d)
+    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'test_ADP_CLARABEL'), solver='CLARABEL', prefix='ADP_CLARABEL')
+    mod._SOLVER.lib_path = sim_lib
+    g = GOLD['ADP']['0']                                 # theta0 = seed 0 of the reference test
+    val = prob.solve(method='CPG')
+    assert abs(val - g['obj']) <= 1e-7 * g['obj'] and prob.value == val
+    assert prob.status.startswith('1 (for description visit')          # integer status, utils.py:1598-1601
+    assert np.abs(prob.var_dict['u'].value[0] - g['u0']).max() <= 1e-5
+    assert abs(prob.constraints[0].dual_value[0] - g['dual_norm_u0']) <= 1e-6
+    assert prob.solver_stats.solver_name == 'CLARABEL' and prob.solver_stats.num_iters <= 12
+    # new parameter values, as assign_data(prob, name, seed=1) of the reference test does
+    g1 = GOLD['ADP']['1']
+    prob.param_dict['f'].value = np.array(g1['f'])
+    prob.param_dict['G'].value = np.array(g1['G'])
+    val = prob.solve(method='CPG', updated_params=['f', 'G'])
+    assert abs(val - g1['obj']) <= 1e-7 * g1['obj']
+    with pytest.raises(NotImplementedError):
+        cpg.generate_code(d, code_dir=str(tmp_path / 'x'), solver='CLARABEL', gradient=True)
+    with pytest.raises(ValueError, match='canonicalised for'):
+        cpg.generate_code(d, code_dir=str(tmp_path / 'y'), solver='OSQP')
+
+
 def test_conic_solver_rejects_wrong_family(sim_lib):
     with pytest.raises(ValueError, match='conic'):
         ConicBatchSolver(families.nonneg_ls(), lib_path=sim_lib)
