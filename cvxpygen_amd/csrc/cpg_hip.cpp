@@ -590,7 +590,8 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
         TRY(upload<unsigned short>(h, h->owned, f->kkt_ragged.cols, (size_t)f->kkt_ragged.nnz, &F.kkt_ragged.cols));
     }
 #ifdef CPG_GEN_HEADER
-    {   // this build contains an executor generated for one specific family: refuse any other
+    if (f->kkt_ragged.n_chunks > 0) {   // (handles without a shared program only serve the refactorisation / adjoint kernels)
+        // this build contains an executor generated for one specific family: refuse any other
         unsigned hsh = 0x811C9DC5u;
         auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = (const unsigned char *)p;
             for (size_t i = 0; i < nbytes; i++) hsh = (hsh ^ b[i]) * 0x01000193u; };
@@ -599,6 +600,14 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
         if (rg.n_chunks != CPG_GEN_NCHUNKS || rg.nnz != CPG_GEN_NNZ || hsh != CPG_GEN_FINGERPRINT) {
             set_error("this library was generated for a different problem family (solve-program fingerprint mismatch)");
             cpg_hip_destroy(h); return CPG_E_BADARG; }
+#ifdef CPG_GEN_N
+        {   // dimensions and uniform row classes are literals in the generated kernel
+            bool ok = f->n == (int)cpg::GenFam::n && f->m == (int)cpg::GenFam::m && f->n_slots == cpg::GenFam::n_slots;
+            for (int i = 0; ok && i < f->m; i++) { const int c = cpg::GenFam::ct(i / 64); if (c != 2 && c != (int)f->ctype[i]) ok = false; }
+            if (!ok) { set_error("this library was generated for a different problem family (dimensions / row classes)");
+                       cpg_hip_destroy(h); return CPG_E_BADARG; }
+        }
+#endif
         h->program_in_lds = 1;
     }
 #endif
@@ -958,7 +967,12 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
 #else
     const size_t tab_doubles = (size_t)R.n_chunks * 34;     // desc (u32 x 64) + ctab (int x 4)
 #endif
-    const size_t prog_bytes = R.n_chunks > 0 ? ((size_t)R.nnz + (size_t)((R.nnz + 3) / 4) + tab_doubles) * 8 : 0;
+#ifdef CPG_GEN_HEADER
+    const size_t nnzp = (size_t)R.nnz + CPG_GEN_PAD;
+#else
+    const size_t nnzp = (size_t)R.nnz;
+#endif
+    const size_t prog_bytes = R.n_chunks > 0 ? (nnzp + (nnzp + 3) / 4 + tab_doubles) * 8 : 0;
     bool in_lds = false;
     int W = h->waves_per_block;
     if (h->program_in_lds != 0 && R.n_chunks > 0) {

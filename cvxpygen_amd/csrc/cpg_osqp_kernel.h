@@ -236,12 +236,14 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
             A[g_] = fma(v_, *(const double *)(wb + (unsigned)g_ * ldwb + co_), A[g_]);             \
     }
-// lanes >= CNT read the trailing dummy entry (zero coefficient)
+// lanes >= CNT load with the same constant offsets (they hit later entries of the program, or the
+// zero padding behind it) and get their coefficient replaced by zero: no address arithmetic
+#define CPG_GEN_PAD 64
 #define CPG_GEN_STEP_PART(A, E, CNT)                                                               \
     {                                                                                              \
-        const bool a_ = lane < (CNT);                                                              \
-        const double v_ = *(const double *)(a_ ? vb + (E) * 8u : vdum);                            \
-        const unsigned co_ = *(const unsigned short *)(a_ ? cb + (E) * 2u : cdum);                 \
+        const double vl_ = *(const double *)(vb + (E) * 8u);                                       \
+        const unsigned co_ = *(const unsigned short *)(cb + (E) * 2u);                             \
+        const double v_ = lane < (CNT) ? vl_ : 0.0;                                                \
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
             A[g_] = fma(v_, *(const double *)(wb + (unsigned)g_ * ldwb + co_), A[g_]);             \
     }
@@ -257,6 +259,14 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
 }  // namespace cpg
 #include CPG_GEN_HEADER
 namespace cpg {
+#ifdef CPG_GEN_N
+// dimensions and per-slot row classes of the family this build was generated for
+struct GenFam {
+    static constexpr unsigned n = CPG_GEN_N, m = CPG_GEN_M;
+    static constexpr int n_slots = CPG_GEN_NSLOTS;
+    static constexpr int ct(int s) { constexpr signed char t[] = CPG_GEN_CT_INIT; return t[s]; }
+};
+#endif
 #endif
 
 // natural-layout product: chunk s delivers element lane + 64 s of the result to this lane
@@ -298,7 +308,7 @@ CPG_DEV double csr_row(const DevCsr &mp, unsigned row, const double *theta, doub
 template <int NSX, int NSZ, int NV>
 struct SharedCtx {
     const DevFamily &F;
-    const double *sh;
+    const double *sh, *shu;       // base q / base u (block-shared LDS copy, or the global arrays)
     const Inst<NSX, NSZ, NV> &I;
     const double *w;
     int lane;
@@ -306,7 +316,7 @@ struct SharedCtx {
         return s < Inst<NSX, NSZ, NV>::NVX ? I.qv[s < Inst<NSX, NSZ, NV>::NVX ? s : 0] : sh[i];
     }
     CPG_DEV double u(int s, unsigned i) const {
-        return s < Inst<NSX, NSZ, NV>::NVZ ? I.uv[s < Inst<NSX, NSZ, NV>::NVZ ? s : 0] : sh[(unsigned)F.n + i];
+        return s < Inst<NSX, NSZ, NV>::NVZ ? I.uv[s < Inst<NSX, NSZ, NV>::NVZ ? s : 0] : shu[i];
     }
     CPG_DEV double ax(int s) const { return natural_chunk(F.A_rows, s, w, lane); }     // (A v)_i, v = w[0..n)
     CPG_DEV double px(int s) const { return natural_chunk(F.P_rows, s, w, lane); }     // (P v)_j
@@ -530,27 +540,51 @@ CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)
     cpgw::lds_order();
 }
 
+// row class of slot s in the hot loop: a literal where the generated family has a uniform slot
+#if defined(CPG_GEN_N)
+#define CPG_ROW_CLASS(s) (GenFam::ct(s) != 2 ? GenFam::ct(s) : (int)ct[s])
+#else
+#define CPG_ROW_CLASS(s) ((int)ct[s])
+#endif
+
 // ------------------------------------------------------------------------------------ the kernel body
 template <int NSX, int NSZ, int NV, int G, bool LDSPROG>
 CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevSettings &S,
                               const DevBatch &Bt, double *lds, int wave_global) {
     typedef Inst<NSX, NSZ, NV> InstT;
     const int lane = cpgw::lane_id();
+#if defined(CPG_GEN_N)
+    // family-specialised build: dimensions are literals, so the bounds checks of full slots fold away
+    constexpr unsigned n_c = GenFam::n, m_c = GenFam::m;
+    constexpr int ldw = GenFam::n_slots;
+    static_assert(!LDSPROG || ((n_c + 63) / 64 == (unsigned)NSX && (m_c + 63) / 64 == (unsigned)NSZ), "slot class of the generated family");
+#else
+    const unsigned n_c = (unsigned)F.n, m_c = (unsigned)F.m;
     const int ldw = F.n_slots;
+#endif
     const int N = F.n + F.m;
     // block-shared copy of the family's base vectors, then one work vector per instance
     double *sh = lds;
     for (unsigned t = cpgw::thread_in_block(); t < (unsigned)N; t += cpgw::block_threads())
         sh[t] = t < (unsigned)F.n ? cpgw::gld(U.q_base, t) : cpgw::gld(U.u_base, t - (unsigned)F.n);
+    const double *shu = sh + n_c;
     // LDS-resident program: [vals | cols | desc | ctab] right after the base vectors
     LdsProg LP;
     size_t lds_off = (size_t)N;
     if (LDSPROG) {
         const DevRagged &R = F.kkt_ragged;
-        double *lv = lds + lds_off;                         lds_off += (size_t)R.nnz;
-        unsigned short *lc = (unsigned short *)(lds + lds_off); lds_off += (size_t)((R.nnz + 3) / 4);
+#ifdef CPG_GEN_HEADER
+        const unsigned nnzp = (unsigned)R.nnz + CPG_GEN_PAD;   // zero padding, see CPG_GEN_STEP_PART
+#else
+        const unsigned nnzp = (unsigned)R.nnz;
+#endif
+        double *lv = lds + lds_off;                         lds_off += (size_t)nnzp;
+        unsigned short *lc = (unsigned short *)(lds + lds_off); lds_off += (size_t)((nnzp + 3) / 4);
         const unsigned nt = cpgw::block_threads(), t0 = cpgw::thread_in_block();
-        for (unsigned t = t0; t < (unsigned)R.nnz; t += nt) { lv[t] = cpgw::gld(R.vals, t); lc[t] = cpgw::gld(R.cols, t); }
+        for (unsigned t = t0; t < nnzp; t += nt) {
+            const bool in = t < (unsigned)R.nnz;
+            lv[t] = in ? cpgw::gld(R.vals, t) : 0.0; lc[t] = in ? cpgw::gld(R.cols, t) : (unsigned short)0;
+        }
         LP.vals = lv; LP.cols = lc; LP.n_chunks = R.n_chunks; LP.dummy = (unsigned)R.nnz - 1u;
 #ifdef CPG_GEN_HEADER
         // the generated executor has every count / offset baked in; it only needs the per-lane
@@ -625,14 +659,15 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma unroll
                     for (int s = 0; s < NSX; s++) {
                         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < (unsigned)F.n) wg[i] = F.sigma * I[g].x[s] - SharedCtx<NSX, NSZ, NV>{F, sh, I[g], wg, lane}.q(s, i);
+                        if (i < n_c) wg[i] = F.sigma * I[g].x[s] - SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.q(s, i);
                         CPG_FENCE_EVERY(s);
                     }
 #pragma unroll
                     for (int s = 0; s < NSZ; s++) {
                         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
-                        if (i < (unsigned)F.m) wg[(unsigned)F.n + i] = I[g].z[s] - ri * I[g].y[s];
+                        const int cts = CPG_ROW_CLASS(s);
+                        const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
+                        if (i < m_c) wg[n_c + i] = I[g].z[s] - ri * I[g].y[s];
                         CPG_FENCE_EVERY(s);
                     }
                 }
@@ -647,11 +682,11 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const double *wg = w + g * ldw;
-                    double *sdx = scr + (size_t)g * N, *sdy = sdx + F.n;
+                    double *sdx = scr + (size_t)g * N, *sdy = sdx + n_c;
 #pragma unroll
                     for (int s = 0; s < NSX; s++) {
                         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < (unsigned)F.n) {
+                        if (i < n_c) {
                             const double xn = F.alpha * wg[fpx[s]] + (1.0 - F.alpha) * I[g].x[s];
                             if (chk) cpgw::gst(sdx, i, xn - I[g].x[s]);
                             I[g].x[s] = xn;
@@ -661,15 +696,16 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma unroll
                     for (int s = 0; s < NSZ; s++) {
                         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < (unsigned)F.m) {
-                            const double rv = ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr);
-                            const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+                        if (i < m_c) {
+                            const int cts = CPG_ROW_CLASS(s);
+                            const double rv = cts == 1 ? rho_eq : (cts == 0 ? rho_in : rho_fr);
+                            const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
                             const double zp = I[g].z[s], yp = I[g].y[s];
                             const double zt = (zp - ri * yp) + ri * wg[fpz[s]];
                             const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
                             // projection on [l, u]: equality rows have l = u, all others l = -inf
-                            const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, I[g], wg, lane}.u(s, i);
-                            const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
+                            const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.u(s, i);
+                            const double zn = cts == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
                             const double dyv = rv * (zr - zn);
                             I[g].z[s] = zn; I[g].y[s] = yp + dyv;
                             if (chk) cpgw::gst(sdy, i, dyv);
@@ -691,7 +727,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma nounroll
                     for (int pass = 0; pass < 2; pass++) {
                         if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                        o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(F, SharedCtx<NSX, NSZ, NV>{F, sh, I[g], wg, lane}, ct, S,
+                        o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct, S,
                                                                     I[g].x, I[g].z, I[g].y, wg, sdx, sdy, lane, pass == 1);
                     }
                     if (o.status == 11 && iter >= S.max_iter) o.status = 7;
