@@ -158,20 +158,21 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
     const char *wb = (const char *)w;
     const unsigned ldwb = (unsigned)ldw * 8u;
     // descriptors of chunk c + 1 are fetched while chunk c runs
-    int t0 = P.ctab[0], t1 = P.ctab[1], t2 = P.ctab[2];
+    int t0 = P.ctab[0], t1 = P.ctab[1], t2 = P.ctab[2], t3 = P.ctab[3];
     unsigned dn = P.desc[(unsigned)lane];
 #pragma nounroll
     for (int c = 0; c < P.n_chunks; c++) {
         const int L = cpgw::read_first_lane(t0);
         const int lg = cpgw::read_first_lane(t1);
         unsigned base = (unsigned)cpgw::read_first_lane(t2);
+        const int balanced = cpgw::read_first_lane(t3);      // rows over a variable number of lanes
         const unsigned d = dn;
         if (c + 1 < P.n_chunks) {
-            t0 = P.ctab[4 * c + 4]; t1 = P.ctab[4 * c + 5]; t2 = P.ctab[4 * c + 6];
+            t0 = P.ctab[4 * c + 4]; t1 = P.ctab[4 * c + 5]; t2 = P.ctab[4 * c + 6]; t3 = P.ctab[4 * c + 7];
             dn = P.desc[(unsigned)(c + 1) * 64u + (unsigned)lane];
         }
         const unsigned row = d & 0xFFFFu;
-        const int len = (int)(d >> 16);
+        const int len = balanced ? (int)((d >> 16) & 0xFFFu) : (int)(d >> 16);
         double acc[G];
 #pragma unroll
         for (int g = 0; g < G; g++) acc[g] = 0.0;
@@ -214,8 +215,13 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
                 acc[g] = fma(v, *(const double *)(wb + (unsigned)g * ldwb + co), acc[g]);
         }
         double r[G];
+        if (balanced) {
 #pragma unroll
-        for (int g = 0; g < G; g++) r[g] = cpgw::group_sum_first_dyn(acc[g], lg);
+            for (int g = 0; g < G; g++) r[g] = cpgw::seg_sum_first_dyn(acc[g], d >> 28, lg);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; g++) r[g] = cpgw::group_sum_first_dyn(acc[g], lg);
+        }
         cpgw::lds_order();
         if (row != CPG_NO_ROW) {
 #pragma unroll
@@ -247,12 +253,24 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
             A[g_] = fma(v_, *(const double *)(wb + (unsigned)g_ * ldwb + co_), A[g_]);             \
     }
+// per (chunk, lane) table entry: output slot (13 bits, 0x1FFF none) | segmented-reduction mask << 13
+#define CPG_GEN_NO_SLOT 0x1FFFu
 #define CPG_GEN_REDUCE_STORE(A, LG, C)                                                             \
     {                                                                                              \
-        const unsigned row_ = rows[(C) * 64u + (unsigned)lane];                                    \
+        const unsigned row_ = rows[(C) * 64u + (unsigned)lane] & CPG_GEN_NO_SLOT;                  \
         double r_[G];                                                                              \
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) r_[g_] = cpgw::group_sum_first<LG>(A[g_]); \
-        if (row_ != CPG_NO_ROW) {                                                                  \
+        if (row_ != CPG_GEN_NO_SLOT) {                                                             \
+            _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) w[(unsigned)(g_ * ldw) + row_] = r_[g_]; \
+        }                                                                                          \
+    }
+#define CPG_GEN_SEGREDUCE_STORE(A, S, C)                                                           \
+    {                                                                                              \
+        const unsigned e_ = rows[(C) * 64u + (unsigned)lane];                                      \
+        const unsigned row_ = e_ & CPG_GEN_NO_SLOT;                                                \
+        double r_[G];                                                                              \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) r_[g_] = cpgw::seg_sum_first<S>(A[g_], e_ >> 13); \
+        if (row_ != CPG_GEN_NO_SLOT) {                                                             \
             _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) w[(unsigned)(g_ * ldw) + row_] = r_[g_]; \
         }                                                                                          \
     }
@@ -590,7 +608,11 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
         // the generated executor has every count / offset baked in; it only needs the per-lane
         // output slots as a 16-bit table
         unsigned short *lr = (unsigned short *)(lds + lds_off); lds_off += (size_t)R.n_chunks * 16;
-        for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) lr[t] = (unsigned short)(cpgw::gld(R.desc, t) & 0xFFFFu);
+        for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) {
+            const unsigned d = cpgw::gld(R.desc, t);
+            const unsigned slot = (d & 0xFFFFu) == CPG_NO_ROW ? CPG_GEN_NO_SLOT : (d & 0xFFFFu);
+            lr[t] = (unsigned short)(slot | ((d >> 28) << 13));
+        }
         LP.rows16 = lr; LP.ctab = nullptr; LP.desc = nullptr;
 #else
         unsigned *ld = (unsigned *)(lds + lds_off);         lds_off += (size_t)R.n_chunks * 32;

@@ -215,6 +215,24 @@ CPG_DEV double group_sum_first_dyn(double v, int lg) {   // lg wave-uniform
         default: return group_sum_first<6>(v);
     }
 }
+// Segmented sum for rows that occupy a variable number (<= 8) of ADJACENT lanes inside one 16-lane
+// DPP row: in stage j lane t adds lane t + 2^j iff bit j of its mask is set (the source lane belongs
+// to the same row); after S stages the first lane of every row holds the row sum.
+template <int S>
+CPG_DEV double seg_sum_first(double v, unsigned mask) {
+    if (S >= 1) { const double t = row_shl<1>(v); v += (mask & 1u) ? t : 0.0; }
+    if (S >= 2) { const double t = row_shl<2>(v); v += (mask & 2u) ? t : 0.0; }
+    if (S >= 3) { const double t = row_shl<4>(v); v += (mask & 4u) ? t : 0.0; }
+    return v;
+}
+CPG_DEV double seg_sum_first_dyn(double v, unsigned mask, int stages) {   // stages wave-uniform
+    switch (stages) {
+        case 0: return v;
+        case 1: return seg_sum_first<1>(v, mask);
+        case 2: return seg_sum_first<2>(v, mask);
+        default: return seg_sum_first<3>(v, mask);
+    }
+}
 CPG_DEV double dmax2(double a, double b) { return a > b ? a : b; }
 CPG_DEV double dmin2(double a, double b) { return a < b ? a : b; }
 

@@ -227,7 +227,7 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
     phases = _sp.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=merge,
                              devpos=devpos)
     kkt = _sp.pack(phases, N=N)
-    kkt_ragged = _sp.pack_ragged(phases, N)
+    kkt_ragged = _sp.pack_ragged(phases, N, balanced=True)
     assert kkt_ragged.n_slots == kkt.n_slots and np.array_equal(kkt_ragged.final_pos, kkt.final_pos)
     if kkt.n_slots >= 0xFFFF:
         raise NotImplementedError('problem family too large for 16-bit LDS slot indices')

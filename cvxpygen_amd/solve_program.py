@@ -396,8 +396,14 @@ def execute_packed(prog: PackedProgram, w: np.ndarray, natural: bool = False):
 class RaggedProgram:
     """Compact (padding-free) form of a solve program, small enough to stay resident in LDS.
 
-    ctab int32 [n_chunks, 4]: (max len, log2 g, first entry, 0)
+    ctab int32 [n_chunks, 4]: (max len, log2 g, first entry, 0)  -- uniform chunk: every row is split
+                              over g = 2^k lanes, butterfly reduction;
+                              (max len, stages S, first entry, 1) -- balanced chunk: a row occupies a
+                              variable number (<= 16) of ADJACENT lanes inside one 16-lane DPP row;
+                              segmented reduction in S masked shift-add stages (lane t adds lane
+                              t + 2^j iff bit j of its mask is set), the row's first lane stores
     desc uint32 [n_chunks, 64]: output slot (low 16 bits, 0xFFFF none) | number of entries << 16
+                              (12 bits) | stage mask << 28 (balanced chunks)
     vals float64 [nnz + 1]; cols uint16 [nnz + 1]: entries step-major.  Inside a chunk the lanes are
     ordered by non-increasing number of entries, so the lanes that still have an entry at step s
     are a prefix [0, cnt_s) and lane t finds its entry at  first + sum_{s' < s} cnt_s' + t.
@@ -434,7 +440,80 @@ class RaggedProgram:
         return 8 * self.nnz + 8 * (-(-self.nnz // 4)) + 4 * 64 * self.n_chunks + 16 * self.n_chunks
 
 
-def pack_ragged(phases: List[Phase], N: int) -> RaggedProgram:
+DPP_ROW = 16            # cross-lane shifts of the segmented reduction stay inside 16-lane DPP rows
+SEG_KMAX = 8            # lanes per row in a balanced chunk (3 mask bits next to a 13-bit slot)
+STAGE_COST = 1.0
+
+
+def _balanced_layout(lens: np.ndarray, seg_len: int):
+    """Rows split into k = ceil(len / seg_len) <= 16 adjacent lanes of s = ceil(len / k) entries each
+    (short tails padded with zero coefficients), placed in order of non-increasing s so that lane
+    lengths are monotone inside a chunk; a row never straddles a 16-lane DPP row (dummy lanes of the
+    current length fill the gap).  Returns [chunk]: chunk = [(row position | -1, lane of the row, k, s)]."""
+    rows = []
+    for r, ln in enumerate(lens):
+        ln = max(int(ln), 1)
+        k = min(SEG_KMAX, -(-ln // seg_len))
+        rows.append((-(-ln // k), k, r))
+    rows.sort(key=lambda t: (-t[0], -t[1], t[2]))
+    chunks, cur = [], []
+    pending = list(rows)
+    while pending:
+        s_cur = pending[0][0]
+        off = len(cur) % DPP_ROW
+        room_row = DPP_ROW - off
+        room_chunk = LANES - len(cur)
+        # among the rows with the current (largest remaining) segment length take the widest that fits
+        pick = None
+        for i, (sr, k, r) in enumerate(pending):
+            if sr != s_cur:
+                break
+            if k <= room_row and k <= room_chunk:
+                pick = i
+                break
+        if pick is None:
+            if room_chunk < DPP_ROW and all(k > room_chunk for (sr, k, r) in pending if sr == s_cur):
+                chunks.append(cur)      # nothing of this length fits the rest of the chunk
+                cur = []
+                continue
+            cur.append((-1, 0, 1, s_cur))                              # dummy lane: s_cur zero entries
+            if len(cur) == LANES:
+                chunks.append(cur)
+                cur = []
+            continue
+        sr, k, r = pending.pop(pick)
+        for j in range(k):
+            cur.append((r, j, k, sr))
+        if len(cur) == LANES:
+            chunks.append(cur)
+            cur = []
+    if cur:
+        chunks.append(cur)
+    return chunks
+
+
+def _balanced_plan(lens: Sequence[int]):
+    """Segment length that minimises  sum_chunks (steps + CHUNK_COST + STAGE_COST * stages)."""
+    lens = np.asarray(lens, dtype=np.int64)
+    if len(lens) == 0:
+        return 0.0, []
+    best = None
+    mx = int(max(lens.max(), 1))
+    for seg_len in sorted(set(list(range(1, min(mx, 24) + 1)) + [mx, -(-mx // 2), -(-mx // 3), -(-mx // 4)])):
+        chunks = _balanced_layout(lens, seg_len)
+        cost = 0.0
+        for ch in chunks:
+            kmax = max(k for (_, _, k, _) in ch)
+            cost += ch[0][3] + CHUNK_COST + STAGE_COST * int(np.ceil(np.log2(kmax))) if kmax > 1 else ch[0][3] + CHUNK_COST
+        if best is None or cost < best[0]:
+            best = (cost, chunks)
+    return best
+
+
+def pack_ragged(phases: List[Phase], N: int, balanced: bool = False) -> RaggedProgram:
+    """balanced=False: rows of a chunk are split over a uniform power-of-two number of lanes;
+    balanced=True: variable number of adjacent lanes per row + segmented reduction (fewer steps when
+    row lengths are uneven)."""
     outs, ins, n_slots, final_pos = assign_slots(phases, N)
     if n_slots * 8 > 0xFFFF:
         raise NotImplementedError('work vector too large for 16-bit byte offsets')
@@ -442,6 +521,46 @@ def pack_ragged(phases: List[Phase], N: int) -> RaggedProgram:
     first = 0
     for pi, (ph, out_slots, col_slots) in enumerate(zip(phases, outs, ins)):
         lens = [len(c) for c in ph.cols]
+        if balanced and max(lens, default=0) < 4096 and n_slots < 0x1FFF:
+            _, chunks = _balanced_plan(lens)
+            for ch in chunks:
+                chunk_phase.append(pi)
+                lane_c = [np.zeros(0, dtype=np.int64)] * LANES
+                lane_v = [np.zeros(0)] * LANES
+                D = np.full(LANES, NO_ROW, dtype=np.uint32)
+                mask = np.zeros(LANES, dtype=np.uint32)
+                kmax = 1
+                for t, (rp, j, k, sr) in enumerate(ch):
+                    if rp < 0:
+                        lane_c[t], lane_v[t] = np.zeros(sr, dtype=np.int64), np.zeros(sr)
+                        continue
+                    c, v = np.asarray(col_slots[rp], dtype=np.int64), np.asarray(ph.vals[rp], dtype=np.float64)
+                    cs, vs = c[j * sr:(j + 1) * sr], v[j * sr:(j + 1) * sr]
+                    pad = sr - len(cs)
+                    lane_c[t] = np.concatenate([cs, np.zeros(pad, dtype=np.int64)])
+                    lane_v[t] = np.concatenate([vs, np.zeros(pad)])
+                    if j == 0:
+                        D[t] = out_slots[rp]
+                        assert t % DPP_ROW + k <= DPP_ROW
+                    kmax = max(kmax, k)
+                    for st in range(3):
+                        if j + (1 << st) < k:
+                            mask[t] |= 1 << st
+                S = int(np.ceil(np.log2(kmax))) if kmax > 1 else 0
+                ll = np.array([len(x) for x in lane_c], dtype=np.int64)
+                assert np.all(np.diff(ll) <= 0), 'lane lengths must be non-increasing'
+                L = int(ll.max())
+                D = D | (ll.astype(np.uint32) << 16) | (mask << 28)
+                n_ent = 0
+                for s in range(L):
+                    cnt = int((ll > s).sum())
+                    vals.append(np.array([lane_v[t][s] for t in range(cnt)]))
+                    cols.append(np.array([8 * lane_c[t][s] for t in range(cnt)], dtype=np.uint16))
+                    n_ent += cnt
+                ctab.append([L, S, first, 1])
+                desc.append(D)
+                first += n_ent
+            continue
         _, _, plan = _chunk_plan(lens)
         for g, ln, sel in plan:
             chunk_phase.append(pi)
@@ -493,6 +612,24 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
         L, lg, first, _ = prog.ctab[c]
         d = prog.desc[c]
         row, ln = d & 0xFFFF, d >> 16
+        if prog.ctab[c, 3] == 1:
+            ln = ln & 0xFFF            # balanced chunk: segmented shift-add reduction
+            acc = np.zeros(LANES)
+            base = first
+            for s in range(L):
+                act = ln > s
+                e = np.where(act, base + lane, dummy)
+                acc += prog.vals[e] * w[prog.cols[e] // 8]
+                base += int(act.sum())
+            for st in range(lg):
+                sh = np.zeros(LANES)
+                src = lane + (1 << st)
+                okl = (src < LANES) & (src // DPP_ROW == lane // DPP_ROW)
+                sh[okl] = acc[src[okl]]
+                acc = acc + np.where(((d >> 28) >> st) & 1, sh, 0.0)
+            ok = row != NO_ROW
+            w[row[ok]] = acc[ok]
+            continue
         g = 1 << lg
         acc = np.zeros(LANES)
         base = first
