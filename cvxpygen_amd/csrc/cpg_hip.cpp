@@ -959,7 +959,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     }
     const int G = h->inst_per_wave;
     const size_t N = (size_t)(h->F.n + h->F.m);
+#if defined(CPG_GEN_HEADER) && defined(CPG_GEN_N)
+    const size_t per_wave = (size_t)G * (h->F.n_slots + CPG_GEN_DUMMY_SLOTS) * sizeof(double);
+#else
     const size_t per_wave = (size_t)G * h->F.n_slots * sizeof(double);
+#endif
     // LDS-resident program: one workgroup per CU, as many waves as fit next to the program
     const cpg::DevRagged &R = h->F.kkt_ragged;
 #ifdef CPG_GEN_HEADER

@@ -19,6 +19,7 @@
 //               solutions out, delta_x / delta_y stash written at check iterations only
 #pragma once
 
+#include <type_traits>
 #include "cpg_wave.h"
 
 namespace cpg {
@@ -234,49 +235,47 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
 #ifdef CPG_GEN_HEADER
 // ---- family-specialised executor generated by cvxpygen_amd/codegen.py ---------------------------
 #define CPG_GEN_ZERO(A) _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = 0.0
-// all 64 lanes have an entry: constant offsets only
-#define CPG_GEN_STEP_FULL(A, E)                                                                    \
-    {                                                                                              \
-        const double v_ = *(const double *)(vb + (E) * 8u);                                        \
-        const unsigned co_ = *(const unsigned short *)(cb + (E) * 2u);                             \
-        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
-            A[g_] = fma(v_, *(const double *)(wb + (unsigned)g_ * ldwb + co_), A[g_]);             \
-    }
-// lanes >= CNT load with the same constant offsets (they hit later entries of the program, or the
-// zero padding behind it) and get their coefficient replaced by zero: no address arithmetic
+// One multiply-add step in three separately scheduled parts (software pipeline, see codegen.py):
+// offset + coefficient loads with literal LDS offsets, the gather from the work vector, the FMA.
+// In a partial step lanes >= CNT load like everybody else (they hit later entries of the program, or
+// the zero padding behind it) and get their coefficient replaced by zero: no address arithmetic.
 #define CPG_GEN_PAD 64
-#define CPG_GEN_STEP_PART(A, E, CNT)                                                               \
+#define CPG_GEN_LOAD_CV(ID, E)                                                                     \
+    const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
+    const unsigned co##ID = *(const unsigned short *)(cb + (E) * 2u);
+#define CPG_GEN_LOAD_W(ID)                                                                         \
+    double x##ID[G];                                                                               \
+    _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) x##ID[g_] = *(const double *)(wb + (unsigned)g_ * ldwb + co##ID);
+#define CPG_GEN_FMA_FULL(A, ID)                                                                    \
+    _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = fma(vl##ID, x##ID[g_], A[g_]);
+#define CPG_GEN_FMA_PART(A, ID, CNT)                                                               \
     {                                                                                              \
-        const double vl_ = *(const double *)(vb + (E) * 8u);                                       \
-        const unsigned co_ = *(const unsigned short *)(cb + (E) * 2u);                             \
-        const double v_ = lane < (CNT) ? vl_ : 0.0;                                                \
-        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
-            A[g_] = fma(v_, *(const double *)(wb + (unsigned)g_ * ldwb + co_), A[g_]);             \
+        const double v_ = lane < (CNT) ? vl##ID : 0.0;                                             \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = fma(v_, x##ID[g_], A[g_]);        \
     }
-// per (chunk, lane) table entry: output slot (13 bits, 0x1FFF none) | segmented-reduction mask << 13
-#define CPG_GEN_NO_SLOT 0x1FFFu
+// per (chunk, lane) table entry: output slot (13 bits) | segmented-reduction mask << 13.  Lanes that
+// own no row store to a private dummy slot behind the work vector (n_slots + lane): the store is
+// unconditional and the whole program stays one basic block.
+#define CPG_GEN_SLOT_MASK 0x1FFFu
+#define CPG_GEN_DUMMY_SLOTS 64
 #define CPG_GEN_REDUCE_STORE(A, LG, C)                                                             \
     {                                                                                              \
-        const unsigned row_ = rows[(C) * 64u + (unsigned)lane] & CPG_GEN_NO_SLOT;                  \
-        double r_[G];                                                                              \
-        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) r_[g_] = cpgw::group_sum_first<LG>(A[g_]); \
-        if (row_ != CPG_GEN_NO_SLOT) {                                                             \
-            _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) w[(unsigned)(g_ * ldw) + row_] = r_[g_]; \
-        }                                                                                          \
+        const unsigned row_ = rows[(C) * 64u + (unsigned)lane] & CPG_GEN_SLOT_MASK;                \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
+            w[(unsigned)(g_ * ldw) + row_] = cpgw::group_sum_first<LG>(A[g_]);                     \
     }
 #define CPG_GEN_SEGREDUCE_STORE(A, S, C)                                                           \
     {                                                                                              \
         const unsigned e_ = rows[(C) * 64u + (unsigned)lane];                                      \
-        const unsigned row_ = e_ & CPG_GEN_NO_SLOT;                                                \
-        double r_[G];                                                                              \
-        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) r_[g_] = cpgw::seg_sum_first<S>(A[g_], e_ >> 13); \
-        if (row_ != CPG_GEN_NO_SLOT) {                                                             \
-            _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) w[(unsigned)(g_ * ldw) + row_] = r_[g_]; \
-        }                                                                                          \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
+            w[(unsigned)(g_ * ldw) + (e_ & CPG_GEN_SLOT_MASK)] = cpgw::seg_sum_first<S>(A[g_], e_ >> 13); \
     }
 }  // namespace cpg
 #include CPG_GEN_HEADER
 namespace cpg {
+#ifndef CPG_GEN_N
+#error "generated program headers must carry the family dimensions (codegen.write_program_header(plan=...))"
+#endif
 #ifdef CPG_GEN_N
 // dimensions and per-slot row classes of the family this build was generated for
 struct GenFam {
@@ -574,7 +573,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #if defined(CPG_GEN_N)
     // family-specialised build: dimensions are literals, so the bounds checks of full slots fold away
     constexpr unsigned n_c = GenFam::n, m_c = GenFam::m;
-    constexpr int ldw = GenFam::n_slots;
+    constexpr int ldw = GenFam::n_slots + CPG_GEN_DUMMY_SLOTS;   // + one dummy store target per lane
     static_assert(!LDSPROG || ((n_c + 63) / 64 == (unsigned)NSX && (m_c + 63) / 64 == (unsigned)NSZ), "slot class of the generated family");
 #else
     const unsigned n_c = (unsigned)F.n, m_c = (unsigned)F.m;
@@ -610,7 +609,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
         unsigned short *lr = (unsigned short *)(lds + lds_off); lds_off += (size_t)R.n_chunks * 16;
         for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) {
             const unsigned d = cpgw::gld(R.desc, t);
-            const unsigned slot = (d & 0xFFFFu) == CPG_NO_ROW ? CPG_GEN_NO_SLOT : (d & 0xFFFFu);
+            const unsigned slot = (d & 0xFFFFu) == CPG_NO_ROW ? (unsigned)F.n_slots + (t & 63u) : (d & 0xFFFFu);
             lr[t] = (unsigned short)(slot | ((d >> 28) << 13));
         }
         LP.rows16 = lr; LP.ctab = nullptr; LP.desc = nullptr;
@@ -668,6 +667,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
             bool chk = false;
             const int lane_outer = lane;
             const int lane = cpgw::opaque(lane_outer);   // per-iteration copy, see cpgw::opaque
+            cpgw::assume((unsigned)lane < 64u);
             signed char ct[NSZ];
 #pragma unroll
             for (int s = 0; s < NSZ; s++) ct[s] = (signed char)cpgw::opaque((int)ct_reg[s]);
@@ -700,41 +700,46 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                 if (LDSPROG) run_program_lds<G>(LP, w, ldw, lane);
 #endif
                 else run_program<G>(F.kkt, w, ldw, lane);
-                // ---- relaxation, projection on [l, u], dual update
+                // ---- relaxation, projection on [l, u], dual update; the delta_x / delta_y stash of a check
+                // iteration is a separate instantiation so that ordinary iterations carry no branches
+                auto update = [&](auto stash_c) {
+                    constexpr bool STASH = decltype(stash_c)::value;
 #pragma unroll
-                for (int g = 0; g < G; g++) {
-                    const double *wg = w + g * ldw;
-                    double *sdx = scr + (size_t)g * N, *sdy = sdx + n_c;
+                    for (int g = 0; g < G; g++) {
+                        const double *wg = w + g * ldw;
+                        double *sdx = scr + (size_t)g * N, *sdy = sdx + n_c;
 #pragma unroll
-                    for (int s = 0; s < NSX; s++) {
-                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < n_c) {
-                            const double xn = F.alpha * wg[fpx[s]] + (1.0 - F.alpha) * I[g].x[s];
-                            if (chk) cpgw::gst(sdx, i, xn - I[g].x[s]);
-                            I[g].x[s] = xn;
+                        for (int s = 0; s < NSX; s++) {
+                            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                            if (i < n_c) {
+                                const double xn = F.alpha * wg[fpx[s]] + (1.0 - F.alpha) * I[g].x[s];
+                                if (STASH) cpgw::gst(sdx, i, xn - I[g].x[s]);
+                                I[g].x[s] = xn;
+                            }
+                            CPG_FENCE_EVERY(s);
                         }
-                        CPG_FENCE_EVERY(s);
-                    }
 #pragma unroll
-                    for (int s = 0; s < NSZ; s++) {
-                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < m_c) {
-                            const int cts = CPG_ROW_CLASS(s);
-                            const double rv = cts == 1 ? rho_eq : (cts == 0 ? rho_in : rho_fr);
-                            const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
-                            const double zp = I[g].z[s], yp = I[g].y[s];
-                            const double zt = (zp - ri * yp) + ri * wg[fpz[s]];
-                            const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
-                            // projection on [l, u]: equality rows have l = u, all others l = -inf
-                            const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.u(s, i);
-                            const double zn = cts == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
-                            const double dyv = rv * (zr - zn);
-                            I[g].z[s] = zn; I[g].y[s] = yp + dyv;
-                            if (chk) cpgw::gst(sdy, i, dyv);
+                        for (int s = 0; s < NSZ; s++) {
+                            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                            if (i < m_c) {
+                                const int cts = CPG_ROW_CLASS(s);
+                                const double rv = cts == 1 ? rho_eq : (cts == 0 ? rho_in : rho_fr);
+                                const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
+                                const double zp = I[g].z[s], yp = I[g].y[s];
+                                const double zt = (zp - ri * yp) + ri * wg[fpz[s]];
+                                const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
+                                // projection on [l, u]: equality rows have l = u, all others l = -inf
+                                const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.u(s, i);
+                                const double zn = cts == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
+                                const double dyv = rv * (zr - zn);
+                                I[g].z[s] = zn; I[g].y[s] = yp + dyv;
+                                if (STASH) cpgw::gst(sdy, i, dyv);
+                            }
+                            CPG_FENCE_EVERY(s);
                         }
-                        CPG_FENCE_EVERY(s);
                     }
-                }
+                };
+                if (__builtin_expect(chk, 0)) update(std::true_type{}); else update(std::false_type{});
                 cpgw::lds_order();
             }
             first = false;

@@ -70,6 +70,8 @@ CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and
 // keeping alive) everything derived from it
 CPG_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// tells the optimiser a fact it lost (e.g. the lane range after opaque()): bounds checks fold again
+CPG_DEV void assume(bool c) { __builtin_assume(c); }
 
 }  // namespace cpgw
 
@@ -172,6 +174,7 @@ inline unsigned mbcnt(unsigned long long mask) {
 inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
+inline void assume(bool) {}
 
 }  // namespace cpgw
 #endif
