@@ -203,6 +203,8 @@ def main():
                  'solved': int((alli[:, 1] == 1).sum()), 'not_solved': int((alli[:, 1] != 1).sum())}
 
     if rank == 0:
+        if stats['not_solved'] and args.workload in ('mpc12', 'mpc6', 'adp') and not args.all_params:
+            print(f"WARNING: {stats['not_solved']} instances of a feasible workload were not solved", file=sys.stderr)
         n_prim, n_dual = len(solver.plan.prim_idx), len(solver.plan.dual_idx)
         bytes_per_inst = 8 * (solver.np_var + n_prim + n_dual) + 32
         if args.workload == 'portfolio':
@@ -210,6 +212,13 @@ def main():
         if args.workload == 'adp':
             bytes_per_inst = 8 * (27 + 6 + 2) + 32                      # config 4: theta 27, u 6, dual 2, info
         k_ms = float(np.mean(kernel_ms))
+        traffic = None          # recorded PMC measurement of the same command (profiles/), not re-measured live
+        try:
+            rec = json.load(open(os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json'))).get(args.workload)
+            if rec and rec['instances'] == B and not args.all_params:
+                traffic = rec['fetch_bytes'] + rec['write_bytes']
+        except (OSError, ValueError, KeyError):
+            pass
         achieved = bytes_per_inst * B / (k_ms * 1e-3) / 1e9
         value = world * B * args.steps / elapsed
         out = {
@@ -237,7 +246,8 @@ def main():
                        'plan': {k: (round(v, 3) if isinstance(v, float) else v)
                                 for k, v in solver.plan.stats.items()}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_note': 'bytes per launch from rocprofv3 PMC passes recorded in profiles/r1_hbm_traffic.json' if traffic else None,
                          'kernel': ('clarabel_kernel' if args.workload == 'adp' else
                                     'osqp_refactor_kernel' if (args.all_params or args.workload == 'portfolio')
                                     else 'osqp_shared_kernel'), 'kernel_ms': k_ms,

@@ -984,7 +984,15 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
         int wfit = fixed < h->lds_limit ? (int)((h->lds_limit - fixed) / per_wave) : 0;
         // every slot class has an LDS kernel for <= 8 waves (<= 4 for G = 2 on the larger classes);
         // more waves only on explicit request (cpg_hip_set_launch) where such a kernel exists
-        const int wcap = h->waves_per_block > 0 ? 16 : (G == 2 ? 4 : 8);
+        int wcap = h->waves_per_block > 0 ? 16 : (G == 2 ? 4 : 8);
+#ifdef CPG_GEN_HEADER
+        if (h->waves_per_block <= 0) {   // family library: as many waves as its widest compiled kernel admits
+            const int nsx_ = (h->F.n + 63) / 64, nsz_ = (h->F.m + 63) / 64;
+#define Y(a, b, v, g, wm) if (nsx_ <= a && nsz_ <= b && G == g && wm > wcap) wcap = wm;
+            CPG_KERNELS_LDS(Y)
+#undef Y
+        }
+#endif
         if (wfit > wcap) wfit = wcap;
         if (wfit >= 4 || (h->program_in_lds == 1 && wfit >= 1)) {
             in_lds = true;

@@ -648,6 +648,14 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
         InstT I[G];
         CheckOut co[G];
         int n_open = 0;
+#ifdef CPG_GEN_HEADER
+        // The generated executor gathers in partial steps with ALL lanes (the coefficient of the idle
+        // lanes is forced to zero): every slot they can touch must hold a finite number, so the work
+        // vector starts from zeros for every instance (no stale NaN / Inf from LDS or from a
+        // diverged previous instance).
+        for (unsigned t = (unsigned)lane; t < (unsigned)(G * ldw); t += 64u) w[t] = 0.0;
+        cpgw::lds_order();
+#endif
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const long long b = (long long)ig * G + g;

@@ -148,6 +148,19 @@ def test_generated_family_library_vs_oracle(oracle_lib, tmp_path):
         r = bs.solve({'x_init': x0}, updated_params=['x_init'])
         _check(r, oracle_lib.cpg_solve_batch(d, _theta(d, 'x_init', x0), ['x_init']), d)
         bs.close()
+    # full batch, several launches in a row (stale LDS contents between launches): the specialised
+    # executor must agree with the table-driven kernels instance by instance
+    x0 = -2 + 4 * np.random.default_rng(22).random((100_000, 12))
+    ref = BatchSolver(d, plan=plan)
+    r0 = ref.solve({'x_init': x0}, updated_params=['x_init'])
+    ref.close()
+    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    for _ in range(3):
+        r = bs.solve({'x_init': x0}, updated_params=['x_init'])
+        assert (r.status == 1).all()
+        assert (r.iter == r0.iter).all()
+        assert np.abs(r.prim_flat - r0.prim_flat).max() <= 1e-9 * np.abs(r0.prim_flat).max()
+    bs.close()
 
 
 @pytest.mark.parametrize('make,B', [(lambda: families.nonneg_ls(10, 5, sparsity=None, seed=0), 200),
