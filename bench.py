@@ -119,6 +119,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--check', action='store_true', help='compare a sample with the oracle')
+    ap.add_argument('--max-iter', type=int, default=0, help='experiments: cap the iteration count')
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
     args = ap.parse_args()
 
@@ -159,7 +160,7 @@ def main():
     else:
         solver.set_updated(['x_init'])
         theta = make_theta(desc, B, seed=1000 + rank)
-    solver.apply_settings()                      # reference defaults
+    solver.apply_settings(**({'max_iter': args.max_iter} if args.max_iter else {}))   # reference defaults
     dev = DeviceBatch(solver, B)
     dev.upload(theta)
 

@@ -138,3 +138,26 @@ def test_shard_bounds_cover_batch():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize('make', [lambda: families.nonneg_ls(), lambda: families.mpc(6, 3, 10),
+                                  lambda: families.portfolio(8, 3), lambda: families.adp(),
+                                  lambda: families.toy_lp(solver='CLARABEL')])
+def test_canonicalizer_core_round_trip(make):
+    """the cvxpy-free core of the cvxpy front door: [A | b] entry maps in cvxpy's sign convention ->
+    per-canonical-parameter maps (cvxpygen/solvers/_interface.py:39-79, 132-173); driven with the
+    arrays rebuilt from a hand-made descriptor (cvxpy itself is not installed)"""
+    from cvxpygen_amd import canonicalizer as cz
+    d = make()
+    red_P, P_index, q_map, red_A, A_index = cz.reduced_from_descriptor(d)
+    d2 = cz.descriptor_from_reduced(d.name, d.solver, d.n_var, d.n_eq, d.n_ineq, red_P, P_index, q_map, red_A,
+                                    A_index, d.theta0, d.params, d.variables, d.duals, d.is_maximization, d.cones)
+    assert (d2.A.indptr == d.A.indptr).all() and (d2.A.indices == d.A.indices).all()
+    assert np.allclose(d2.A.data, d.A.data) and np.allclose(d2.P.toarray(), d.P.toarray())
+    rng = np.random.default_rng(0)
+    th = d.theta0.copy(); th[:-1] += rng.standard_normal(d.NP)
+    c1, c2 = d.canon_at(th), d2.canon_at(th)
+    assert set(c1) == set(c2)
+    for k in c1:
+        assert np.allclose(c1[k], c2[k]), k
+    assert d2.changes == d.changes and d2.nonzero_d == d.nonzero_d
