@@ -103,6 +103,45 @@ def cpu_baseline(desc, target_seconds: float = 12.0):
                       f'OpenMP static over instances, {t:.1f} s wall'}
 
 
+def cpu_baseline_portfolio(desc, target_seconds: float = 12.0):
+    """config 3 on the host: the C oracle with per-instance osqp_update_data_mat, all host cores"""
+    from oracle import binding as ob
+    ob.build()
+    cores = ob.lib().oracle_num_threads()
+
+    def run(B, seed):
+        pv = portfolio_params(desc, B, seed)
+        th = np.tile(desc.theta0, (B, 1))
+        for nm, v in pv.items():
+            p = desc.param(nm)
+            for k in range(B):
+                th[k, p.col:p.col + p.size] = desc.flatten_param(nm, v[k])
+        t0 = time.time()
+        ob.cpg_solve_batch(desc, th, list(pv.keys()), nthreads=cores)
+        return time.time() - t0
+
+    t_probe = run(2 * cores, 1)
+    B = int(max(2 * cores, min(20000, target_seconds / max(t_probe / (2 * cores), 1e-9))))
+    t = run(B, 2)
+    return {'value': B / t, 'unit': 'QP instances/s', 'cores': int(cores), 'kind': 'port',
+            'sample': f'{B} instances of the same workload, OpenMP static over instances, {t:.1f} s wall'}
+
+
+def cpu_baseline_adp(desc, target_seconds: float = 10.0):
+    """config 4 on the host: the numpy interior-point oracle, ONE core (pure-Python restatement)"""
+    from oracle import clarabel_numpy as cl
+    B = 64
+    pv = adp_params(B, 1)
+    th = np.stack([desc.theta_from_values({k: v[i] for k, v in pv.items()}) for i in range(B)])
+    t0 = time.time(); cl.cpg_solve_batch(desc, th); t = time.time() - t0
+    B2 = int(max(B, min(5000, target_seconds / (t / B))))
+    pv = adp_params(B2, 2)
+    th = np.stack([desc.theta_from_values({k: v[i] for k, v in pv.items()}) for i in range(B2)])
+    t0 = time.time(); cl.cpg_solve_batch(desc, th); t = time.time() - t0
+    return {'value': B2 / t, 'unit': 'SOCP instances/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{B2} instances of the same workload, dense numpy restatement on one core, {t:.1f} s wall'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -257,8 +296,13 @@ def main():
                                  'state never leaves registers/LDS, so this path is latency / LDS '
                                  'bound, not HBM bound (DESIGN.md section 6)'},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload not in ('portfolio', 'adp') and not args.all_params:
-            out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds)
+        if world == 1 and not args.no_cpu_baseline and not args.all_params:
+            if args.workload == 'portfolio':
+                out['cpu_baseline'] = cpu_baseline_portfolio(desc, args.cpu_seconds)
+            elif args.workload == 'adp':
+                out['cpu_baseline'] = cpu_baseline_adp(desc, min(args.cpu_seconds, 10.0))
+            else:
+                out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds)
         if args.check:
             from oracle import binding as ob
             nchk = 256
