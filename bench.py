@@ -17,6 +17,7 @@ the CPU baseline (the scalar-C oracle restatement, timed on the host cores of th
 """
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -29,6 +30,10 @@ sys.path.insert(0, ROOT)
 
 from cvxpygen_amd import families                      # noqa: E402
 from cvxpygen_amd.runtime import BatchSolver, DeviceBatch   # noqa: E402
+
+def C_float():
+    return ctypes.c_float(0)
+
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
@@ -159,6 +164,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--check', action='store_true', help='compare a sample with the oracle')
     ap.add_argument('--max-iter', type=int, default=0, help='experiments: cap the iteration count')
+    ap.add_argument('--eps', type=float, default=0.0, help='eps_abs = eps_rel (tight run of SURVEY.md 8(d): 1e-6)')
+    ap.add_argument('--adjoint', action='store_true', help='config 5: also time the batched QP adjoint (gradient=True path)')
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
     args = ap.parse_args()
 
@@ -199,7 +206,12 @@ def main():
     else:
         solver.set_updated(['x_init'])
         theta = make_theta(desc, B, seed=1000 + rank)
-    solver.apply_settings(**({'max_iter': args.max_iter} if args.max_iter else {}))   # reference defaults
+    stg = {}
+    if args.max_iter:
+        stg['max_iter'] = args.max_iter
+    if args.eps:
+        stg['eps_abs'] = stg['eps_rel'] = args.eps
+    solver.apply_settings(**stg)                 # reference defaults unless an experiment overrides them
     dev = DeviceBatch(solver, B)
     dev.upload(theta)
 
@@ -303,6 +315,25 @@ def main():
                 out['cpu_baseline'] = cpu_baseline_adp(desc, min(args.cpu_seconds, 10.0))
             else:
                 out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds)
+        if args.adjoint and desc.solver == 'OSQP':
+            # config 5: forward as above, then the adjoint with upstream dX = dU = 0.1
+            gs = BatchSolver(desc, device=local_rank, lib_path=lib_path, full_output=True)
+            Bg = min(B, 20000)
+            x0 = make_theta(desc, Bg, seed=77)
+            fw = gs.solve({'x_init': x0}, updated_params=['x_init'])
+            dv = {v.name: np.full((Bg,) + tuple(v.shape), 0.1) for v in desc.variables}
+            t0 = time.perf_counter()
+            gs.gradient({'x_init': x0}, fw.sol_x, fw.sol_y, dv, updated_params=['x_init'])
+            tg = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            g = gs.gradient({'x_init': x0}, fw.sol_x, fw.sol_y, dv, updated_params=['x_init'])
+            tg = min(tg, time.perf_counter() - t0)
+            ms = C_float()
+            gs.lib.L.cpg_hip_last_kernel_ms(gs.h_ref, ms)
+            out['adjoint'] = {'instances': Bg, 'wall_ms_incl_pcie': 1e3 * tg, 'kernel_ms': float(ms.value),
+                              'adjoints_per_s_kernel': Bg / (ms.value * 1e-3),
+                              'dtheta_shape': list(g['_flat'].shape), 'kernel': 'osqp_gradient_kernel'}
+            gs.close()
         if args.check:
             from oracle import binding as ob
             nchk = 256
