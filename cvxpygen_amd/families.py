@@ -265,6 +265,42 @@ def toy_lp(name: str = 'toy_lp', solver: str = 'OSQP') -> FamilyDescriptor:
     return cb.build({'c': 1.0}, solver=solver)
 
 
+def actuator(name: str = 'actuator') -> FamilyDescriptor:
+    """`tests/test_E2E_QP.py:14-41` (degenerate sizes n = 1, m = 3; data of :104-112 with seed 0):
+    minimise ||A u - w||^2 + lamb_sm ||delta_u||^2 + kappa |u|   s.t. u_min <= u <= u_max,
+    delta_u == u - u_prev.  The only reference family whose P depends on a parameter (lamb_sm), so
+    it exercises osqp_update_data_mat with new P values.
+    x = [u; delta_u; t (3) = A u - w; s = |u|]; eq 4 (t, delta_u), ineq 4 (bounds, |u| epigraph)."""
+    cb = CanonBuilder(name)
+    A = cb.param('A', (3, 1))
+    w = cb.param('w', (3,))
+    lamb = cb.param('lamb_sm', ())
+    kappa = cb.param('kappa', (1,))
+    u_prev = cb.param('u_prev', (1,))
+    u_min = cb.param('u_min', (1,))
+    u_max = cb.param('u_max', (1,))
+    u = cb.var('u', (1,))
+    du = cb.var('delta_u', (1, 1))
+    t = cb.aux(3)
+    s_ = cb.aux(1)
+    cb.sum_squares(t)
+    cb.quad(du[0, 0], du[0, 0], {lamb.up.col: 2.0})
+    cb.lin(s_[0], {kappa.idx(0): 1.0})
+    for i in range(3):
+        cb.eq([(t[i], 1.0), (u[0], cmul(A[i, 0], -1.0))], cmul(w[i], -1.0))
+    r_du = cb.eq([(du[0, 0], 1.0), (u[0], -1.0)], cmul(u_prev[0], -1.0))
+    r_min = cb.ineq([(u[0], -1.0)], cmul(u_min[0], -1.0))
+    r_max = cb.ineq([(u[0], 1.0)], u_max[0])
+    cb.ineq([(u[0], 1.0), (s_[0], -1.0)], 0.0)
+    cb.ineq([(u[0], -1.0), (s_[0], -1.0)], 0.0)
+    cb.dual('d0', [r_min], (1,))
+    cb.dual('d1', [r_max], (1,))
+    cb.dual('d2', [r_du], (1, 1))
+    lam0 = float(np.random.RandomState(0).rand())              # np.random.seed(0); np.random.rand()
+    return cb.build({'A': np.ones((3, 1)), 'w': np.array([2.0, 3.0, 5.0]), 'lamb_sm': lam0,
+                     'kappa': 0.1 * np.ones(1), 'u_prev': np.zeros(1), 'u_min': -np.ones(1), 'u_max': np.ones(1)})
+
+
 def adp_dynamics(state: np.ndarray):
     """discrete-time dynamics of `tests/test_E2E_SOCP.py:42-55` (td = 0.1, unit mass)"""
     A_cont = np.zeros((6, 6))
@@ -331,4 +367,4 @@ def toy_qa(n: int = 3, name: str = 'toy_qa') -> FamilyDescriptor:
 
 
 FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio, 'toy_box': toy_box,
-            'toy_lp': toy_lp, 'toy_qa': toy_qa, 'ADP': adp}
+            'toy_lp': toy_lp, 'toy_qa': toy_qa, 'ADP': adp, 'actuator': actuator}

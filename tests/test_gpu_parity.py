@@ -235,3 +235,22 @@ def test_portfolio_config3_vs_oracle(oracle_lib):
     assert r.prim['w'].shape == (B, 100) and r.dual['d3'].shape == (B, 100)
     assert np.abs(r.prim['w'].sum(axis=1) - 1).max() < 1e-2          # 1'w == 1
     bs.close()
+
+
+def test_actuator_parameter_in_P_vs_oracle(oracle_lib):
+    """tests/test_E2E_QP.py:14-41, 104-112: the family whose P depends on a parameter (lamb_sm)"""
+    d = families.actuator()
+    B = 257
+    rng = np.random.default_rng(5)
+    th = np.tile(d.theta0, (B, 1))
+    th[:, d.param('lamb_sm').col] = rng.random(B)
+    th[:, d.param('w').col:d.param('w').col + 3] += rng.standard_normal((B, 3))
+    th[:, d.param('kappa').col] = 0.1 + 0.2 * rng.random(B)
+    bs = BatchSolver(d)
+    r = bs.solve({p.name: th[:, p.col:p.col + p.size] for p in d.params})
+    _check(r, oracle_lib.cpg_solve_batch(d, th, None), d)
+    # reference data of seed 0: u is clipped at u_max = 1, objective 21 + lamb_sm + 0.1
+    r0 = bs.solve({p.name: d.theta0[None, p.col:p.col + p.size] for p in d.params})
+    lam = d.theta0[d.param('lamb_sm').col]
+    assert abs(r0.prim["u"][0, 0] - 1.0) < 2e-2 and abs(r0.obj_val[0] - (21.1 + lam)) < 0.1
+    bs.close()

@@ -163,3 +163,21 @@ def test_refactor_path_matrix_and_vector_update_order(sim_lib, oracle_lib):
     o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
     _assert_parity(r, o, prim, dual)
     bs.close()
+
+
+def test_refactor_path_parameter_in_P(sim_lib, oracle_lib):
+    """tests/test_E2E_QP.py 'actuator': lamb_sm enters P -> osqp_update_data_mat with new P values"""
+    d = families.actuator()
+    rng = np.random.default_rng(1)
+    B = 3
+    th = np.tile(d.theta0, (B, 1))
+    th[:, d.param('lamb_sm').col] = rng.random(B)                     # np.random.rand() per seed in the reference test
+    th[:, d.param('w').col:d.param('w').col + 3] += rng.standard_normal((B, 3))
+    bs = BatchSolver(d, lib_path=sim_lib)
+    # (this family needs > 2000 ADMM iterations at the default tolerances: three checks are enough here)
+    r = bs.solve({p.name: th[:, p.col:p.col + p.size] for p in d.params}, max_iter=75)
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, None, max_iter=75)
+    assert (o['status'] == 7).all()
+    _assert_parity(r, o, prim, dual)
+    assert r.prim['delta_u'].shape == (B, 1, 1) and r.dual['d2'].shape == (B, 1, 1)
+    bs.close()
