@@ -54,7 +54,7 @@ def test_adjoint_kernel_vs_oracle_emulator(sim_lib, oracle_lib):
     th[:, :d.NP] *= 1 + 0.05 * rng.standard_normal((B, d.NP))
     bs = BatchSolver(d, lib_path=sim_lib, full_output=True)
     vals = {p.name: th[:, p.col:p.col + p.size] for p in d.params}
-    r = bs.solve(vals, eps_abs=1e-5, eps_rel=1e-5, max_iter=300)
+    r = bs.solve(vals, eps_abs=1e-4, eps_rel=1e-4, max_iter=100)     # the adjoint is checked at whatever (x, y) comes out
     assert r.sol_x.shape == (B, d.n_var) and r.prim['x'].shape == (B, 5)
     g = bs.gradient(vals, r.sol_x, r.sol_y, {'x': 0.1 * np.ones((B, 5))})
     assert g['A'].shape == (B, 10, 5) and g['b'].shape == (B, 10)

@@ -159,8 +159,8 @@ def test_refactor_path_matrix_and_vector_update_order(sim_lib, oracle_lib):
     th[:, :d.NP] += 0.5 * rng.standard_normal((B, d.NP))
     th[:, d.param('c').col:d.param('c').col + 3] *= 40.0      # make ||q|| decide the cost scaling
     bs = BatchSolver(d, lib_path=sim_lib)
-    r = bs.solve({p.name: th[:, p.col:p.col + p.size] for p in d.params})
-    o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
+    r = bs.solve({p.name: th[:, p.col:p.col + p.size] for p in d.params}, max_iter=100)
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, None, max_iter=100)
     _assert_parity(r, o, prim, dual)
     bs.close()
 
