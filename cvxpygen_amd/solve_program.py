@@ -39,9 +39,13 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import scipy.sparse as sp
 
+import os as _os
+
 LANES = 64
-PHASE_COST = 14.0        # fixed cost of a phase, in units of one multiply-add step of a wavefront
-CHUNK_COST = 3.0         # fixed cost of one more chunk inside a phase
+# cost model of the packer, in units of one multiply-add step of a wavefront (environment overrides are
+# tuning knobs for experiments; a family library and the runtime must be built with the same values)
+PHASE_COST = float(_os.environ.get('CPG_PHASE_COST', 14.0))      # fixed cost of a phase
+CHUNK_COST = float(_os.environ.get('CPG_CHUNK_COST', 3.0))       # fixed cost of one more chunk inside a phase
 MAX_GROUP_ROWS = 128
 
 
@@ -442,7 +446,7 @@ class RaggedProgram:
 
 DPP_ROW = 16            # cross-lane shifts of the segmented reduction stay inside 16-lane DPP rows
 SEG_KMAX = 8            # lanes per row in a balanced chunk (3 mask bits next to a 13-bit slot)
-STAGE_COST = 1.0
+STAGE_COST = float(_os.environ.get('CPG_STAGE_COST', 1.0))       # one stage of the segmented reduction
 
 
 def _balanced_layout(lens: np.ndarray, seg_len: int):
