@@ -104,7 +104,10 @@ class ConicBatchSolver(BatchSolver):
                 raise AttributeError(f'Solver setting "{k}" not available.')
 
     def set_program_placement(self, in_lds: int = -1):
-        pass
+        """-1 / 1: block-shared LDS copy of the family's index tables when it fits; 0: tables stay in L2"""
+        self._placement = in_lds
+        if self.h.value:
+            self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h, in_lds), 'set_program_placement')
 
     def gradient(self, *a, **k):
         raise NotImplementedError('differentiation is available for OSQP families only '
@@ -176,6 +179,8 @@ class ConicBatchSolver(BatchSolver):
         self._update_key, self._keep = key, keep
         self._var_cols, self.np_var = cols, len(cols)
         self._updated_names = names
+        if getattr(self, '_placement', None) is not None:
+            self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h, self._placement), 'set_program_placement')
         launch = getattr(self, '_launch', None)
         if launch:
             self.lib.check(self.lib.L.cpg_hip_set_launch(self.h, *launch), 'set_launch')

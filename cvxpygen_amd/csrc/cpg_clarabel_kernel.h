@@ -64,6 +64,8 @@ struct DevConic {
     int n_prim, n_dual;
     const int *prim_idx, *dual_idx;
     int lds_doubles;                         // per wavefront
+    int fac_triples, n_pfull;                // table lengths needed to stage the tables in LDS
+    int tab_doubles;                         // LDS doubles of the block-shared copy of all index tables
 };
 
 struct ConicBuf {
@@ -463,7 +465,51 @@ CPG_DEV void conic_step(const ConicCtx &cx, const LdsProg &SP, double rhs_tau, d
     dkap = -(rhs_kap + kap * dtau) / tau;
 }
 
-CPG_DEV void clarabel_body(const DevConic &C, const DevConicSettings &S, const DevBatch &Bt, double *lds, int /*wave_global*/) {
+// Block-shared LDS copy of every index table of the family (patterns, factorisation schedule,
+// substitution program): the interior-point loop chases these indices in every sparse product and
+// every chunk; an L2 round trip per index bounded the first version of the kernel (ADP: 20.0 ms with
+// the tables in L2, 15.8 ms with the LDS copy, 8 waves per workgroup, 100 000 instances).
+template <typename T>
+CPG_DEV const T *conic_stage(const T *src, unsigned count, double *&cur) {
+    T *dst = (T *)cur;
+    for (unsigned t = cpgw::thread_in_block(); t < count; t += cpgw::block_threads()) dst[t] = cpgw::gld(src, t);
+    cur += ((size_t)count * sizeof(T) + 7) / 8;
+    return dst;
+}
+
+template <bool TABLES_IN_LDS>
+CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const DevBatch &Bt, double *lds, int /*wave_global*/) {
+    DevConic C = C0;
+    if (TABLES_IN_LDS) {
+        double *cur = lds;
+        const unsigned n1 = (unsigned)C.n + 1u, m1 = (unsigned)C.m + 1u, NN = (unsigned)(C.n + C.m);
+        C.soc_start = conic_stage(C0.soc_start, (unsigned)C.n_soc, cur);
+        C.soc_dim = conic_stage(C0.soc_dim, (unsigned)C.n_soc, cur);
+        C.row_cone = conic_stage(C0.row_cone, (unsigned)C.m, cur);
+        C.Ap = conic_stage(C0.Ap, n1, cur); C.Ai = conic_stage(C0.Ai, (unsigned)C.nnzA, cur);
+        C.Arp = conic_stage(C0.Arp, m1, cur); C.Aent = conic_stage(C0.Aent, (unsigned)C.nnzA, cur);
+        C.Acol = conic_stage(C0.Acol, (unsigned)C.nnzA, cur);
+        C.Pp = conic_stage(C0.Pp, n1, cur); C.Pi = conic_stage(C0.Pi, (unsigned)C.nnzP, cur);
+        C.Prp = conic_stage(C0.Prp, n1, cur); C.Pent = conic_stage(C0.Pent, (unsigned)C.n_pfull, cur);
+        C.Pcol = conic_stage(C0.Pcol, (unsigned)C.n_pfull, cur);
+        C.Lcol = conic_stage(C0.Lcol, (unsigned)C.nnzL, cur);
+        C.ksrc_kind = conic_stage(C0.ksrc_kind, (unsigned)C.nnzL + NN, cur);
+        C.ksrc_idx = conic_stage(C0.ksrc_idx, (unsigned)C.nnzL + NN, cur);
+        C.fac_ctab = conic_stage(C0.fac_ctab, (unsigned)C.fac_chunks * 4u, cur);
+        C.fac_task = conic_stage(C0.fac_task, (unsigned)C.fac_chunks * 64u, cur);
+        C.fac_len = conic_stage(C0.fac_len, (unsigned)C.fac_chunks * 64u, cur);
+        C.fac_a = conic_stage(C0.fac_a, (unsigned)C.fac_triples, cur);
+        C.fac_b = conic_stage(C0.fac_b, (unsigned)C.fac_triples, cur);
+        C.fac_k = conic_stage(C0.fac_k, (unsigned)C.fac_triples, cur);
+        C.sol_ctab = conic_stage(C0.sol_ctab, (unsigned)C.sol_chunks * 4u, cur);
+        C.sol_desc = conic_stage(C0.sol_desc, (unsigned)C.sol_chunks * 64u, cur);
+        C.sol_cols = conic_stage(C0.sol_cols, (unsigned)C.sol_nnz, cur);
+        C.sol_kind = conic_stage(C0.sol_kind, (unsigned)C.sol_nnz, cur);
+        C.sol_idx = conic_stage(C0.sol_idx, (unsigned)C.sol_nnz, cur);
+        C.sol_fpos = conic_stage(C0.sol_fpos, NN, cur);
+        lds += C.tab_doubles;
+        cpgw::block_sync();
+    }
     const int lane = cpgw::lane_id();
     const unsigned n = (unsigned)C.n, m = (unsigned)C.m, N = n + m;
     const ConicBuf B = conic_carve(lds + (size_t)cpgw::wave_in_block() * (size_t)C.lds_doubles, C);

@@ -328,14 +328,16 @@ static int launch_refactor(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, 
 #define CPG_CONIC_WAVES_PER_SIMD 4   // <= 128 VGPRs
 #endif
 #ifndef CPG_HOST_SIM
+template <bool TABLES_IN_LDS>
 __global__ void __launch_bounds__(512, CPG_CONIC_WAVES_PER_SIMD)
 clarabel_kernel(cpg::DevConic C, cpg::DevConicSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    cpg::clarabel_body(C, S, Bt, cpg_lds, wave_global);
+    cpg::clarabel_body<TABLES_IN_LDS>(C, S, Bt, cpg_lds, wave_global);
 }
-static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    auto kern = clarabel_kernel;
+template <bool TABLES_IN_LDS>
+static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = clarabel_kernel<TABLES_IN_LDS>;
     if (lds > 48 * 1024)
         RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->C, h->CS, Bt);
@@ -343,7 +345,8 @@ static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int
     return CPG_OK;
 }
 #else
-static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+template <bool TABLES_IN_LDS>
+static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
     for (int b = 0; b < blocks; b++) {
         std::vector<char> ldsbuf(lds + 64);
         std::vector<cpgw::SimWave> wv(waves);
@@ -356,7 +359,7 @@ static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int
                 cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
                 cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
                 cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
-                cpg::clarabel_body(h->C, h->CS, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
+                cpg::clarabel_body<TABLES_IN_LDS>(h->C, h->CS, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
             });
         for (auto &t : th) t.join();
         for (auto &w : wv) pthread_barrier_destroy(&w.bar);
@@ -365,6 +368,10 @@ static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int
     return CPG_OK;
 }
 #endif
+static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds, bool tables_in_lds) {
+    return tables_in_lds ? launch_conic_t<true>(h, Bt, blocks, waves, lds) : launch_conic_t<false>(h, Bt, blocks, waves, lds);
+}
+
 
 // Instantiated kernels.  (NSX, NSZ): slot class (ceil(n/64), ceil(m/64)); NV: leading slots with
 // per-instance q / u (1: at most 64 parameter-dependent entries; NS: all); G instances per wave.
@@ -691,6 +698,20 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     TRY(upload_csr(h, own, f->map_P, &C.map_P)); TRY(upload_csr(h, own, f->map_A, &C.map_A));
     TRY(upload_csr(h, own, f->map_q, &C.map_q)); TRY(upload_csr(h, own, f->map_b, &C.map_b));
     TRY(upload_csr(h, own, f->map_d, &C.map_d));
+    {   // LDS doubles of the block-shared copy of the index tables, same order and rounding as
+        // clarabel_body<true> (conic_stage)
+        C.fac_triples = f->fac_triples; C.n_pfull = f->Prp[n];
+        auto dbl = [](size_t count, size_t elem) { return (count * elem + 7) / 8; };
+        size_t t = 0;
+        t += 2 * dbl((size_t)f->n_soc, 4) + dbl((size_t)m, 4);
+        t += dbl((size_t)n + 1, 4) + dbl((size_t)f->nnzA, 4) + dbl((size_t)m + 1, 4) + 2 * dbl((size_t)f->nnzA, 4);
+        t += dbl((size_t)n + 1, 4) + dbl((size_t)f->nnzP, 4) + dbl((size_t)n + 1, 4) + 2 * dbl((size_t)C.n_pfull, 4);
+        t += dbl((size_t)f->nnzL, 4) + 2 * dbl((size_t)f->nnzL + N, 4);
+        t += dbl((size_t)f->fac_chunks * 4, 4) + 2 * dbl((size_t)f->fac_chunks * 64, 4) + 3 * dbl((size_t)f->fac_triples, 4);
+        t += dbl((size_t)f->sol_chunks * 4, 4) + dbl((size_t)f->sol_chunks * 64, 4) + dbl((size_t)f->sol_nnz, 2);
+        t += 2 * dbl((size_t)f->sol_nnz, 4) + dbl((size_t)N, 2);
+        C.tab_doubles = (int)t;
+    }
     {   // per-wavefront LDS slice, see conic_carve()
         const long long d = (long long)f->nnzP + f->nnzA + 7LL * n + 14LL * m + 6LL * N + f->nnzL + f->sol_nnz + f->sol_slots;
         C.lds_doubles = (int)((d + 1) & ~1LL);
@@ -901,11 +922,15 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     if (rc) return rc;
     if (h->conic) {
         const size_t per_wave = (size_t)h->C.lds_doubles * sizeof(double);
-        // the kernel is compiled for CPG_CONIC_WAVES_PER_SIMD waves per SIMD (register budget); measured
-        // best on MI355X: workgroups of 4 waves, as many per CU as LDS and that budget admit
-        int W = h->waves_per_block > 0 ? (h->waves_per_block > 8 ? 8 : h->waves_per_block) : 4;
-        while (W > 1 && (size_t)W * per_wave > h->lds_limit) W--;
-        const size_t lds = (size_t)W * per_wave;
+        // the kernel is compiled for CPG_CONIC_WAVES_PER_SIMD waves per SIMD (register budget).  The
+        // family's index tables get a block-shared LDS copy whenever a workgroup still fits; measured
+        // best on MI355X (ADP): workgroups of 8 waves (15.8 ms; 17.3 with 7, 19.4 with 6).
+        int W = h->waves_per_block > 0 ? (h->waves_per_block > 8 ? 8 : h->waves_per_block) : 8;
+        const size_t tab = (size_t)h->C.tab_doubles * sizeof(double);
+        const bool tables_in_lds = h->program_in_lds != 0 && tab + per_wave <= h->lds_limit;
+        const size_t fixed = tables_in_lds ? tab : 0;
+        while (W > 1 && fixed + (size_t)W * per_wave > h->lds_limit) W--;
+        const size_t lds = fixed + (size_t)W * per_wave;
         long long blocks = (B + W - 1) / W;
         int per_cu = (int)(h->lds_limit / lds); if (per_cu < 1) per_cu = 1;
         if (h->blocks_per_cu > 0 && per_cu > h->blocks_per_cu) per_cu = h->blocks_per_cu;
@@ -923,7 +948,7 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
 #else
         *h->d_counter = 0;
 #endif
-        rc = launch_conic(h, Bt, (int)blocks, W, lds);
+        rc = launch_conic(h, Bt, (int)blocks, W, lds, tables_in_lds);
         if (rc) return rc;
 #ifndef CPG_HOST_SIM
         RT_CHECK(hipEventRecord(h->ev1, h->stream));

@@ -1,0 +1,8 @@
+#!/bin/bash
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+run() { echo "== $*"; timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), d['unit'], round(d['roofline']['kernel_ms'],2),'ms', d['config']['mean_iter'], d['config']['not_solved'])"; }
+run --workload adp
+run --workload adp --placement 0
+timeout 600 python -m pytest tests/test_conic.py -m gpu -x -q 2>&1 | tail -3
+echo "== done"
