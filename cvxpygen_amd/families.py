@@ -23,7 +23,7 @@ from .descriptor import FamilyDescriptor
 
 # ------------------------------------------------------------------------------------------------
 def nonneg_ls(m: int = 3, n: int = 2, sparsity=((0, 0, 1), (0, 1, 1)), seed: int = 1,
-              name: str = 'nonneg_LS') -> FamilyDescriptor:
+              name: str = 'nonneg_LS', solver: str = 'OSQP') -> FamilyDescriptor:
     """minimise ||A x - b||^2  s.t. x >= 0   (`examples/main.py:16-25`).
 
     x = [x (n); t (m)];  eq: A x - t = b (m rows);  ineq: -x <= 0 (n rows).
@@ -51,7 +51,7 @@ def nonneg_ls(m: int = 3, n: int = 2, sparsity=((0, 0, 1), (0, 1, 1)), seed: int
     else:
         Aval = rng.randn(m, n)
     bval = rng.randn(m)
-    return cb.build({'A': Aval, 'b': bval})
+    return cb.build({'A': Aval, 'b': bval}, solver=solver)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -55,6 +55,24 @@ def test_oracle_matches_exact_adp_solutions():
         assert o['pri_res'][0] < 1e-8 and o['dua_res'][0] < 1e-8
 
 
+def test_oracle_on_the_nonneg_ls_example_in_conic_form():
+    """`examples/main.py` family handed to the conic path (zero + nonnegative cones, P = 2I on t): the
+    interior-point oracle against the exact NNLS answer of tests/golden, and against the OSQP
+    oracle's solution of the same instance -- the two restatements share no code"""
+    g = GOLD['nonneg_LS']
+    d = families.nonneg_ls(solver='CLARABEL')
+    th = d.theta_from_values({'A': np.array(g['A_data']), 'b': np.array(g['b'])})
+    o = cl.cpg_solve_batch(d, th[None])
+    assert o['status'][0] == cl.SOLVED
+    assert np.abs(o['prim']['x'][0] - g['x']).max() < 1e-7 and abs(o['obj_val'][0] - g['obj']) < 1e-7
+    assert np.abs(o['dual']['d0'][0] - g['dual_x_ge_0']).max() < 1e-6
+    from oracle import binding
+    dq = families.nonneg_ls()
+    oq = binding.cpg_solve_batch(dq, dq.theta_from_values({'A': np.array(g['A_data']), 'b': np.array(g['b'])})[None],
+                                 None, eps_abs=1e-9, eps_rel=1e-9)
+    assert np.abs(o['prim']['x'][0] - oq['prim']['x'][0]).max() < 1e-6
+
+
 def test_adp_descriptor_matches_survey_dimensions():
     d = families.adp()
     assert (d.n_var, d.n_eq, d.n_ineq, d.NP) == (17, 9, 10, 27)          # SURVEY.md Appendix B
@@ -243,6 +261,23 @@ def test_adp_known_answers_on_gpu():
         assert abs(r.obj_val[0] - g['obj']) <= 1e-7 * g['obj']
         assert np.abs(r.prim['u'][0][0] - g['u0']).max() <= 1e-5
         assert abs(r.dual['d0'][0][0] - g['dual_norm_u0']) <= 1e-6
+    bs.close()
+
+
+@pytest.mark.gpu
+def test_nonneg_ls_in_conic_form_on_gpu():
+    """QP with zero + nonnegative cones through the interior-point kernel: known NNLS answer, oracle parity"""
+    g = GOLD['nonneg_LS']
+    d = families.nonneg_ls(solver='CLARABEL')
+    rng = np.random.default_rng(9)
+    B = 333
+    A = np.tile(np.array(g['A_data']), (B, 1)); b = np.tile(np.array(g['b']), (B, 1))
+    A[1:] += 0.3 * rng.standard_normal((B - 1, 3)); b[1:] += rng.standard_normal((B - 1, 3))
+    bs = ConicBatchSolver(d, full_output=True)
+    r = bs.solve({'A': A, 'b': b})
+    th = np.stack([d.theta_from_values({'A': A[k], 'b': b[k]}) for k in range(B)])
+    _assert_parity(r, cl.cpg_solve_batch(d, th))
+    assert np.abs(r.prim['x'][0] - g['x']).max() < 1e-7 and abs(r.obj_val[0] - g['obj']) < 1e-7
     bs.close()
 
 
