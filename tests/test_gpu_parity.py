@@ -254,3 +254,27 @@ def test_actuator_parameter_in_P_vs_oracle(oracle_lib):
     lam = d.theta0[d.param('lamb_sm').col]
     assert abs(r0.prim["u"][0, 0] - 1.0) < 2e-2 and abs(r0.obj_val[0] - (21.1 + lam)) < 0.1
     bs.close()
+
+
+def test_portfolio_full_shard_properties():
+    """config 3 at shard scale (20 000 instances here; the kernel's memory does not grow with B):
+    every instance solved, budget and leverage constraints hold to the solver tolerance,
+    batch-order invariance and duplicates"""
+    d = families.portfolio(100, 10)
+    B = 20_000
+    rng = np.random.default_rng(41)
+    sig = np.zeros((B, 10, 10)); sig[:, np.arange(10), np.arange(10)] = rng.random((B, 10))
+    pv = {'a': rng.standard_normal((B, 100)), 'F': np.round(rng.standard_normal((B, 100, 10))),
+          'Sig_f_sqrt': sig, 'd_sqrt': rng.random((B, 100)), 'w_prev': np.zeros((B, 100))}
+    pv['a'][1] = pv['a'][0]; pv['F'][1] = pv['F'][0]; pv['Sig_f_sqrt'][1] = pv['Sig_f_sqrt'][0]; pv['d_sqrt'][1] = pv['d_sqrt'][0]
+    bs = BatchSolver(d)
+    r = bs.solve(pv, updated_params=list(pv.keys()))
+    assert (r.status == 1).all()
+    w = r.prim['w']
+    # ||w||_1 <= L is 100 epigraph rows |w_i| <= t_i plus sum(t) <= L, each met to ~eps * ||Ax||: the sum may exceed L by ~0.2
+    assert np.abs(w.sum(axis=1) - 1).max() < 2e-2 and (np.abs(w).sum(axis=1) <= 1.6 + 0.3).all()
+    assert r.iter[0] == r.iter[1] and np.array_equal(w[0], w[1])
+    perm = rng.permutation(B)[:4000]
+    r2 = bs.solve({k: v[perm] for k, v in pv.items()}, updated_params=list(pv.keys()))
+    assert (r2.iter == r.iter[perm]).all() and np.array_equal(r2.prim_flat, r.prim_flat[perm])
+    bs.close()
