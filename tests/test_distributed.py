@@ -8,20 +8,23 @@ import numpy as np
 import pytest
 
 
-def _worker(rank, world, port, sim_lib, q):
+def _worker(rank, world, port, sim_lib, q, conic=False):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from cvxpygen_amd import families
     from cvxpygen_amd.runtime import BatchSolver
+    from cvxpygen_amd.conic_runtime import ConicBatchSolver
     from cvxpygen_amd.sharding import solve_sharded
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    d = families.nonneg_ls()
     rng = np.random.default_rng(0)
     tv = rng.standard_normal((5, 3))
-    bs = BatchSolver(d, lib_path=sim_lib)
-    bs.set_launch(1, 1, 0)
+    if conic:                       # the same family through the interior-point path
+        bs = ConicBatchSolver(families.nonneg_ls(solver='CLARABEL'), lib_path=sim_lib)
+    else:
+        bs = BatchSolver(families.nonneg_ls(), lib_path=sim_lib)
+        bs.set_launch(1, 1, 0)
     bs.set_updated(['b'])
     out = solve_sharded(bs, tv)
     if rank == 0:
@@ -30,22 +33,31 @@ def _worker(rank, world, port, sim_lib, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather(sim_lib, oracle_lib):
+@pytest.mark.parametrize('conic', [False, True])
+def test_two_rank_shard_and_gather(sim_lib, oracle_lib, conic):
     import torch.multiprocessing as mp
     from cvxpygen_amd import families
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, sim_lib, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, sim_lib, q, conic)) for r in range(2)]
     for p in procs:
         p.start()
     out = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    d = families.nonneg_ls()
     rng = np.random.default_rng(0)
     tv = rng.standard_normal((5, 3))
+    if conic:
+        from oracle import clarabel_numpy as cl
+        d = families.nonneg_ls(solver='CLARABEL')
+        th = np.tile(d.theta0, (5, 1)); th[:, 3:6] = tv
+        o = cl.cpg_solve_batch(d, th)
+        assert out['iter'].tolist() == o['iter'].tolist()
+        assert np.allclose(out['prim'], o['sol_x'][:, d.variables[0].indices], atol=1e-9)
+        return
+    d = families.nonneg_ls()
     th = np.tile(d.theta0, (5, 1)); th[:, 3:6] = tv
     o = oracle_lib.cpg_solve_batch(d, th, ['b'])
     assert out['iter'].tolist() == o['iter'].tolist()
