@@ -112,17 +112,7 @@ struct ConicCtx {
         for (unsigned k = a; k < e; k++) acc = fma(B.A[k], v[(unsigned)cpgw::gld(C.Ai, k)], acc);
         return acc;
     }
-    CPG_DEV double dot_n(const double *a, const double *b) const {
-        double acc = 0.0;
-        for (unsigned i = (unsigned)lane; i < n; i += 64u) acc = fma(a[i], b[i], acc);
-        return cpgw::wave_sum(acc);
-    }
-    CPG_DEV double dot_m(const double *a, const double *b) const {
-        double acc = 0.0;
-        for (unsigned i = (unsigned)lane; i < m; i += 64u) acc = fma(a[i], b[i], acc);
-        return cpgw::wave_sum(acc);
-    }
-    // per-cone dot products  sum_r wv[r] v[r] * eta  are written to tmp[first row of the cone]
+    // per-cone dot products  sum_r wv[r] v[r]  are written to tmp[first row of the cone]
     CPG_DEV void soc_dots(const double *v, double *tmp) const {
         for (int k = lane; k < C.n_soc; k += 64) {
             const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);

@@ -1,5 +1,5 @@
 // C-ABI of the MI355X batched-solve backend (declared in include/cpg_hip.h) and the launch code
-// of the OSQP kernels.  Built by hipcc for gfx950 into libcpg_hip.so (see csrc/build.py).
+// of the OSQP (shared factor, refactorisation, adjoint) and conic interior-point kernels.  Built by hipcc for gfx950 into libcpg_hip.so (see csrc/build.py).
 //
 // With -DCPG_HOST_SIM the same file builds, with g++, into the TEST-ONLY emulator library used by
 // tests/sim (64 lock-stepped host threads per wavefront); the product never loads that build.

@@ -2,7 +2,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 2>&1 | tail -14 | tee $OUT/pytest_gpu17.log
+echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 2>&1 | tail -14 | tee $OUT/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
 echo "== bench default"; timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), 'inst/s', round(d['roofline']['kernel_ms'],2),'ms', d['config']['library'])"
 echo "== done"
