@@ -265,10 +265,12 @@ def main():
             bytes_per_inst = 8 * (27 + 6 + 2) + 32                      # config 4: theta 27, u 6, dual 2, info
         k_ms = float(np.mean(kernel_ms))
         traffic = None          # recorded PMC measurement of the same command (profiles/), not re-measured live
+        binding = None
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json'))).get(args.workload)
             if rec and rec['instances'] == B and not args.all_params:
                 traffic = rec['fetch_bytes'] + rec['write_bytes']
+                binding = rec.get('binding_resource')
         except (OSError, ValueError, KeyError):
             pass
         achieved = bytes_per_inst * B / (k_ms * 1e-3) / 1e9
@@ -300,6 +302,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': 'bytes per launch from rocprofv3 PMC passes recorded in profiles/r1_hbm_traffic.json' if traffic else None,
+                         'binding_resource': binding,
                          'kernel': ('clarabel_kernel' if args.workload == 'adp' else
                                     'osqp_refactor_kernel' if (args.all_params or args.workload == 'portfolio')
                                     else 'osqp_shared_kernel'), 'kernel_ms': k_ms,
