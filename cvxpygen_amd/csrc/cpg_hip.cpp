@@ -170,6 +170,16 @@ static int upload_csr(cpg_handle_t h, std::vector<void *> &own, const cpg_csr_t 
 
 // ------------------------------------------------------------------------------------ kernels
 #define CPG_BLOCK_MAX 1024
+// the refactorisation kernel waits on dependent global loads: a third wavefront per SIMD (168 VGPRs,
+// more spills) still pays -- 306 -> 286 ms on the portfolio family, 982 -> 771 ms on MPC 12/4/10 with
+// all parameters per instance; a fourth (128 VGPRs) does not (308 ms)
+#ifndef CPG_REFACTOR_WAVES_PER_SIMD
+#define CPG_REFACTOR_WAVES_PER_SIMD 3
+#endif
+// (the adjoint kernel is bound by its LDS scratch: one workgroup per CU either way)
+#ifndef CPG_GRADIENT_WAVES_PER_SIMD
+#define CPG_GRADIENT_WAVES_PER_SIMD 2
+#endif
 #ifndef CPG_MIN_WAVES_PER_SIMD
 #define CPG_MIN_WAVES_PER_SIMD 4   // 16 waves per CU: <= 128 VGPRs
 #endif
@@ -223,7 +233,7 @@ static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int wav
 
 #ifndef CPG_HOST_SIM
 template <int NSX, int NSZ>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, CPG_REFACTOR_WAVES_PER_SIMD)
 osqp_refactor_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -267,7 +277,7 @@ static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks
 #endif
 #ifndef CPG_HOST_SIM
 template <int NSX, int NSZ>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, CPG_GRADIENT_WAVES_PER_SIMD)
 osqp_gradient_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevGradient Gd, cpg::DevGradBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -862,7 +872,7 @@ int cpg_hip_gradient_batch(cpg_handle_t h, int64_t B, const double *theta, const
     const size_t lds = (size_t)W * per_wave * sizeof(double);
     if (lds > h->lds_limit) { set_error("adjoint work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
     long long blocks = (B + W - 1) / W;
-    int per_cu = (int)(h->lds_limit / lds); if (per_cu > 2) per_cu = 2; if (per_cu < 1) per_cu = 1;
+    int per_cu = (int)(h->lds_limit / lds); if (per_cu > CPG_GRADIENT_WAVES_PER_SIMD) per_cu = CPG_GRADIENT_WAVES_PER_SIMD; if (per_cu < 1) per_cu = 1;
     const long long cap = (long long)h->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
     if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
@@ -960,7 +970,8 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
         const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
         if (lds > h->lds_limit) { set_error("work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
         long long blocks = (B + W - 1) / W;
-        int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : 2;
+        int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : CPG_REFACTOR_WAVES_PER_SIMD;    // workgroups of 4 waves
+        if (per_cu > CPG_REFACTOR_WAVES_PER_SIMD) per_cu = CPG_REFACTOR_WAVES_PER_SIMD;
         if ((long long)per_cu * (long long)lds > (long long)h->lds_limit) per_cu = (int)(h->lds_limit / lds);
         const long long cap = (long long)h->num_cu * per_cu;
         if (blocks > cap) blocks = cap;

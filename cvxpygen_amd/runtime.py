@@ -368,6 +368,10 @@ class BatchSolver:
             n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip))
         self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), self.device, C.byref(self.h_ref)),
                        'cpg_hip_create_osqp (refactor handle)')
+        if getattr(self, '_launch', None):
+            self.lib.check(self.lib.L.cpg_hip_set_launch(self.h_ref, *self._launch), 'set_launch')
+        if getattr(self, '_placement', None) is not None:
+            self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h_ref, self._placement), 'set_program_placement')
 
     def _set_refactor(self, cols: np.ndarray, th_fixed: np.ndarray):
         self._ensure_refactor_handle()
@@ -433,12 +437,18 @@ class BatchSolver:
                 raise AttributeError(f'Solver setting "{k}" not available.')
 
     def set_launch(self, waves_per_block=0, inst_per_wave=0, blocks_per_cu=0):
-        self.lib.check(self.lib.L.cpg_hip_set_launch(self.h, waves_per_block, inst_per_wave,
-                                                    blocks_per_cu), 'set_launch')
+        """launch geometry of both handles (shared-factor and refactorisation path)"""
+        self._launch = (waves_per_block, inst_per_wave, blocks_per_cu)
+        for hh in (self.h_shared, self.h_ref):
+            if hh is not None and hh.value:
+                self.lib.check(self.lib.L.cpg_hip_set_launch(hh, *self._launch), 'set_launch')
 
     def set_program_placement(self, in_lds: int = -1):
         """-1 automatic, 0 stream the solve program from L2/HBM, 1 keep it resident in LDS"""
-        self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h, in_lds), 'set_program_placement')
+        self._placement = in_lds
+        for hh in (self.h_shared, self.h_ref):
+            if hh is not None and hh.value:
+                self.lib.check(self.lib.L.cpg_hip_set_program_placement(hh, in_lds), 'set_program_placement')
 
     # ---- which parameters vary ----------------------------------------------------------------------
     def set_updated(self, updated_params: Optional[Sequence[str]] = None) -> None:
