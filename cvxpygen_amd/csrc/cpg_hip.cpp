@@ -810,7 +810,38 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     UP(int, fac_ctab, (size_t)r->fac_chunks * 4); UP(unsigned, fac_task, (size_t)r->fac_chunks * 64);
     UP(unsigned, fac_len, (size_t)r->fac_chunks * 64);
     UP(unsigned, fac_a, r->fac_triples); UP(unsigned, fac_b, r->fac_triples); UP(unsigned, fac_k, r->fac_triples);
-    UP(int, sol_ctab, (size_t)r->sol_chunks * 4); UP(unsigned, sol_desc, (size_t)r->sol_chunks * 64);
+    UP(int, sol_ctab, (size_t)r->sol_chunks * 4);
+    UP(unsigned, sol_desc, (size_t)r->sol_chunks * 64);
+    std::vector<unsigned> st, cr((size_t)r->sol_nnz);            // alive until the sync below
+    {   // flattened step table and entry table of the streaming substitution executor
+        // (run_program_stream, cpg_osqp_refactor.h documents the encoding)
+        constexpr int D = CPG_STREAM_DEPTH;
+        if (r->sol_nnz > 0xFFFFF) { set_error("refactor substitution program: more than 2^20 entries"); return CPG_E_BADARG; }
+        for (int e = 0; e < r->sol_nnz; e++) cr[e] = (unsigned)r->sol_cols[e] | (0xFFFFu << 16);
+        for (int c = 0; c < r->sol_chunks; c++) {
+            const int L = r->sol_ctab[4 * c], lg = r->sol_ctab[4 * c + 1];
+            unsigned base = (unsigned)r->sol_ctab[4 * c + 2];
+            if (r->sol_ctab[4 * c + 3] != 0 || L < 1 || lg > 6) { set_error("refactor substitution program: unsupported chunk kind"); return CPG_E_BADARG; }
+            for (int s = 0; s < L; s++) {
+                unsigned cnt = 0;
+                for (int l = 0; l < 64; l++) {
+                    const unsigned d = r->sol_desc[(size_t)c * 64 + l];
+                    const bool act = (int)(d >> 16) > s;
+                    if (act && (unsigned)l != cnt) { set_error("refactor substitution program: active lanes are not a prefix"); return CPG_E_BADARG; }
+                    if (!act && s == 0 && (d & 0xFFFFu) != 0xFFFFu) { set_error("refactor substitution program: empty output row"); return CPG_E_BADARG; }
+                    if (act && s == 0) cr[base + l] = (cr[base + l] & 0xFFFFu) | ((d & 0xFFFFu) << 16);
+                    cnt += act;
+                }
+                st.push_back(base | (cnt << 20) | ((unsigned)lg << 27) | (s == 0 ? 0x40000000u : 0u) | (s == L - 1 ? 0x80000000u : 0u));
+                base += cnt;
+            }
+        }
+        while (st.size() % D) st.push_back(0u);
+        R.sol_steps = (int)st.size();
+        st.resize(st.size() + 2 * D, 0u);
+        if ((rc = upload<unsigned>(h, own, st.data(), st.size(), &R.sol_stab))) return rc;
+        if ((rc = upload<unsigned>(h, own, cr.data(), cr.size(), &R.sol_cr))) return rc;
+    }
     UP(unsigned short, sol_cols, r->sol_nnz); UP(int, sol_kind, r->sol_nnz); UP(int, sol_idx, r->sol_nnz);
     UP(unsigned short, sol_fpos, N);
     UP(double, P_base, r->nnzP); UP(double, A_base, r->nnzA); UP(double, q_base, n); UP(double, u_base, m);

@@ -35,6 +35,9 @@ struct DevRefactor {
     const int *sol_kind, *sol_idx;
     const unsigned short *sol_fpos;
     int sol_chunks, sol_nnz, sol_slots;
+    const unsigned *sol_stab;     // flattened step table and entry table of run_program_stream
+    const unsigned *sol_cr;       // (built by cpg_hip_set_refactor from ctab / desc / cols)
+    int sol_steps;
     // canonicalisation of everything (UNSCALED): p = base + map @ theta_var
     const double *P_base, *A_base, *q_base, *u_base;
     const double *q_setup;   // unscaled q of the code-generation-time workspace (cost scaling sees this one)
@@ -107,6 +110,75 @@ struct InstCtx {
         return acc;
     }
 };
+
+// run_program_lds<1> for coefficients that live in HBM (this path: the values of the substitution
+// program are per instance, 8 bytes per entry and iteration, far more than the caches hold across
+// the resident waves).  The walk over (chunk, step) is flattened into one stream of steps and the
+// operands of step g + D (D = CPG_STREAM_DEPTH) are requested when step g is consumed -- they do
+// not depend on the work vector -- so a wave keeps D x 768 bytes in flight across chunk boundaries
+// instead of one chunk's worth.  The per-lane operands arrive through the in-order queue of vector
+// loads, with no load under a branch, so that every wait is for the oldest request only:
+//   stab[g]  one word per step, through the scalar cache one block of D steps ahead: entry base |
+//            active lanes << 20 | log2(reduction width) << 27 | first step of a chunk << 30 |
+//            last step << 31
+//   cr[e]    per entry: byte offset of the operand in the work vector | output row << 16 (the row
+//            is picked up at the first step of a chunk, where every lane that writes is active)
+//   vals[e]  per instance
+// The tables end with 2 D empty steps (no active lane) and the step count is a multiple of D.  Same
+// accumulation order as run_program_lds<1>; idle lanes read the trailing zero entry.
+#ifndef CPG_STREAM_DEPTH
+#define CPG_STREAM_DEPTH 8
+#endif
+struct StreamProg {
+    const unsigned *stab;
+    const unsigned *cr;
+    const double *vals;
+    int n_steps;                  // multiple of CPG_STREAM_DEPTH
+    unsigned dummy;
+};
+CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
+    constexpr int D = CPG_STREAM_DEPTH;
+    const char *wb = (const char *)w;
+    double v[D];
+    unsigned cr[D], fl[D], sn[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        const unsigned st = cpgw::sld(P.stab, (unsigned)u);
+        const unsigned e = (unsigned)lane < ((st >> 20) & 0x7Fu) ? (st & 0xFFFFFu) + (unsigned)lane : P.dummy;
+        v[u] = cpgw::gld(P.vals, e);
+        cr[u] = cpgw::gld(P.cr, e);
+        fl[u] = st;
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++) sn[u] = cpgw::sld(P.stab, (unsigned)(D + u));
+    unsigned row = CPG_NO_ROW;
+    double acc = 0.0;
+#pragma nounroll
+    for (int g0 = 0; g0 < P.n_steps; g0 += D) {
+        unsigned sc[D];
+#pragma unroll
+        for (int u = 0; u < D; u++) { sc[u] = sn[u]; sn[u] = cpgw::sld(P.stab, (unsigned)(g0 + 2 * D + u)); }
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            const unsigned f = fl[u];
+            const unsigned x = cr[u];
+            acc = fma(v[u], *(const double *)(wb + (x & 0xFFFFu)), acc);
+            if (f & 0x40000000u) row = x >> 16;
+            const unsigned st = sc[u];
+            const unsigned e = (unsigned)lane < ((st >> 20) & 0x7Fu) ? (st & 0xFFFFFu) + (unsigned)lane : P.dummy;
+            v[u] = cpgw::gld(P.vals, e);
+            cr[u] = cpgw::gld(P.cr, e);
+            fl[u] = st;
+            if (f & 0x80000000u) {                              // last step of a chunk (uniform)
+                const double r = cpgw::group_sum_first_dyn(acc, (int)((f >> 27) & 7u));
+                cpgw::lds_order();
+                if (row != CPG_NO_ROW) w[row] = r;
+                cpgw::lds_order();
+                acc = 0.0;
+            }
+        }
+    }
+}
 
 template <int NSX, int NSZ>
 CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const DevSettings &S,
@@ -294,6 +366,9 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         LdsProg SP;
         SP.ctab = R.sol_ctab; SP.desc = R.sol_desc; SP.vals = B.sv; SP.cols = R.sol_cols;
         SP.n_chunks = R.sol_chunks; SP.dummy = (unsigned)R.sol_nnz - 1u; SP.rows16 = nullptr;
+        StreamProg ST;
+        ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
+        ST.n_steps = R.sol_steps; ST.dummy = SP.dummy;
         const InstCtx<NSX, NSZ> cx{F, R, B, w, lane};
         double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
@@ -317,7 +392,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 if (i < m) w[n + i] = z[s] - ri * y[s];
             }
             cpgw::lds_order();
-            run_program_lds<1>(SP, w, ldw, lane);
+            run_program_stream(ST, w, lane);
 #pragma unroll
             for (int s = 0; s < NSX; s++) {
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;

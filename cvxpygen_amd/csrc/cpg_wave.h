@@ -72,6 +72,13 @@ CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 CPG_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // tells the optimiser a fact it lost (e.g. the lane range after opaque()): bounds checks fold again
 CPG_DEV void assume(bool c) { __builtin_assume(c); }
+// Word of a read-only table at a wave-uniform index through the SCALAR cache (s_load): the constant
+// address space tells the compiler that no store of the kernel can alias it, which it cannot prove
+// for a plain global pointer in kernels that also write global memory.
+CPG_DEV unsigned sld(const unsigned *base, unsigned idx) {
+    typedef const unsigned __attribute__((address_space(4))) *cptr_t;
+    return ((cptr_t)(unsigned long long)base)[idx];
+}
 
 }  // namespace cpgw
 
@@ -175,6 +182,7 @@ inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcou
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
 inline void assume(bool) {}
+inline unsigned sld(const unsigned *base, unsigned idx) { return base[idx]; }
 
 }  // namespace cpgw
 #endif
