@@ -77,37 +77,46 @@ struct InstCtx {
     const InstBuf &B;
     const double *w;
     int lane;
-    CPG_DEV double q(int, unsigned i) const { return cpgw::gld((const double *)B.q, i); }
-    CPG_DEV double u(int, unsigned i) const { return cpgw::gld((const double *)B.u, i); }
-    CPG_DEV double ax(int s) const {
-        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+    // the instance's scaled q and u stay in registers for the whole ADMM loop (they are read in
+    // every iteration; a global load there is a full memory latency on the critical path)
+    const double (&qr)[NSX];
+    const double (&ur)[NSZ];
+    CPG_DEV double q(int s, unsigned) const { return qr[s]; }
+    CPG_DEV double u(int s, unsigned) const { return ur[s]; }
+    // Row products: every entry needs three loads in a chain (entry number / column -> value), so
+    // four entries are requested together and accumulated in order (same sums as a plain loop).
+    template <bool ENT, bool OFFS>
+    CPG_DEV double row_dot(const int *ptr, const int *ent, const int *col, const double *val, unsigned r) const {
+        const unsigned a = (unsigned)cpgw::gld(ptr, r), e = (unsigned)cpgw::gld(ptr, r + 1u);
         double acc = 0.0;
-        if (i < (unsigned)F.m) {
-            const unsigned a = (unsigned)cpgw::gld(R.Arp, i), e = (unsigned)cpgw::gld(R.Arp, i + 1u);
-            for (unsigned k = a; k < e; k++)
-                acc = fma(cpgw::gld((const double *)B.A, (unsigned)cpgw::gld(R.Aent, k)), w[(unsigned)cpgw::gld(R.Acol, k)], acc);
+        for (unsigned k = a; k < e; k += 4u) {
+            unsigned en[4], co[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const unsigned kk = k + (unsigned)t < e ? k + (unsigned)t : a;
+                en[t] = ENT ? (unsigned)cpgw::gld(ent, kk) : kk;
+                co[t] = (unsigned)cpgw::gld(col, kk);
+            }
+            double av[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) av[t] = cpgw::gld(val, en[t]);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (k + (unsigned)t < e) acc = fma(av[t], w[(OFFS ? (unsigned)F.n : 0u) + co[t]], acc);
         }
         return acc;
+    }
+    CPG_DEV double ax(int s) const {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        return i < (unsigned)F.m ? row_dot<true, false>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i) : 0.0;
     }
     CPG_DEV double px(int s) const {
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
-        double acc = 0.0;
-        if (j < (unsigned)F.n) {
-            const unsigned a = (unsigned)cpgw::gld(R.Prp, j), e = (unsigned)cpgw::gld(R.Prp, j + 1u);
-            for (unsigned k = a; k < e; k++)
-                acc = fma(cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)), w[(unsigned)cpgw::gld(R.Pcol, k)], acc);
-        }
-        return acc;
+        return j < (unsigned)F.n ? row_dot<true, false>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j) : 0.0;
     }
     CPG_DEV double atx(int s) const {
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
-        double acc = 0.0;
-        if (j < (unsigned)F.n) {
-            const unsigned a = (unsigned)cpgw::gld(R.Ap, j), e = (unsigned)cpgw::gld(R.Ap, j + 1u);
-            for (unsigned k = a; k < e; k++)
-                acc = fma(cpgw::gld((const double *)B.A, k), w[(unsigned)F.n + (unsigned)cpgw::gld(R.Ai, k)], acc);
-        }
-        return acc;
+        return j < (unsigned)F.n ? row_dot<false, true>(R.Ap, nullptr, R.Ai, (const double *)B.A, j) : 0.0;
     }
 };
 
@@ -124,7 +133,7 @@ struct InstCtx {
 //   cr[e]    per entry: byte offset of the operand in the work vector | output row << 16 (the row
 //            is picked up at the first step of a chunk, where every lane that writes is active)
 //   vals[e]  per instance
-// The tables end with 2 D empty steps (no active lane) and the step count is a multiple of D.  Same
+// The step table ends with 2 D empty steps (no active lane) and the step count is a multiple of D.  Same
 // accumulation order as run_program_lds<1>; idle lanes read the trailing zero entry.
 #ifndef CPG_STREAM_DEPTH
 #define CPG_STREAM_DEPTH 8
@@ -139,36 +148,26 @@ struct StreamProg {
 CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
     constexpr int D = CPG_STREAM_DEPTH;
     const char *wb = (const char *)w;
+    // The ring starts with D empty steps (zero coefficient) and the loop runs D steps past the end of
+    // the stream, so that every vector load of this function is issued from the loop body in one
+    // fixed order: the wait before a step then names exactly the loads issued after its operands.
     double v[D];
     unsigned cr[D], fl[D], sn[D];
 #pragma unroll
-    for (int u = 0; u < D; u++) {
-        const unsigned st = cpgw::sld(P.stab, (unsigned)u);
-        const unsigned e = (unsigned)lane < ((st >> 20) & 0x7Fu) ? (st & 0xFFFFFu) + (unsigned)lane : P.dummy;
-        v[u] = cpgw::gld(P.vals, e);
-        cr[u] = cpgw::gld(P.cr, e);
-        fl[u] = st;
-    }
-#pragma unroll
-    for (int u = 0; u < D; u++) sn[u] = cpgw::sld(P.stab, (unsigned)(D + u));
+    for (int u = 0; u < D; u++) { v[u] = 0.0; cr[u] = 0xFFFF0000u; fl[u] = 0u; sn[u] = cpgw::sld(P.stab, (unsigned)u); }
     unsigned row = CPG_NO_ROW;
     double acc = 0.0;
+    double wv = *(const double *)wb;                            // operand of the step about to be consumed
 #pragma nounroll
-    for (int g0 = 0; g0 < P.n_steps; g0 += D) {
+    for (int g0 = 0; g0 < P.n_steps + D; g0 += D) {
         unsigned sc[D];
 #pragma unroll
-        for (int u = 0; u < D; u++) { sc[u] = sn[u]; sn[u] = cpgw::sld(P.stab, (unsigned)(g0 + 2 * D + u)); }
+        for (int u = 0; u < D; u++) { sc[u] = sn[u]; sn[u] = cpgw::sld(P.stab, (unsigned)(g0 + D + u)); }
 #pragma unroll
         for (int u = 0; u < D; u++) {
             const unsigned f = fl[u];
-            const unsigned x = cr[u];
-            acc = fma(v[u], *(const double *)(wb + (x & 0xFFFFu)), acc);
-            if (f & 0x40000000u) row = x >> 16;
-            const unsigned st = sc[u];
-            const unsigned e = (unsigned)lane < ((st >> 20) & 0x7Fu) ? (st & 0xFFFFFu) + (unsigned)lane : P.dummy;
-            v[u] = cpgw::gld(P.vals, e);
-            cr[u] = cpgw::gld(P.cr, e);
-            fl[u] = st;
+            acc = fma(v[u], wv, acc);
+            if (f & 0x40000000u) row = cr[u] >> 16;
             if (f & 0x80000000u) {                              // last step of a chunk (uniform)
                 const double r = cpgw::group_sum_first_dyn(acc, (int)((f >> 27) & 7u));
                 cpgw::lds_order();
@@ -176,6 +175,13 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
                 cpgw::lds_order();
                 acc = 0.0;
             }
+            wv = *(const double *)(wb + (cr[(u + 1) % D] & 0xFFFFu));   // gather of the next step, after the store
+            cpgw::sched_fence();                                // ... and before the requests below, not next to its use
+            const unsigned st = sc[u];
+            const unsigned e = (unsigned)lane < ((st >> 20) & 0x7Fu) ? (st & 0xFFFFFu) + (unsigned)lane : P.dummy;
+            v[u] = cpgw::gld(P.vals, e);
+            cr[u] = cpgw::gld(P.cr, e);
+            fl[u] = st;
         }
     }
 }
@@ -311,16 +317,26 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
                 double acc = 0.0;
 #pragma nounroll
-                for (int s = 0; s < L; s++) {
-                    const bool act = s < len;
-                    if (act) {
-                        const unsigned e = base + (unsigned)lane;
-                        const double la = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_a, e));
-                        const double lb = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_b, e));
-                        const double dk = cpgw::gld((const double *)B.Dg, cpgw::gld(R.fac_k, e));
-                        acc = fma(la * dk, lb, acc);
+                for (int s = 0; s < L; s += 4) {   // four steps of index and value loads in flight
+                    bool act[4];
+                    unsigned ia[4], ib[4], ik[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        act[t] = s + t < len;
+                        const unsigned e = act[t] ? base + (unsigned)lane : 0u;
+                        base += cpgw::popc64(cpgw::ballot(act[t]));
+                        ia[t] = cpgw::gld(R.fac_a, e); ib[t] = cpgw::gld(R.fac_b, e); ik[t] = cpgw::gld(R.fac_k, e);
                     }
-                    base += cpgw::popc64(cpgw::ballot(act));
+                    double la[4], lb[4], dk[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        la[t] = cpgw::gld((const double *)B.Lx, ia[t]);
+                        lb[t] = cpgw::gld((const double *)B.Lx, ib[t]);
+                        dk[t] = cpgw::gld((const double *)B.Dg, ik[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (act[t]) acc = fma(la[t] * dk[t], lb[t], acc);
                 }
                 if (task != 0xFFFFFFFFu) {
                     const int kind = cpgw::gld(R.ksrc_kind, task);
@@ -368,8 +384,16 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         SP.n_chunks = R.sol_chunks; SP.dummy = (unsigned)R.sol_nnz - 1u; SP.rows16 = nullptr;
         StreamProg ST;
         ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
+#ifdef CPG_EXP_SHARED_SV
+        ST.vals = carve(Bt.scratch + (size_t)(wave_global % 64) * (size_t)R.buf_doubles, F0, R).sv;
+#endif
         ST.n_steps = R.sol_steps; ST.dummy = SP.dummy;
-        const InstCtx<NSX, NSZ> cx{F, R, B, w, lane};
+        double qr[NSX], ur[NSZ];
+#pragma unroll
+        for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qr[s] = i < n ? cpgw::gld((const double *)B.q, i) : 0.0; }
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; ur[s] = i < m ? cpgw::gld((const double *)B.u, i) : 0.0; }
+        const InstCtx<NSX, NSZ> cx{F, R, B, w, lane, qr, ur};
         double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
         for (int s = 0; s < NSX; s++) x[s] = 0.0;
@@ -378,11 +402,8 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         CheckOut o;
         o.prim_res = 0; o.dual_res = 0; o.obj = 0; o.status = 11;
         int iter = 0;
-#pragma nounroll
-        while (o.status == 11) {
-            if (iter >= S.max_iter) { o.status = 7; break; }
-            iter++;
-            const bool chk = (S.check_termination > 0 && iter % S.check_termination == 0) || iter >= S.max_iter;
+        // One ADMM iteration; `chk` also stores the steps delta x / delta y for the termination check.
+        auto admm_iteration = [&](const bool chk) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < n) w[i] = F.sigma * x[s] - cx.q(s, i); }
 #pragma unroll
@@ -392,7 +413,9 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 if (i < m) w[n + i] = z[s] - ri * y[s];
             }
             cpgw::lds_order();
+#ifndef CPG_EXP_SKIP_SOLVE
             run_program_stream(ST, w, lane);
+#endif
 #pragma unroll
             for (int s = 0; s < NSX; s++) {
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;
@@ -419,15 +442,29 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 }
             }
             cpgw::lds_order();
-            if (chk) {
-                cpgw::mem_order();
+        };
+        // The iterations between two termination checks run in their own inner loop: the check (row
+        // products, norms, infeasibility tests) needs many registers, and with its code inside the
+        // hot loop the iterates were spilled and reloaded in every iteration.
 #pragma nounroll
-                for (int pass = 0; pass < 2; pass++) {
-                    if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                    o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, w, B.sdx, B.sdy, lane, pass == 1);
-                }
-                if (o.status == 11 && iter >= S.max_iter) o.status = 7;
+        while (o.status == 11) {
+            if (iter >= S.max_iter) { o.status = 7; break; }
+            int next_chk = S.max_iter;                          // checked iterations: multiples of
+            if (S.check_termination > 0) {                      // check_termination, and max_iter
+                const int c = (iter / S.check_termination + 1) * S.check_termination;
+                if (c < next_chk) next_chk = c;
             }
+#pragma nounroll
+            for (; iter < next_chk - 1; iter++) admm_iteration(false);
+            iter++;
+            admm_iteration(true);
+            cpgw::mem_order();
+#pragma nounroll
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
+                o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, w, B.sdx, B.sdy, lane, pass == 1);
+            }
+            if (o.status == 11 && iter >= S.max_iter) o.status = 7;
         }
         finalize<NSX, NSZ>(F, Bt, x, y, dconst, b, w, lane, iter, o);
     }

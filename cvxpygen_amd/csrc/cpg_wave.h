@@ -49,6 +49,21 @@ CPG_DEV double read_lane(double v, int lane) {   // `lane` must be wave-uniform
     return __hiloint2double(hi, lo);
 }
 CPG_DEV double shfl_down(double v, int delta) { return __shfl_down(v, delta, 64); }
+// Value of lane + 16 (lane + 32) on the lanes of the even 16-lane rows (of the lower half); other
+// lanes receive values that must not be used.  gfx950 row / half swaps: plain VALU, no LDS crossbar
+// and no index register, unlike the ds_bpermute behind __shfl_down.
+CPG_DEV double up16(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+CPG_DEV double up32(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
 CPG_DEV int read_first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 CPG_DEV bool wave_any(bool p) { return __any(p) != 0; }
 // orders GLOBAL stores and loads of one wavefront among its own lanes (per-wavefront buffers:
@@ -145,6 +160,8 @@ inline double shfl_down(double v, int delta) {
     wave_sync();
     return r;
 }
+inline double up16(double v) { return shfl_down(v, 16); }
+inline double up32(double v) { return shfl_down(v, 32); }
 inline int read_first_lane(int v) {
     SimWave *w = tls.wv;
     w->ixch[tls.lane] = v;
@@ -211,8 +228,8 @@ CPG_DEV double group_sum_first(double v) {
     if (LG >= 2) v += row_shl<2>(v);
     if (LG >= 3) v += row_shl<4>(v);
     if (LG >= 4) v += row_shl<8>(v);
-    if (LG >= 5) v += shfl_down(v, 16);
-    if (LG >= 6) v += shfl_down(v, 32);
+    if (LG >= 5) v += up16(v);
+    if (LG >= 6) v += up32(v);
     return v;
 }
 CPG_DEV double group_sum_first_dyn(double v, int lg) {   // lg wave-uniform
