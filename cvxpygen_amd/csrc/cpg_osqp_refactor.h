@@ -186,6 +186,85 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
     }
 }
 
+// Numeric LDL' of the instance's (permuted) KKT matrix through the dot-product schedule: chunk by
+// chunk every lane accumulates sum_k L_ik d_k L_jk for its destination, subtracts it from the KKT
+// entry and stores the pivot (and its reciprocal) or the unscaled column entry; when a level of the
+// elimination tree is complete its columns are divided by their pivots.  `reg` is what the matrix
+// carries on the (1,1) diagonal: sigma for the ADMM system, the adjoint's regularisation otherwise.
+// The three index loads of a step do not depend on the factor, and the steps of a chunk are
+// independent: four steps are requested together (index loads, then values), accumulated in order.
+CPG_DEV void numeric_ldl(const DevRefactor &R, const InstBuf &B, double reg, int lane) {
+    int level_start = 0;
+#pragma nounroll
+    for (int c = 0; c < R.fac_chunks; c++) {
+        const int L = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c));
+        const int last = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 1u));
+        unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 2u));
+        const unsigned task = cpgw::gld(R.fac_task, (unsigned)c * 64u + (unsigned)lane);
+        const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
+        double acc = 0.0;
+#pragma nounroll
+        for (int s = 0; s < L; s += 4) {
+            bool act[4];
+            unsigned ia[4], ib[4], ik[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                act[t] = s + t < len;
+                const unsigned e = act[t] ? base + (unsigned)lane : 0u;
+                base += cpgw::popc64(cpgw::ballot(act[t]));
+                ia[t] = cpgw::gld(R.fac_a, e); ib[t] = cpgw::gld(R.fac_b, e); ik[t] = cpgw::gld(R.fac_k, e);
+            }
+            double la[4], lb[4], dk[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                la[t] = cpgw::gld((const double *)B.Lx, ia[t]);
+                lb[t] = cpgw::gld((const double *)B.Lx, ib[t]);
+                dk[t] = cpgw::gld((const double *)B.Dg, ik[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (act[t]) acc = fma(la[t] * dk[t], lb[t], acc);
+        }
+        if (task != 0xFFFFFFFFu) {
+            const int kind = cpgw::gld(R.ksrc_kind, task);
+            const unsigned idx = (unsigned)cpgw::gld(R.ksrc_idx, task);
+            const bool piv = task >= (unsigned)R.nnzL;
+            double kv = 0.0;
+            if (kind == CPG_K_P) kv = cpgw::gld((const double *)B.P, idx) + (piv ? reg : 0.0);
+            else if (kind == CPG_K_A) kv = cpgw::gld((const double *)B.A, idx);
+            else if (kind == CPG_K_SIGMA) kv = reg;
+            else if (kind == CPG_K_RHO) kv = -cpgw::gld((const double *)B.rinv, idx);
+            const double v = kv - acc;
+            if (piv) { cpgw::gst(B.Dg, task - (unsigned)R.nnzL, v); cpgw::gst(B.Dginv, task - (unsigned)R.nnzL, 1.0 / v); }
+            else cpgw::gst(B.Lx, task, v);
+        }
+        if (last) {   // level complete: divide the new columns by their pivots
+            cpgw::mem_order();
+#pragma nounroll
+            for (int c2 = level_start; c2 <= c; c2++) {
+                const unsigned t2 = cpgw::gld(R.fac_task, (unsigned)c2 * 64u + (unsigned)lane);
+                if (t2 < (unsigned)R.nnzL)
+                    cpgw::gst(B.Lx, t2, cpgw::gld((const double *)B.Lx, t2) * cpgw::gld((const double *)B.Dginv, (unsigned)cpgw::gld(R.Lcol, t2)));
+            }
+            cpgw::mem_order();
+            level_start = c + 1;
+        }
+    }
+}
+// Coefficients of the substitution program from the factor (1, -L_ij or 1 / d_j per entry).
+CPG_DEV void substitution_values(const DevRefactor &R, const InstBuf &B, int lane) {
+    for (unsigned e = (unsigned)lane; e < (unsigned)R.sol_nnz; e += 64u) {
+        const int kind = cpgw::gld(R.sol_kind, e);
+        const unsigned idx = (unsigned)cpgw::gld(R.sol_idx, e);
+        double v = 0.0;
+        if (kind == 1) v = 1.0;
+        else if (kind == 2) v = -cpgw::gld((const double *)B.Lx, idx);
+        else if (kind == 3) v = cpgw::gld((const double *)B.Dginv, idx);
+        cpgw::gst(B.sv, e, v);
+    }
+    cpgw::mem_order();
+}
+
 template <int NSX, int NSZ>
 CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const DevSettings &S,
                                 const DevBatch &Bt, double *lds, int wave_global) {
@@ -305,89 +384,16 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         cpgw::lds_order();
         cpgw::mem_order();
 
-        // ---- 4. numeric LDL' through the dot-product schedule (levels of the elimination tree)
-        {
-            int level_start = 0;
-#pragma nounroll
-            for (int c = 0; c < R.fac_chunks; c++) {
-                const int L = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c));
-                const int last = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 1u));
-                unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 2u));
-                const unsigned task = cpgw::gld(R.fac_task, (unsigned)c * 64u + (unsigned)lane);
-                const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
-                double acc = 0.0;
-#pragma nounroll
-                for (int s = 0; s < L; s += 4) {   // four steps of index and value loads in flight
-                    bool act[4];
-                    unsigned ia[4], ib[4], ik[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        act[t] = s + t < len;
-                        const unsigned e = act[t] ? base + (unsigned)lane : 0u;
-                        base += cpgw::popc64(cpgw::ballot(act[t]));
-                        ia[t] = cpgw::gld(R.fac_a, e); ib[t] = cpgw::gld(R.fac_b, e); ik[t] = cpgw::gld(R.fac_k, e);
-                    }
-                    double la[4], lb[4], dk[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        la[t] = cpgw::gld((const double *)B.Lx, ia[t]);
-                        lb[t] = cpgw::gld((const double *)B.Lx, ib[t]);
-                        dk[t] = cpgw::gld((const double *)B.Dg, ik[t]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        if (act[t]) acc = fma(la[t] * dk[t], lb[t], acc);
-                }
-                if (task != 0xFFFFFFFFu) {
-                    const int kind = cpgw::gld(R.ksrc_kind, task);
-                    const unsigned idx = (unsigned)cpgw::gld(R.ksrc_idx, task);
-                    const bool piv = task >= (unsigned)R.nnzL;
-                    double kv = 0.0;
-                    if (kind == CPG_K_P) kv = cpgw::gld((const double *)B.P, idx) + (piv ? F0.sigma : 0.0);
-                    else if (kind == CPG_K_A) kv = cpgw::gld((const double *)B.A, idx);
-                    else if (kind == CPG_K_SIGMA) kv = F0.sigma;
-                    else if (kind == CPG_K_RHO) kv = -cpgw::gld((const double *)B.rinv, idx);
-                    const double v = kv - acc;
-                    if (piv) { cpgw::gst(B.Dg, task - (unsigned)R.nnzL, v); cpgw::gst(B.Dginv, task - (unsigned)R.nnzL, 1.0 / v); }
-                    else cpgw::gst(B.Lx, task, v);
-                }
-                if (last) {   // level complete: divide the new columns by their pivots
-                    cpgw::mem_order();
-#pragma nounroll
-                    for (int c2 = level_start; c2 <= c; c2++) {
-                        const unsigned t2 = cpgw::gld(R.fac_task, (unsigned)c2 * 64u + (unsigned)lane);
-                        if (t2 < (unsigned)R.nnzL)
-                            cpgw::gst(B.Lx, t2, cpgw::gld((const double *)B.Lx, t2) * cpgw::gld((const double *)B.Dginv, (unsigned)cpgw::gld(R.Lcol, t2)));
-                    }
-                    cpgw::mem_order();
-                    level_start = c + 1;
-                }
-            }
-        }
-        // ---- 5. coefficients of the substitution program
-        for (unsigned e = (unsigned)lane; e < (unsigned)R.sol_nnz; e += 64u) {
-            const int kind = cpgw::gld(R.sol_kind, e);
-            const unsigned idx = (unsigned)cpgw::gld(R.sol_idx, e);
-            double v = 0.0;
-            if (kind == 1) v = 1.0;
-            else if (kind == 2) v = -cpgw::gld((const double *)B.Lx, idx);
-            else if (kind == 3) v = cpgw::gld((const double *)B.Dginv, idx);
-            cpgw::gst(B.sv, e, v);
-        }
-        cpgw::mem_order();
+        // ---- 4. numeric LDL' through the dot-product schedule, 5. coefficients of the substitution program
+        numeric_ldl(R, B, F0.sigma, lane);
+        substitution_values(R, B, lane);
 
         // ---- 6. ADMM from cold start with the instance's own factor
         DevFamily F = F0;
         F.D = B.D; F.Dinv = B.Dinv; F.E = B.E; F.Einv = B.Einv; F.c = cs; F.cinv = 1.0 / cs;
-        LdsProg SP;
-        SP.ctab = R.sol_ctab; SP.desc = R.sol_desc; SP.vals = B.sv; SP.cols = R.sol_cols;
-        SP.n_chunks = R.sol_chunks; SP.dummy = (unsigned)R.sol_nnz - 1u; SP.rows16 = nullptr;
         StreamProg ST;
         ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
-#ifdef CPG_EXP_SHARED_SV
-        ST.vals = carve(Bt.scratch + (size_t)(wave_global % 64) * (size_t)R.buf_doubles, F0, R).sv;
-#endif
-        ST.n_steps = R.sol_steps; ST.dummy = SP.dummy;
+        ST.n_steps = R.sol_steps; ST.dummy = (unsigned)R.sol_nnz - 1u;
         double qr[NSX], ur[NSZ];
 #pragma unroll
         for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qr[s] = i < n ? cpgw::gld((const double *)B.q, i) : 0.0; }
@@ -413,9 +419,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 if (i < m) w[n + i] = z[s] - ri * y[s];
             }
             cpgw::lds_order();
-#ifndef CPG_EXP_SKIP_SOLVE
             run_program_stream(ST, w, lane);
-#endif
 #pragma unroll
             for (int s = 0; s < NSX; s++) {
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;
@@ -516,9 +520,9 @@ CPG_DEV void osqp_gradient_body(const DevFamily &F, const DevRefactor &R, const 
     double *rr = w + ldw, *xs = rr + N, *ys = xs + n, *dxs = ys + m, *act = dxs + n;
     const InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F, R);
     const double eps = 1e-6;
-    LdsProg SP;
-    SP.ctab = R.sol_ctab; SP.desc = R.sol_desc; SP.vals = B.sv; SP.cols = R.sol_cols;
-    SP.n_chunks = R.sol_chunks; SP.dummy = (unsigned)R.sol_nnz - 1u; SP.rows16 = nullptr;
+    StreamProg ST;
+    ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
+    ST.n_steps = R.sol_steps; ST.dummy = (unsigned)R.sol_nnz - 1u;
 
     for (;;) {
         unsigned ig = 0;
@@ -546,64 +550,8 @@ CPG_DEV void osqp_gradient_body(const DevFamily &F, const DevRefactor &R, const 
         cpgw::lds_order();
         cpgw::mem_order();
         // ---- numeric LDL' of the masked, regularised KKT matrix
-        {
-            int level_start = 0;
-#pragma nounroll
-            for (int c = 0; c < R.fac_chunks; c++) {
-                const int L = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c));
-                const int last = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 1u));
-                unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 2u));
-                const unsigned task = cpgw::gld(R.fac_task, (unsigned)c * 64u + (unsigned)lane);
-                const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
-                double acc = 0.0;
-#pragma nounroll
-                for (int s = 0; s < L; s++) {
-                    const bool on = s < len;
-                    if (on) {
-                        const unsigned e = base + (unsigned)lane;
-                        const double la = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_a, e));
-                        const double lb = cpgw::gld((const double *)B.Lx, cpgw::gld(R.fac_b, e));
-                        const double dk = cpgw::gld((const double *)B.Dg, cpgw::gld(R.fac_k, e));
-                        acc = fma(la * dk, lb, acc);
-                    }
-                    base += cpgw::popc64(cpgw::ballot(on));
-                }
-                if (task != 0xFFFFFFFFu) {
-                    const int kind = cpgw::gld(R.ksrc_kind, task);
-                    const unsigned idx = (unsigned)cpgw::gld(R.ksrc_idx, task);
-                    const bool piv = task >= (unsigned)R.nnzL;
-                    double kv = 0.0;
-                    if (kind == CPG_K_P) kv = cpgw::gld((const double *)B.P, idx) + (piv ? eps : 0.0);
-                    else if (kind == CPG_K_A) kv = cpgw::gld((const double *)B.A, idx);
-                    else if (kind == CPG_K_SIGMA) kv = eps;
-                    else if (kind == CPG_K_RHO) kv = -cpgw::gld((const double *)B.rinv, idx);
-                    const double v = kv - acc;
-                    if (piv) { cpgw::gst(B.Dg, task - (unsigned)R.nnzL, v); cpgw::gst(B.Dginv, task - (unsigned)R.nnzL, 1.0 / v); }
-                    else cpgw::gst(B.Lx, task, v);
-                }
-                if (last) {
-                    cpgw::mem_order();
-#pragma nounroll
-                    for (int c2 = level_start; c2 <= c; c2++) {
-                        const unsigned t2 = cpgw::gld(R.fac_task, (unsigned)c2 * 64u + (unsigned)lane);
-                        if (t2 < (unsigned)R.nnzL)
-                            cpgw::gst(B.Lx, t2, cpgw::gld((const double *)B.Lx, t2) * cpgw::gld((const double *)B.Dginv, (unsigned)cpgw::gld(R.Lcol, t2)));
-                    }
-                    cpgw::mem_order();
-                    level_start = c + 1;
-                }
-            }
-        }
-        for (unsigned e = (unsigned)lane; e < (unsigned)R.sol_nnz; e += 64u) {
-            const int kind = cpgw::gld(R.sol_kind, e);
-            const unsigned idx = (unsigned)cpgw::gld(R.sol_idx, e);
-            double v = 0.0;
-            if (kind == 1) v = 1.0;
-            else if (kind == 2) v = -cpgw::gld((const double *)B.Lx, idx);
-            else if (kind == 3) v = cpgw::gld((const double *)B.Dginv, idx);
-            cpgw::gst(B.sv, e, v);
-        }
-        cpgw::mem_order();
+        numeric_ldl(R, B, eps, lane);
+        substitution_values(R, B, lane);
         // ---- r = K^-1 [dx; 0] and three sweeps of refinement against the exact masked KKT matrix
 #pragma nounroll
         for (int sweep = 0; sweep < 4; sweep++) {
@@ -633,7 +581,7 @@ CPG_DEV void osqp_gradient_body(const DevFamily &F, const DevRefactor &R, const 
                 }
             }
             cpgw::lds_order();
-            run_program_lds<1>(SP, w, ldw, lane);
+            run_program_stream(ST, w, lane);
             for (unsigned i = (unsigned)lane; i < N; i += 64u) {
                 const double v = w[(unsigned)cpgw::gld(R.sol_fpos, i)];
                 rr[i] = sweep == 0 ? v : rr[i] + v;
