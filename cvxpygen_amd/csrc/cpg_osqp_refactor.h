@@ -69,6 +69,29 @@ CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
     return o;
 }
 
+// Walks row r of a sparse pattern (ptr / optional entry numbers / columns) over the instance's values
+// and calls f(value, column) for every entry in storage order.  An entry costs a chain of dependent
+// loads (entry number -> value), so four entries are requested together before f consumes them.
+template <bool ENT, class Fn>
+CPG_DEV void for_row_entries(const int *ptr, const int *ent, const int *col, const double *val, unsigned r, Fn f) {
+    const unsigned a = (unsigned)cpgw::gld(ptr, r), e = (unsigned)cpgw::gld(ptr, r + 1u);
+    for (unsigned k = a; k < e; k += 4u) {
+        unsigned en[4], co[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const unsigned kk = k + (unsigned)t < e ? k + (unsigned)t : a;
+            en[t] = ENT ? (unsigned)cpgw::gld(ent, kk) : kk;
+            co[t] = (unsigned)cpgw::gld(col, kk);
+        }
+        double av[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) av[t] = cpgw::gld(val, en[t]);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (k + (unsigned)t < e) f(av[t], co[t]);
+    }
+}
+
 // row products with the instance's own scaled matrices (values gathered from the buffer)
 template <int NSX, int NSZ>
 struct InstCtx {
@@ -83,27 +106,11 @@ struct InstCtx {
     const double (&ur)[NSZ];
     CPG_DEV double q(int s, unsigned) const { return qr[s]; }
     CPG_DEV double u(int s, unsigned) const { return ur[s]; }
-    // Row products: every entry needs three loads in a chain (entry number / column -> value), so
-    // four entries are requested together and accumulated in order (same sums as a plain loop).
     template <bool ENT, bool OFFS>
     CPG_DEV double row_dot(const int *ptr, const int *ent, const int *col, const double *val, unsigned r) const {
-        const unsigned a = (unsigned)cpgw::gld(ptr, r), e = (unsigned)cpgw::gld(ptr, r + 1u);
         double acc = 0.0;
-        for (unsigned k = a; k < e; k += 4u) {
-            unsigned en[4], co[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const unsigned kk = k + (unsigned)t < e ? k + (unsigned)t : a;
-                en[t] = ENT ? (unsigned)cpgw::gld(ent, kk) : kk;
-                co[t] = (unsigned)cpgw::gld(col, kk);
-            }
-            double av[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) av[t] = cpgw::gld(val, en[t]);
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                if (k + (unsigned)t < e) acc = fma(av[t], w[(OFFS ? (unsigned)F.n : 0u) + co[t]], acc);
-        }
+        const double *wv = w + (OFFS ? (unsigned)F.n : 0u);
+        for_row_entries<ENT>(ptr, ent, col, val, r, [&](double v, unsigned c) { acc = fma(v, wv[c], acc); });
         return acc;
     }
     CPG_DEV double ax(int s) const {
@@ -310,12 +317,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 double acc = 0.0;
                 if (j < n) {
                     const double dj = w[j];
-                    unsigned a = (unsigned)cpgw::gld(R.Prp, j), e = (unsigned)cpgw::gld(R.Prp, j + 1u);
-                    for (unsigned k = a; k < e; k++)
-                        acc = cpgw::dmax2(acc, fabs(cs * dj * cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)) * w[(unsigned)cpgw::gld(R.Pcol, k)]));
-                    a = (unsigned)cpgw::gld(R.Ap, j); e = (unsigned)cpgw::gld(R.Ap, j + 1u);
-                    for (unsigned k = a; k < e; k++)
-                        acc = cpgw::dmax2(acc, fabs(w[n + (unsigned)cpgw::gld(R.Ai, k)] * cpgw::gld((const double *)B.A, k) * dj));
+                    for_row_entries<true>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j,
+                                          [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(cs * dj * v * w[c])); });
+                    for_row_entries<false>(R.Ap, nullptr, R.Ai, (const double *)B.A, j,
+                                           [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(w[n + c] * v * dj)); });
                 }
                 dn[s] = acc;
             }
@@ -325,9 +330,8 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 double acc = 0.0;
                 if (i < m) {
                     const double ei = w[n + i];
-                    const unsigned a = (unsigned)cpgw::gld(R.Arp, i), e = (unsigned)cpgw::gld(R.Arp, i + 1u);
-                    for (unsigned k = a; k < e; k++)
-                        acc = cpgw::dmax2(acc, fabs(ei * cpgw::gld((const double *)B.A, (unsigned)cpgw::gld(R.Aent, k)) * w[(unsigned)cpgw::gld(R.Acol, k)]));
+                    for_row_entries<true>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i,
+                                          [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(ei * v * w[c])); });
                 }
                 en[s] = acc;
             }
@@ -345,9 +349,8 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 if (j < n) {
                     const double dj = w[j];
                     double acc = 0.0;
-                    const unsigned a = (unsigned)cpgw::gld(R.Prp, j), e = (unsigned)cpgw::gld(R.Prp, j + 1u);
-                    for (unsigned k = a; k < e; k++)
-                        acc = cpgw::dmax2(acc, fabs(cs * dj * cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)) * w[(unsigned)cpgw::gld(R.Pcol, k)]));
+                    for_row_entries<true>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j,
+                                          [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(cs * dj * v * w[c])); });
                     psum += acc;
                     qn = cpgw::dmax2(qn, fabs(cs * dj * cpgw::gld(R.q_setup, j)));   // update_mat runs before update_vec
                 }
@@ -562,20 +565,14 @@ CPG_DEV void osqp_gradient_body(const DevFamily &F, const DevRefactor &R, const 
                 // delta = rhs - K_true r, inactive rows / columns skipped (template :460-476)
                 for (unsigned j = (unsigned)lane; j < n; j += 64u) {
                     double d = dxs[j];
-                    unsigned a0 = (unsigned)cpgw::gld(R.Prp, j), e0 = (unsigned)cpgw::gld(R.Prp, j + 1u);
-                    for (unsigned k = a0; k < e0; k++)
-                        d -= cpgw::gld((const double *)B.P, (unsigned)cpgw::gld(R.Pent, k)) * rr[(unsigned)cpgw::gld(R.Pcol, k)];
-                    a0 = (unsigned)cpgw::gld(R.Ap, j); e0 = (unsigned)cpgw::gld(R.Ap, j + 1u);
-                    for (unsigned k = a0; k < e0; k++)
-                        d -= cpgw::gld((const double *)B.A, k) * rr[n + (unsigned)cpgw::gld(R.Ai, k)];
+                    for_row_entries<true>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j, [&](double v, unsigned c) { d -= v * rr[c]; });
+                    for_row_entries<false>(R.Ap, nullptr, R.Ai, (const double *)B.A, j, [&](double v, unsigned c) { d -= v * rr[n + c]; });
                     w[j] = d;
                 }
                 for (unsigned i = (unsigned)lane; i < m; i += 64u) {
                     double d = 0.0;
                     if (act[i] != 0.0) {
-                        const unsigned a0 = (unsigned)cpgw::gld(R.Arp, i), e0 = (unsigned)cpgw::gld(R.Arp, i + 1u);
-                        for (unsigned k = a0; k < e0; k++)
-                            d -= cpgw::gld((const double *)B.A, (unsigned)cpgw::gld(R.Aent, k)) * rr[(unsigned)cpgw::gld(R.Acol, k)];
+                        for_row_entries<true>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i, [&](double v, unsigned c) { d -= v * rr[c]; });
                     }
                     w[n + i] = d;
                 }

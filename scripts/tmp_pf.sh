@@ -1,0 +1,6 @@
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+timeout 300 python bench.py --adjoint --batch 20000 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('adjoint', round(d['value']), d['ms_per_step'], d.get('adjoint'))"
+timeout 300 python bench.py --workload portfolio --batch 20000 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('portfolio', round(d['value']), d['ms_per_step'])"
+timeout 300 python bench.py --workload portfolio --batch 20000 --steps 2 --warmup 1 --no-cpu-baseline --max-iter 25 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('portfolio mi25', round(d['value']), d['ms_per_step'])"
+timeout 300 python bench.py --all-params --batch 20000 --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mpc12 all', round(d['value']), d['ms_per_step'])"
+timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | tail -2
