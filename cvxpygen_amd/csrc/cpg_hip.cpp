@@ -816,23 +816,29 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     {   // flattened step table and entry table of the streaming substitution executor
         // (run_program_stream, cpg_osqp_refactor.h documents the encoding)
         constexpr int D = CPG_STREAM_DEPTH;
-        if (r->sol_nnz > 0xFFFFF) { set_error("refactor substitution program: more than 2^20 entries"); return CPG_E_BADARG; }
-        for (int e = 0; e < r->sol_nnz; e++) cr[e] = (unsigned)r->sol_cols[e] | (0xFFFFu << 16);
+        if (r->sol_nnz > 0x7FFFF || r->sol_slots >= 0x1FFF) { set_error("refactor substitution program: too large for the packed step / entry tables"); return CPG_E_BADARG; }
+        for (int e = 0; e < r->sol_nnz; e++) cr[e] = (unsigned)r->sol_cols[e] | (0x1FFFu << 16);
         for (int c = 0; c < r->sol_chunks; c++) {
-            const int L = r->sol_ctab[4 * c], lg = r->sol_ctab[4 * c + 1];
+            const int L = r->sol_ctab[4 * c], stages = r->sol_ctab[4 * c + 1], kind = r->sol_ctab[4 * c + 3];
             unsigned base = (unsigned)r->sol_ctab[4 * c + 2];
-            if (r->sol_ctab[4 * c + 3] != 0 || L < 1 || lg > 6) { set_error("refactor substitution program: unsupported chunk kind"); return CPG_E_BADARG; }
+            if (kind < 0 || kind > 1 || L < 1 || stages > 6) { set_error("refactor substitution program: unsupported chunk kind"); return CPG_E_BADARG; }
             for (int s = 0; s < L; s++) {
                 unsigned cnt = 0;
                 for (int l = 0; l < 64; l++) {
                     const unsigned d = r->sol_desc[(size_t)c * 64 + l];
-                    const bool act = (int)(d >> 16) > s;
+                    const int len = kind ? (int)((d >> 16) & 0xFFFu) : (int)(d >> 16);
+                    const unsigned row = d & 0xFFFFu, mask = kind ? d >> 28 : 0u;
+                    const bool act = len > s;
                     if (act && (unsigned)l != cnt) { set_error("refactor substitution program: active lanes are not a prefix"); return CPG_E_BADARG; }
-                    if (!act && s == 0 && (d & 0xFFFFu) != 0xFFFFu) { set_error("refactor substitution program: empty output row"); return CPG_E_BADARG; }
-                    if (act && s == 0) cr[base + l] = (cr[base + l] & 0xFFFFu) | ((d & 0xFFFFu) << 16);
+                    if (!act && s == 0 && (row != 0xFFFFu || mask)) { set_error("refactor substitution program: empty output row"); return CPG_E_BADARG; }
+                    if (act && s == 0) {
+                        if (mask > 7u || (row != 0xFFFFu && row >= 0x1FFFu)) { set_error("refactor substitution program: row / mask out of range"); return CPG_E_BADARG; }
+                        cr[base + l] = (cr[base + l] & 0xFFFFu) | ((row == 0xFFFFu ? 0x1FFFu : row) << 16) | (mask << 29);
+                    }
                     cnt += act;
                 }
-                st.push_back(base | (cnt << 20) | ((unsigned)lg << 27) | (s == 0 ? 0x40000000u : 0u) | (s == L - 1 ? 0x80000000u : 0u));
+                st.push_back(base | (cnt << 19) | ((unsigned)stages << 26) | ((unsigned)kind << 29) |
+                             (s == 0 ? 0x40000000u : 0u) | (s == L - 1 ? 0x80000000u : 0u));
                 base += cnt;
             }
         }

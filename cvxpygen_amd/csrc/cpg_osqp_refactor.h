@@ -135,10 +135,11 @@ struct InstCtx {
 // instead of one chunk's worth.  The per-lane operands arrive through the in-order queue of vector
 // loads, with no load under a branch, so that every wait is for the oldest request only:
 //   stab[g]  one word per step, through the scalar cache one block of D steps ahead: entry base |
-//            active lanes << 20 | log2(reduction width) << 27 | first step of a chunk << 30 |
-//            last step << 31
-//   cr[e]    per entry: byte offset of the operand in the work vector | output row << 16 (the row
-//            is picked up at the first step of a chunk, where every lane that writes is active)
+//            active lanes << 19 | reduction stages << 26 | segmented (balanced) chunk << 29 |
+//            first step of a chunk << 30 | last step << 31
+//   cr[e]    per entry: byte offset of the operand in the work vector | output row << 16 | segment
+//            mask << 29 (row and mask are picked up at the first step of a chunk, where every lane
+//            that writes or belongs to a multi-lane row is active; no row = 0x1FFF)
 //   vals[e]  per instance
 // The step table ends with 2 D empty steps (no active lane) and the step count is a multiple of D.  Same
 // accumulation order as run_program_lds<1>; idle lanes read the trailing zero entry.
@@ -161,8 +162,8 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
     double v[D];
     unsigned cr[D], fl[D], sn[D];
 #pragma unroll
-    for (int u = 0; u < D; u++) { v[u] = 0.0; cr[u] = 0xFFFF0000u; fl[u] = 0u; sn[u] = cpgw::sld(P.stab, (unsigned)u); }
-    unsigned row = CPG_NO_ROW;
+    for (int u = 0; u < D; u++) { v[u] = 0.0; cr[u] = 0x1FFF0000u; fl[u] = 0u; sn[u] = cpgw::sld(P.stab, (unsigned)u); }
+    unsigned row = 0x1FFFu;                                     // output row | segment mask << 13
     double acc = 0.0;
     double wv = *(const double *)wb;                            // operand of the step about to be consumed
 #pragma nounroll
@@ -176,16 +177,18 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
             acc = fma(v[u], wv, acc);
             if (f & 0x40000000u) row = cr[u] >> 16;
             if (f & 0x80000000u) {                              // last step of a chunk (uniform)
-                const double r = cpgw::group_sum_first_dyn(acc, (int)((f >> 27) & 7u));
+                const int stages = (int)((f >> 26) & 7u);
+                const double r = (f & 0x20000000u) ? cpgw::seg_sum_first_dyn(acc, row >> 13, stages)
+                                                   : cpgw::group_sum_first_dyn(acc, stages);
                 cpgw::lds_order();
-                if (row != CPG_NO_ROW) w[row] = r;
+                if ((row & 0x1FFFu) != 0x1FFFu) w[row & 0x1FFFu] = r;
                 cpgw::lds_order();
                 acc = 0.0;
             }
             wv = *(const double *)(wb + (cr[(u + 1) % D] & 0xFFFFu));   // gather of the next step, after the store
             cpgw::sched_fence();                                // ... and before the requests below, not next to its use
             const unsigned st = sc[u];
-            const unsigned e = (unsigned)lane < ((st >> 20) & 0x7Fu) ? (st & 0xFFFFFu) + (unsigned)lane : P.dummy;
+            const unsigned e = (unsigned)lane < ((st >> 19) & 0x7Fu) ? (st & 0x7FFFFu) + (unsigned)lane : P.dummy;
             v[u] = cpgw::gld(P.vals, e);
             cr[u] = cpgw::gld(P.cr, e);
             fl[u] = st;

@@ -188,7 +188,7 @@ def build_schedules(N: int, perm: np.ndarray, Lp: np.ndarray, Li: np.ndarray, sr
             cs.append(perm[np.concatenate([[r], Li[s:e]]).astype(np.int64)])
             vs.append(np.array([code(SRC_DINV, r)] + [code(SRC_NEG_L, p) for p in range(s, e)]))
         phases.append(_sp.Phase(perm[rr], cs, vs, False, f'B{a}'))
-    sol = _sp.pack_ragged(phases, N)
+    sol = _sp.pack_ragged(phases, N, balanced='auto')
     codes = sol.vals.astype(np.int64)
     sol_kind = (codes >> 32).astype(np.int32)
     sol_idx = (codes & 0xFFFFFFFF).astype(np.int32)

@@ -446,6 +446,7 @@ class RaggedProgram:
 
 DPP_ROW = 16            # cross-lane shifts of the segmented reduction stay inside 16-lane DPP rows
 SEG_KMAX = 8            # lanes per row in a balanced chunk (3 mask bits next to a 13-bit slot)
+AUTO_BALANCED_MARGIN = float(_os.environ.get('CPG_AUTO_BALANCED_MARGIN', 0.9))
 STAGE_COST = float(_os.environ.get('CPG_STAGE_COST', 1.0))       # one stage of the segmented reduction
 
 
@@ -514,10 +515,10 @@ def _balanced_plan(lens: Sequence[int]):
     return best
 
 
-def pack_ragged(phases: List[Phase], N: int, balanced: bool = False) -> RaggedProgram:
+def pack_ragged(phases: List[Phase], N: int, balanced=False) -> RaggedProgram:
     """balanced=False: rows of a chunk are split over a uniform power-of-two number of lanes;
     balanced=True: variable number of adjacent lanes per row + segmented reduction (fewer steps when
-    row lengths are uneven)."""
+    row lengths are uneven); balanced='auto': per phase whichever of the two the cost model prefers."""
     outs, ins, n_slots, final_pos = assign_slots(phases, N)
     if n_slots * 8 > 0xFFFF:
         raise NotImplementedError('work vector too large for 16-bit byte offsets')
@@ -525,7 +526,13 @@ def pack_ragged(phases: List[Phase], N: int, balanced: bool = False) -> RaggedPr
     first = 0
     for pi, (ph, out_slots, col_slots) in enumerate(zip(phases, outs, ins)):
         lens = [len(c) for c in ph.cols]
-        if balanced and max(lens, default=0) < 4096 and n_slots < 0x1FFF:
+        use_balanced = bool(balanced) and max(lens, default=0) < 4096 and n_slots < 0x1FFF
+        if use_balanced and balanced == 'auto':
+            # per phase whichever layout the cost model prefers (few long rows: power-of-two groups
+            # across the wave; many short rows: variable segments inside 16-lane rows)
+            # (the segmented reduction is dearer than its stage count suggests: demand a clear win)
+            use_balanced = _balanced_plan(lens)[0] < AUTO_BALANCED_MARGIN * _chunk_plan(lens)[0]
+        if use_balanced:
             _, chunks = _balanced_plan(lens)
             for ch in chunks:
                 chunk_phase.append(pi)
