@@ -801,7 +801,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     const size_t n = h->F.n, m = h->F.m, N = n + m;
     R.nnzP = r->nnzP; R.nnzA = r->nnzA; R.nnzL = r->nnzL; R.n_eq = h->F.n_eq; R.np_var = r->np_var;
     R.scaling_iters = r->scaling_iters; R.d_base = r->d_base;
-    R.fac_chunks = r->fac_chunks; R.sol_chunks = r->sol_chunks; R.sol_nnz = r->sol_nnz; R.sol_slots = r->sol_slots;
+    R.fac_chunks = r->fac_chunks; R.sol_nnz = r->sol_nnz; R.sol_slots = r->sol_slots;
 #define UP(T, field, count) if ((rc = upload<T>(h, own, (const T *)r->field, (size_t)(count), (const T **)&R.field))) return rc
     UP(int, Ap, n + 1); UP(int, Ai, r->nnzA); UP(int, Arp, m + 1); UP(int, Aent, r->nnzA); UP(int, Acol, r->nnzA);
     UP(int, Pp, n + 1); UP(int, Pi, r->nnzP); UP(int, Prp, n + 1);
@@ -810,14 +810,19 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     UP(int, fac_ctab, (size_t)r->fac_chunks * 4); UP(unsigned, fac_task, (size_t)r->fac_chunks * 64);
     UP(unsigned, fac_len, (size_t)r->fac_chunks * 64);
     UP(unsigned, fac_a, r->fac_triples); UP(unsigned, fac_b, r->fac_triples); UP(unsigned, fac_k, r->fac_triples);
-    UP(int, sol_ctab, (size_t)r->sol_chunks * 4);
-    UP(unsigned, sol_desc, (size_t)r->sol_chunks * 64);
-    std::vector<unsigned> st, cr((size_t)r->sol_nnz);            // alive until the sync below
-    {   // flattened step table and entry table of the streaming substitution executor
-        // (run_program_stream, cpg_osqp_refactor.h documents the encoding)
-        constexpr int D = CPG_STREAM_DEPTH;
-        if (r->sol_nnz > 0x7FFFF || r->sol_slots >= 0x1FFF) { set_error("refactor substitution program: too large for the packed step / entry tables"); return CPG_E_BADARG; }
-        for (int e = 0; e < r->sol_nnz; e++) cr[e] = (unsigned)r->sol_cols[e] | (0x1FFFu << 16);
+    // Substitution program in the layout of the streaming executor (run_program_stream in
+    // cpg_osqp_refactor.h documents the encoding): the (chunk, step) walk is flattened, consecutive
+    // steps are PAIRED -- a lane's two entries sit next to each other, so that one 16-byte load
+    // brings the coefficients and one 8-byte load the operand offsets of two steps -- and the value
+    // sources are permuted accordingly.  Lanes that are active in only one step of a pair get a zero
+    // entry.
+    std::vector<unsigned> st, cr;                                 // alive until the sync below
+    std::vector<int> kind2, idx2;
+    {
+        constexpr int DP = CPG_STREAM_DEPTH / 2;
+        if (r->sol_slots >= 0x1FFF) { set_error("refactor substitution program: work vector too large for the packed entry table"); return CPG_E_BADARG; }
+        struct Step { unsigned base, cnt, flags; int chunk; };
+        std::vector<Step> steps;
         for (int c = 0; c < r->sol_chunks; c++) {
             const int L = r->sol_ctab[4 * c], stages = r->sol_ctab[4 * c + 1], kind = r->sol_ctab[4 * c + 3];
             unsigned base = (unsigned)r->sol_ctab[4 * c + 2];
@@ -831,24 +836,50 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                     const bool act = len > s;
                     if (act && (unsigned)l != cnt) { set_error("refactor substitution program: active lanes are not a prefix"); return CPG_E_BADARG; }
                     if (!act && s == 0 && (row != 0xFFFFu || mask)) { set_error("refactor substitution program: empty output row"); return CPG_E_BADARG; }
-                    if (act && s == 0) {
-                        if (mask > 7u || (row != 0xFFFFu && row >= 0x1FFFu)) { set_error("refactor substitution program: row / mask out of range"); return CPG_E_BADARG; }
-                        cr[base + l] = (cr[base + l] & 0xFFFFu) | ((row == 0xFFFFu ? 0x1FFFu : row) << 16) | (mask << 29);
-                    }
+                    if (act && s == 0 && (mask > 7u || (row != 0xFFFFu && row >= 0x1FFFu))) { set_error("refactor substitution program: row / mask out of range"); return CPG_E_BADARG; }
                     cnt += act;
                 }
-                st.push_back(base | (cnt << 19) | ((unsigned)stages << 26) | ((unsigned)kind << 29) |
-                             (s == 0 ? 0x40000000u : 0u) | (s == L - 1 ? 0x80000000u : 0u));
+                steps.push_back({base, cnt, (unsigned)stages | ((unsigned)kind << 3) | (s == 0 ? 16u : 0u) | (s == L - 1 ? 32u : 0u), c});
                 base += cnt;
             }
         }
-        while (st.size() % D) st.push_back(0u);
-        R.sol_steps = (int)st.size();
-        st.resize(st.size() + 2 * D, 0u);
+        if (steps.size() % 2) steps.push_back({0u, 0u, 0u, 0});
+        unsigned pb = 0;                                          // pair base, in pairs of entries
+        for (size_t p = 0; p < steps.size(); p += 2) {
+            const Step &A = steps[p], &Bs = steps[p + 1];
+            const unsigned cnt = A.cnt > Bs.cnt ? A.cnt : Bs.cnt;
+            st.push_back(pb | (cnt << 19) | (A.flags << 26));
+            st.push_back(Bs.flags);
+            for (unsigned l = 0; l < cnt; l++)
+                for (int t = 0; t < 2; t++) {
+                    const Step &S = t ? Bs : A;
+                    int kd = 0, ix = 0;
+                    unsigned x = 0x1FFFu << 16;
+                    if (l < S.cnt) {
+                        const unsigned eo = S.base + l;
+                        kd = r->sol_kind[eo]; ix = r->sol_idx[eo];
+                        x = (unsigned)r->sol_cols[eo] | (0x1FFFu << 16);
+                        if (S.flags & 16u) {
+                            const unsigned d = r->sol_desc[(size_t)S.chunk * 64 + l];
+                            const unsigned row = d & 0xFFFFu, mask = (S.flags & 8u) ? d >> 28 : 0u;
+                            x = (unsigned)r->sol_cols[eo] | ((row == 0xFFFFu ? 0x1FFFu : row) << 16) | (mask << 29);
+                        }
+                    }
+                    kind2.push_back(kd); idx2.push_back(ix); cr.push_back(x);
+                }
+            pb += cnt;
+        }
+        if (pb >= 0x7FFFFu) { set_error("refactor substitution program: too many entries for the packed step table"); return CPG_E_BADARG; }
+        for (int t = 0; t < 2; t++) { kind2.push_back(0); idx2.push_back(0); cr.push_back(0x1FFFu << 16); }   // the idle pair
+        while ((st.size() / 2) % DP) { st.push_back(0u); st.push_back(0u); }
+        R.sol_pairs = (int)(st.size() / 2);
+        st.resize(st.size() + 4 * DP, 0u);
+        R.sol_nnz = (int)cr.size();
         if ((rc = upload<unsigned>(h, own, st.data(), st.size(), &R.sol_stab))) return rc;
         if ((rc = upload<unsigned>(h, own, cr.data(), cr.size(), &R.sol_cr))) return rc;
+        if ((rc = upload<int>(h, own, kind2.data(), kind2.size(), &R.sol_kind))) return rc;
+        if ((rc = upload<int>(h, own, idx2.data(), idx2.size(), &R.sol_idx))) return rc;
     }
-    UP(unsigned short, sol_cols, r->sol_nnz); UP(int, sol_kind, r->sol_nnz); UP(int, sol_idx, r->sol_nnz);
     UP(unsigned short, sol_fpos, N);
     UP(double, P_base, r->nnzP); UP(double, A_base, r->nnzA); UP(double, q_base, n); UP(double, u_base, m);
     UP(double, q_setup, n);
@@ -858,7 +889,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     if ((rc = upload_csr(h, own, r->map_q, &R.map_q))) return rc;
     if ((rc = upload_csr(h, own, r->map_u, &R.map_u))) return rc;
     if ((rc = upload_csr(h, own, r->map_d, &R.map_d))) return rc;
-    R.buf_doubles = (long long)(r->nnzP + r->nnzA + 4 * n + 5 * m + r->nnzL + 2 * N + r->sol_nnz + 64);   // see carve()
+    R.buf_doubles = (long long)(r->nnzP + r->nnzA + 4 * n + 5 * m + r->nnzL + 2 * N + R.sol_nnz + 64);   // see carve()
     if ((rc = rt_sync(h))) return rc;
     h->refactor_mode = true;
     h->have_update = true;

@@ -28,16 +28,13 @@ struct DevRefactor {
     const int *fac_ctab;
     const unsigned *fac_task, *fac_len, *fac_a, *fac_b, *fac_k;
     int fac_chunks;
-    // substitution program (ragged layout, tables shared, values per instance)
-    const int *sol_ctab;
-    const unsigned *sol_desc;
-    const unsigned short *sol_cols;
+    // substitution program (tables shared, values per instance) in the layout of run_program_stream
     const int *sol_kind, *sol_idx;
     const unsigned short *sol_fpos;
-    int sol_chunks, sol_nnz, sol_slots;
-    const unsigned *sol_stab;     // flattened step table and entry table of run_program_stream
-    const unsigned *sol_cr;       // (built by cpg_hip_set_refactor from ctab / desc / cols)
-    int sol_steps;
+    int sol_nnz, sol_slots;
+    const unsigned *sol_stab;     // pair table and entry table of run_program_stream; sol_nnz, sol_kind and
+    const unsigned *sol_cr;       // sol_idx are in ITS entry layout (cpg_hip_set_refactor builds all of
+    int sol_pairs;                // them from the plan's ctab / desc / cols / kind / idx)
     // canonicalisation of everything (UNSCALED): p = base + map @ theta_var
     const double *P_base, *A_base, *q_base, *u_base;
     const double *q_setup;   // unscaled q of the code-generation-time workspace (cost scaling sees this one)
@@ -129,20 +126,26 @@ struct InstCtx {
 
 // run_program_lds<1> for coefficients that live in HBM (this path: the values of the substitution
 // program are per instance, 8 bytes per entry and iteration, far more than the caches hold across
-// the resident waves).  The walk over (chunk, step) is flattened into one stream of steps and the
-// operands of step g + D (D = CPG_STREAM_DEPTH) are requested when step g is consumed -- they do
-// not depend on the work vector -- so a wave keeps D x 768 bytes in flight across chunk boundaries
-// instead of one chunk's worth.  The per-lane operands arrive through the in-order queue of vector
-// loads, with no load under a branch, so that every wait is for the oldest request only:
-//   stab[g]  one word per step, through the scalar cache one block of D steps ahead: entry base |
-//            active lanes << 19 | reduction stages << 26 | segmented (balanced) chunk << 29 |
-//            first step of a chunk << 30 | last step << 31
-//   cr[e]    per entry: byte offset of the operand in the work vector | output row << 16 | segment
-//            mask << 29 (row and mask are picked up at the first step of a chunk, where every lane
-//            that writes or belongs to a multi-lane row is active; no row = 0x1FFF)
-//   vals[e]  per instance
-// The step table ends with 2 D empty steps (no active lane) and the step count is a multiple of D.  Same
-// accumulation order as run_program_lds<1>; idle lanes read the trailing zero entry.
+// the resident waves).  What bounds this executor is the number of vector memory instructions (each
+// occupies the CU's address unit for ~16 cycles) and how many of them a wave keeps in flight, so:
+//   * the walk over (chunk, step) is flattened into one stream and consecutive steps are PAIRED: a
+//     lane's two entries are adjacent, one 16-byte load brings both coefficients and one 8-byte load
+//     both entry words -- one vector load per step instead of two;
+//   * the operands of pair p + DP (DP = CPG_STREAM_DEPTH / 2) are requested when pair p is consumed
+//     -- they do not depend on the work vector -- so a wave keeps CPG_STREAM_DEPTH steps in flight
+//     across chunk boundaries; no load sits under a branch and all of them are issued from the loop
+//     body in one fixed order, so every wait names exactly the loads issued after its operands;
+//   * the per-step control word comes through the scalar cache (s_load), one block of pairs ahead.
+// Tables (cpg_hip_set_refactor builds them):
+//   stab[2p]   entry-pair base | lanes << 19 | control of the first step << 26;  stab[2p+1] control
+//              of the second step.  Control: reduction stages | segmented (balanced) chunk << 3 |
+//              first step of its chunk << 4 | last step << 5
+//   cr[e]      per entry: byte offset of the operand in the work vector | output row << 16 | segment
+//              mask << 29 (row and mask are picked up at the first step of a chunk, where every lane
+//              that writes or belongs to a multi-lane row is active; no row = 0x1FFF)
+//   vals[e]    per instance, entry e = 2 * (pair base + lane) + step of the pair
+// The pair table ends with 2 DP empty pairs and the pair count is a multiple of DP.  Same accumulation
+// order as run_program_lds<1>; idle lanes read the trailing zero pair.
 #ifndef CPG_STREAM_DEPTH
 #define CPG_STREAM_DEPTH 8
 #endif
@@ -150,48 +153,61 @@ struct StreamProg {
     const unsigned *stab;
     const unsigned *cr;
     const double *vals;
-    int n_steps;                  // multiple of CPG_STREAM_DEPTH
-    unsigned dummy;
+    int n_pairs;                  // multiple of CPG_STREAM_DEPTH / 2
+    unsigned dummy;               // pair index of the trailing zero pair
 };
+struct StreamPairD { double a, b; };
+struct StreamPairU { unsigned a, b; };
+CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double *w) {
+    const int stages = (int)(f & 7u);
+    const double r = (f & 8u) ? cpgw::seg_sum_first_dyn(acc, rowmask >> 13, stages) : cpgw::group_sum_first_dyn(acc, stages);
+    cpgw::lds_order();
+    if ((rowmask & 0x1FFFu) != 0x1FFFu) w[rowmask & 0x1FFFu] = r;
+    cpgw::lds_order();
+    acc = 0.0;
+}
 CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
-    constexpr int D = CPG_STREAM_DEPTH;
+    constexpr int DP = CPG_STREAM_DEPTH / 2;
     const char *wb = (const char *)w;
-    // The ring starts with D empty steps (zero coefficient) and the loop runs D steps past the end of
-    // the stream, so that every vector load of this function is issued from the loop body in one
-    // fixed order: the wait before a step then names exactly the loads issued after its operands.
-    double v[D];
-    unsigned cr[D], fl[D], sn[D];
+    // The ring starts with DP empty pairs (zero coefficients) and the loop runs DP pairs past the end
+    // of the stream: see above (one fixed order of loads).
+    StreamPairD v[DP];
+    StreamPairU cr[DP];
+    unsigned fa[DP], fb[DP], na[DP], nb[DP];
 #pragma unroll
-    for (int u = 0; u < D; u++) { v[u] = 0.0; cr[u] = 0x1FFF0000u; fl[u] = 0u; sn[u] = cpgw::sld(P.stab, (unsigned)u); }
+    for (int u = 0; u < DP; u++) {
+        v[u].a = 0.0; v[u].b = 0.0; cr[u].a = 0x1FFF0000u; cr[u].b = 0x1FFF0000u; fa[u] = 0u; fb[u] = 0u;
+        na[u] = cpgw::sld(P.stab, 2u * (unsigned)u); nb[u] = cpgw::sld(P.stab, 2u * (unsigned)u + 1u);
+    }
     unsigned row = 0x1FFFu;                                     // output row | segment mask << 13
     double acc = 0.0;
     double wv = *(const double *)wb;                            // operand of the step about to be consumed
 #pragma nounroll
-    for (int g0 = 0; g0 < P.n_steps + D; g0 += D) {
-        unsigned sc[D];
+    for (int p0 = 0; p0 < P.n_pairs + DP; p0 += DP) {
+        unsigned ca[DP], cb[DP];
 #pragma unroll
-        for (int u = 0; u < D; u++) { sc[u] = sn[u]; sn[u] = cpgw::sld(P.stab, (unsigned)(g0 + D + u)); }
+        for (int u = 0; u < DP; u++) {
+            ca[u] = na[u]; cb[u] = nb[u];
+            na[u] = cpgw::sld(P.stab, 2u * (unsigned)(p0 + DP + u)); nb[u] = cpgw::sld(P.stab, 2u * (unsigned)(p0 + DP + u) + 1u);
+        }
 #pragma unroll
-        for (int u = 0; u < D; u++) {
-            const unsigned f = fl[u];
-            acc = fma(v[u], wv, acc);
-            if (f & 0x40000000u) row = cr[u] >> 16;
-            if (f & 0x80000000u) {                              // last step of a chunk (uniform)
-                const int stages = (int)((f >> 26) & 7u);
-                const double r = (f & 0x20000000u) ? cpgw::seg_sum_first_dyn(acc, row >> 13, stages)
-                                                   : cpgw::group_sum_first_dyn(acc, stages);
-                cpgw::lds_order();
-                if ((row & 0x1FFFu) != 0x1FFFu) w[row & 0x1FFFu] = r;
-                cpgw::lds_order();
-                acc = 0.0;
-            }
-            wv = *(const double *)(wb + (cr[(u + 1) % D] & 0xFFFFu));   // gather of the next step, after the store
-            cpgw::sched_fence();                                // ... and before the requests below, not next to its use
-            const unsigned st = sc[u];
+        for (int u = 0; u < DP; u++) {
+            const unsigned f0 = fa[u] >> 26, f1 = fb[u];
+            acc = fma(v[u].a, wv, acc);
+            if (f0 & 16u) row = cr[u].a >> 16;
+            if (f0 & 32u) stream_chunk_end(f0, row, acc, w);
+            wv = *(const double *)(wb + (cr[u].b & 0xFFFFu));   // gathers come after the store of a chunk end
+            cpgw::sched_fence();
+            acc = fma(v[u].b, wv, acc);
+            if (f1 & 16u) row = cr[u].b >> 16;
+            if (f1 & 32u) stream_chunk_end(f1, row, acc, w);
+            wv = *(const double *)(wb + (cr[(u + 1) % DP].a & 0xFFFFu));
+            cpgw::sched_fence();                                // ... and before the requests below, not next to their use
+            const unsigned st = ca[u];
             const unsigned e = (unsigned)lane < ((st >> 19) & 0x7Fu) ? (st & 0x7FFFFu) + (unsigned)lane : P.dummy;
-            v[u] = cpgw::gld(P.vals, e);
-            cr[u] = cpgw::gld(P.cr, e);
-            fl[u] = st;
+            v[u] = cpgw::gld((const StreamPairD *)P.vals, e);
+            cr[u] = cpgw::gld((const StreamPairU *)P.cr, e);
+            fa[u] = st; fb[u] = cb[u];
         }
     }
 }
@@ -399,7 +415,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         F.D = B.D; F.Dinv = B.Dinv; F.E = B.E; F.Einv = B.Einv; F.c = cs; F.cinv = 1.0 / cs;
         StreamProg ST;
         ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
-        ST.n_steps = R.sol_steps; ST.dummy = (unsigned)R.sol_nnz - 1u;
+        ST.n_pairs = R.sol_pairs; ST.dummy = (unsigned)R.sol_nnz / 2u - 1u;
         double qr[NSX], ur[NSZ];
 #pragma unroll
         for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qr[s] = i < n ? cpgw::gld((const double *)B.q, i) : 0.0; }
@@ -528,7 +544,7 @@ CPG_DEV void osqp_gradient_body(const DevFamily &F, const DevRefactor &R, const 
     const double eps = 1e-6;
     StreamProg ST;
     ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
-    ST.n_steps = R.sol_steps; ST.dummy = (unsigned)R.sol_nnz - 1u;
+    ST.n_pairs = R.sol_pairs; ST.dummy = (unsigned)R.sol_nnz / 2u - 1u;
 
     for (;;) {
         unsigned ig = 0;
