@@ -273,6 +273,15 @@ def main():
                 binding = rec.get('binding_resource')
         except (OSError, ValueError, KeyError):
             pass
+        rnote = ('compulsory traffic only (theta in, solution out); the iteration state never leaves '
+                 'registers/LDS, so this path is latency / LDS bound, not HBM bound (DESIGN.md section 6)')
+        if solver.desc.solver == 'OSQP' and getattr(solver, '_rplan', None) is not None and (args.all_params or args.workload == 'portfolio'):
+            # per-instance factor: every ADMM iteration streams the substitution coefficients of the
+            # instance (8 bytes per entry of the streaming layout) from its buffer in HBM
+            sv = 8 * int(solver._rplan.stats['sol_stream_entries'])
+            bytes_per_inst = int(bytes_per_inst + stats['mean_iter'] * sv)
+            rnote = (f'compulsory traffic + mean_iter x {sv} B of per-instance substitution coefficients streamed '
+                     'from HBM in every ADMM iteration (DESIGN.md section 4.2); the shared index tables stay in L2')
         achieved = bytes_per_inst * B / (k_ms * 1e-3) / 1e9
         value = world * B * args.steps / elapsed
         out = {
@@ -307,9 +316,7 @@ def main():
                                     'osqp_refactor_kernel' if (args.all_params or args.workload == 'portfolio')
                                     else 'osqp_shared_kernel'), 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_instance': bytes_per_inst,
-                         'note': 'compulsory traffic only (theta in, solution out); the iteration '
-                                 'state never leaves registers/LDS, so this path is latency / LDS '
-                                 'bound, not HBM bound (DESIGN.md section 6)'},
+                         'note': rnote},
         }
         if world == 1 and not args.no_cpu_baseline and not args.all_params:
             if args.workload == 'portfolio':

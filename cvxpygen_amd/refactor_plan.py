@@ -192,7 +192,15 @@ def build_schedules(N: int, perm: np.ndarray, Lp: np.ndarray, Li: np.ndarray, sr
     codes = sol.vals.astype(np.int64)
     sol_kind = (codes >> 32).astype(np.int32)
     sol_idx = (codes & 0xFFFFFFFF).astype(np.int32)
-    stats = dict(nnzL=nnzL, fac_chunks=fac.n_chunks, fac_triples=len(fac_a), fac_steps=int(fac.ctab[:, 0].sum()),
+    # entries of the streaming executor's layout (cpg_hip_set_refactor pairs consecutive steps; a lane
+    # active in one step of a pair gets a zero entry in the other): what one iteration streams
+    cnt = []
+    for c in range(sol.n_chunks):
+        ln = (sol.desc[c] >> 16) & (0xFFF if sol.ctab[c, 3] else 0xFFFF)
+        cnt += [int((ln > s).sum()) for s in range(int(sol.ctab[c, 0]))]
+    cnt = np.asarray(cnt + [0] * (len(cnt) % 2), dtype=np.int64)
+    stream_entries = int(2 * np.maximum(cnt[0::2], cnt[1::2]).sum()) if len(cnt) else 0
+    stats = dict(nnzL=nnzL, fac_chunks=fac.n_chunks, sol_stream_entries=stream_entries, fac_triples=len(fac_a), fac_steps=int(fac.ctab[:, 0].sum()),
                  sol_chunks=sol.n_chunks, sol_steps=int(sol.ctab[:, 0].sum()), sol_nnz=sol.nnz, levels=nlev)
     return (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol, sol_kind, sol_idx, stats)
 
