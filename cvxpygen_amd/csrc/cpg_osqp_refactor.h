@@ -218,7 +218,11 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
 // elimination tree is complete its columns are divided by their pivots.  `reg` is what the matrix
 // carries on the (1,1) diagonal: sigma for the ADMM system, the adjoint's regularisation otherwise.
 // The three index loads of a step do not depend on the factor, and the steps of a chunk are
-// independent: four steps are requested together (index loads, then values), accumulated in order.
+// independent: CPG_LDL_BATCH steps are requested together (values of this batch, then the indices of
+// the next one), accumulated in order.
+#ifndef CPG_LDL_BATCH
+#define CPG_LDL_BATCH 4
+#endif
 CPG_DEV void numeric_ldl(const DevRefactor &R, const InstBuf &B, double reg, int lane) {
     int level_start = 0;
 #pragma nounroll
@@ -229,27 +233,36 @@ CPG_DEV void numeric_ldl(const DevRefactor &R, const InstBuf &B, double reg, int
         const unsigned task = cpgw::gld(R.fac_task, (unsigned)c * 64u + (unsigned)lane);
         const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
         double acc = 0.0;
-#pragma nounroll
-        for (int s = 0; s < L; s += 4) {
-            bool act[4];
-            unsigned ia[4], ib[4], ik[4];
+        // NB steps per batch; the index triples of batch k + 1 are requested before the values of
+        // batch k are consumed, so a batch exposes one memory round trip (its value gathers)
+        constexpr int NB = CPG_LDL_BATCH;
+        unsigned ia[NB], ib[NB], ik[NB];
+        auto load_indices = [&](int s0, unsigned (&xa)[NB], unsigned (&xb)[NB], unsigned (&xk)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                act[t] = s + t < len;
-                const unsigned e = act[t] ? base + (unsigned)lane : 0u;
-                base += cpgw::popc64(cpgw::ballot(act[t]));
-                ia[t] = cpgw::gld(R.fac_a, e); ib[t] = cpgw::gld(R.fac_b, e); ik[t] = cpgw::gld(R.fac_k, e);
+            for (int t = 0; t < NB; t++) {
+                const bool on = s0 + t < len;
+                const unsigned e = on ? base + (unsigned)lane : 0u;
+                base += cpgw::popc64(cpgw::ballot(on));
+                xa[t] = cpgw::gld(R.fac_a, e); xb[t] = cpgw::gld(R.fac_b, e); xk[t] = cpgw::gld(R.fac_k, e);
             }
-            double la[4], lb[4], dk[4];
+        };
+        load_indices(0, ia, ib, ik);
+#pragma nounroll
+        for (int s = 0; s < L; s += NB) {
+            double la[NB], lb[NB], dk[NB];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < NB; t++) {
                 la[t] = cpgw::gld((const double *)B.Lx, ia[t]);
                 lb[t] = cpgw::gld((const double *)B.Lx, ib[t]);
                 dk[t] = cpgw::gld((const double *)B.Dg, ik[t]);
             }
+            unsigned na[NB], nb[NB], nk[NB];
+            if (s + NB < L) load_indices(s + NB, na, nb, nk);   // uniform
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                if (act[t]) acc = fma(la[t] * dk[t], lb[t], acc);
+            for (int t = 0; t < NB; t++)
+                if (s + t < len) acc = fma(la[t] * dk[t], lb[t], acc);
+#pragma unroll
+            for (int t = 0; t < NB; t++) { ia[t] = na[t]; ib[t] = nb[t]; ik[t] = nk[t]; }
         }
         if (task != 0xFFFFFFFFu) {
             const int kind = cpgw::gld(R.ksrc_kind, task);
