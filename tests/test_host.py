@@ -110,6 +110,39 @@ def test_solve_program_equals_substitution(fam, merge):
         assert prog.n_phases * 8 < unmerged.n_phases      # the point of the transformation
 
 
+@pytest.mark.parametrize('fam', ['nnls', 'mpc6', 'portfolio'])
+@pytest.mark.parametrize('layout', [False, True, 'auto'])
+def test_ragged_layouts_equal_substitution(fam, layout):
+    """the ragged packing of the LDS-resident / streamed executors in its three lane layouts
+    (power-of-two groups, segmented rows, per-phase choice) replays to the plain LDL' solve"""
+    d = {'nnls': families.nonneg_ls, 'mpc6': lambda: families.mpc(6, 3, 10),
+         'portfolio': lambda: families.portfolio(20, 4)}[fam]()
+    c = d.default_canon(); l, u = canon_lu(d, c)
+    plan = S.setup(d.P, c['q'], d.A, l, u, ordering='mindeg')
+    N = plan.N
+    phases = SP.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=False)
+    prog = SP.pack_ragged(phases, N, balanced=layout)
+    kinds = set(prog.ctab[:, 3].tolist())
+    assert kinds <= {0, 1} and (layout is not False or kinds == {0})
+    # the streaming executor addresses entries as base + lane: active lanes must form a prefix
+    for ch in range(prog.n_chunks):
+        ln = (prog.desc[ch] >> 16) & (0xFFF if prog.ctab[ch, 3] else 0xFFFF)
+        assert np.all(np.diff(ln.astype(np.int64)) <= 0)
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        b = rng.standard_normal(N)
+        w = np.zeros(prog.n_slots); w[:N] = b
+        SP.execute_ragged(prog, w)
+        ref = S.ldl_solve(plan, b)
+        # (another summation order than the column sweeps of ldl_solve; the portfolio KKT matrix
+        # with rho = 0.1, sigma = 1e-6 is the ill-conditioned one)
+        assert np.abs(w[prog.final_pos] - ref).max() <= 1e-9 * np.abs(ref).max()
+    if layout == 'auto':
+        steps = lambda q: int(q.ctab[:, 0].sum()) + 3 * q.n_chunks
+        assert steps(prog) <= 1.15 * min(steps(SP.pack_ragged(phases, N, balanced=False)),
+                                         steps(SP.pack_ragged(phases, N, balanced=True)))
+
+
 def test_family_plan_device_ordering():
     d = families.mpc(6, 3, 10)
     p = build_family_plan(d)
