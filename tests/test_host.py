@@ -139,8 +139,8 @@ def test_ragged_layouts_equal_substitution(fam, layout):
         assert np.abs(w[prog.final_pos] - ref).max() <= 1e-9 * np.abs(ref).max()
     if layout == 'auto':
         steps = lambda q: int(q.ctab[:, 0].sum()) + 3 * q.n_chunks
-        assert steps(prog) <= 1.15 * min(steps(SP.pack_ragged(phases, N, balanced=False)),
-                                         steps(SP.pack_ragged(phases, N, balanced=True)))
+        # segmented rows are only taken where they clearly win: never worse than the uniform layout
+        assert steps(prog) <= 1.05 * steps(SP.pack_ragged(phases, N, balanced=False))
 
 
 def test_family_plan_device_ordering():
