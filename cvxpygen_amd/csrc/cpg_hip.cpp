@@ -826,20 +826,22 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         for (int c = 0; c < r->sol_chunks; c++) {
             const int L = r->sol_ctab[4 * c], stages = r->sol_ctab[4 * c + 1], kind = r->sol_ctab[4 * c + 3];
             unsigned base = (unsigned)r->sol_ctab[4 * c + 2];
-            if (kind < 0 || kind > 1 || L < 1 || stages > 6) { set_error("refactor substitution program: unsupported chunk kind"); return CPG_E_BADARG; }
+            // kind: bit 0 segmented (balanced) chunk, bit 1 rows accumulate into their slot
+            if (kind < 0 || kind > 3 || L < 1 || stages > 6) { set_error("refactor substitution program: unsupported chunk kind"); return CPG_E_BADARG; }
             for (int s = 0; s < L; s++) {
                 unsigned cnt = 0;
                 for (int l = 0; l < 64; l++) {
                     const unsigned d = r->sol_desc[(size_t)c * 64 + l];
-                    const int len = kind ? (int)((d >> 16) & 0xFFFu) : (int)(d >> 16);
-                    const unsigned row = d & 0xFFFFu, mask = kind ? d >> 28 : 0u;
+                    const int len = (kind & 1) ? (int)((d >> 16) & 0xFFFu) : (int)(d >> 16);
+                    const unsigned row = d & 0xFFFFu, mask = (kind & 1) ? d >> 28 : 0u;
                     const bool act = len > s;
                     if (act && (unsigned)l != cnt) { set_error("refactor substitution program: active lanes are not a prefix"); return CPG_E_BADARG; }
                     if (!act && s == 0 && (row != 0xFFFFu || mask)) { set_error("refactor substitution program: empty output row"); return CPG_E_BADARG; }
                     if (act && s == 0 && (mask > 7u || (row != 0xFFFFu && row >= 0x1FFFu))) { set_error("refactor substitution program: row / mask out of range"); return CPG_E_BADARG; }
                     cnt += act;
                 }
-                steps.push_back({base, cnt, (unsigned)stages | ((unsigned)kind << 3) | (s == 0 ? 16u : 0u) | (s == L - 1 ? 32u : 0u), c});
+                steps.push_back({base, cnt, (unsigned)stages | ((unsigned)(kind & 1) << 3) | (s == 0 ? 16u : 0u) | (s == L - 1 ? 32u : 0u) |
+                                 ((kind & 2) ? 64u : 0u), c});
                 base += cnt;
             }
         }
@@ -848,7 +850,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         for (size_t p = 0; p < steps.size(); p += 2) {
             const Step &A = steps[p], &Bs = steps[p + 1];
             const unsigned cnt = A.cnt > Bs.cnt ? A.cnt : Bs.cnt;
-            st.push_back(pb | (cnt << 19) | (A.flags << 26));
+            st.push_back(pb | (cnt << 18) | (A.flags << 25));
             st.push_back(Bs.flags);
             for (unsigned l = 0; l < cnt; l++)
                 for (int t = 0; t < 2; t++) {
@@ -869,7 +871,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                 }
             pb += cnt;
         }
-        if (pb >= 0x7FFFFu) { set_error("refactor substitution program: too many entries for the packed step table"); return CPG_E_BADARG; }
+        if (pb >= 0x3FFFFu) { set_error("refactor substitution program: too many entries for the packed step table"); return CPG_E_BADARG; }
         for (int t = 0; t < 2; t++) { kind2.push_back(0); idx2.push_back(0); cr.push_back(0x1FFFu << 16); }   // the idle pair
         while ((st.size() / 2) % DP) { st.push_back(0u); st.push_back(0u); }
         R.sol_pairs = (int)(st.size() / 2);

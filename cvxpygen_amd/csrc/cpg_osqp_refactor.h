@@ -137,9 +137,10 @@ struct InstCtx {
 //     body in one fixed order, so every wait names exactly the loads issued after its operands;
 //   * the per-step control word comes through the scalar cache (s_load), one block of pairs ahead.
 // Tables (cpg_hip_set_refactor builds them):
-//   stab[2p]   entry-pair base | lanes << 19 | control of the first step << 26;  stab[2p+1] control
+//   stab[2p]   entry-pair base | lanes << 18 | control of the first step << 25;  stab[2p+1] control
 //              of the second step.  Control: reduction stages | segmented (balanced) chunk << 3 |
-//              first step of its chunk << 4 | last step << 5
+//              first step of its chunk << 4 | last step << 5 | rows accumulate into their slot << 6
+//              (forward sweep: w[r] += -sum L_rk w[k], no unit-diagonal entry to stream)
 //   cr[e]      per entry: byte offset of the operand in the work vector | output row << 16 | segment
 //              mask << 29 (row and mask are picked up at the first step of a chunk, where every lane
 //              that writes or belongs to a multi-lane row is active; no row = 0x1FFF)
@@ -162,7 +163,7 @@ CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double 
     const int stages = (int)(f & 7u);
     const double r = (f & 8u) ? cpgw::seg_sum_first_dyn(acc, rowmask >> 13, stages) : cpgw::group_sum_first_dyn(acc, stages);
     cpgw::lds_order();
-    if ((rowmask & 0x1FFFu) != 0x1FFFu) w[rowmask & 0x1FFFu] = r;
+    if ((rowmask & 0x1FFFu) != 0x1FFFu) w[rowmask & 0x1FFFu] = (f & 64u) ? w[rowmask & 0x1FFFu] + r : r;
     cpgw::lds_order();
     acc = 0.0;
 }
@@ -192,7 +193,7 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
         }
 #pragma unroll
         for (int u = 0; u < DP; u++) {
-            const unsigned f0 = fa[u] >> 26, f1 = fb[u];
+            const unsigned f0 = fa[u] >> 25, f1 = fb[u];
             acc = fma(v[u].a, wv, acc);
             if (f0 & 16u) row = cr[u].a >> 16;
             if (f0 & 32u) stream_chunk_end(f0, row, acc, w);
@@ -204,7 +205,7 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
             wv = *(const double *)(wb + (cr[(u + 1) % DP].a & 0xFFFFu));
             cpgw::sched_fence();                                // ... and before the requests below, not next to their use
             const unsigned st = ca[u];
-            const unsigned e = (unsigned)lane < ((st >> 19) & 0x7Fu) ? (st & 0x7FFFFu) + (unsigned)lane : P.dummy;
+            const unsigned e = (unsigned)lane < ((st >> 18) & 0x7Fu) ? (st & 0x3FFFFu) + (unsigned)lane : P.dummy;
             v[u] = cpgw::gld((const StreamPairD *)P.vals, e);
             cr[u] = cpgw::gld((const StreamPairU *)P.cr, e);
             fa[u] = st; fb[u] = cb[u];

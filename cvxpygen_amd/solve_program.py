@@ -57,6 +57,7 @@ class Phase:
     vals: List[np.ndarray]
     intra: bool = False      # some row reads another row of the same phase -> deferred stores
     name: str = ''
+    accumulate: bool = False  # w[row] += sum instead of w[row] = sum (ragged packing only; in-place rows)
 
     @property
     def nnz(self) -> int:
@@ -568,7 +569,7 @@ def pack_ragged(phases: List[Phase], N: int, balanced=False) -> RaggedProgram:
                     vals.append(np.array([lane_v[t][s] for t in range(cnt)]))
                     cols.append(np.array([8 * lane_c[t][s] for t in range(cnt)], dtype=np.uint16))
                     n_ent += cnt
-                ctab.append([L, S, first, 1])
+                ctab.append([L, S, first, 1 | (2 if ph.accumulate else 0)])
                 desc.append(D)
                 first += n_ent
             continue
@@ -602,7 +603,7 @@ def pack_ragged(phases: List[Phase], N: int, balanced=False) -> RaggedProgram:
                 vals.append(np.array([lane_v[t][s] for t in range(cnt)]))
                 cols.append(np.array([8 * lane_c[t][s] for t in range(cnt)], dtype=np.uint16))
                 n_ent += cnt
-            ctab.append([L, int(np.log2(g)), first, 0])
+            ctab.append([L, int(np.log2(g)), first, 2 if ph.accumulate else 0])
             desc.append(D)
             first += n_ent
     vals.append(np.zeros(1))
@@ -623,7 +624,8 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
         L, lg, first, _ = prog.ctab[c]
         d = prog.desc[c]
         row, ln = d & 0xFFFF, d >> 16
-        if prog.ctab[c, 3] == 1:
+        accumulate = bool(prog.ctab[c, 3] & 2)
+        if prog.ctab[c, 3] & 1:
             ln = ln & 0xFFF            # balanced chunk: segmented shift-add reduction
             acc = np.zeros(LANES)
             base = first
@@ -639,7 +641,7 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
                 sh[okl] = acc[src[okl]]
                 acc = acc + np.where(((d >> 28) >> st) & 1, sh, 0.0)
             ok = row != NO_ROW
-            w[row[ok]] = acc[ok]
+            w[row[ok]] = (w[row[ok]] + acc[ok]) if accumulate else acc[ok]
             continue
         g = 1 << lg
         acc = np.zeros(LANES)
@@ -652,5 +654,5 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
         red = acc.reshape(LANES // g, g).sum(axis=1)
         R = row[::g]
         ok = R != NO_ROW
-        w[R[ok]] = red[ok]
+        w[R[ok]] = (w[R[ok]] + red[ok]) if accumulate else red[ok]
     return w

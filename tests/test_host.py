@@ -126,7 +126,7 @@ def test_ragged_layouts_equal_substitution(fam, layout):
     assert kinds <= {0, 1} and (layout is not False or kinds == {0})
     # the streaming executor addresses entries as base + lane: active lanes must form a prefix
     for ch in range(prog.n_chunks):
-        ln = (prog.desc[ch] >> 16) & (0xFFF if prog.ctab[ch, 3] else 0xFFFF)
+        ln = (prog.desc[ch] >> 16) & (0xFFF if prog.ctab[ch, 3] & 1 else 0xFFFF)
         assert np.all(np.diff(ln.astype(np.int64)) <= 0)
     rng = np.random.default_rng(3)
     for _ in range(2):
