@@ -161,7 +161,8 @@ struct StreamPairD { double a, b; };
 struct StreamPairU { unsigned a, b; };
 CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double *w) {
     const int stages = (int)(f & 7u);
-    const double r = (f & 8u) ? cpgw::seg_sum_first_dyn(acc, rowmask >> 13, stages) : cpgw::group_sum_first_dyn(acc, stages);
+    // segmented chunks: all three stages, branch-free (the mask of an unused stage is zero)
+    const double r = (f & 8u) ? cpgw::seg_sum_first<3>(acc, rowmask >> 13) : cpgw::group_sum_first_dyn(acc, stages);
     cpgw::lds_order();
     if ((rowmask & 0x1FFFu) != 0x1FFFu) w[rowmask & 0x1FFFu] = (f & 64u) ? w[rowmask & 0x1FFFu] + r : r;
     cpgw::lds_order();
