@@ -218,7 +218,7 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
         double r[G];
         if (balanced) {
 #pragma unroll
-            for (int g = 0; g < G; g++) r[g] = cpgw::seg_sum_first_dyn(acc[g], d >> 28, lg);
+            for (int g = 0; g < G; g++) r[g] = cpgw::seg_sum_first<3>(acc[g], d >> 28);   // branch-free: the mask of an unused stage is zero
         } else {
 #pragma unroll
             for (int g = 0; g < G; g++) r[g] = cpgw::group_sum_first_dyn(acc[g], lg);
