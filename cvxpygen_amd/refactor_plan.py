@@ -17,6 +17,8 @@ tables with.
 
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -107,10 +109,14 @@ class RefactorPlan:
 # a level holds many rows.  Measured: +5 % on the portfolio family (1 442 rows in 24 levels), -8 % on
 # MPC 12/4/10 (504 rows in 242 levels).
 IN_PLACE_MIN_ROWS_PER_LEVEL = 8
+# A step of the streaming executor is a memory request (~16 cycles of the CU's address unit plus
+# latency), a reduction stage a handful of VALU instructions: plan with cheaper stages than the
+# LDS-resident executor's defaults (MPC 12/4/10: 1 159 -> 671 steps per iteration).
+STREAM_STAGE_SCALE = float(os.environ.get('CPG_STREAM_STAGE_SCALE', 0.5))
 
 
 def build_schedules(N: int, perm: np.ndarray, Lp: np.ndarray, Li: np.ndarray, src: Dict[tuple, tuple],
-                    forward_in_place: bool = False):
+                    forward_in_place: bool = False, stage_scale: float = 1.0):
     """Everything that only depends on the pattern of the permuted factor: for a symmetric
     quasi-definite matrix whose permuted upper-triangle entries (r <= c) have the value sources
     `src[(r, c)] = (kind, idx)`, returns (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol,
@@ -207,7 +213,7 @@ def build_schedules(N: int, perm: np.ndarray, Lp: np.ndarray, Li: np.ndarray, sr
             cs.append(perm[np.concatenate([[r], Li[s:e]]).astype(np.int64)])
             vs.append(np.array([code(SRC_DINV, r)] + [code(SRC_NEG_L, p) for p in range(s, e)]))
         phases.append(_sp.Phase(perm[rr], cs, vs, False, f'B{a}'))
-    sol = _sp.pack_ragged(phases, N, balanced='auto')
+    sol = _sp.pack_ragged(phases, N, balanced='auto', stage_scale=stage_scale)
     codes = sol.vals.astype(np.int64)
     sol_kind = (codes >> 32).astype(np.int32)
     sol_idx = (codes & 0xFFFFFFFF).astype(np.int32)
@@ -274,7 +280,7 @@ def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPla
     for i in range(m):
         put(n + i, n + i, K_RHO, i)
     (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol, sol_kind, sol_idx, stats) = \
-        build_schedules(N, perm, Lp, Li, src, forward_in_place='auto')
+        build_schedules(N, perm, Lp, Li, src, forward_in_place='auto', stage_scale=STREAM_STAGE_SCALE)
     return RefactorPlan(n=n, m=m, nnzP=nnzP, nnzA=nnzA, nnzL=nnzL, Ap=A.indptr.astype(np.int32),
                         Ai=A.indices.astype(np.int32), Arp=Arp, Aent=Aent, Acol=Acol, Prp=Prp, Pent=Pent,
                         Pcol=Pcol, Pp=P.indptr.astype(np.int32), Pi=P.indices.astype(np.int32),

@@ -46,6 +46,7 @@ LANES = 64
 # tuning knobs for experiments; a family library and the runtime must be built with the same values)
 PHASE_COST = float(_os.environ.get('CPG_PHASE_COST', 14.0))      # fixed cost of a phase
 CHUNK_COST = float(_os.environ.get('CPG_CHUNK_COST', 3.0))       # fixed cost of one more chunk inside a phase
+GROUP_STAGE_COST = float(_os.environ.get('CPG_GROUP_STAGE_COST', 1.5))   # one stage of a power-of-two group reduction
 MAX_GROUP_ROWS = 128
 
 
@@ -102,7 +103,7 @@ def _chunk_plan(lens: Sequence[int]) -> Tuple[float, int, List[Tuple[int, int, L
                 ln = int(-(-lens[sel].max() // gv)) if len(sel) else 0
                 ln = max(ln, 1)
                 chunks.append((int(gv), ln, [int(v) for v in sel]))
-                cost += ln + CHUNK_COST + 1.5 * np.log2(gv)
+                cost += ln + CHUNK_COST + GROUP_STAGE_COST * np.log2(gv)
         if best is None or cost < best[0]:
             best = (cost, len(chunks), chunks)
     return best
@@ -516,10 +517,21 @@ def _balanced_plan(lens: Sequence[int]):
     return best
 
 
-def pack_ragged(phases: List[Phase], N: int, balanced=False) -> RaggedProgram:
+def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0) -> RaggedProgram:
     """balanced=False: rows of a chunk are split over a uniform power-of-two number of lanes;
     balanced=True: variable number of adjacent lanes per row + segmented reduction (fewer steps when
-    row lengths are uneven); balanced='auto': per phase whichever of the two the cost model prefers."""
+    row lengths are uneven); balanced='auto': per phase whichever of the two the cost model prefers.
+    stage_scale scales what the planner charges for a reduction stage relative to a step: the
+    executors whose steps are memory requests (run_program_stream) want fewer, wider steps than the
+    LDS-resident one the defaults were tuned on."""
+    global STAGE_COST, GROUP_STAGE_COST
+    if stage_scale != 1.0:
+        saved = (STAGE_COST, GROUP_STAGE_COST)
+        STAGE_COST, GROUP_STAGE_COST = saved[0] * stage_scale, saved[1] * stage_scale
+        try:
+            return pack_ragged(phases, N, balanced)
+        finally:
+            STAGE_COST, GROUP_STAGE_COST = saved
     outs, ins, n_slots, final_pos = assign_slots(phases, N)
     if n_slots * 8 > 0xFFFF:
         raise NotImplementedError('work vector too large for 16-bit byte offsets')
