@@ -16,6 +16,7 @@ schedule of the numeric factorisation and the ragged substitution program with v
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List
 
@@ -29,6 +30,10 @@ from .refactor_plan import RaggedTable, build_schedules
 
 # KKT value sources (device: cpg_clarabel_kernel.h)
 K_NONE, K_P, K_A, K_DIAGX, K_HDIAG, K_HSOC = 0, 1, 2, 3, 5, 6
+# what the planner of the substitution program charges for a reduction stage, relative to the defaults
+# tuned on the large OSQP programs: small KKT systems (ADP: 36 rows) want wider rows and fewer steps
+# (29 -> 18 steps per solve, +5 % instances/s)
+CONIC_STAGE_SCALE = float(os.environ.get('CPG_CONIC_STAGE_SCALE', 0.5))
 
 
 @dataclass
@@ -123,7 +128,7 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
         a, b = int(pinv[r]), int(pinv[c])
         src[(min(a, b), max(a, b))] = v
     (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol, sol_kind, sol_idx, stats) = \
-        build_schedules(N, perm, Lp, Li, src)
+        build_schedules(N, perm, Lp, Li, src, stage_scale=CONIC_STAGE_SCALE)
     stats = dict(stats)
     stats['etree_height'] = int(_ord.etree_height(etree))
     return ConicPlan(n=n, m=m, nnzP=P.nnz, nnzA=A.nnz, nnzL=len(Li), n_zero=nz, n_nonneg=nn, soc_dims=soc,
