@@ -206,13 +206,15 @@ struct ConicCtx {
             const int L = cpgw::read_first_lane(cpgw::gld(C.fac_ctab, 4u * (unsigned)c));
             const int last = cpgw::read_first_lane(cpgw::gld(C.fac_ctab, 4u * (unsigned)c + 1u));
             unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(C.fac_ctab, 4u * (unsigned)c + 2u));
+            const int lg = cpgw::read_first_lane(cpgw::gld(C.fac_ctab, 4u * (unsigned)c + 3u));
             const unsigned task = cpgw::gld(C.fac_task, (unsigned)c * 64u + (unsigned)lane);
-            const int len = (int)cpgw::gld(C.fac_len, (unsigned)c * 64u + (unsigned)lane);
+            const unsigned lw = cpgw::gld(C.fac_len, (unsigned)c * 64u + (unsigned)lane);
+            const int len = (int)(lw & 0xFFFFu), rlen = (int)(lw >> 16);   // addressing length | real terms of this lane
             double acc = 0.0;
 #pragma nounroll
             for (int s = 0; s < L; s++) {
                 const bool act = s < len;
-                if (act) {
+                if (s < rlen) {
                     const unsigned e = base + (unsigned)lane;
                     const double la = B.Lx[cpgw::gld(C.fac_a, e)];
                     const double lb = B.Lx[cpgw::gld(C.fac_b, e)];
@@ -221,6 +223,7 @@ struct ConicCtx {
                 }
                 base += cpgw::popc64(cpgw::ballot(act));
             }
+            acc = cpgw::group_sum_first_dyn(acc, lg);           // dot products split over 2^lg lanes (refactor_plan._pack_tasks)
             if (task != 0xFFFFFFFFu) {
                 const int kind = cpgw::gld(C.ksrc_kind, task);
                 const unsigned idx = (unsigned)cpgw::gld(C.ksrc_idx, task);

@@ -215,7 +215,8 @@ CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
 }
 
 // Numeric LDL' of the instance's (permuted) KKT matrix through the dot-product schedule: chunk by
-// chunk every lane accumulates sum_k L_ik d_k L_jk for its destination, subtracts it from the KKT
+// chunk every lane (or group of 2^lg lanes, when a level has few destinations) accumulates
+// sum_k L_ik d_k L_jk for its destination, subtracts it from the KKT
 // entry and stores the pivot (and its reciprocal) or the unscaled column entry; when a level of the
 // elimination tree is complete its columns are divided by their pivots.  `reg` is what the matrix
 // carries on the (1,1) diagonal: sigma for the ADMM system, the adjoint's regularisation otherwise.
@@ -232,8 +233,10 @@ CPG_DEV void numeric_ldl(const DevRefactor &R, const InstBuf &B, double reg, int
         const int L = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c));
         const int last = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 1u));
         unsigned base = (unsigned)cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 2u));
+        const int lg = cpgw::read_first_lane(cpgw::gld(R.fac_ctab, 4u * (unsigned)c + 3u));
         const unsigned task = cpgw::gld(R.fac_task, (unsigned)c * 64u + (unsigned)lane);
-        const int len = (int)cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
+        const unsigned lw = cpgw::gld(R.fac_len, (unsigned)c * 64u + (unsigned)lane);
+        const int len = (int)(lw & 0xFFFFu), rlen = (int)(lw >> 16);     // addressing length | real terms of this lane
         double acc = 0.0;
         // NB steps per batch; the index triples of batch k + 1 are requested before the values of
         // batch k are consumed, so a batch exposes one memory round trip (its value gathers)
@@ -262,10 +265,11 @@ CPG_DEV void numeric_ldl(const DevRefactor &R, const InstBuf &B, double reg, int
             if (s + NB < L) load_indices(s + NB, na, nb, nk);   // uniform
 #pragma unroll
             for (int t = 0; t < NB; t++)
-                if (s + t < len) acc = fma(la[t] * dk[t], lb[t], acc);
+                if (s + t < rlen) acc = fma(la[t] * dk[t], lb[t], acc);
 #pragma unroll
             for (int t = 0; t < NB; t++) { ia[t] = na[t]; ib[t] = nb[t]; ik[t] = nk[t]; }
         }
+        acc = cpgw::group_sum_first_dyn(acc, lg);               // dot products split over 2^lg lanes (refactor_plan._pack_tasks)
         if (task != 0xFFFFFFFFu) {
             const int kind = cpgw::gld(R.ksrc_kind, task);
             const unsigned idx = (unsigned)cpgw::gld(R.ksrc_idx, task);

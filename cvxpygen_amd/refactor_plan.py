@@ -50,30 +50,59 @@ class RaggedTable:
 NO_TASK = 0xFFFFFFFF
 
 
-def _pack_tasks(levels: List[List[int]], lens: np.ndarray):
-    """levels: lists of task ids; returns (RaggedTable, entry order: list of (task, step))"""
+def _pack_tasks(levels: List[List[int]], lens: np.ndarray, split: bool = True):
+    """levels: lists of task ids (one dot product of lens[t] terms each).  Returns (RaggedTable, entry
+    order: list of (task, term) or None for a padding entry).
+
+    A chunk holds up to 64 lanes.  When a level has few tasks their dot products are SPLIT over
+    g = 2^lg adjacent lanes (lane j of a task takes terms j, j + g, ...; the chunk's lg is ctab[:, 3],
+    the first lane of the group owns the task and receives the group sum): the schedule's length is
+    set by the longest dot product divided by g instead of the longest dot product.  Entry addressing
+    is `base + lane` over the lanes whose ADDRESSING length (low 16 bits of tlen; the same for all
+    lanes of a task, so that lengths stay non-increasing across the chunk) exceeds the step; the high
+    16 bits of tlen are the lane's REAL number of terms, the rest are padding entries."""
     ctab, task, tlen, order = [], [], [], []
     first = 0
     for li, tasks in enumerate(levels):
         tasks = sorted(tasks, key=lambda t: -int(lens[t]))
-        for s0 in range(0, len(tasks), LANES):
-            sel = tasks[s0:s0 + LANES]
+        s0 = 0
+        while s0 < len(tasks) or (s0 == 0 and not tasks):
+            rest = len(tasks) - s0
+            g = 1
+            if split and 0 < rest <= LANES // 2:
+                longest = int(lens[tasks[s0]])
+                while 2 * g * rest <= LANES and 2 * g <= max(1, longest):
+                    g *= 2
+            sel = tasks[s0:s0 + LANES // g]
             T = np.full(LANES, NO_TASK, dtype=np.uint32)
-            Ln = np.zeros(LANES, dtype=np.uint32)
-            T[:len(sel)] = sel
-            Ln[:len(sel)] = [lens[t] for t in sel]
-            L = int(Ln.max()) if len(sel) else 0
+            AL = np.zeros(LANES, dtype=np.int64)
+            RL = np.zeros(LANES, dtype=np.int64)
+            owner = [None] * LANES
+            for i, t in enumerate(sel):
+                n_t = int(lens[t])
+                T[i * g] = t
+                for j in range(g):
+                    AL[i * g + j] = -(-n_t // g)
+                    RL[i * g + j] = max(0, -(-(n_t - j) // g))
+                    owner[i * g + j] = (t, j)
+            assert np.all(np.diff(AL) <= 0) and AL.max(initial=0) < 0x10000
+            L = int(AL.max()) if len(sel) else 0
             n_ent = 0
             for s in range(L):
-                for t in sel:
-                    if lens[t] > s:
-                        order.append((t, s))
+                for ln in range(LANES):
+                    if AL[ln] > s:
+                        t, j = owner[ln]
+                        term = s * g + j
+                        order.append((t, term) if term < int(lens[t]) else None)
                         n_ent += 1
-            last = 1 if s0 + LANES >= len(tasks) else 0
-            ctab.append([L, last, first, len(sel)])
+            s0 += len(sel)
+            last = 1 if s0 >= len(tasks) else 0
+            ctab.append([L, last, first, int(np.log2(g))])
             task.append(T)
-            tlen.append(Ln)
+            tlen.append((AL | (RL << 16)).astype(np.uint32))
             first += n_ent
+            if not tasks:
+                break
     return (RaggedTable(np.asarray(ctab, dtype=np.int32).reshape(-1, 4),
                         np.asarray(task, dtype=np.uint32).reshape(-1, LANES),
                         np.asarray(tlen, dtype=np.uint32).reshape(-1, LANES)), order)
@@ -175,9 +204,9 @@ def build_schedules(N: int, perm: np.ndarray, Lp: np.ndarray, Li: np.ndarray, sr
     for a in range(nlev):
         levels.append(lv_piv[a] + lv_ent[a])
     fac, order = _pack_tasks(levels, lens)
-    fac_a = np.array([trip_a[t][s] for t, s in order], dtype=np.uint32)
-    fac_b = np.array([trip_b[t][s] for t, s in order], dtype=np.uint32)
-    fac_k = np.array([trip_k[t][s] for t, s in order], dtype=np.uint32)
+    fac_a = np.array([trip_a[o[0]][o[1]] if o else 0 for o in order], dtype=np.uint32)
+    fac_b = np.array([trip_b[o[0]][o[1]] if o else 0 for o in order], dtype=np.uint32)
+    fac_k = np.array([trip_k[o[0]][o[1]] if o else 0 for o in order], dtype=np.uint32)
 
     # ---- substitution program with value sources (codes instead of values)
     def code(kind, idx):

@@ -132,13 +132,15 @@ def test_conic_plan_factor_replay():
         return 0.0
     level_start = 0
     for c in range(cp.fac.n_chunks):
-        L, last, base, _ = cp.fac.ctab[c]
+        L, last, base, lg = cp.fac.ctab[c]
         acc = np.zeros(64)
+        alen, rlen = cp.fac.tlen[c] & 0xFFFF, cp.fac.tlen[c] >> 16      # addressing length | real terms per lane
         for s in range(L):
-            act = np.nonzero(cp.fac.tlen[c] > s)[0]
+            act = np.nonzero(alen > s)[0]
             e = base + np.arange(len(act))
-            acc[act] += Lx[cp.fac_a[e]] * Dg[cp.fac_k[e]] * Lx[cp.fac_b[e]]
+            acc[act] += np.where(rlen[act] > s, Lx[cp.fac_a[e]] * Dg[cp.fac_k[e]] * Lx[cp.fac_b[e]], 0.0)
             base += len(act)
+        acc = np.repeat(acc.reshape(-1, 1 << lg).sum(axis=1), 1 << lg)   # group sums (first lane owns the task)
         for ln in range(64):
             t = int(cp.fac.task[c, ln])
             if t == 0xFFFFFFFF:
