@@ -170,15 +170,16 @@ static int upload_csr(cpg_handle_t h, std::vector<void *> &own, const cpg_csr_t 
 
 // ------------------------------------------------------------------------------------ kernels
 #define CPG_BLOCK_MAX 1024
-// the refactorisation kernel waits on dependent global loads: a third wavefront per SIMD (168 VGPRs,
-// more spills) still pays -- 306 -> 286 ms on the portfolio family, 982 -> 771 ms on MPC 12/4/10 with
-// all parameters per instance; a fourth (128 VGPRs) does not (308 ms)
+// the refactorisation kernel streams its per-instance factor and waits on memory: a third wavefront
+// per SIMD (168 VGPRs) pays on the portfolio family (10 + 13 slots); family libraries with few slots
+// build it with four (128 VGPRs suffice: codegen.build_family_library)
 #ifndef CPG_REFACTOR_WAVES_PER_SIMD
 #define CPG_REFACTOR_WAVES_PER_SIMD 3
 #endif
-// (the adjoint kernel is bound by its LDS scratch: one workgroup per CU either way)
+// (the adjoint kernel needs ~72 VGPRs; its residency is bound by the LDS vectors of a wavefront, the
+// launch picks the workgroup shape that keeps the most wavefronts resident: cpg_hip_gradient_batch)
 #ifndef CPG_GRADIENT_WAVES_PER_SIMD
-#define CPG_GRADIENT_WAVES_PER_SIMD 2
+#define CPG_GRADIENT_WAVES_PER_SIMD 3
 #endif
 #ifndef CPG_MIN_WAVES_PER_SIMD
 #define CPG_MIN_WAVES_PER_SIMD 4   // 16 waves per CU: <= 128 VGPRs
@@ -277,7 +278,7 @@ static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks
 #endif
 #ifndef CPG_HOST_SIM
 template <int NSX, int NSZ>
-__global__ void __launch_bounds__(256, CPG_GRADIENT_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(512, CPG_GRADIENT_WAVES_PER_SIMD)
 osqp_gradient_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevGradient Gd, cpg::DevGradBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -937,12 +938,19 @@ int cpg_hip_gradient_batch(cpg_handle_t h, int64_t B, const double *theta, const
     if ((rc = rt_h2d(h, h->g_x.p, sol_x, b * n * sizeof(double)))) return rc;
     if ((rc = rt_h2d(h, h->g_y.p, sol_y, b * m * sizeof(double)))) return rc;
     if ((rc = rt_h2d(h, h->g_dprim.p, dx, b * n * sizeof(double)))) return rc;
-    const int W = 4;
+    // workgroup shape: the LDS vectors of a wavefront bound the residency; W waves per workgroup and
+    // per_cu workgroups are chosen to keep as many wavefronts resident as LDS and the register budget
+    // (4 x CPG_GRADIENT_WAVES_PER_SIMD per CU) allow -- the kernel waits on dependent loads
     const size_t per_wave = (size_t)h->R.sol_slots + N + n + m + n + m;
+    if (4 * per_wave * sizeof(double) > h->lds_limit) { set_error("adjoint work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
+    int W = 4, per_cu = 1;
+    for (int w = 4; w <= 8; w++) {
+        int pc = (int)(h->lds_limit / ((size_t)w * per_wave * sizeof(double)));
+        if (pc * w > 4 * CPG_GRADIENT_WAVES_PER_SIMD) pc = 4 * CPG_GRADIENT_WAVES_PER_SIMD / w;
+        if (pc >= 1 && pc * w > per_cu * W) { W = w; per_cu = pc; }
+    }
     const size_t lds = (size_t)W * per_wave * sizeof(double);
-    if (lds > h->lds_limit) { set_error("adjoint work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
     long long blocks = (B + W - 1) / W;
-    int per_cu = (int)(h->lds_limit / lds); if (per_cu > CPG_GRADIENT_WAVES_PER_SIMD) per_cu = CPG_GRADIENT_WAVES_PER_SIMD; if (per_cu < 1) per_cu = 1;
     const long long cap = (long long)h->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
     if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
