@@ -285,8 +285,16 @@ class BatchSolver:
         if desc.solver != 'OSQP':
             raise ValueError(f'BatchSolver handles OSQP families, not {desc.solver}')
         self.desc = desc
-        self.lib = CpgLibrary(lib_path)
         self.plan = plan or build_family_plan(desc, ordering=ordering)
+        if lib_path is None and not os.environ.get('CPG_HIP_LIBRARY'):
+            from . import codegen
+            if max(-(-desc.n_var // 64), -(-desc.m // 64)) > codegen.GENERIC_MAX_SLOTS:
+                # the generic library carries slot classes up to 16 x 16 (n_var, m <= 1024): larger
+                # families get the same table-driven kernels compiled for their own class
+                tag = ''.join(ch if ch.isalnum() else '_' for ch in (desc.name or 'family'))
+                out = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'generated', f'{tag}_{desc.n_var}x{desc.m}')
+                lib_path = codegen.build_streamed_family_library(self.plan, out, tag, verbose=True)
+        self.lib = CpgLibrary(lib_path)
         self._keep: list = []
         self._update_key = None
         self._update_keep: list = []

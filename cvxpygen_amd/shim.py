@@ -54,8 +54,8 @@ class GeneratedSolver:
         if lib_path is None:
             # the library generate_code compiled for this family, else the generic table-driven one
             tag = ''.join(ch if ch.isalnum() else '_' for ch in self.desc.name)
-            cand = os.path.join(code_dir, f'libcpg_{tag}.so')
-            lib_path = cand if os.path.exists(cand) else None
+            cands = [os.path.join(code_dir, f'libcpg_{tag}.so'), os.path.join(code_dir, f'libcpg_{tag}_streamed.so')]
+            lib_path = next((c for c in cands if os.path.exists(c)), None)
         self.lib_path = lib_path
         self._bs: Optional[BatchSolver] = None
 

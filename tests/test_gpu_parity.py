@@ -183,6 +183,28 @@ def test_refactor_path_vs_oracle(oracle_lib, make, B):
     bs.close()
 
 
+def test_large_family_beyond_the_generic_slot_classes(oracle_lib):
+    """MPC 12/4 with horizon 30: n_var = 1104, m = 1224 (KKT dimension 2328) -- more than the 16 x 16
+    slot classes (1024) of the generic library, and a solve program (294 KB) that cannot be LDS
+    resident: BatchSolver compiles the table-driven kernels for the family's own class
+    (codegen.build_streamed_family_library); shared-factor and per-instance-factor paths vs oracle"""
+    d = families.mpc(12, 4, 30)
+    rng = np.random.default_rng(5)
+    p = d.param('x_init')
+    bs = BatchSolver(d)
+    assert bs.lib.path.endswith('_streamed.so')
+    B = 12
+    th = np.tile(d.theta0, (B, 1)); th[:, p.col:p.col + p.size] = -2 + 4 * rng.random((B, p.size))
+    r = bs.solve({'x_init': th[:, p.col:p.col + p.size]}, updated_params=['x_init'])
+    _check(r, oracle_lib.cpg_solve_batch(d, th, ['x_init']), d)
+    B = 4
+    th = np.tile(d.theta0, (B, 1)); th[:, :d.NP] *= 1 + 0.05 * rng.standard_normal((B, d.NP))
+    th[:, p.col:p.col + p.size] = -2 + 4 * rng.random((B, p.size))
+    r = bs.solve({q.name: th[:, q.col:q.col + q.size] for q in d.params})
+    _check(r, oracle_lib.cpg_solve_batch(d, th, None), d)
+    bs.close()
+
+
 @pytest.mark.parametrize('make,B,upd', [
     (lambda: families.nonneg_ls(10, 5, sparsity=None, seed=0), 300, None),        # tests/test_diff.py family
     (lambda: families.mpc(6, 3, 10), 24, ['x_init']),                             # BASELINE config 5 shape
