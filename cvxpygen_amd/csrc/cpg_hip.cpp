@@ -168,6 +168,79 @@ static int upload_csr(cpg_handle_t h, std::vector<void *> &own, const cpg_csr_t 
     return CPG_OK;
 }
 
+// A ragged program (solve_program.RaggedProgram: ctab / desc / cols) in the layout of the streaming
+// executor (run_program_stream in cpg_osqp_kernel.h documents the encoding): the (chunk, step) walk
+// is flattened, consecutive steps are PAIRED -- a lane's two entries sit next to each other, so that
+// one 16-byte load brings the coefficients and one 8-byte load the operand offsets of two steps.
+// Lanes that are active in only one step of a pair get a zero entry.  src[e]: entry of the ragged
+// program behind entry e of the new layout (-1: padding).
+struct StreamTables {
+    std::vector<unsigned> st, cr;
+    std::vector<int> src;
+    int n_pairs = 0;
+};
+static int build_stream_tables(const int *ctab, const unsigned *desc, const unsigned short *cols, int n_chunks,
+                               int n_slots, StreamTables &T) {
+    constexpr int DP = CPG_STREAM_DEPTH / 2;
+    if (n_slots >= 0x1FFF) { set_error("substitution program: work vector too large for the packed entry table"); return CPG_E_BADARG; }
+    struct Step { unsigned base, cnt, flags; int chunk; };
+    std::vector<Step> steps;
+    for (int c = 0; c < n_chunks; c++) {
+        const int L = ctab[4 * c], stages = ctab[4 * c + 1], kind = ctab[4 * c + 3];
+        unsigned base = (unsigned)ctab[4 * c + 2];
+        // kind: bit 0 segmented (balanced) chunk, bit 1 rows accumulate into their slot
+        if (kind < 0 || kind > 3 || L < 1 || stages > 6) { set_error("substitution program: unsupported chunk kind"); return CPG_E_BADARG; }
+        for (int s = 0; s < L; s++) {
+            unsigned cnt = 0;
+            for (int l = 0; l < 64; l++) {
+                const unsigned d = desc[(size_t)c * 64 + l];
+                const int len = (kind & 1) ? (int)((d >> 16) & 0xFFFu) : (int)(d >> 16);
+                const unsigned row = d & 0xFFFFu, mask = (kind & 1) ? d >> 28 : 0u;
+                const bool act = len > s;
+                if (act && (unsigned)l != cnt) { set_error("substitution program: active lanes are not a prefix"); return CPG_E_BADARG; }
+                if (!act && s == 0 && (row != 0xFFFFu || mask)) { set_error("substitution program: empty output row"); return CPG_E_BADARG; }
+                if (act && s == 0 && (mask > 7u || (row != 0xFFFFu && row >= 0x1FFFu))) { set_error("substitution program: row / mask out of range"); return CPG_E_BADARG; }
+                cnt += act;
+            }
+            steps.push_back({base, cnt, (unsigned)stages | ((unsigned)(kind & 1) << 3) | (s == 0 ? 16u : 0u) | (s == L - 1 ? 32u : 0u) |
+                             ((kind & 2) ? 64u : 0u), c});
+            base += cnt;
+        }
+    }
+    if (steps.size() % 2) steps.push_back({0u, 0u, 0u, 0});
+    unsigned pb = 0;                                          // pair base, in pairs of entries
+    for (size_t p = 0; p < steps.size(); p += 2) {
+        const Step &A = steps[p], &Bs = steps[p + 1];
+        const unsigned cnt = A.cnt > Bs.cnt ? A.cnt : Bs.cnt;
+        T.st.push_back(pb | (cnt << 18) | (A.flags << 25));
+        T.st.push_back(Bs.flags);
+        for (unsigned l = 0; l < cnt; l++)
+            for (int t = 0; t < 2; t++) {
+                const Step &S = t ? Bs : A;
+                int from = -1;
+                unsigned x = 0x1FFFu << 16;
+                if (l < S.cnt) {
+                    const unsigned eo = S.base + l;
+                    from = (int)eo;
+                    x = (unsigned)cols[eo] | (0x1FFFu << 16);
+                    if (S.flags & 16u) {
+                        const unsigned d = desc[(size_t)S.chunk * 64 + l];
+                        const unsigned row = d & 0xFFFFu, mask = (S.flags & 8u) ? d >> 28 : 0u;
+                        x = (unsigned)cols[eo] | ((row == 0xFFFFu ? 0x1FFFu : row) << 16) | (mask << 29);
+                    }
+                }
+                T.src.push_back(from); T.cr.push_back(x);
+            }
+        pb += cnt;
+    }
+    if (pb >= 0x3FFFFu) { set_error("substitution program: too many entries for the packed step table"); return CPG_E_BADARG; }
+    for (int t = 0; t < 2; t++) { T.src.push_back(-1); T.cr.push_back(0x1FFFu << 16); }   // the idle pair
+    while ((T.st.size() / 2) % DP) { T.st.push_back(0u); T.st.push_back(0u); }
+    T.n_pairs = (int)(T.st.size() / 2);
+    T.st.resize(T.st.size() + 4 * DP, 0u);
+    return CPG_OK;
+}
+
 // ------------------------------------------------------------------------------------ kernels
 #define CPG_BLOCK_MAX 1024
 // the refactorisation kernel streams its per-instance factor and waits on memory: a third wavefront
@@ -601,11 +674,28 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     TRY(upload_program(h, f->P_rows, &F.P_rows));
     TRY(upload_program(h, f->At_rows, &F.At_rows));
     F.kkt_ragged.n_chunks = f->kkt_ragged.n_chunks; F.kkt_ragged.nnz = f->kkt_ragged.nnz;
+    F.kkt_stream = cpg::StreamProg{nullptr, nullptr, nullptr, 0, 0u};
     if (f->kkt_ragged.n_chunks > 0) {
         TRY(upload<int>(h, h->owned, f->kkt_ragged.ctab, (size_t)f->kkt_ragged.n_chunks * 4, &F.kkt_ragged.ctab));
         TRY(upload<unsigned>(h, h->owned, f->kkt_ragged.desc, (size_t)f->kkt_ragged.n_chunks * 64, &F.kkt_ragged.desc));
         TRY(upload<double>(h, h->owned, f->kkt_ragged.vals, (size_t)f->kkt_ragged.nnz, &F.kkt_ragged.vals));
         TRY(upload<unsigned short>(h, h->owned, f->kkt_ragged.cols, (size_t)f->kkt_ragged.nnz, &F.kkt_ragged.cols));
+        // the same program for the streaming executor (used when the program is not LDS resident)
+        if (f->n_slots < 0x1FFF) {
+            StreamTables stt;
+            std::vector<double> v2;
+            int rcs = build_stream_tables(f->kkt_ragged.ctab, f->kkt_ragged.desc, f->kkt_ragged.cols, f->kkt_ragged.n_chunks, f->n_slots, stt);
+            if (rcs == CPG_OK) {
+                v2.resize(stt.src.size());
+                for (size_t e = 0; e < stt.src.size(); e++) v2[e] = stt.src[e] >= 0 ? f->kkt_ragged.vals[stt.src[e]] : 0.0;
+                TRY(upload<unsigned>(h, h->owned, stt.st.data(), stt.st.size(), &F.kkt_stream.stab));
+                TRY(upload<unsigned>(h, h->owned, stt.cr.data(), stt.cr.size(), &F.kkt_stream.cr));
+                TRY(upload<double>(h, h->owned, v2.data(), v2.size(), &F.kkt_stream.vals));
+                TRY(rt_sync(h));
+                F.kkt_stream.n_pairs = stt.n_pairs;
+                F.kkt_stream.dummy = (unsigned)(stt.cr.size() / 2 - 1);
+            }
+        }
     }
 #ifdef CPG_GEN_HEADER
     if (f->kkt_ragged.n_chunks > 0) {   // (handles without a shared program only serve the refactorisation / adjoint kernels)
@@ -811,75 +901,21 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     UP(int, fac_ctab, (size_t)r->fac_chunks * 4); UP(unsigned, fac_task, (size_t)r->fac_chunks * 64);
     UP(unsigned, fac_len, (size_t)r->fac_chunks * 64);
     UP(unsigned, fac_a, r->fac_triples); UP(unsigned, fac_b, r->fac_triples); UP(unsigned, fac_k, r->fac_triples);
-    // Substitution program in the layout of the streaming executor (run_program_stream in
-    // cpg_osqp_refactor.h documents the encoding): the (chunk, step) walk is flattened, consecutive
-    // steps are PAIRED -- a lane's two entries sit next to each other, so that one 16-byte load
-    // brings the coefficients and one 8-byte load the operand offsets of two steps -- and the value
-    // sources are permuted accordingly.  Lanes that are active in only one step of a pair get a zero
-    // entry.
-    std::vector<unsigned> st, cr;                                 // alive until the sync below
+    // Substitution program in the layout of the streaming executor; the value sources are permuted
+    // accordingly (build_stream_tables above).
+    StreamTables stt;                                             // alive until the sync below
     std::vector<int> kind2, idx2;
     {
-        constexpr int DP = CPG_STREAM_DEPTH / 2;
-        if (r->sol_slots >= 0x1FFF) { set_error("refactor substitution program: work vector too large for the packed entry table"); return CPG_E_BADARG; }
-        struct Step { unsigned base, cnt, flags; int chunk; };
-        std::vector<Step> steps;
-        for (int c = 0; c < r->sol_chunks; c++) {
-            const int L = r->sol_ctab[4 * c], stages = r->sol_ctab[4 * c + 1], kind = r->sol_ctab[4 * c + 3];
-            unsigned base = (unsigned)r->sol_ctab[4 * c + 2];
-            // kind: bit 0 segmented (balanced) chunk, bit 1 rows accumulate into their slot
-            if (kind < 0 || kind > 3 || L < 1 || stages > 6) { set_error("refactor substitution program: unsupported chunk kind"); return CPG_E_BADARG; }
-            for (int s = 0; s < L; s++) {
-                unsigned cnt = 0;
-                for (int l = 0; l < 64; l++) {
-                    const unsigned d = r->sol_desc[(size_t)c * 64 + l];
-                    const int len = (kind & 1) ? (int)((d >> 16) & 0xFFFu) : (int)(d >> 16);
-                    const unsigned row = d & 0xFFFFu, mask = (kind & 1) ? d >> 28 : 0u;
-                    const bool act = len > s;
-                    if (act && (unsigned)l != cnt) { set_error("refactor substitution program: active lanes are not a prefix"); return CPG_E_BADARG; }
-                    if (!act && s == 0 && (row != 0xFFFFu || mask)) { set_error("refactor substitution program: empty output row"); return CPG_E_BADARG; }
-                    if (act && s == 0 && (mask > 7u || (row != 0xFFFFu && row >= 0x1FFFu))) { set_error("refactor substitution program: row / mask out of range"); return CPG_E_BADARG; }
-                    cnt += act;
-                }
-                steps.push_back({base, cnt, (unsigned)stages | ((unsigned)(kind & 1) << 3) | (s == 0 ? 16u : 0u) | (s == L - 1 ? 32u : 0u) |
-                                 ((kind & 2) ? 64u : 0u), c});
-                base += cnt;
-            }
+        if ((rc = build_stream_tables(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_slots, stt))) return rc;
+        kind2.resize(stt.src.size()); idx2.resize(stt.src.size());
+        for (size_t e = 0; e < stt.src.size(); e++) {
+            kind2[e] = stt.src[e] >= 0 ? r->sol_kind[stt.src[e]] : 0;
+            idx2[e] = stt.src[e] >= 0 ? r->sol_idx[stt.src[e]] : 0;
         }
-        if (steps.size() % 2) steps.push_back({0u, 0u, 0u, 0});
-        unsigned pb = 0;                                          // pair base, in pairs of entries
-        for (size_t p = 0; p < steps.size(); p += 2) {
-            const Step &A = steps[p], &Bs = steps[p + 1];
-            const unsigned cnt = A.cnt > Bs.cnt ? A.cnt : Bs.cnt;
-            st.push_back(pb | (cnt << 18) | (A.flags << 25));
-            st.push_back(Bs.flags);
-            for (unsigned l = 0; l < cnt; l++)
-                for (int t = 0; t < 2; t++) {
-                    const Step &S = t ? Bs : A;
-                    int kd = 0, ix = 0;
-                    unsigned x = 0x1FFFu << 16;
-                    if (l < S.cnt) {
-                        const unsigned eo = S.base + l;
-                        kd = r->sol_kind[eo]; ix = r->sol_idx[eo];
-                        x = (unsigned)r->sol_cols[eo] | (0x1FFFu << 16);
-                        if (S.flags & 16u) {
-                            const unsigned d = r->sol_desc[(size_t)S.chunk * 64 + l];
-                            const unsigned row = d & 0xFFFFu, mask = (S.flags & 8u) ? d >> 28 : 0u;
-                            x = (unsigned)r->sol_cols[eo] | ((row == 0xFFFFu ? 0x1FFFu : row) << 16) | (mask << 29);
-                        }
-                    }
-                    kind2.push_back(kd); idx2.push_back(ix); cr.push_back(x);
-                }
-            pb += cnt;
-        }
-        if (pb >= 0x3FFFFu) { set_error("refactor substitution program: too many entries for the packed step table"); return CPG_E_BADARG; }
-        for (int t = 0; t < 2; t++) { kind2.push_back(0); idx2.push_back(0); cr.push_back(0x1FFFu << 16); }   // the idle pair
-        while ((st.size() / 2) % DP) { st.push_back(0u); st.push_back(0u); }
-        R.sol_pairs = (int)(st.size() / 2);
-        st.resize(st.size() + 4 * DP, 0u);
-        R.sol_nnz = (int)cr.size();
-        if ((rc = upload<unsigned>(h, own, st.data(), st.size(), &R.sol_stab))) return rc;
-        if ((rc = upload<unsigned>(h, own, cr.data(), cr.size(), &R.sol_cr))) return rc;
+        R.sol_pairs = stt.n_pairs;
+        R.sol_nnz = (int)stt.cr.size();
+        if ((rc = upload<unsigned>(h, own, stt.st.data(), stt.st.size(), &R.sol_stab))) return rc;
+        if ((rc = upload<unsigned>(h, own, stt.cr.data(), stt.cr.size(), &R.sol_cr))) return rc;
         if ((rc = upload<int>(h, own, kind2.data(), kind2.size(), &R.sol_kind))) return rc;
         if ((rc = upload<int>(h, own, idx2.data(), idx2.size(), &R.sol_idx))) return rc;
     }
@@ -1093,7 +1129,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     const size_t prog_bytes = R.n_chunks > 0 ? (nnzp + (nnzp + 3) / 4 + tab_doubles) * 8 : 0;
     bool in_lds = false;
     int W = h->waves_per_block;
-    if (h->program_in_lds != 0 && R.n_chunks > 0) {
+    // table-driven kernels, automatic placement: the streaming executor (program through L2, operands
+    // of eight steps in flight, more resident waves) beats the LDS-resident table walk -- 1.44 M vs
+    // 1.10 M instances/s on MPC 12/4/10; the LDS-resident form remains for G = 2 and on request
+    const bool prefer_stream = h->program_in_lds == -1 && G == 1 && h->F.kkt_stream.n_pairs > 0;
+    if (h->program_in_lds != 0 && R.n_chunks > 0 && !prefer_stream) {
         const size_t fixed = N * 8 + prog_bytes;
         int wfit = fixed < h->lds_limit ? (int)((h->lds_limit - fixed) / per_wave) : 0;
         // every slot class has an LDS kernel for <= 8 waves (<= 4 for G = 2 on the larger classes);

@@ -60,6 +60,16 @@ struct DevCsr {
     const double *val;
     int nnz;
 };
+#ifndef CPG_STREAM_DEPTH
+#define CPG_STREAM_DEPTH 8
+#endif
+struct StreamProg {
+    const unsigned *stab;
+    const unsigned *cr;
+    const double *vals;
+    int n_pairs;                  // multiple of CPG_STREAM_DEPTH / 2
+    unsigned dummy;               // pair index of the trailing zero pair
+};
 struct DevFamily {
     int n, m, n_eq, is_max, n_slots;
     double sigma, alpha, rho;
@@ -69,6 +79,7 @@ struct DevFamily {
     const unsigned short *fpos;   // [n + m] LDS slot holding entry i after the KKT program
     DevProgram kkt, A_rows, P_rows, At_rows;
     DevRagged kkt_ragged;
+    StreamProg kkt_stream;        // the same program in the layout of run_program_stream (n_pairs == 0: none)
     int n_prim, n_dual;
     const int *prim_idx, *dual_idx;
 };
@@ -139,6 +150,86 @@ CPG_DEV void run_program(const DevProgram &P, double *w, int ldw, int lane) {
             for (int g = 0; g < G; g++) w[(unsigned)(g * ldw) + row] = r[g];
         }
         cpgw::lds_order();
+    }
+}
+
+// run_program_lds<1> for coefficients that are not LDS resident: the per-instance substitution values
+// of the refactorisation / adjoint kernels (HBM: 8 bytes per entry and iteration, far more than the
+// caches hold across the resident waves) and shared programs too large for the LDS (L2).  What bounds this executor is the number of vector memory instructions (each
+// occupies the CU's address unit for ~16 cycles) and how many of them a wave keeps in flight, so:
+//   * the walk over (chunk, step) is flattened into one stream and consecutive steps are PAIRED: a
+//     lane's two entries are adjacent, one 16-byte load brings both coefficients and one 8-byte load
+//     both entry words -- one vector load per step instead of two;
+//   * the operands of pair p + DP (DP = CPG_STREAM_DEPTH / 2) are requested when pair p is consumed
+//     -- they do not depend on the work vector -- so a wave keeps CPG_STREAM_DEPTH steps in flight
+//     across chunk boundaries; no load sits under a branch and all of them are issued from the loop
+//     body in one fixed order, so every wait names exactly the loads issued after its operands;
+//   * the per-step control word comes through the scalar cache (s_load), one block of pairs ahead.
+// Tables (cpg_hip_set_refactor builds them):
+//   stab[2p]   entry-pair base | lanes << 18 | control of the first step << 25;  stab[2p+1] control
+//              of the second step.  Control: reduction stages | segmented (balanced) chunk << 3 |
+//              first step of its chunk << 4 | last step << 5 | rows accumulate into their slot << 6
+//              (forward sweep: w[r] += -sum L_rk w[k], no unit-diagonal entry to stream)
+//   cr[e]      per entry: byte offset of the operand in the work vector | output row << 16 | segment
+//              mask << 29 (row and mask are picked up at the first step of a chunk, where every lane
+//              that writes or belongs to a multi-lane row is active; no row = 0x1FFF)
+//   vals[e]    per instance, entry e = 2 * (pair base + lane) + step of the pair
+// The pair table ends with 2 DP empty pairs and the pair count is a multiple of DP.  Same accumulation
+// order as run_program_lds<1>; idle lanes read the trailing zero pair.
+struct StreamPairD { double a, b; };
+struct StreamPairU { unsigned a, b; };
+CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double *w) {
+    const int stages = (int)(f & 7u);
+    // segmented chunks: all three stages, branch-free (the mask of an unused stage is zero)
+    const double r = (f & 8u) ? cpgw::seg_sum_first<3>(acc, rowmask >> 13) : cpgw::group_sum_first_dyn(acc, stages);
+    cpgw::lds_order();
+    if ((rowmask & 0x1FFFu) != 0x1FFFu) w[rowmask & 0x1FFFu] = (f & 64u) ? w[rowmask & 0x1FFFu] + r : r;
+    cpgw::lds_order();
+    acc = 0.0;
+}
+CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
+    constexpr int DP = CPG_STREAM_DEPTH / 2;
+    const char *wb = (const char *)w;
+    // The ring starts with DP empty pairs (zero coefficients) and the loop runs DP pairs past the end
+    // of the stream: see above (one fixed order of loads).
+    StreamPairD v[DP];
+    StreamPairU cr[DP];
+    unsigned fa[DP], fb[DP], na[DP], nb[DP];
+#pragma unroll
+    for (int u = 0; u < DP; u++) {
+        v[u].a = 0.0; v[u].b = 0.0; cr[u].a = 0x1FFF0000u; cr[u].b = 0x1FFF0000u; fa[u] = 0u; fb[u] = 0u;
+        na[u] = cpgw::sld(P.stab, 2u * (unsigned)u); nb[u] = cpgw::sld(P.stab, 2u * (unsigned)u + 1u);
+    }
+    unsigned row = 0x1FFFu;                                     // output row | segment mask << 13
+    double acc = 0.0;
+    double wv = *(const double *)wb;                            // operand of the step about to be consumed
+#pragma nounroll
+    for (int p0 = 0; p0 < P.n_pairs + DP; p0 += DP) {
+        unsigned ca[DP], cb[DP];
+#pragma unroll
+        for (int u = 0; u < DP; u++) {
+            ca[u] = na[u]; cb[u] = nb[u];
+            na[u] = cpgw::sld(P.stab, 2u * (unsigned)(p0 + DP + u)); nb[u] = cpgw::sld(P.stab, 2u * (unsigned)(p0 + DP + u) + 1u);
+        }
+#pragma unroll
+        for (int u = 0; u < DP; u++) {
+            const unsigned f0 = fa[u] >> 25, f1 = fb[u];
+            acc = fma(v[u].a, wv, acc);
+            if (f0 & 16u) row = cr[u].a >> 16;
+            if (f0 & 32u) stream_chunk_end(f0, row, acc, w);
+            wv = *(const double *)(wb + (cr[u].b & 0xFFFFu));   // gathers come after the store of a chunk end
+            cpgw::sched_fence();
+            acc = fma(v[u].b, wv, acc);
+            if (f1 & 16u) row = cr[u].b >> 16;
+            if (f1 & 32u) stream_chunk_end(f1, row, acc, w);
+            wv = *(const double *)(wb + (cr[(u + 1) % DP].a & 0xFFFFu));
+            cpgw::sched_fence();                                // ... and before the requests below, not next to their use
+            const unsigned st = ca[u];
+            const unsigned e = (unsigned)lane < ((st >> 18) & 0x7Fu) ? (st & 0x3FFFFu) + (unsigned)lane : P.dummy;
+            v[u] = cpgw::gld((const StreamPairD *)P.vals, e);
+            cr[u] = cpgw::gld((const StreamPairU *)P.cr, e);
+            fa[u] = st; fb[u] = cb[u];
+        }
     }
 }
 
@@ -707,6 +798,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #else
                 if (LDSPROG) run_program_lds<G>(LP, w, ldw, lane);
 #endif
+                else if (G == 1 && F.kkt_stream.n_pairs > 0) run_program_stream(F.kkt_stream, w, lane);
                 else run_program<G>(F.kkt, w, ldw, lane);
                 // ---- relaxation, projection on [l, u], dual update; the delta_x / delta_y stash of a check
                 // iteration is a separate instantiation so that ordinary iterations carry no branches

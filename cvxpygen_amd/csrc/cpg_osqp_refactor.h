@@ -124,95 +124,8 @@ struct InstCtx {
     }
 };
 
-// run_program_lds<1> for coefficients that live in HBM (this path: the values of the substitution
-// program are per instance, 8 bytes per entry and iteration, far more than the caches hold across
-// the resident waves).  What bounds this executor is the number of vector memory instructions (each
-// occupies the CU's address unit for ~16 cycles) and how many of them a wave keeps in flight, so:
-//   * the walk over (chunk, step) is flattened into one stream and consecutive steps are PAIRED: a
-//     lane's two entries are adjacent, one 16-byte load brings both coefficients and one 8-byte load
-//     both entry words -- one vector load per step instead of two;
-//   * the operands of pair p + DP (DP = CPG_STREAM_DEPTH / 2) are requested when pair p is consumed
-//     -- they do not depend on the work vector -- so a wave keeps CPG_STREAM_DEPTH steps in flight
-//     across chunk boundaries; no load sits under a branch and all of them are issued from the loop
-//     body in one fixed order, so every wait names exactly the loads issued after its operands;
-//   * the per-step control word comes through the scalar cache (s_load), one block of pairs ahead.
-// Tables (cpg_hip_set_refactor builds them):
-//   stab[2p]   entry-pair base | lanes << 18 | control of the first step << 25;  stab[2p+1] control
-//              of the second step.  Control: reduction stages | segmented (balanced) chunk << 3 |
-//              first step of its chunk << 4 | last step << 5 | rows accumulate into their slot << 6
-//              (forward sweep: w[r] += -sum L_rk w[k], no unit-diagonal entry to stream)
-//   cr[e]      per entry: byte offset of the operand in the work vector | output row << 16 | segment
-//              mask << 29 (row and mask are picked up at the first step of a chunk, where every lane
-//              that writes or belongs to a multi-lane row is active; no row = 0x1FFF)
-//   vals[e]    per instance, entry e = 2 * (pair base + lane) + step of the pair
-// The pair table ends with 2 DP empty pairs and the pair count is a multiple of DP.  Same accumulation
-// order as run_program_lds<1>; idle lanes read the trailing zero pair.
-#ifndef CPG_STREAM_DEPTH
-#define CPG_STREAM_DEPTH 8
-#endif
-struct StreamProg {
-    const unsigned *stab;
-    const unsigned *cr;
-    const double *vals;
-    int n_pairs;                  // multiple of CPG_STREAM_DEPTH / 2
-    unsigned dummy;               // pair index of the trailing zero pair
-};
-struct StreamPairD { double a, b; };
-struct StreamPairU { unsigned a, b; };
-CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double *w) {
-    const int stages = (int)(f & 7u);
-    // segmented chunks: all three stages, branch-free (the mask of an unused stage is zero)
-    const double r = (f & 8u) ? cpgw::seg_sum_first<3>(acc, rowmask >> 13) : cpgw::group_sum_first_dyn(acc, stages);
-    cpgw::lds_order();
-    if ((rowmask & 0x1FFFu) != 0x1FFFu) w[rowmask & 0x1FFFu] = (f & 64u) ? w[rowmask & 0x1FFFu] + r : r;
-    cpgw::lds_order();
-    acc = 0.0;
-}
-CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
-    constexpr int DP = CPG_STREAM_DEPTH / 2;
-    const char *wb = (const char *)w;
-    // The ring starts with DP empty pairs (zero coefficients) and the loop runs DP pairs past the end
-    // of the stream: see above (one fixed order of loads).
-    StreamPairD v[DP];
-    StreamPairU cr[DP];
-    unsigned fa[DP], fb[DP], na[DP], nb[DP];
-#pragma unroll
-    for (int u = 0; u < DP; u++) {
-        v[u].a = 0.0; v[u].b = 0.0; cr[u].a = 0x1FFF0000u; cr[u].b = 0x1FFF0000u; fa[u] = 0u; fb[u] = 0u;
-        na[u] = cpgw::sld(P.stab, 2u * (unsigned)u); nb[u] = cpgw::sld(P.stab, 2u * (unsigned)u + 1u);
-    }
-    unsigned row = 0x1FFFu;                                     // output row | segment mask << 13
-    double acc = 0.0;
-    double wv = *(const double *)wb;                            // operand of the step about to be consumed
-#pragma nounroll
-    for (int p0 = 0; p0 < P.n_pairs + DP; p0 += DP) {
-        unsigned ca[DP], cb[DP];
-#pragma unroll
-        for (int u = 0; u < DP; u++) {
-            ca[u] = na[u]; cb[u] = nb[u];
-            na[u] = cpgw::sld(P.stab, 2u * (unsigned)(p0 + DP + u)); nb[u] = cpgw::sld(P.stab, 2u * (unsigned)(p0 + DP + u) + 1u);
-        }
-#pragma unroll
-        for (int u = 0; u < DP; u++) {
-            const unsigned f0 = fa[u] >> 25, f1 = fb[u];
-            acc = fma(v[u].a, wv, acc);
-            if (f0 & 16u) row = cr[u].a >> 16;
-            if (f0 & 32u) stream_chunk_end(f0, row, acc, w);
-            wv = *(const double *)(wb + (cr[u].b & 0xFFFFu));   // gathers come after the store of a chunk end
-            cpgw::sched_fence();
-            acc = fma(v[u].b, wv, acc);
-            if (f1 & 16u) row = cr[u].b >> 16;
-            if (f1 & 32u) stream_chunk_end(f1, row, acc, w);
-            wv = *(const double *)(wb + (cr[(u + 1) % DP].a & 0xFFFFu));
-            cpgw::sched_fence();                                // ... and before the requests below, not next to their use
-            const unsigned st = ca[u];
-            const unsigned e = (unsigned)lane < ((st >> 18) & 0x7Fu) ? (st & 0x3FFFFu) + (unsigned)lane : P.dummy;
-            v[u] = cpgw::gld((const StreamPairD *)P.vals, e);
-            cr[u] = cpgw::gld((const StreamPairU *)P.cr, e);
-            fa[u] = st; fb[u] = cb[u];
-        }
-    }
-}
+// (the streaming substitution executor, run_program_stream, lives in cpg_osqp_kernel.h: the shared-
+// factor kernel uses it for programs that do not fit the LDS)
 
 // Numeric LDL' of the instance's (permuted) KKT matrix through the dot-product schedule: chunk by
 // chunk every lane (or group of 2^lg lanes, when a level has few destinations) accumulates

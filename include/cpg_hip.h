@@ -69,8 +69,9 @@ typedef struct {
 typedef struct {
     int32_t n_chunks;
     int32_t nnz;
-    const int32_t *ctab;  /* [n_chunks][4]: max len, log2(lanes per row), first entry, 0 */
-    const uint32_t *desc; /* [n_chunks][64]: output slot | (entries of the lane << 16) */
+    const int32_t *ctab;  /* [n_chunks][4]: max len, reduction stages, first entry, kind (bit 0: rows occupy a
+                           * variable number of adjacent lanes, segmented reduction; bit 1: rows accumulate) */
+    const uint32_t *desc; /* [n_chunks][64]: output slot | (entries of the lane << 16) [| segment mask << 28] */
     const double *vals;   /* [nnz] */
     const uint16_t *cols; /* [nnz] */
 } cpg_ragged_t;
