@@ -1132,7 +1132,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     // table-driven kernels, automatic placement: the streaming executor (program through L2, operands
     // of eight steps in flight, more resident waves) beats the LDS-resident table walk -- 1.44 M vs
     // 1.10 M instances/s on MPC 12/4/10; the LDS-resident form remains for G = 2 and on request
+#ifdef CPG_GEN_HEADER
+    const bool prefer_stream = false;   // family library: the generated executor works on the LDS-resident program
+#else
     const bool prefer_stream = h->program_in_lds == -1 && G == 1 && h->F.kkt_stream.n_pairs > 0;
+#endif
     if (h->program_in_lds != 0 && R.n_chunks > 0 && !prefer_stream) {
         const size_t fixed = N * 8 + prog_bytes;
         int wfit = fixed < h->lds_limit ? (int)((h->lds_limit - fixed) / per_wave) : 0;

@@ -145,6 +145,7 @@ def test_generated_family_library_vs_oracle(oracle_lib, tmp_path):
     for G in (1, 2):
         bs = BatchSolver(d, lib_path=lib, plan=plan)
         bs.set_launch(0, G, 0)
+        bs.set_program_placement(-1)       # "automatic" (what bench.py passes): the library's own choice
         r = bs.solve({'x_init': x0}, updated_params=['x_init'])
         _check(r, oracle_lib.cpg_solve_batch(d, _theta(d, 'x_init', x0), ['x_init']), d)
         bs.close()
