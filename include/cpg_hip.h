@@ -260,8 +260,9 @@ int cpg_hip_synchronize(cpg_handle_t h);
 int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms);
 /* launch geometry: waves per block (1..16), instances per wave (1 or 2), blocks per CU; 0 = auto */
 int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, int blocks_per_cu);
-/* where the solve program lives: 0 = streamed from L2/HBM, 1 = resident in LDS (one workgroup per
- * CU; fails if it does not fit), -1 = automatic (LDS when it fits) */
+/* where the solve program lives: 0 = streamed through L2, 1 = resident in LDS (one workgroup per
+ * CU; fails if it does not fit), -1 = the library's choice (family library with a generated executor:
+ * LDS resident; table-driven kernels: streamed for one instance per wave, which measures faster) */
 int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds);
 
 /* ---- device memory helpers for the device-resident variant ---------------------------------------- */
