@@ -164,6 +164,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--check', action='store_true', help='compare a sample with the oracle')
     ap.add_argument('--max-iter', type=int, default=0, help='experiments: cap the iteration count')
+    ap.add_argument('--check-termination', type=int, default=0, help='experiments: termination check interval (reference default 25)')
     ap.add_argument('--eps', type=float, default=0.0, help='eps_abs = eps_rel (tight run of SURVEY.md 8(d): 1e-6)')
     ap.add_argument('--adjoint', action='store_true', help='config 5: also time the batched QP adjoint (gradient=True path)')
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
@@ -211,6 +212,8 @@ def main():
         stg['max_iter'] = args.max_iter
     if args.eps:
         stg['eps_abs'] = stg['eps_rel'] = args.eps
+    if args.check_termination:
+        stg['check_termination'] = args.check_termination
     solver.apply_settings(**stg)                 # reference defaults unless an experiment overrides them
     dev = DeviceBatch(solver, B)
     dev.upload(theta)
