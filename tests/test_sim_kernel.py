@@ -129,22 +129,19 @@ def test_generated_executor_parity(oracle_lib, tmp_path, fam, G):
         BatchSolver(other, lib_path=lib)
 
 
-def test_streamed_family_library_parity(oracle_lib, tmp_path):
-    """codegen.build_streamed_family_library (what large families get instead of the generic library):
-    table-driven kernels for the family's exact slot class; the program streamed and LDS-resident
-    placements and the per-instance-factor path give the oracle's results"""
-    from cvxpygen_amd import codegen
-    from cvxpygen_amd.runtime import build_family_plan
+def test_program_placements_parity(sim_lib, oracle_lib):
+    """table-driven kernels with the solve program streamed (run_program_stream: what large families
+    and the generic library's automatic placement use) and LDS resident: both give the oracle's
+    results (the streamed family library itself, codegen.build_streamed_family_library, is compiled
+    by __graft_entry__.build and exercised on the GPU by test_large_family_beyond_the_generic_slot_classes)"""
     d = families.mpc(6, 3, 10)
-    vals = -2 + 4 * np.random.default_rng(4).random((3, 6))
-    plan = build_family_plan(d)
-    lib = codegen.build_streamed_family_library(plan, str(tmp_path), 'mpc6', sim=True)
-    bs = BatchSolver(d, lib_path=lib, plan=plan)
-    o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, 'x_init', vals), ['x_init'])
+    vals = -2 + 4 * np.random.default_rng(4).random((2, 6))
+    bs = BatchSolver(d, lib_path=sim_lib)
+    o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, 'x_init', vals), ['x_init'], max_iter=50)
     for placement in (0, 1):
         bs.set_program_placement(placement)
         bs.set_launch(waves_per_block=2, inst_per_wave=1)
-        r = bs.solve({'x_init': vals}, updated_params=['x_init'])
+        r = bs.solve({'x_init': vals}, updated_params=['x_init'], max_iter=50)
         _assert_parity(r, o, prim, dual)
     bs.close()
 
