@@ -1,8 +1,5 @@
 // C-ABI of the MI355X batched-solve backend (declared in include/cpg_hip.h) and the launch code
 // of the OSQP (shared factor, refactorisation, adjoint) and conic interior-point kernels.  Built by hipcc for gfx950 into libcpg_hip.so (see csrc/build.py).
-//
-// With -DCPG_HOST_SIM the same file builds, with g++, into the TEST-ONLY emulator library used by
-// tests/sim (64 lock-stepped host threads per wavefront); the product never loads that build.
 #include "../../include/cpg_hip.h"
 
 #include <math.h>
@@ -18,7 +15,6 @@
 #include "cpg_clarabel_kernel.h"
 
 // ------------------------------------------------------------------------------------ runtime layer
-#ifndef CPG_HOST_SIM
 #include <hip/hip_runtime.h>
 typedef hipStream_t rt_stream_t;
 typedef hipEvent_t rt_event_t;
@@ -30,14 +26,6 @@ typedef hipEvent_t rt_event_t;
             return CPG_E_HIP;                                                                  \
         }                                                                                      \
     } while (0)
-#else
-#include <pthread.h>
-#include <thread>
-typedef int rt_stream_t;
-typedef double rt_event_t;
-namespace cpgw { thread_local SimThread tls; }
-#define RT_CHECK(expr) do { (void)(expr); } while (0)
-#endif
 
 static thread_local std::string g_err;
 static void set_error(const std::string &s) { g_err = s; }
@@ -87,54 +75,29 @@ struct cpg_solver_s {
 // ---- runtime primitives -------------------------------------------------------------------------
 static int rt_malloc(void **p, size_t bytes) {
     if (bytes == 0) bytes = 8;
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipMalloc(p, bytes));
-#else
-    *p = malloc(bytes);
-    if (!*p) { set_error("malloc failed"); return CPG_E_NOMEM; }
-#endif
     return CPG_OK;
 }
 static int rt_free(void *p) {
-#ifndef CPG_HOST_SIM
     if (p) RT_CHECK(hipFree(p));
-#else
-    free(p);
-#endif
     return CPG_OK;
 }
 static int rt_h2d(cpg_handle_t h, void *dst, const void *src, size_t bytes) {
     if (!bytes) return CPG_OK;
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
-#else
-    (void)h; memcpy(dst, src, bytes);
-#endif
     return CPG_OK;
 }
 static int rt_d2h(cpg_handle_t h, void *dst, const void *src, size_t bytes) {
     if (!bytes) return CPG_OK;
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-#else
-    (void)h; memcpy(dst, src, bytes);
-#endif
     return CPG_OK;
 }
 static int rt_sync(cpg_handle_t h) {
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipStreamSynchronize(h->stream));
-#else
-    (void)h;
-#endif
     return CPG_OK;
 }
 static int rt_set_device(int dev) {
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipSetDevice(dev));
-#else
-    (void)dev;
-#endif
     return CPG_OK;
 }
 
@@ -258,7 +221,6 @@ static int build_stream_tables(const int *ctab, const unsigned *desc, const unsi
 #define CPG_MIN_WAVES_PER_SIMD 4   // 16 waves per CU: <= 128 VGPRs
 #endif
 
-#ifndef CPG_HOST_SIM
 // WMAX = waves per workgroup the kernel may be launched with; it fixes the register budget:
 // streaming kernels run several 4-wave workgroups per CU (CPG_MIN_WAVES_PER_SIMD), LDS-resident
 // kernels run ONE workgroup of up to WMAX waves per CU (WMAX / 4 waves per SIMD).
@@ -278,34 +240,7 @@ static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int wav
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
-#else
-// emulator: every block runs as waves*64 host threads; blocks run one after the other
-template <int NSX, int NSZ, int NV, int G, bool LDSPROG, int WMAX>
-static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    for (int b = 0; b < blocks; b++) {
-        std::vector<char> ldsbuf(lds + 64);
-        std::vector<cpgw::SimWave> wv(waves);
-        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
-        pthread_barrier_t block_bar;
-        pthread_barrier_init(&block_bar, nullptr, waves * 64);
-        std::vector<std::thread> th;
-        for (int t = 0; t < waves * 64; t++)
-            th.emplace_back([&, t]() {
-                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
-                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
-                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
-                cpg::osqp_shared_body<NSX, NSZ, NV, G, LDSPROG>(h->F, h->U, h->S, Bt, (double *)ldsbuf.data(),
-                                                                b * waves + (t >> 6));
-            });
-        for (auto &t : th) t.join();
-        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&block_bar);
-    }
-    return CPG_OK;
-}
-#endif
 
-#ifndef CPG_HOST_SIM
 template <int NSX, int NSZ>
 __global__ void __launch_bounds__(256, CPG_REFACTOR_WAVES_PER_SIMD)
 osqp_refactor_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, cpg::DevBatch Bt) {
@@ -322,34 +257,9 @@ static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
-#else
-template <int NSX, int NSZ>
-static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    for (int b = 0; b < blocks; b++) {
-        std::vector<char> ldsbuf(lds + 64);
-        std::vector<cpgw::SimWave> wv(waves);
-        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
-        pthread_barrier_t block_bar;
-        pthread_barrier_init(&block_bar, nullptr, waves * 64);
-        std::vector<std::thread> th;
-        for (int t = 0; t < waves * 64; t++)
-            th.emplace_back([&, t]() {
-                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
-                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
-                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
-                cpg::osqp_refactor_body<NSX, NSZ>(h->F, h->R, h->S, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
-            });
-        for (auto &t : th) t.join();
-        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&block_bar);
-    }
-    return CPG_OK;
-}
-#endif
 #ifndef CPG_KERNELS_REFACTOR
 #define CPG_KERNELS_REFACTOR(Z) Z(1, 1) Z(4, 4) Z(8, 8) Z(16, 16)
 #endif
-#ifndef CPG_HOST_SIM
 template <int NSX, int NSZ>
 __global__ void __launch_bounds__(512, CPG_GRADIENT_WAVES_PER_SIMD)
 osqp_gradient_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevGradient Gd, cpg::DevGradBatch Bt) {
@@ -366,30 +276,6 @@ static int launch_gradient_t(cpg_handle_t h, const cpg::DevGradBatch &Bt, int bl
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
-#else
-template <int NSX, int NSZ>
-static int launch_gradient_t(cpg_handle_t h, const cpg::DevGradBatch &Bt, int blocks, int waves, size_t lds) {
-    for (int b = 0; b < blocks; b++) {
-        std::vector<char> ldsbuf(lds + 64);
-        std::vector<cpgw::SimWave> wv(waves);
-        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
-        pthread_barrier_t block_bar;
-        pthread_barrier_init(&block_bar, nullptr, waves * 64);
-        std::vector<std::thread> th;
-        for (int t = 0; t < waves * 64; t++)
-            th.emplace_back([&, t]() {
-                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
-                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
-                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
-                cpg::osqp_gradient_body<NSX, NSZ>(h->F, h->R, h->Gd, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
-            });
-        for (auto &t : th) t.join();
-        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&block_bar);
-    }
-    return CPG_OK;
-}
-#endif
 static int launch_gradient(cpg_handle_t h, const cpg::DevGradBatch &Bt, int blocks, int waves, size_t lds) {
     const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
 #define Z(a, b) if (nsx <= a && nsz <= b) return launch_gradient_t<a, b>(h, Bt, blocks, waves, lds);
@@ -411,7 +297,6 @@ static int launch_refactor(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, 
 #ifndef CPG_CONIC_WAVES_PER_SIMD
 #define CPG_CONIC_WAVES_PER_SIMD 4   // <= 128 VGPRs
 #endif
-#ifndef CPG_HOST_SIM
 template <bool TABLES_IN_LDS>
 __global__ void __launch_bounds__(512, CPG_CONIC_WAVES_PER_SIMD)
 clarabel_kernel(cpg::DevConic C, cpg::DevConicSettings S, cpg::DevBatch Bt) {
@@ -428,30 +313,6 @@ static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, i
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
-#else
-template <bool TABLES_IN_LDS>
-static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    for (int b = 0; b < blocks; b++) {
-        std::vector<char> ldsbuf(lds + 64);
-        std::vector<cpgw::SimWave> wv(waves);
-        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
-        pthread_barrier_t block_bar;
-        pthread_barrier_init(&block_bar, nullptr, waves * 64);
-        std::vector<std::thread> th;
-        for (int t = 0; t < waves * 64; t++)
-            th.emplace_back([&, t]() {
-                cpgw::tls.lane = t & 63; cpgw::tls.wave = t >> 6; cpgw::tls.block = b;
-                cpgw::tls.nblocks = blocks; cpgw::tls.waves_per_block = waves;
-                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = ldsbuf.data(); cpgw::tls.block_bar = &block_bar;
-                cpg::clarabel_body<TABLES_IN_LDS>(h->C, h->CS, Bt, (double *)ldsbuf.data(), b * waves + (t >> 6));
-            });
-        for (auto &t : th) t.join();
-        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&block_bar);
-    }
-    return CPG_OK;
-}
-#endif
 static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds, bool tables_in_lds) {
     return tables_in_lds ? launch_conic_t<true>(h, Bt, blocks, waves, lds) : launch_conic_t<false>(h, Bt, blocks, waves, lds);
 }
@@ -518,11 +379,7 @@ const char *cpg_hip_status_string(int32_t s) {
 
 int cpg_hip_device_count(int *count) {
     if (!count) { set_error("count is NULL"); return CPG_E_BADARG; }
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipGetDeviceCount(count));
-#else
-    *count = 1;
-#endif
     return CPG_OK;
 }
 
@@ -642,7 +499,6 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     if (rc) return rc;
     cpg_handle_t h = new cpg_solver_s();
     h->device = device;
-#ifndef CPG_HOST_SIM
     {
         hipDeviceProp_t prop;
         hipError_t e = hipGetDeviceProperties(&prop, device);
@@ -654,9 +510,6 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
         if (e != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); delete h; return CPG_E_HIP; }
         hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); h->have_events = true;
     }
-#else
-    h->num_cu = 2;
-#endif
     cpg::DevFamily &F = h->F;
     F.n = f->n; F.m = f->m; F.n_eq = f->n_eq; F.is_max = f->is_maximization;
     F.sigma = f->sigma; F.alpha = f->alpha; F.rho = f->rho; F.c = f->c; F.cinv = 1.0 / f->c;
@@ -737,7 +590,6 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
 int cpg_hip_destroy(cpg_handle_t h);
 static int open_device(cpg_handle_t h, int device) {
     h->device = device;
-#ifndef CPG_HOST_SIM
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { set_error(std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)); return CPG_E_HIP; }
@@ -747,9 +599,6 @@ static int open_device(cpg_handle_t h, int device) {
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); return CPG_E_HIP; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); h->have_events = true;
-#else
-    h->num_cu = 2;
-#endif
     return CPG_OK;
 }
 
@@ -843,10 +692,8 @@ int cpg_hip_destroy(cpg_handle_t h) {
     free_buf(h->scratch);
     free_buf(h->s_theta); free_buf(h->s_prim); free_buf(h->s_dual); free_buf(h->s_obj);
     free_buf(h->s_pri); free_buf(h->s_dua); free_buf(h->s_iter); free_buf(h->s_status);
-#ifndef CPG_HOST_SIM
     if (h->have_events) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
     if (h->stream) hipStreamDestroy(h->stream);
-#endif
     delete h;
     return CPG_OK;
 }
@@ -994,17 +841,11 @@ int cpg_hip_gradient_batch(cpg_handle_t h, int64_t B, const double *theta, const
     Bt.B = B; Bt.theta = (const double *)h->g_theta.p; Bt.sol_x = (const double *)h->g_x.p;
     Bt.sol_y = (const double *)h->g_y.p; Bt.dx = (const double *)h->g_dprim.p; Bt.dtheta = (double *)h->g_dtheta.p;
     Bt.counter = h->d_counter; Bt.scratch = (double *)h->scratch.p;
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
     RT_CHECK(hipEventRecord(h->ev0, h->stream));
-#else
-    *h->d_counter = 0;
-#endif
     rc = launch_gradient(h, Bt, (int)blocks, W, lds);
     if (rc) return rc;
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipEventRecord(h->ev1, h->stream));
-#endif
     if ((rc = rt_d2h(h, dtheta, h->g_dtheta.p, b * h->Gd.NP * sizeof(double)))) return rc;
     return rt_sync(h);
 }
@@ -1066,17 +907,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
         Bt.scratch = nullptr;
         Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
         Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
-#ifndef CPG_HOST_SIM
         RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
         RT_CHECK(hipEventRecord(h->ev0, h->stream));
-#else
-        *h->d_counter = 0;
-#endif
         rc = launch_conic(h, Bt, (int)blocks, W, lds, tables_in_lds);
         if (rc) return rc;
-#ifndef CPG_HOST_SIM
         RT_CHECK(hipEventRecord(h->ev1, h->stream));
-#endif
         return CPG_OK;
     }
     if (h->refactor_mode) {
@@ -1094,17 +929,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
         Bt.scratch = (double *)h->scratch.p;
         Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
         Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
-#ifndef CPG_HOST_SIM
         RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
         RT_CHECK(hipEventRecord(h->ev0, h->stream));
-#else
-        *h->d_counter = 0;
-#endif
         rc = launch_refactor(h, Bt, (int)blocks, W, lds);
         if (rc) return rc;
-#ifndef CPG_HOST_SIM
         RT_CHECK(hipEventRecord(h->ev1, h->stream));
-#endif
         return CPG_OK;
     }
     const int G = h->inst_per_wave;
@@ -1179,17 +1008,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     Bt.scratch = (double *)h->scratch.p;
     Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
     Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
     RT_CHECK(hipEventRecord(h->ev0, h->stream));
-#else
-    *h->d_counter = 0;
-#endif
     rc = launch(h, Bt, (int)blocks, W, G, lds, in_lds);
     if (rc) return rc;
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipEventRecord(h->ev1, h->stream));
-#endif
     return CPG_OK;
 }
 
@@ -1202,12 +1025,8 @@ int cpg_hip_synchronize(cpg_handle_t h) {
 
 int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms) {
     if (!h || !ms) { set_error("null argument"); return CPG_E_BADARG; }
-#ifndef CPG_HOST_SIM
     RT_CHECK(hipEventSynchronize(h->ev1));
     RT_CHECK(hipEventElapsedTime(ms, h->ev0, h->ev1));
-#else
-    *ms = 0.f;
-#endif
     return CPG_OK;
 }
 

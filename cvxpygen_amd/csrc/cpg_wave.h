@@ -1,208 +1,10 @@
-// Wavefront-level primitives for gfx950 (CDNA4): 64-lane cross-lane moves via DPP / readlane,
-// wave-uniform reductions, and LDS ordering inside one wavefront.
-//
-// The kernels in this directory are written against these few functions only.  Besides the real
-// gfx950 implementation there is a second, host-side implementation (CPG_HOST_SIM) that runs the 64
-// lanes of a wavefront as lock-stepped threads; it exists solely so that tests/ can execute the
-// very same kernel source on a machine without a GPU (tests/sim/).  The product library
-// (libcpg_hip.so) is never built with CPG_HOST_SIM.
+// Wavefront-level building blocks of the kernels: the gfx950 primitives (cpg_wave_gfx950.h) and the
+// reductions / addressing helpers built on them.
 #pragma once
 
 #include <stdint.h>
 
-#ifndef CPG_HOST_SIM
-// =================================================================================== gfx950
-#include <hip/hip_runtime.h>
-
-#define CPG_DEV __device__ __forceinline__
-#define CPG_LANES 64
-
-namespace cpgw {
-
-CPG_DEV int lane_id() { return (int)(threadIdx.x & 63); }
-CPG_DEV int wave_in_block() { return (int)(threadIdx.x >> 6); }
-CPG_DEV unsigned thread_in_block() { return threadIdx.x; }
-CPG_DEV unsigned block_threads() { return blockDim.x; }
-CPG_DEV void block_sync() { __syncthreads(); }
-
-// Orders the LDS traffic of ONE wavefront: DS operations of a wave are executed in program order
-// by the hardware; this only stops the compiler from moving loads above earlier stores.
-CPG_DEV void lds_order() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <int CTRL>
-CPG_DEV double dpp_move_zero(double v) {   // invalid source lanes deliver 0 (bound_ctrl)
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-// lane i receives the value of lane i + N of the same 16-lane row, 0 when i + N leaves the row
-template <int N>
-CPG_DEV double row_shl(double v) { return dpp_move_zero<0x100 + N>(v); }
-
-CPG_DEV double read_lane(double v, int lane) {   // `lane` must be wave-uniform
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-CPG_DEV double shfl_down(double v, int delta) { return __shfl_down(v, delta, 64); }
-// Value of lane + 16 (lane + 32) on the lanes of the even 16-lane rows (of the lower half); other
-// lanes receive values that must not be used.  gfx950 row / half swaps: plain VALU, no LDS crossbar
-// and no index register, unlike the ds_bpermute behind __shfl_down.
-CPG_DEV double up16(double v) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double((int)b[1], (int)a[1]);
-}
-CPG_DEV double up32(double v) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double((int)b[1], (int)a[1]);
-}
-CPG_DEV int read_first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
-CPG_DEV bool wave_any(bool p) { return __any(p) != 0; }
-// orders GLOBAL stores and loads of one wavefront among its own lanes (per-wavefront buffers:
-// written by some lanes, read by others later); the CU's L1 is coherent for its own traffic
-CPG_DEV void mem_order() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-CPG_DEV unsigned long long ballot(bool p) { return __ballot(p); }
-// number of set bits of `mask` below this lane
-CPG_DEV unsigned mbcnt(unsigned long long mask) {
-    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-CPG_DEV unsigned popc64(unsigned long long m) { return (unsigned)__popcll(m); }
-
-CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
-// keeps the instruction scheduler from interleaving unrolled loop bodies (register pressure)
-CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-// value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and
-// keeping alive) everything derived from it
-CPG_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-// tells the optimiser a fact it lost (e.g. the lane range after opaque()): bounds checks fold again
-CPG_DEV void assume(bool c) { __builtin_assume(c); }
-// Word of a read-only table at a wave-uniform index through the SCALAR cache (s_load): the constant
-// address space tells the compiler that no store of the kernel can alias it, which it cannot prove
-// for a plain global pointer in kernels that also write global memory.
-CPG_DEV unsigned sld(const unsigned *base, unsigned idx) {
-    typedef const unsigned __attribute__((address_space(4))) *cptr_t;
-    return ((cptr_t)(unsigned long long)base)[idx];
-}
-
-}  // namespace cpgw
-
-#else
-// =================================================================================== host emulation
-#include <atomic>
-#include <cmath>
-#include <cstring>
-#include <pthread.h>
-
-#define CPG_DEV inline
-#define CPG_LANES 64
-#define __global__
-#define __restrict__
-
-namespace cpgw {
-
-struct SimWave {                 // shared by the 64 threads of one emulated wavefront
-    pthread_barrier_t bar;
-    double xch[64];
-    int ixch[64];
-};
-struct SimThread {
-    int lane, wave, block, nblocks, waves_per_block;
-    SimWave *wv;
-    pthread_barrier_t *block_bar;
-    char *lds;                   // block-wide dynamic LDS
-};
-extern thread_local SimThread tls;
-
-inline void wave_sync() { pthread_barrier_wait(&tls.wv->bar); }
-
-inline int lane_id() { return tls.lane; }
-inline int wave_in_block() { return tls.wave; }
-inline unsigned thread_in_block() { return (unsigned)(tls.wave * 64 + tls.lane); }
-inline unsigned block_threads() { return (unsigned)(tls.waves_per_block * 64); }
-inline void block_sync() { pthread_barrier_wait(tls.block_bar); }
-inline void lds_order() { wave_sync(); }
-
-template <int N>
-inline double row_shl(double v) {
-    SimWave *w = tls.wv;
-    w->xch[tls.lane] = v;
-    wave_sync();
-    int src = tls.lane + N;
-    double r = ((src >> 4) == (tls.lane >> 4)) ? w->xch[src] : 0.0;
-    wave_sync();
-    return r;
-}
-inline double read_lane(double v, int lane) {
-    SimWave *w = tls.wv;
-    w->xch[tls.lane] = v;
-    wave_sync();
-    double r = w->xch[lane];
-    wave_sync();
-    return r;
-}
-inline double shfl_down(double v, int delta) {
-    SimWave *w = tls.wv;
-    w->xch[tls.lane] = v;
-    wave_sync();
-    int src = tls.lane + delta;
-    double r = src < 64 ? w->xch[src] : v;
-    wave_sync();
-    return r;
-}
-inline double up16(double v) { return shfl_down(v, 16); }
-inline double up32(double v) { return shfl_down(v, 32); }
-inline int read_first_lane(int v) {
-    SimWave *w = tls.wv;
-    w->ixch[tls.lane] = v;
-    wave_sync();
-    int r = w->ixch[0];
-    wave_sync();
-    return r;
-}
-inline bool wave_any(bool p) {
-    SimWave *w = tls.wv;
-    w->ixch[tls.lane] = p ? 1 : 0;
-    wave_sync();
-    int r = 0;
-    for (int i = 0; i < 64; i++) r |= w->ixch[i];
-    wave_sync();
-    return r != 0;
-}
-inline unsigned atomic_next(unsigned *ctr) {
-    return __atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED);
-}
-inline void mem_order() { wave_sync(); }
-inline unsigned long long ballot(bool p) {
-    SimWave *w = tls.wv;
-    w->ixch[tls.lane] = p ? 1 : 0;
-    wave_sync();
-    unsigned long long m = 0;
-    for (int i = 0; i < 64; i++) if (w->ixch[i]) m |= 1ULL << i;
-    wave_sync();
-    return m;
-}
-inline unsigned mbcnt(unsigned long long mask) {
-    return (unsigned)__builtin_popcountll(mask & ((1ULL << tls.lane) - 1ULL));
-}
-inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
-inline void sched_fence() {}
-inline int opaque(int v) { return v; }
-inline void assume(bool) {}
-inline unsigned sld(const unsigned *base, unsigned idx) { return base[idx]; }
-
-}  // namespace cpgw
-#endif
+#include "cpg_wave_gfx950.h"
 
 namespace cpgw {
 
@@ -218,7 +20,7 @@ CPG_DEV void gst(T *base, unsigned idx, T v) {
     *(T *)((char *)base + (size_t)(idx * (unsigned)sizeof(T))) = v;
 }
 
-// ---- reductions built on the primitives (identical code on both back ends) ----------------------
+// ---- reductions built on the primitives ------------------------------------------------
 
 // Sum over groups of G = 2^LG consecutive lanes; the FIRST lane of every group holds the group sum
 // afterwards (other lanes hold partial sums that must not be used).

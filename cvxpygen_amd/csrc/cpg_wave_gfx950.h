@@ -1,0 +1,94 @@
+// Wavefront-level primitives for gfx950 (CDNA4): 64-lane cross-lane moves via DPP / readlane /
+// permlane swaps, wave-uniform broadcasts, and LDS / memory ordering inside one wavefront.
+// The kernels in this directory are written against these few functions (and the reductions that
+// cpg_wave.h builds from them) only.
+#ifndef CPG_WAVE_PRIMITIVES_H
+#define CPG_WAVE_PRIMITIVES_H
+
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define CPG_DEV __device__ __forceinline__
+#define CPG_LANES 64
+
+namespace cpgw {
+
+CPG_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+CPG_DEV int wave_in_block() { return (int)(threadIdx.x >> 6); }
+CPG_DEV unsigned thread_in_block() { return threadIdx.x; }
+CPG_DEV unsigned block_threads() { return blockDim.x; }
+CPG_DEV void block_sync() { __syncthreads(); }
+
+// Orders the LDS traffic of ONE wavefront: DS operations of a wave are executed in program order
+// by the hardware; this only stops the compiler from moving loads above earlier stores.
+CPG_DEV void lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int CTRL>
+CPG_DEV double dpp_move_zero(double v) {   // invalid source lanes deliver 0 (bound_ctrl)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// lane i receives the value of lane i + N of the same 16-lane row, 0 when i + N leaves the row
+template <int N>
+CPG_DEV double row_shl(double v) { return dpp_move_zero<0x100 + N>(v); }
+
+CPG_DEV double read_lane(double v, int lane) {   // `lane` must be wave-uniform
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+CPG_DEV double shfl_down(double v, int delta) { return __shfl_down(v, delta, 64); }
+// Value of lane + 16 (lane + 32) on the lanes of the even 16-lane rows (of the lower half); other
+// lanes receive values that must not be used.  gfx950 row / half swaps: plain VALU, no LDS crossbar
+// and no index register, unlike the ds_bpermute behind __shfl_down.
+CPG_DEV double up16(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+CPG_DEV double up32(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+CPG_DEV int read_first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+CPG_DEV bool wave_any(bool p) { return __any(p) != 0; }
+// orders GLOBAL stores and loads of one wavefront among its own lanes (per-wavefront buffers:
+// written by some lanes, read by others later); the CU's L1 is coherent for its own traffic
+CPG_DEV void mem_order() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+CPG_DEV unsigned long long ballot(bool p) { return __ballot(p); }
+// number of set bits of `mask` below this lane
+CPG_DEV unsigned mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+CPG_DEV unsigned popc64(unsigned long long m) { return (unsigned)__popcll(m); }
+
+CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
+// keeps the instruction scheduler from interleaving unrolled loop bodies (register pressure)
+CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and
+// keeping alive) everything derived from it
+CPG_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// tells the optimiser a fact it lost (e.g. the lane range after opaque()): bounds checks fold again
+CPG_DEV void assume(bool c) { __builtin_assume(c); }
+// Word of a read-only table at a wave-uniform index through the SCALAR cache (s_load): the constant
+// address space tells the compiler that no store of the kernel can alias it, which it cannot prove
+// for a plain global pointer in kernels that also write global memory.
+CPG_DEV unsigned sld(const unsigned *base, unsigned idx) {
+    typedef const unsigned __attribute__((address_space(4))) *cptr_t;
+    return ((cptr_t)(unsigned long long)base)[idx];
+}
+
+}  // namespace cpgw
+
+#endif  // CPG_WAVE_PRIMITIVES_H

@@ -9,7 +9,7 @@ This is the batched counterpart of the reference's L6/L7 layers: the Python shim
 static workspace the reference emits per problem family (`cvxpygen/utils.py:470-689`).
 
 There is no CPU fallback: if the HIP library is missing or no GPU is present the constructor
-raises.  (tests/ may inject the lock-step emulator build of the same sources through `lib_path`.)
+raises.  `lib_path` selects a family-specialised build of the same library (cvxpygen_amd/codegen.py).
 """
 
 from __future__ import annotations
@@ -112,7 +112,7 @@ class CpgLibrary:
                'cpg_hip_memcpy_d2h']
 
     def __init__(self, path: Optional[str] = None):
-        path = path or os.environ.get('CPG_HIP_LIBRARY') or default_lib_path()
+        path = path or default_lib_path()
         if not os.path.exists(path):
             raise RuntimeError(
                 f'HIP extension {path} not found: build it with `python -m cvxpygen_amd.csrc.build` '
@@ -286,7 +286,7 @@ class BatchSolver:
             raise ValueError(f'BatchSolver handles OSQP families, not {desc.solver}')
         self.desc = desc
         self.plan = plan or build_family_plan(desc, ordering=ordering)
-        if lib_path is None and not os.environ.get('CPG_HIP_LIBRARY'):
+        if lib_path is None:
             from . import codegen
             if max(-(-desc.n_var // 64), -(-desc.m // 64)) > codegen.GENERIC_MAX_SLOTS:
                 # the generic library carries slot classes up to 16 x 16 (n_var, m <= 1024): larger

@@ -1,32 +1,62 @@
 """
-TEST INFRASTRUCTURE ONLY.  Builds the lock-step emulator variant of the product's kernel sources
-(cvxpygen_amd/csrc/*.h, cpg_hip.cpp compiled with g++ -DCPG_HOST_SIM): every wavefront runs as 64
-host threads that synchronise at each cross-lane primitive (cvxpygen_amd/csrc/cpg_wave.h).  It lets
-the CPU-only test tier execute the real kernel logic -- executor, ADMM loop, termination and
-infeasibility tests, retrieval -- through the real C-ABI.  The product never loads this library:
-cvxpygen_amd.runtime only opens csrc/libcpg_hip.so unless a test passes lib_path explicitly.
+TEST INFRASTRUCTURE ONLY.  Builds the lock-step emulator of the product's kernel SOURCES: g++ compiles
+cvxpygen_amd/csrc/cpg_hip.cpp unchanged, with
+  * tests/sim/cpg_wave_sim.h force-included first -- host versions of the wavefront primitives of
+    csrc/cpg_wave_gfx950.h (every wavefront = 64 host threads that meet at a barrier in each
+    cross-lane primitive); it defines that header's include guard, so the product header is skipped;
+  * tests/sim/fake_hip/hip/hip_runtime.h standing in for the HIP runtime (malloc / memcpy, launches
+    run the workgroups one after the other).
+This lets the CPU-only test tier execute the real kernel logic -- executors, ADMM loop, termination and
+infeasibility tests, factorisation, retrieval -- through the real C-ABI and Python runtime.  Nothing
+under cvxpygen_amd/ refers to the emulator; tests hand the library to BatchSolver(lib_path=...).
 """
 import os
-import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, '..', '..', 'cvxpygen_amd', 'csrc')
+ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cvxpygen_amd import codegen  # noqa: E402  (kernel configuration macros of the product build)
+
+SIM_HEADERS = [os.path.join(HERE, 'cpg_wave_sim.h'), os.path.join(HERE, 'fake_hip', 'hip', 'hip_runtime.h'),
+               os.path.abspath(__file__)]
+
+
+def _gxx_cmd(src, defs, out):
+    return ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-I', os.path.join(HERE, 'fake_hip'),
+            '-include', os.path.join(HERE, 'cpg_wave_sim.h'), '-x', 'c++', src, *defs, '-o', out]
 
 
 def lib_path():
     return os.path.join(HERE, 'libcpg_sim.so')
 
 
-def build(force=False):
+def build(force=False, verbose=False):
+    """the generic (table-driven) library"""
     out = lib_path()
-    deps = [os.path.join(SRC, f) for f in ('cpg_hip.cpp', 'cpg_osqp_kernel.h', 'cpg_osqp_refactor.h', 'cpg_clarabel_kernel.h', 'cpg_wave.h')]
-    if not force and os.path.exists(out) and all(os.path.getmtime(d) < os.path.getmtime(out) for d in deps):
-        return out
-    cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-DCPG_HOST_SIM', '-x', 'c++',
-           os.path.join(SRC, 'cpg_hip.cpp'), '-o', out]
-    subprocess.check_call(cmd)
-    return out
+    if force and os.path.exists(out):
+        os.remove(out)
+    src, deps = codegen.source_files()
+    return codegen.compile_if_stale(_gxx_cmd(src, [], out), out, deps + SIM_HEADERS, verbose)
+
+
+def build_family(plan, out_dir, name='family', verbose=False, **kw):
+    """emulator build of the family-specialised library (generated straight-line executor)"""
+    hdr, defs = codegen.family_library_defs(plan, out_dir, name, **kw)
+    out = os.path.join(out_dir, f'libcpg_{name}_sim.so')
+    src, deps = codegen.source_files()
+    return codegen.compile_if_stale(_gxx_cmd(src, defs, out), out, [hdr] + deps + SIM_HEADERS, verbose)
+
+
+def build_streamed_family(plan, out_dir, name='family', verbose=False):
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f'libcpg_{name}_streamed_sim.so')
+    src, deps = codegen.source_files()
+    return codegen.compile_if_stale(_gxx_cmd(src, codegen.streamed_library_defs(plan), out), out,
+                                    deps + SIM_HEADERS, verbose)
 
 
 if __name__ == '__main__':
-    print(build(force=True))
+    print(build(force=True, verbose=True))

@@ -50,3 +50,5 @@ def test_product_never_references_oracle_or_emulator():
                 txt = open(os.path.join(dp, fn)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt, fn
                 assert 'liboracle' not in txt and 'libcpg_sim' not in txt, fn
+                # no second backend inside the product: the emulator lives entirely under tests/sim
+                assert 'CPG_HOST_SIM' not in txt and 'pthread' not in txt and 'CPG_HIP_LIBRARY' not in txt, fn

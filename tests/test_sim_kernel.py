@@ -110,14 +110,14 @@ def test_settings_and_errors(sim_lib):
 def test_generated_executor_parity(oracle_lib, tmp_path, fam, G):
     """cvxpygen_amd.codegen: the family-specialised straight-line executor (emulator build of the
     generated source) gives the oracle's results; a library generated for one family refuses another."""
-    from cvxpygen_amd import codegen
     from cvxpygen_amd.runtime import build_family_plan
+    from sim import build_sim
     if fam == 'nnls':
         d, name, vals = families.nonneg_ls(), 'b', np.random.default_rng(0).standard_normal((5, 3))
     else:
         d, name, vals = families.mpc(6, 3, 10), 'x_init', -2 + 4 * np.random.default_rng(1).random((3, 6))
     plan = build_family_plan(d)
-    lib = codegen.build_family_library(plan, str(tmp_path), fam, sim=True)
+    lib = build_sim.build_family(plan, str(tmp_path), fam)
     bs = BatchSolver(d, lib_path=lib, plan=plan)
     bs.set_launch(waves_per_block=2, inst_per_wave=G)
     r = bs.solve({name: vals}, updated_params=[name])
