@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -54,7 +55,6 @@ struct cpg_solver_s {
     std::vector<void *> gradient_owned;
     DevBuf g_theta, g_x, g_y, g_dprim, g_dtheta;
     cpg::DevSettings S{};
-    int warm_starting = 1;              // accepted for API parity; a batch is always cold-started
     int waves_per_block = 0, inst_per_wave = 1, blocks_per_cu = 0;
     int program_in_lds = -1;            // -1 auto, 0 stream from L2/HBM, 1 resident in LDS
     int num_cu = 256;
@@ -69,7 +69,7 @@ struct cpg_solver_s {
            min_switch_step_length = 0.1;
     DevBuf scratch;                     // delta_x / delta_y stash, [waves][G][n + m]
     // staging for the host-pointer entry point
-    DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status;
+    DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status, s_state_in, s_state_out;
 };
 
 // ---- runtime primitives -------------------------------------------------------------------------
@@ -448,7 +448,9 @@ int cpg_hip_set_default_settings(cpg_handle_t h) {
     // defaults of the generated solver, cvxpygen/solvers/osqp.py:102-115
     h->S.max_iter = 4000; h->S.eps_abs = 1e-3; h->S.eps_rel = 1e-3; h->S.eps_prim_inf = 1e-4;
     h->S.eps_dual_inf = 1e-4; h->S.scaled_termination = 0; h->S.check_termination = 25;
-    h->warm_starting = 1;
+    h->S.warm_starting = 1;
+    // (the build options -- adaptive_rho*, check_dualgap -- are workspace constants of the generated code,
+    // not settings the reference resets: cpg_hip_set_build_option)
     return CPG_OK;
 }
 
@@ -467,8 +469,20 @@ int cpg_hip_set_setting(cpg_handle_t h, const char *name, double v) {
     else if (s == "eps_dual_inf") h->S.eps_dual_inf = v;
     else if (s == "scaled_termination") h->S.scaled_termination = (int)v;
     else if (s == "check_termination") h->S.check_termination = (int)v;
-    else if (s == "warm_starting") h->warm_starting = (int)v;
+    else if (s == "warm_starting") h->S.warm_starting = (int)v;
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
+    return CPG_OK;
+}
+
+int cpg_hip_set_build_option(cpg_handle_t h, const char *name, double v) {
+    if (!h || !name) { set_error("null argument"); return CPG_E_BADARG; }
+    if (h->conic) { set_error("not available for a conic (interior-point) handle"); return CPG_E_BADARG; }
+    std::string s(name);
+    if (s == "adaptive_rho") h->S.adaptive_rho = (int)v;
+    else if (s == "adaptive_rho_interval") h->S.adaptive_rho_interval = (int)v;
+    else if (s == "adaptive_rho_tolerance") h->S.adaptive_rho_tolerance = v;
+    else if (s == "check_dualgap") h->S.check_dualgap = (int)v;
+    else { set_error("Build option \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
 }
 
@@ -487,7 +501,11 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     else if (s == "eps_dual_inf") *v = h->S.eps_dual_inf;
     else if (s == "scaled_termination") *v = h->S.scaled_termination;
     else if (s == "check_termination") *v = h->S.check_termination;
-    else if (s == "warm_starting") *v = h->warm_starting;
+    else if (s == "warm_starting") *v = h->S.warm_starting;
+    else if (s == "adaptive_rho") *v = h->S.adaptive_rho;
+    else if (s == "adaptive_rho_interval") *v = h->S.adaptive_rho_interval;
+    else if (s == "adaptive_rho_tolerance") *v = h->S.adaptive_rho_tolerance;
+    else if (s == "check_dualgap") *v = h->S.check_dualgap;
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
 }
@@ -550,6 +568,32 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
             }
         }
     }
+    F.kkt_ragged.dict = nullptr; F.kkt_ragged.words = nullptr; F.kkt_ragged.n_dict = 0;
+#ifdef CPG_GEN_COMPRESSED
+    if (f->kkt_ragged.n_chunks > 0) {
+        // dictionary of the distinct coefficients (bit patterns, sorted) and one word per entry
+        const cpg_ragged_t &rg = f->kkt_ragged;
+        std::vector<unsigned long long> bits((size_t)rg.nnz);
+        memcpy(bits.data(), rg.vals, (size_t)rg.nnz * 8);
+        std::vector<unsigned long long> uniq(bits);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        if (uniq.size() != (size_t)CPG_GEN_NDICT || uniq.size() > 8192) {
+            set_error("this library was generated for a different problem family (coefficient dictionary)");
+            cpg_hip_destroy(h); return CPG_E_BADARG; }
+        std::vector<double> dict(uniq.size());
+        memcpy(dict.data(), uniq.data(), uniq.size() * 8);
+        std::vector<unsigned> words((size_t)rg.nnz);
+        for (int e = 0; e < rg.nnz; e++) {
+            const unsigned di = (unsigned)(std::lower_bound(uniq.begin(), uniq.end(), bits[e]) - uniq.begin());
+            words[e] = (unsigned)rg.cols[e] | ((di * 8u) << 16);
+        }
+        TRY(upload<double>(h, h->owned, dict.data(), dict.size(), &F.kkt_ragged.dict));
+        TRY(upload<unsigned>(h, h->owned, words.data(), words.size(), &F.kkt_ragged.words));
+        TRY(rt_sync(h));
+        F.kkt_ragged.n_dict = (int)dict.size();
+    }
+#endif
 #ifdef CPG_GEN_HEADER
     if (f->kkt_ragged.n_chunks > 0) {   // (handles without a shared program only serve the refactorisation / adjoint kernels)
         // this build contains an executor generated for one specific family: refuse any other
@@ -579,10 +623,14 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     F.n_prim = f->n_prim; F.n_dual = f->n_dual;
     TRY(upload<int>(h, h->owned, f->prim_idx, f->n_prim, &F.prim_idx));
     TRY(upload<int>(h, h->owned, f->dual_idx, f->n_dual, &F.dual_idx));
+    F.ord = nullptr;
+    if (f->ord) TRY(upload<int>(h, h->owned, f->ord, (size_t)f->n + f->m, &F.ord));
     { void *p = nullptr; TRY(rt_malloc(&p, 64)); h->d_counter = (unsigned *)p; }
     TRY(rt_sync(h));   // Dinv / Einv are stack-lifetime buffers
 #undef TRY
     cpg_hip_set_default_settings(h);
+    // build options: fixed rho, no duality-gap test; cpg_hip_set_build_option
+    h->S.adaptive_rho = 0; h->S.adaptive_rho_interval = 50; h->S.adaptive_rho_tolerance = 5.0; h->S.check_dualgap = 0;
     *out = h;
     return CPG_OK;
 }
@@ -692,6 +740,7 @@ int cpg_hip_destroy(cpg_handle_t h) {
     free_buf(h->scratch);
     free_buf(h->s_theta); free_buf(h->s_prim); free_buf(h->s_dual); free_buf(h->s_obj);
     free_buf(h->s_pri); free_buf(h->s_dua); free_buf(h->s_iter); free_buf(h->s_status);
+    free_buf(h->s_state_in); free_buf(h->s_state_out);
     if (h->have_events) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -775,7 +824,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     if ((rc = upload_csr(h, own, r->map_q, &R.map_q))) return rc;
     if ((rc = upload_csr(h, own, r->map_u, &R.map_u))) return rc;
     if ((rc = upload_csr(h, own, r->map_d, &R.map_d))) return rc;
-    R.buf_doubles = (long long)(r->nnzP + r->nnzA + 4 * n + 5 * m + r->nnzL + 2 * N + R.sol_nnz + 64);   // see carve()
+    R.buf_doubles = (long long)(r->nnzP + r->nnzA + 3 * n + 4 * m + r->nnzL + 2 * N + R.sol_nnz + 64);   // see carve()
     if ((rc = rt_sync(h))) return rc;
     h->refactor_mode = true;
     h->have_update = true;
@@ -876,9 +925,13 @@ int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds) {
     return CPG_OK;
 }
 
-int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta, double *d_prim, double *d_dual,
-                               double *d_obj, int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
+int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_theta, const double *d_state_in,
+                                     double *d_state_out, double *d_prim, double *d_dual, double *d_obj,
+                                     int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    if (h->conic && (d_state_in || d_state_out)) {
+        // the reference builds a new Clarabel solver per solve (solvers/clarabel.py:201-204): nothing carries over
+        set_error("a conic (interior-point) handle has no state between solves"); return CPG_E_BADARG; }
     if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
     if (B < 0 || !d_prim || !d_dual || !d_obj || !d_iter || !d_status || !d_pri || !d_dua || ((h->conic ? h->C.np_var : h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !d_theta)) {
         set_error("null buffer"); return CPG_E_BADARG; }
@@ -904,7 +957,7 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
         const long long cap = (long long)h->num_cu * per_cu;
         if (blocks > cap) blocks = cap;
         cpg::DevBatch Bt;
-        Bt.scratch = nullptr;
+        Bt.scratch = nullptr; Bt.state_in = nullptr; Bt.state_out = nullptr;
         Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
         Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
         RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
@@ -926,7 +979,7 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
         if (blocks > cap) blocks = cap;
         if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
         cpg::DevBatch Bt;
-        Bt.scratch = (double *)h->scratch.p;
+        Bt.scratch = (double *)h->scratch.p; Bt.state_in = d_state_in; Bt.state_out = d_state_out;
         Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
         Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
         RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
@@ -936,6 +989,9 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
         RT_CHECK(hipEventRecord(h->ev1, h->stream));
         return CPG_OK;
     }
+    if (h->S.adaptive_rho && h->S.adaptive_rho_interval > 0) {
+        // rho adaptation gives every instance its own factor: only the per-instance factor path serves it
+        set_error("adaptive_rho needs the per-instance factor path (cpg_hip_set_refactor)"); return CPG_E_UNSUPPORTED; }
     const int G = h->inst_per_wave;
     const size_t N = (size_t)(h->F.n + h->F.m);
 #if defined(CPG_GEN_HEADER) && defined(CPG_GEN_N)
@@ -955,7 +1011,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
 #else
     const size_t nnzp = (size_t)R.nnz;
 #endif
+#ifdef CPG_GEN_COMPRESSED
+    const size_t prog_bytes = R.n_chunks > 0 ? ((size_t)R.n_dict + (nnzp + 1) / 2 + tab_doubles) * 8 : 0;
+#else
     const size_t prog_bytes = R.n_chunks > 0 ? (nnzp + (nnzp + 3) / 4 + tab_doubles) * 8 : 0;
+#endif
     bool in_lds = false;
     int W = h->waves_per_block;
     // table-driven kernels, automatic placement: the streaming executor (program through L2, operands
@@ -1003,9 +1063,8 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     long long blocks = (ngroups + W - 1) / W;
     const long long cap = (long long)h->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
-    if ((rc = ensure(h->scratch, (size_t)blocks * W * G * (h->F.n + h->F.m) * sizeof(double)))) return rc;
     cpg::DevBatch Bt;
-    Bt.scratch = (double *)h->scratch.p;
+    Bt.scratch = nullptr; Bt.state_in = d_state_in; Bt.state_out = d_state_out;
     Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
     Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
     RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
@@ -1014,6 +1073,11 @@ int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta,
     if (rc) return rc;
     RT_CHECK(hipEventRecord(h->ev1, h->stream));
     return CPG_OK;
+}
+
+int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta, double *d_prim, double *d_dual,
+                               double *d_obj, int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
+    return cpg_hip_solve_batch_device_state(h, B, d_theta, nullptr, nullptr, d_prim, d_dual, d_obj, d_iter, d_status, d_pri, d_dua);
 }
 
 int cpg_hip_synchronize(cpg_handle_t h) {
@@ -1032,6 +1096,12 @@ int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms) {
 
 int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta, double *prim, double *dual, double *obj,
                         int32_t *iter, int32_t *status, double *pri_res, double *dua_res) {
+    return cpg_hip_solve_batch_state(h, B, theta, nullptr, nullptr, prim, dual, obj, iter, status, pri_res, dua_res);
+}
+
+int cpg_hip_solve_batch_state(cpg_handle_t h, int64_t B, const double *theta, const double *state_in, double *state_out,
+                              double *prim, double *dual, double *obj, int32_t *iter, int32_t *status,
+                              double *pri_res, double *dua_res) {
     if (!h) { set_error("null handle"); return CPG_E_BADARG; }
     if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
     if (B < 0 || !prim || !dual || !obj || !iter || !status || !pri_res || !dua_res || ((h->conic ? h->C.np_var : h->refactor_mode ? h->R.np_var : h->U.np_var) > 0 && !theta)) {
@@ -1050,10 +1120,15 @@ int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta, double *
     if ((rc = ensure(h->s_iter, b * sizeof(int32_t)))) return rc;
     if ((rc = ensure(h->s_status, b * sizeof(int32_t)))) return rc;
     if ((rc = rt_h2d(h, h->s_theta.p, theta, b * npv * sizeof(double)))) return rc;
-    rc = cpg_hip_solve_batch_device(h, B, (const double *)h->s_theta.p, (double *)h->s_prim.p, (double *)h->s_dual.p,
-                                    (double *)h->s_obj.p, (int32_t *)h->s_iter.p, (int32_t *)h->s_status.p,
-                                    (double *)h->s_pri.p, (double *)h->s_dua.p);
+    const size_t state_bytes = b * ((size_t)h->F.n + 2 * (size_t)h->F.m + 1) * sizeof(double);
+    if (state_in) { if ((rc = ensure(h->s_state_in, state_bytes))) return rc; if ((rc = rt_h2d(h, h->s_state_in.p, state_in, state_bytes))) return rc; }
+    if (state_out) { if ((rc = ensure(h->s_state_out, state_bytes))) return rc; }
+    rc = cpg_hip_solve_batch_device_state(h, B, (const double *)h->s_theta.p, state_in ? (const double *)h->s_state_in.p : nullptr,
+                                          state_out ? (double *)h->s_state_out.p : nullptr, (double *)h->s_prim.p,
+                                          (double *)h->s_dual.p, (double *)h->s_obj.p, (int32_t *)h->s_iter.p,
+                                          (int32_t *)h->s_status.p, (double *)h->s_pri.p, (double *)h->s_dua.p);
     if (rc) return rc;
+    if (state_out) { if ((rc = rt_d2h(h, state_out, h->s_state_out.p, state_bytes))) return rc; }
     if ((rc = rt_d2h(h, prim, h->s_prim.p, b * h->F.n_prim * sizeof(double)))) return rc;
     if ((rc = rt_d2h(h, dual, h->s_dual.p, b * h->F.n_dual * sizeof(double)))) return rc;
     if ((rc = rt_d2h(h, obj, h->s_obj.p, b * sizeof(double)))) return rc;

@@ -27,6 +27,8 @@ namespace cpg {
 #define CPG_INFTY 1e30
 #define CPG_MIN_SCALING 1e-4
 #define CPG_DIV_TOL 1e-30
+#define CPG_RHO_MIN 1e-6
+#define CPG_RHO_MAX 1e6
 #define CPG_NO_ROW 0xFFFF
 #ifndef CPG_ILP
 #define CPG_ILP 2   // unrolled slot iterations the scheduler may interleave in the hot loops
@@ -53,6 +55,11 @@ struct DevRagged {
     const double *vals;         // [nnz]
     const unsigned short *cols; // [nnz]
     int n_chunks, nnz;
+    // dictionary-compressed form (family libraries built with CPG_GEN_COMPRESSED): the distinct
+    // coefficients and, per entry, operand byte offset | dictionary byte offset << 16
+    const double *dict;
+    const unsigned *words;
+    int n_dict;
 };
 struct DevCsr {
     const int *ptr;
@@ -82,6 +89,7 @@ struct DevFamily {
     StreamProg kkt_stream;        // the same program in the layout of run_program_stream (n_pairs == 0: none)
     int n_prim, n_dual;
     const int *prim_idx, *dual_idx;
+    const int *ord;               // [n + m] canonical index of the entry at device position i (state I/O); null: identity
 };
 struct DevUpdate {
     int np_var;
@@ -95,6 +103,12 @@ struct DevUpdate {
 struct DevSettings {
     int max_iter, check_termination, scaled_termination;
     double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+    // what `osqp.OSQP().setup()` bakes into the generated workspace and the reference never touches
+    // again (not among the settings of cvxpygen/solvers/osqp.py:102-115): version dependent, see DESIGN.md
+    int check_dualgap;            // duality-gap term of OSQP >= 1.0's termination test
+    int adaptive_rho, adaptive_rho_interval;   // rho adaptation every `interval` iterations (per-instance factor path only)
+    double adaptive_rho_tolerance;
+    int warm_starting;            // 1: start from DevBatch::state_in when it is given
 };
 struct DevBatch {
     long long B;
@@ -102,7 +116,11 @@ struct DevBatch {
     double *prim, *dual, *obj, *pri_res, *dua_res;
     int *iter, *status;
     unsigned *counter;
-    double *scratch;   // [total waves][G][n + m]: delta_x | delta_y of the last check iteration
+    double *scratch;   // per-wavefront buffers of the refactorisation / adjoint kernels
+    // Sequential use (the reference's static workspace keeps its iterates between solves, warm_starting = 1):
+    // [B][n + 2 m + 1] = scaled iterates x | z | y in CANONICAL order, then rho.  Null: cold start / not wanted.
+    const double *state_in;
+    double *state_out;
 };
 
 template <int A, int B> struct MinI { static const int v = A < B ? A : B; };
@@ -331,12 +349,30 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
 // In a partial step lanes >= CNT load like everybody else (they hit later entries of the program, or
 // the zero padding behind it) and get their coefficient replaced by zero: no address arithmetic.
 #define CPG_GEN_PAD 64
+#ifdef CPG_GEN_COMPRESSED
+// Dictionary-compressed program: structured families repeat their coefficients (MPC 12/4/10: 1 739
+// distinct values among 8 523 entries), so an entry is ONE 32-bit word -- operand byte offset | byte
+// offset of its coefficient in a dictionary << 16 -- read with a literal offset; the coefficient and the
+// operand are then two independent gathers.  Same number of LDS operations per step as the plain form
+// (8-byte coefficient + 2-byte offset + gather), 4 instead of 10 bytes per entry: the program of that
+// family shrinks from 88 to 52 KB and a third wavefront per SIMD fits next to it.
+#define CPG_GEN_VB(vals, lane) ((const char *)(vals))
+#define CPG_GEN_CB(cols, lane) ((const char *)(cols) + (unsigned)(lane) * 4u)
+#define CPG_GEN_LOAD_CV(ID, E) const unsigned wd##ID = *(const unsigned *)(cb + (E) * 4u);
+#define CPG_GEN_LOAD_W(ID)                                                                         \
+    const double vl##ID = *(const double *)(vb + (wd##ID >> 16));                                  \
+    double x##ID[G];                                                                               \
+    _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) x##ID[g_] = *(const double *)(wb + (unsigned)g_ * ldwb + (wd##ID & 0xFFFFu));
+#else
+#define CPG_GEN_VB(vals, lane) ((const char *)(vals) + (unsigned)(lane) * 8u)
+#define CPG_GEN_CB(cols, lane) ((const char *)(cols) + (unsigned)(lane) * 2u)
 #define CPG_GEN_LOAD_CV(ID, E)                                                                     \
     const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
     const unsigned co##ID = *(const unsigned short *)(cb + (E) * 2u);
 #define CPG_GEN_LOAD_W(ID)                                                                         \
     double x##ID[G];                                                                               \
     _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) x##ID[g_] = *(const double *)(wb + (unsigned)g_ * ldwb + co##ID);
+#endif
 #define CPG_GEN_FMA_FULL(A, ID)                                                                    \
     _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = fma(vl##ID, x##ID[g_], A[g_]);
 #define CPG_GEN_FMA_PART(A, ID, CNT)                                                               \
@@ -462,22 +498,25 @@ CPG_DEV bool canonicalise(const DevFamily &F, const DevUpdate &U, const double *
     return cpgw::wave_any(bad);
 }
 
-// is_primal_infeasible on delta_y (OSQP paper sec. 3.4); wave-uniform result
+// is_primal_infeasible on delta_y (OSQP paper sec. 3.4); wave-uniform result.  The steps delta_x /
+// delta_y of the checked iteration are handed over in registers (element i on lane i % 64, slot i / 64).
 template <int NSX, int NSZ, typename Ctx>
 CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
-                               bool unsc, double eps, double *w, double *sdy, int lane) {
+                               bool unsc, double eps, double *w, const double (&dy)[NSZ], int lane) {
     double nrm = 0.0, lhs = 0.0;
+    double dyp[NSZ];                                   // delta_y projected on the polar of the recession cone of [l, u]
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        dyp[s] = 0.0;
         if (i < (unsigned)F.m) {
             const double uu = cx.u(s, i);
             const bool eq = ct[s] == 1;
             const double ll = eq ? uu : -CPG_INFTY;
             const bool iu = uu > CPG_INFTY * CPG_MIN_SCALING, il = !eq;
-            double d = cpgw::gld((const double *)sdy, i);
+            double d = dy[s];
             if (iu && il) d = 0.0; else if (iu) d = cpgw::dmin2(d, 0.0); else if (il) d = cpgw::dmax2(d, 0.0);
-            cpgw::gst(sdy, i, d);
+            dyp[s] = d;
             nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.E, i) * d : d));
             lhs += uu * cpgw::dmax2(d, 0.0) + ll * cpgw::dmin2(d, 0.0);
         }
@@ -488,7 +527,7 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
     lhs = cpgw::wave_sum(lhs);
     if (!(lhs < eps * nrm)) return false;
 #pragma unroll
-    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = cpgw::gld((const double *)sdy, i); }
+    for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = dyp[s]; }
     cpgw::lds_order();
     double r = 0.0;
 #pragma unroll
@@ -506,13 +545,13 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
 // is_dual_infeasible on delta_x; wave-uniform result
 template <int NSX, int NSZ, typename Ctx>
 CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
-                             bool unsc, double eps, double *w, const double *sdx, int lane) {
+                             bool unsc, double eps, double *w, const double (&dx)[NSX], int lane) {
     double nrm = 0.0, qdx = 0.0;
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         if (i < (unsigned)F.n) {
-            const double d = cpgw::gld(sdx, i);
+            const double d = dx[s];
             nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.D, i) * d : d));
             qdx += cx.q(s, i) * d;
         }
@@ -523,7 +562,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
     qdx = cpgw::wave_sum(qdx);
     if (!(qdx < -cs * eps * nrm)) return false;
 #pragma unroll
-    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = cpgw::gld(sdx, i); }
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = dx[s]; }
     cpgw::lds_order();
     double r = 0.0;
 #pragma unroll
@@ -554,13 +593,21 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
     return res;
 }
 
+// The three sparse products of update_info on the staged iterates (w = [x | y]) and the SCALED norms
+// OSQP's compute_rho_estimate needs; shared by the termination test and the rho adaptation.
+struct ScaledNorms {
+    double prim_res, dual_res;    // ||Ax - z||, ||Px + q + A'y||   (scaled space)
+    double nz, nax, nq, naty, npx;
+};
+
 // update_info + check_termination: residuals in the unscaled space (scaled_termination = 0),
 // optimality / infeasibility decisions.  status stays 11 (unsolved) when nothing triggers.
+// `sn` (optional) receives the scaled norms of the same products.
 template <int NSX, int NSZ, typename Ctx>
 CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
                        const DevSettings &S, const double (&Ix)[NSX], const double (&Iz)[NSZ],
-                       const double (&Iy)[NSZ], double *w, double *sdx, double *sdy, int lane,
-                       bool approximate) {
+                       const double (&Iy)[NSZ], const double (&dx)[NSX], const double (&dy)[NSZ],
+                       double *w, int lane, bool approximate, ScaledNorms *sn = nullptr) {
     const bool unsc = !S.scaled_termination;
     CheckOut o;
 #pragma unroll
@@ -568,7 +615,8 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
 #pragma unroll
     for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = Iy[s]; }
     cpgw::lds_order();
-    double rp = 0.0, nz = 0.0, na = 0.0;
+    double rp = 0.0, nz = 0.0, na = 0.0, sup = 0.0;
+    double s_rp = 0.0, s_nz = 0.0, s_na = 0.0;
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
@@ -578,10 +626,17 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
             rp = cpgw::dmax2(rp, fabs(ei * (ax - Iz[s])));
             nz = cpgw::dmax2(nz, fabs(ei * Iz[s]));
             na = cpgw::dmax2(na, fabs(ei * ax));
+            if (sn) { s_rp = cpgw::dmax2(s_rp, fabs(ax - Iz[s])); s_nz = cpgw::dmax2(s_nz, fabs(Iz[s])); s_na = cpgw::dmax2(s_na, fabs(ax)); }
+            if (S.check_dualgap) {   // support function of [l, u] at y: u'y+ + l'y-  (l = u on equality rows, -inf otherwise)
+                const double uu = cx.u(s, i), yy = Iy[s];
+                if (uu < CPG_INFTY * CPG_MIN_SCALING && yy > 0.0) sup += uu * yy;
+                if (ct[s] == 1 && uu > -CPG_INFTY * CPG_MIN_SCALING && yy < 0.0) sup += uu * yy;
+            }
         }
         cpgw::sched_fence();
     }
     double rd = 0.0, nq = 0.0, nat = 0.0, npx = 0.0, quad = 0.0, lin = 0.0;
+    double s_rd = 0.0, s_nq = 0.0, s_nat = 0.0, s_npx = 0.0;
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
@@ -594,6 +649,8 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
             nq = cpgw::dmax2(nq, fabs(di * qq));
             nat = cpgw::dmax2(nat, fabs(di * aty));
             npx = cpgw::dmax2(npx, fabs(di * px));
+            if (sn) { s_rd = cpgw::dmax2(s_rd, fabs(qq + px + aty)); s_nq = cpgw::dmax2(s_nq, fabs(qq));
+                      s_nat = cpgw::dmax2(s_nat, fabs(aty)); s_npx = cpgw::dmax2(s_npx, fabs(px)); }
             quad += Ix[s] * px;
             lin += qq * Ix[s];
         }
@@ -607,30 +664,60 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
                                        cpgw::dmax2(cpgw::wave_max_nonneg(nat), cpgw::wave_max_nonneg(npx)));
     quad = cpgw::wave_sum(quad); lin = cpgw::wave_sum(lin);
     o.prim_res = rp; o.dual_res = rd; o.obj = (0.5 * quad + lin) * F.cinv;
+    if (sn) {
+        sn->prim_res = cpgw::wave_max_nonneg(s_rp); sn->nz = cpgw::wave_max_nonneg(s_nz); sn->nax = cpgw::wave_max_nonneg(s_na);
+        sn->dual_res = cpgw::wave_max_nonneg(s_rd); sn->nq = cpgw::wave_max_nonneg(s_nq);
+        sn->naty = cpgw::wave_max_nonneg(s_nat); sn->npx = cpgw::wave_max_nonneg(s_npx);
+    }
 
     const double mult = approximate ? 10.0 : 1.0;
     const double ea = S.eps_abs * mult, er = S.eps_rel * mult;
     const double epi = S.eps_prim_inf * mult, edi = S.eps_dual_inf * mult;
     o.status = 11;
     if (rp > CPG_INFTY || rd > CPG_INFTY) { o.status = 9; o.obj = NAN; return o; }
-    bool pc = false, dc = false, pic = false, dic = false;
+    bool pc = false, dc = false, pic = false, dic = false, gc = true;
     if (F.m == 0) pc = true;
     else if (rp < ea + er * cpgw::dmax2(nz, na)) pc = true;
-    else pic = primal_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, epi, w, sdy, lane);
+    else pic = primal_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, epi, w, dy, lane);
     if (rd < ea + er * dn) dc = true;
-    else dic = dual_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, edi, w, sdx, lane);
-    if (pc && dc) o.status = approximate ? 2 : 1;
+    else dic = dual_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, edi, w, dx, lane);
+    if (S.check_dualgap) {   // OSQP >= 1.0: |primal - dual objective| against eps_abs + eps_rel max(|primal|, |dual|)
+        sup = cpgw::wave_sum(sup);
+        const double dual_obj = (-0.5 * quad - sup) * F.cinv, gap = fabs(quad + lin + sup) * F.cinv;
+        gc = gap < ea + er * cpgw::dmax2(fabs(o.obj), fabs(dual_obj));
+    }
+    if (pc && dc && gc) o.status = approximate ? 2 : 1;
     else if (pic) { o.status = approximate ? 4 : 3; o.obj = CPG_INFTY; }
     else if (dic) { o.status = approximate ? 6 : 5; o.obj = -CPG_INFTY; }
     return o;
 }
 
-// store_solution + cpg_retrieve_*: unscale, gather the user-facing entries, write the info scalars
+// store_solution + cpg_retrieve_*: unscale, gather the user-facing entries, write the info scalars;
+// with Bt.state_out also the workspace a sequential caller carries to its next solve: the scaled iterates
+// (reset to zero when there is no solution, as osqp_solve does) and rho.
 template <int NSX, int NSZ>
-CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)[NSX],
+CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)[NSX], const double (&Iz)[NSZ],
                       const double (&Iy)[NSZ], double dconst, long long b, double *w, int lane, int iter,
-                      const CheckOut &o) {
+                      const CheckOut &o, double rho) {
     const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
+    if (Bt.state_out) {
+        double *so = Bt.state_out + (size_t)b * (size_t)(F.n + 2 * F.m + 1);
+#pragma unroll
+        for (int s = 0; s < NSX; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            if (i < (unsigned)F.n) cpgw::gst(so, F.ord ? (unsigned)cpgw::gld(F.ord, i) : i, has_sol ? Ix[s] : 0.0);
+        }
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            if (i < (unsigned)F.m) {
+                const unsigned c = F.ord ? (unsigned)cpgw::gld(F.ord, (unsigned)F.n + i) : i;
+                cpgw::gst(so, (unsigned)F.n + c, has_sol ? Iz[s] : 0.0);
+                cpgw::gst(so, (unsigned)(F.n + F.m) + c, has_sol ? Iy[s] : 0.0);
+            }
+        }
+        if (lane == 0) so[F.n + 2 * F.m] = rho;
+    }
 #pragma unroll
     for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = has_sol ? cpgw::gld(F.D, i) * Ix[s] : NAN; }
 #pragma unroll
@@ -646,6 +733,25 @@ CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)
         Bt.pri_res[b] = o.prim_res; Bt.dua_res[b] = o.dual_res;
     }
     cpgw::lds_order();
+}
+
+// osqp_warm_start semantics of a sequential caller: the scaled iterates of the previous solve
+template <int NSX, int NSZ>
+CPG_DEV void load_state(const DevFamily &F, const double *si, double (&Ix)[NSX], double (&Iz)[NSZ],
+                        double (&Iy)[NSZ], int lane) {
+#pragma unroll
+    for (int s = 0; s < NSX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        if (i < (unsigned)F.n) Ix[s] = cpgw::gld(si, F.ord ? (unsigned)cpgw::gld(F.ord, i) : i);
+    }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        if (i < (unsigned)F.m) {
+            const unsigned c = F.ord ? (unsigned)cpgw::gld(F.ord, (unsigned)F.n + i) : i;
+            Iz[s] = cpgw::gld(si, (unsigned)F.n + c); Iy[s] = cpgw::gld(si, (unsigned)(F.n + F.m) + c);
+        }
+    }
 }
 
 // row class of slot s in the hot loop: a literal where the generated family has a uniform slot
@@ -686,13 +792,21 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #else
         const unsigned nnzp = (unsigned)R.nnz;
 #endif
+        const unsigned nt = cpgw::block_threads(), t0 = cpgw::thread_in_block();
+#ifdef CPG_GEN_COMPRESSED
+        double *lv = lds + lds_off;                         lds_off += (size_t)R.n_dict;
+        unsigned *lw = (unsigned *)(lds + lds_off);         lds_off += (size_t)((nnzp + 1) / 2);
+        for (unsigned t = t0; t < (unsigned)R.n_dict; t += nt) lv[t] = cpgw::gld(R.dict, t);
+        for (unsigned t = t0; t < nnzp; t += nt) lw[t] = t < (unsigned)R.nnz ? cpgw::gld(R.words, t) : 0u;   // padding: 0 * w[0]
+        const unsigned short *lc = (const unsigned short *)lw;
+#else
         double *lv = lds + lds_off;                         lds_off += (size_t)nnzp;
         unsigned short *lc = (unsigned short *)(lds + lds_off); lds_off += (size_t)((nnzp + 3) / 4);
-        const unsigned nt = cpgw::block_threads(), t0 = cpgw::thread_in_block();
         for (unsigned t = t0; t < nnzp; t += nt) {
             const bool in = t < (unsigned)R.nnz;
             lv[t] = in ? cpgw::gld(R.vals, t) : 0.0; lc[t] = in ? cpgw::gld(R.cols, t) : (unsigned short)0;
         }
+#endif
         LP.vals = lv; LP.cols = lc; LP.n_chunks = R.n_chunks; LP.dummy = (unsigned)R.nnz - 1u;
 #ifdef CPG_GEN_HEADER
         // the generated executor has every count / offset baked in; it only needs the per-lane
@@ -714,7 +828,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
     }
     cpgw::block_sync();
     double *w = lds + lds_off + (size_t)cpgw::wave_in_block() * G * ldw;
-    double *scr = Bt.scratch + (size_t)wave_global * G * N;
+    (void)wave_global;
     const long long ngroups = (Bt.B + G - 1) / G;
     const double rho_eq = 1e3 * F.rho, rho_in = F.rho, rho_fr = 1e-6;
     const double ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in, ri_fr = 1.0 / rho_fr;
@@ -755,114 +869,146 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
             co[g].prim_res = 0; co[g].dual_res = 0; co[g].obj = 0; co[g].status = 11;
             const double *theta = Bt.theta + (size_t)(b < Bt.B ? b : 0) * U.np_var;
             const bool bad = canonicalise<NSX, NSZ, NV>(F, U, theta, I[g], lane);
-            if (bad) { co[g].status = -2; co[g].obj = NAN; }
+            if (Bt.state_in && S.warm_starting && b < Bt.B)
+                load_state<NSX, NSZ>(F, Bt.state_in + (size_t)b * (size_t)(F.n + 2 * F.m + 1), I[g].x, I[g].z, I[g].y, lane);
+            if (__builtin_expect(bad && !I[g].done, 0)) {
+                // a row changed class: the family's factor does not serve this instance (the host layer
+                // sends it through the per-instance factor path, cvxpygen_amd/runtime.py)
+                co[g].status = -2; co[g].obj = NAN;
+                finalize<NSX, NSZ>(F, Bt, I[g].x, I[g].z, I[g].y, I[g].dconst, I[g].b, w + g * ldw, lane, 0, co[g], F.rho);
+                I[g].done = 1;
+            }
             n_open += I[g].done ? 0 : 1;
         }
 
         int iter = 0;
-        bool first = true;
-#pragma nounroll
-        while (n_open > 0) {
-            bool chk = false;
+        // right-hand side of the KKT system and its solution (the hot code: no termination test here)
+        auto rhs_and_solve = [&]() __attribute__((always_inline)) {
             const int lane_outer = lane;
             const int lane = cpgw::opaque(lane_outer);   // per-iteration copy, see cpgw::opaque
             cpgw::assume((unsigned)lane < 64u);
             signed char ct[NSZ];
 #pragma unroll
             for (int s = 0; s < NSZ; s++) ct[s] = (signed char)cpgw::opaque((int)ct_reg[s]);
-            if (!first) {
-                iter++;
-                chk = (S.check_termination > 0 && iter % S.check_termination == 0) || iter >= S.max_iter;
-                // ---- right-hand side of the KKT system
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                double *wg = w + g * ldw;
+#pragma unroll
+                for (int s = 0; s < NSX; s++) {
+                    const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                    if (i < n_c) wg[i] = F.sigma * I[g].x[s] - SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.q(s, i);
+                    CPG_FENCE_EVERY(s);
+                }
+#pragma unroll
+                for (int s = 0; s < NSZ; s++) {
+                    const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                    const int cts = CPG_ROW_CLASS(s);
+                    const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
+                    if (i < m_c) wg[n_c + i] = I[g].z[s] - ri * I[g].y[s];
+                    CPG_FENCE_EVERY(s);
+                }
+            }
+            cpgw::lds_order();
+#ifdef CPG_GEN_HEADER
+            if (LDSPROG) run_program_gen<G>(LP.vals, LP.cols, LP.rows16, w, ldw, lane);
+#else
+            if (LDSPROG) run_program_lds<G>(LP, w, ldw, lane);
+#endif
+            else if (G == 1 && F.kkt_stream.n_pairs > 0) run_program_stream(F.kkt_stream, w, lane);
+            else run_program<G>(F.kkt, w, ldw, lane);
+        };
+        // relaxation, projection on [l, u], dual update; the instantiation of a checked iteration also
+        // keeps the steps delta_x / delta_y (registers) for OSQP's infeasibility tests
+        auto update = [&](auto stash_c, double (&dxr)[G][NSX], double (&dyr)[G][NSZ]) __attribute__((always_inline)) {
+            constexpr bool STASH = decltype(stash_c)::value;
+            const int lane_outer = lane;
+            const int lane = cpgw::opaque(lane_outer);
+            cpgw::assume((unsigned)lane < 64u);
+            signed char ct[NSZ];
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) ct[s] = (signed char)cpgw::opaque((int)ct_reg[s]);
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const double *wg = w + g * ldw;
+#pragma unroll
+                for (int s = 0; s < NSX; s++) {
+                    const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                    if (STASH) dxr[g][s] = 0.0;
+                    if (i < n_c) {
+                        const double xn = F.alpha * wg[fpx[s]] + (1.0 - F.alpha) * I[g].x[s];
+                        if (STASH) dxr[g][s] = xn - I[g].x[s];
+                        I[g].x[s] = xn;
+                    }
+                    CPG_FENCE_EVERY(s);
+                }
+#pragma unroll
+                for (int s = 0; s < NSZ; s++) {
+                    const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                    if (STASH) dyr[g][s] = 0.0;
+                    if (i < m_c) {
+                        const int cts = CPG_ROW_CLASS(s);
+                        const double rv = cts == 1 ? rho_eq : (cts == 0 ? rho_in : rho_fr);
+                        const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
+                        const double zp = I[g].z[s], yp = I[g].y[s];
+                        const double zt = (zp - ri * yp) + ri * wg[fpz[s]];
+                        const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
+                        // projection on [l, u]: equality rows have l = u, all others l = -inf
+                        const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.u(s, i);
+                        const double zn = cts == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
+                        const double dyv = rv * (zr - zn);
+                        I[g].z[s] = zn; I[g].y[s] = yp + dyv;
+                        if (STASH) dyr[g][s] = dyv;
+                    }
+                    CPG_FENCE_EVERY(s);
+                }
+            }
+            cpgw::lds_order();
+        };
+#pragma nounroll
+        while (n_open > 0) {
+            double dxr[G][NSX], dyr[G][NSZ];
+            if (iter < S.max_iter) {
+                // checked iterations: the multiples of check_termination, and max_iter (osqp_solve)
+                int next_chk = S.max_iter;
+                if (S.check_termination > 0) {
+                    const int c = (iter / S.check_termination + 1) * S.check_termination;
+                    if (c < next_chk) next_chk = c;
+                }
+                // plain iterations in their own loop: the termination test, its products and their
+                // register demand stay outside the hot code
+#pragma nounroll
+                for (;;) {
+                    iter++;
+                    rhs_and_solve();
+                    if (iter >= next_chk) break;
+                    update(std::false_type{}, dxr, dyr);
+                }
+                update(std::true_type{}, dxr, dyr);
+            } else {   // max_iter <= 0: the test runs on the initial iterates
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    double *wg = w + g * ldw;
 #pragma unroll
-                    for (int s = 0; s < NSX; s++) {
-                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < n_c) wg[i] = F.sigma * I[g].x[s] - SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.q(s, i);
-                        CPG_FENCE_EVERY(s);
-                    }
+                    for (int s = 0; s < NSX; s++) dxr[g][s] = 0.0;
 #pragma unroll
-                    for (int s = 0; s < NSZ; s++) {
-                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        const int cts = CPG_ROW_CLASS(s);
-                        const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
-                        if (i < m_c) wg[n_c + i] = I[g].z[s] - ri * I[g].y[s];
-                        CPG_FENCE_EVERY(s);
-                    }
+                    for (int s = 0; s < NSZ; s++) dyr[g][s] = 0.0;
                 }
-                cpgw::lds_order();
-#ifdef CPG_GEN_HEADER
-                if (LDSPROG) run_program_gen<G>(LP.vals, LP.cols, LP.rows16, w, ldw, lane);
-#else
-                if (LDSPROG) run_program_lds<G>(LP, w, ldw, lane);
-#endif
-                else if (G == 1 && F.kkt_stream.n_pairs > 0) run_program_stream(F.kkt_stream, w, lane);
-                else run_program<G>(F.kkt, w, ldw, lane);
-                // ---- relaxation, projection on [l, u], dual update; the delta_x / delta_y stash of a check
-                // iteration is a separate instantiation so that ordinary iterations carry no branches
-                auto update = [&](auto stash_c) {
-                    constexpr bool STASH = decltype(stash_c)::value;
-#pragma unroll
-                    for (int g = 0; g < G; g++) {
-                        const double *wg = w + g * ldw;
-                        double *sdx = scr + (size_t)g * N, *sdy = sdx + n_c;
-#pragma unroll
-                        for (int s = 0; s < NSX; s++) {
-                            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                            if (i < n_c) {
-                                const double xn = F.alpha * wg[fpx[s]] + (1.0 - F.alpha) * I[g].x[s];
-                                if (STASH) cpgw::gst(sdx, i, xn - I[g].x[s]);
-                                I[g].x[s] = xn;
-                            }
-                            CPG_FENCE_EVERY(s);
-                        }
-#pragma unroll
-                        for (int s = 0; s < NSZ; s++) {
-                            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                            if (i < m_c) {
-                                const int cts = CPG_ROW_CLASS(s);
-                                const double rv = cts == 1 ? rho_eq : (cts == 0 ? rho_in : rho_fr);
-                                const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
-                                const double zp = I[g].z[s], yp = I[g].y[s];
-                                const double zt = (zp - ri * yp) + ri * wg[fpz[s]];
-                                const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
-                                // projection on [l, u]: equality rows have l = u, all others l = -inf
-                                const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}.u(s, i);
-                                const double zn = cts == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
-                                const double dyv = rv * (zr - zn);
-                                I[g].z[s] = zn; I[g].y[s] = yp + dyv;
-                                if (STASH) cpgw::gst(sdy, i, dyv);
-                            }
-                            CPG_FENCE_EVERY(s);
-                        }
-                    }
-                };
-                if (__builtin_expect(chk, 0)) update(std::true_type{}); else update(std::false_type{});
-                cpgw::lds_order();
             }
-            first = false;
-            // ---- termination test / bookkeeping (single finalize site)
+            // ---- termination test / bookkeeping
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (I[g].done) continue;
                 CheckOut o = co[g];
                 double *wg = w + g * ldw;
-                double *sdx = scr + (size_t)g * N, *sdy = sdx + F.n;
-                if (__builtin_expect(o.status == 11 && chk, 0)) {
 #pragma nounroll
-                    for (int pass = 0; pass < 2; pass++) {
-                        if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                        o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct, S,
-                                                                    I[g].x, I[g].z, I[g].y, wg, sdx, sdy, lane, pass == 1);
-                    }
-                    if (o.status == 11 && iter >= S.max_iter) o.status = 7;
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
+                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S,
+                                                                I[g].x, I[g].z, I[g].y, dxr[g], dyr[g], wg, lane, pass == 1);
                 }
-                if (o.status == 11 && iter >= S.max_iter) o.status = 7;   // max_iter == 0
+                if (o.status == 11 && iter >= S.max_iter) o.status = 7;
                 co[g] = o;
-                if (__builtin_expect(o.status != 11, 0)) {
-                    finalize<NSX, NSZ>(F, Bt, I[g].x, I[g].y, I[g].dconst, I[g].b, wg, lane, iter, o);
+                if (o.status != 11) {
+                    finalize<NSX, NSZ>(F, Bt, I[g].x, I[g].z, I[g].y, I[g].dconst, I[g].b, wg, lane, iter, o, F.rho);
                     I[g].done = 1; n_open--;
                 }
             }

@@ -53,7 +53,7 @@ CPG_DEV double lim_scaling(double v) { v = v < 1e-4 ? 1.0 : v; return v > 1e4 ? 
 
 // per-wavefront buffer layout (doubles)
 struct InstBuf {
-    double *P, *A, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *Lx, *Dg, *Dginv, *sv, *sdx, *sdy;
+    double *P, *A, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *Lx, *Dg, *Dginv, *sv;
 };
 CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
     InstBuf o;
@@ -62,7 +62,7 @@ CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
     o.D = b; b += n; o.Dinv = b; b += n; o.E = b; b += m; o.Einv = b; b += m;
     o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
     o.Lx = b; b += R.nnzL; o.Dg = b; b += N; o.Dginv = b; b += N;
-    o.sv = b; b += R.sol_nnz; o.sdx = b; b += n; o.sdy = b; b += m;
+    o.sv = b; b += R.sol_nnz;
     return o;
 }
 
@@ -231,8 +231,8 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
     const int ldw = R.sol_slots;
     double *w = lds + (size_t)cpgw::wave_in_block() * ldw;
     const InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F0, R);
-    const double rho_eq = 1e3 * F0.rho, rho_in = F0.rho, rho_fr = 1e-6;
-    const double ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in, ri_fr = 1.0 / rho_fr;
+    const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
+    const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
     unsigned short fpx[NSX], fpz[NSZ];
 #pragma unroll
     for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; fpx[s] = i < n ? cpgw::gld(R.sol_fpos, i) : 0; }
@@ -246,6 +246,12 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         if ((long long)ig >= Bt.B) break;
         const long long b = (long long)ig;
         const double *theta = Bt.theta + (size_t)b * R.np_var;
+        // rho of this instance: the family's, or what a sequential caller's previous solve left (rho
+        // adaptation is workspace state in OSQP); osqp_solve clamps it
+        const double *state_in = (Bt.state_in && S.warm_starting) ? Bt.state_in + (size_t)b * state_len : nullptr;
+        double rho = state_in ? cpgw::gld(state_in, n + 2u * m) : F0.rho;
+        rho = cpgw::dmin2(cpgw::dmax2(rho, CPG_RHO_MIN), CPG_RHO_MAX);
+        double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
         // ---- 1. canonicalise (unscaled): P, A values, q, u, d
         for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) cpgw::gst(B.A, k, csr_row(R.map_A, k, theta, cpgw::gld(R.A_base, k)));
@@ -359,10 +365,16 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         for (int s = 0; s < NSX; s++) x[s] = 0.0;
 #pragma unroll
         for (int s = 0; s < NSZ; s++) { z[s] = 0.0; y[s] = 0.0; }
+        if (state_in) load_state<NSX, NSZ>(F, state_in, x, z, y, lane);
         CheckOut o;
         o.prim_res = 0; o.dual_res = 0; o.obj = 0; o.status = 11;
         int iter = 0;
-        // One ADMM iteration; `chk` also stores the steps delta x / delta y for the termination check.
+        double dxr[NSX], dyr[NSZ];      // steps of the last checked iteration (infeasibility tests)
+#pragma unroll
+        for (int s = 0; s < NSX; s++) dxr[s] = 0.0;
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) dyr[s] = 0.0;
+        // One ADMM iteration; `chk` also keeps the steps delta x / delta y for the termination check.
         auto admm_iteration = [&](const bool chk) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < n) w[i] = F.sigma * x[s] - cx.q(s, i); }
@@ -379,7 +391,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;
                 if (i < n) {
                     const double xn = F.alpha * w[fpx[s]] + (1.0 - F.alpha) * x[s];
-                    if (chk) cpgw::gst(B.sdx, i, xn - x[s]);
+                    if (chk) dxr[s] = xn - x[s];
                     x[s] = xn;
                 }
             }
@@ -396,35 +408,62 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                     const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
                     const double dyv = rv * (zr - zn);
                     z[s] = zn; y[s] = yp + dyv;
-                    if (chk) cpgw::gst(B.sdy, i, dyv);
+                    if (chk) dyr[s] = dyv;
                 }
             }
             cpgw::lds_order();
         };
-        // The iterations between two termination checks run in their own inner loop: the check (row
-        // products, norms, infeasibility tests) needs many registers, and with its code inside the
-        // hot loop the iterates were spilled and reloaded in every iteration.
+        const int chk_int = S.check_termination, ad_int = S.adaptive_rho ? S.adaptive_rho_interval : 0;
+        // The iterations between two events (termination check, rho adaptation, max_iter) run in their own
+        // inner loop: the check (row products, norms, infeasibility tests) needs many registers, and with
+        // its code inside the hot loop the iterates were spilled and reloaded in every iteration.
 #pragma nounroll
         while (o.status == 11) {
-            if (iter >= S.max_iter) { o.status = 7; break; }
-            int next_chk = S.max_iter;                          // checked iterations: multiples of
-            if (S.check_termination > 0) {                      // check_termination, and max_iter
-                const int c = (iter / S.check_termination + 1) * S.check_termination;
-                if (c < next_chk) next_chk = c;
-            }
+            if (iter < S.max_iter) {
+                int next_ev = S.max_iter;
+                if (chk_int > 0) { const int c = (iter / chk_int + 1) * chk_int; if (c < next_ev) next_ev = c; }
+                if (ad_int > 0) { const int c = (iter / ad_int + 1) * ad_int; if (c < next_ev) next_ev = c; }
 #pragma nounroll
-            for (; iter < next_chk - 1; iter++) admm_iteration(false);
-            iter++;
-            admm_iteration(true);
-            cpgw::mem_order();
-#pragma nounroll
-            for (int pass = 0; pass < 2; pass++) {
-                if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, w, B.sdx, B.sdy, lane, pass == 1);
+                for (; iter < next_ev - 1; iter++) admm_iteration(false);
+                iter++;
+                admm_iteration(true);
             }
-            if (o.status == 11 && iter >= S.max_iter) o.status = 7;
+            const bool can_check = chk_int > 0 && iter > 0 && iter % chk_int == 0;
+            const bool adapt = ad_int > 0 && iter > 0 && iter % ad_int == 0;
+            const bool last = iter >= S.max_iter;
+            ScaledNorms sn;
+            bool have_info = false;
+            if (can_check) {
+                o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, false, &sn);
+                have_info = true;
+                if (o.status != 11) break;
+            }
+            if (adapt) {
+                // adapt_rho (OSQP paper sec. 5.2): rho <- rho sqrt(normalised primal / dual residual); a new
+                // factorisation only when it changed by more than adaptive_rho_tolerance
+                if (!have_info) (void)check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, false, &sn);
+                const double pr = sn.prim_res / (cpgw::dmax2(sn.nz, sn.nax) + CPG_DIV_TOL);
+                const double dr = sn.dual_res / (cpgw::dmax2(sn.nq, cpgw::dmax2(sn.naty, sn.npx)) + CPG_DIV_TOL);
+                const double rn = cpgw::dmin2(cpgw::dmax2(rho * sqrt(pr / dr), CPG_RHO_MIN), CPG_RHO_MAX);
+                if (rn > rho * S.adaptive_rho_tolerance || rn < rho / S.adaptive_rho_tolerance) {
+                    rho = rn; rho_eq = 1e3 * rho; rho_in = rho; ri_eq = 1.0 / rho_eq; ri_in = 1.0 / rho_in;
+#pragma unroll
+                    for (int s = 0; s < NSZ; s++) {
+                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                        if (i < m) cpgw::gst(B.rinv, i, ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr));
+                    }
+                    cpgw::mem_order();
+                    numeric_ldl(R, B, F0.sigma, lane);
+                    substitution_values(R, B, lane);
+                }
+            }
+            if (last) {
+                if (!can_check) o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, false);
+                if (o.status == 11) o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, true);
+                if (o.status == 11) o.status = 7;
+            }
         }
-        finalize<NSX, NSZ>(F, Bt, x, y, dconst, b, w, lane, iter, o);
+        finalize<NSX, NSZ>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);
     }
 }
 

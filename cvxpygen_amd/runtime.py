@@ -37,6 +37,11 @@ STATUS_STRINGS = {1: 'solved', 2: 'solved inaccurate', 3: 'primal infeasible',
                   4: 'primal infeasible inaccurate', 5: 'dual infeasible',
                   6: 'dual infeasible inaccurate', 7: 'maximum iterations reached',
                   9: 'problem non convex', 11: 'unsolved', -2: 'needs refactorization'}
+STATUS_NEEDS_REFACTOR = -2
+
+# constants of the generated OSQP workspace (what osqp.OSQP().setup() bakes in at code generation,
+# cvxpygen/solvers/osqp.py:126-131); version dependent, see DESIGN.md section 2
+BUILD_OPTIONS = ('adaptive_rho', 'adaptive_rho_interval', 'adaptive_rho_tolerance', 'check_dualgap')
 
 # cvxpy-style aliases of the reference (`stgs_translation`, cvxpygen/solvers/osqp.py:110,
 # cvxpygen/solvers/_interface.py:196-199)
@@ -66,7 +71,8 @@ class _Family(C.Structure):
                 ('n_slots', C.c_int32), ('fpos', _u16p), ('n_vary_x', C.c_int32), ('n_vary_z', C.c_int32),
                 ('kkt', _Program), ('A_rows', _Program), ('P_rows', _Program), ('At_rows', _Program),
                 ('kkt_ragged', _Ragged),
-                ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip)]
+                ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip),
+                ('ord', _ip)]
 
 
 class _Refactor(C.Structure):
@@ -105,9 +111,9 @@ class CpgLibrary:
 
     SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_create_clarabel', 'cpg_hip_destroy', 'cpg_hip_last_error',
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
-               'cpg_hip_get_setting', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
+               'cpg_hip_get_setting', 'cpg_hip_set_build_option', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
                'cpg_hip_solve_batch',
-               'cpg_hip_solve_batch_device', 'cpg_hip_synchronize', 'cpg_hip_last_kernel_ms',
+               'cpg_hip_solve_batch_device', 'cpg_hip_solve_batch_state', 'cpg_hip_solve_batch_device_state', 'cpg_hip_synchronize', 'cpg_hip_last_kernel_ms',
                'cpg_hip_set_launch', 'cpg_hip_set_program_placement', 'cpg_hip_malloc', 'cpg_hip_free', 'cpg_hip_memcpy_h2d',
                'cpg_hip_memcpy_d2h']
 
@@ -129,12 +135,15 @@ class CpgLibrary:
         L.cpg_hip_set_default_settings.argtypes = [C.c_void_p]
         L.cpg_hip_set_setting.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.cpg_hip_get_setting.argtypes = [C.c_void_p, C.c_char_p, _dp]
+        L.cpg_hip_set_build_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.cpg_hip_set_update.argtypes = [C.c_void_p, C.POINTER(_Update)]
         L.cpg_hip_set_refactor.argtypes = [C.c_void_p, C.POINTER(_Refactor)]
         L.cpg_hip_set_gradient.argtypes = [C.c_void_p, C.POINTER(_Gradient)]
         L.cpg_hip_gradient_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp]
         L.cpg_hip_solve_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
         L.cpg_hip_solve_batch_device.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
+        L.cpg_hip_solve_batch_state.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
+        L.cpg_hip_solve_batch_device_state.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10
         L.cpg_hip_synchronize.argtypes = [C.c_void_p]
         L.cpg_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.cpg_hip_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -268,6 +277,7 @@ class BatchResult:
     dual_flat: Optional[np.ndarray] = None
     sol_x: Optional[np.ndarray] = None      # canonical solution (full_output solvers only)
     sol_y: Optional[np.ndarray] = None
+    state: Optional[np.ndarray] = None      # workspace after the solve (solve(..., return_state=True))
 
     def status_str(self) -> List[str]:
         return [STATUS_STRINGS.get(int(s), 'unknown') for s in self.status]
@@ -278,10 +288,20 @@ class BatchSolver:
     `cpg_solve(prob, updated_params, **kwargs)` for B instances at once."""
 
     def __init__(self, desc: FamilyDescriptor, device: int = 0, lib_path: Optional[str] = None,
-                 plan: Optional[FamilyPlan] = None, ordering: str = 'mindeg', full_output: bool = False):
+                 plan: Optional[FamilyPlan] = None, ordering: str = 'mindeg', full_output: bool = False,
+                 build_options: Optional[Dict[str, float]] = None):
         """full_output: return the complete canonical solution (sol_x, sol_y) -- what the reference's
-        `cpg_solve_and_gradient_info` hands to `cpg_gradient` (templates/cpg_solver.py.jinja2:122-173)"""
+        `cpg_solve_and_gradient_info` hands to `cpg_gradient` (templates/cpg_solver.py.jinja2:122-173).
+        build_options: constants of the generated OSQP workspace (BUILD_OPTIONS), e.g.
+        {'adaptive_rho': 1, 'adaptive_rho_interval': 50, 'check_dualgap': 1} for an OSQP >= 1.0 build."""
         self.full_output = full_output
+        self.build_options = dict(build_options or {})
+        for k in self.build_options:
+            if k not in BUILD_OPTIONS:
+                raise AttributeError(f'Build option "{k}" not available.')
+        self._settings_kwargs: Dict[str, float] = {}
+        self._ref_key = None
+        self._grad_loaded = False
         if desc.solver != 'OSQP':
             raise ValueError(f'BatchSolver handles OSQP families, not {desc.solver}')
         self.desc = desc
@@ -306,7 +326,8 @@ class BatchSolver:
         fpos = np.ascontiguousarray(p.kkt.final_pos, dtype=np.uint16)
         prim_idx = np.ascontiguousarray(p.posx if full_output else p.prim_idx, dtype=np.int32)
         dual_idx = np.ascontiguousarray(p.posz if full_output else p.dual_idx, dtype=np.int32)
-        keep += [D, E, ctype, fpos, prim_idx, dual_idx]
+        ord_ = np.ascontiguousarray(np.concatenate([p.ordx, p.ordz]), dtype=np.int32)
+        keep += [D, E, ctype, fpos, prim_idx, dual_idx, ord_]
         rg = p.kkt_ragged
         rg_ctab = np.ascontiguousarray(rg.ctab, dtype=np.int32)
         rg_desc = np.ascontiguousarray(rg.desc, dtype=np.uint32)
@@ -326,9 +347,10 @@ class BatchSolver:
             P_rows=_program_struct(p.P_rows, keep), At_rows=_program_struct(p.At_rows, keep),
             kkt_ragged=ragged,
             n_prim=len(prim_idx), prim_idx=prim_idx.ctypes.data_as(_ip),
-            n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip))
+            n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip), ord=ord_.ctypes.data_as(_ip))
         self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), device, C.byref(self.h)),
                        'cpg_hip_create_osqp')
+        self._apply_build_options(self.h)
         self.device = device
         self.h_shared = self.h
         self.h_ref = C.c_void_p()          # canonical-order handle of the refactorisation path
@@ -373,17 +395,35 @@ class BatchSolver:
             kkt=empty, A_rows=empty, P_rows=empty, At_rows=empty,
             kkt_ragged=_Ragged(0, 0, None, None, None, None),
             n_prim=len(prim_idx), prim_idx=prim_idx.ctypes.data_as(_ip),
-            n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip))
+            n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip), ord=None)
         self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), self.device, C.byref(self.h_ref)),
                        'cpg_hip_create_osqp (refactor handle)')
+        self._apply_build_options(self.h_ref)
         if getattr(self, '_launch', None):
             self.lib.check(self.lib.L.cpg_hip_set_launch(self.h_ref, *self._launch), 'set_launch')
         if getattr(self, '_placement', None) is not None:
             self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h_ref, self._placement), 'set_program_placement')
 
-    def _set_refactor(self, cols: np.ndarray, th_fixed: np.ndarray):
+    def _apply_build_options(self, hh) -> None:
+        for k, v in self.build_options.items():
+            self.lib.check(self.lib.L.cpg_hip_set_build_option(hh, k.encode(), float(v)), 'cpg_hip_set_build_option')
+
+    @property
+    def adaptive_rho(self) -> bool:
+        bo = self.build_options
+        return bool(bo.get('adaptive_rho', 0)) and int(bo.get('adaptive_rho_interval', 50)) > 0
+
+    def _set_refactor(self, cols: np.ndarray, th_fixed: np.ndarray, q_setup: Optional[np.ndarray] = None):
+        """tables of the per-instance factor path for this column subset; solve and gradient share them,
+        one signature (cols, fixed part of theta, q of the workspace) decides whether they are current"""
         self._ensure_refactor_handle()
         desc, rp, o = self.desc, self._rplan, self.plan.osqp
+        if q_setup is None:
+            q_setup = desc.default_canon()['q']
+        q_setup = np.ascontiguousarray(q_setup, dtype=np.float64)
+        key = (np.asarray(cols).tobytes(), np.asarray(th_fixed).tobytes(), q_setup.tobytes())
+        if key == self._ref_key:
+            return
         keep: list = []
 
         def split(pid, clip=False):
@@ -397,7 +437,6 @@ class BatchSolver:
             return base, _csr_struct(Mv, keep)
 
         Pb, MP = split('P'); Ab, MA = split('A'); qb, Mq = split('q'); ub, Mu = split('u', clip=True)
-        q_setup = np.ascontiguousarray(desc.default_canon()['q'], dtype=np.float64)
         keep.append(q_setup)
         Cd = sp.csr_matrix(desc.maps['d'])
         d_base = float((Cd @ th_fixed)[0]) if desc.nonzero_d else 0.0
@@ -426,6 +465,7 @@ class BatchSolver:
             map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md, q_setup=_d(q_setup))
         self.lib.check(self.lib.L.cpg_hip_set_refactor(self.h_ref, C.byref(rf)), 'cpg_hip_set_refactor')
         self._refactor_keep = keep
+        self._ref_key = key
 
     def __del__(self):
         try:
@@ -437,11 +477,15 @@ class BatchSolver:
     def apply_settings(self, **kwargs) -> None:
         """Reference semantics: reset to defaults, then apply the keyword arguments
         (`cvxpygen/templates/cpg_solver.py.jinja2:55-60`)."""
+        self._settings_kwargs = dict(kwargs)
+        self._apply_settings_to(self.h)
+
+    def _apply_settings_to(self, hh) -> None:
         L = self.lib.L
-        self.lib.check(L.cpg_hip_set_default_settings(self.h), 'set_default_settings')
-        for k, v in kwargs.items():
+        self.lib.check(L.cpg_hip_set_default_settings(hh), 'set_default_settings')
+        for k, v in self._settings_kwargs.items():
             name = SETTING_ALIASES.get(k, k)
-            if L.cpg_hip_set_setting(self.h, name.encode(), float(v)) != 0:
+            if L.cpg_hip_set_setting(hh, name.encode(), float(v)) != 0:
                 raise AttributeError(f'Solver setting "{k}" not available.')
 
     def set_launch(self, waves_per_block=0, inst_per_wave=0, blocks_per_cu=0):
@@ -459,7 +503,15 @@ class BatchSolver:
                 self.lib.check(self.lib.L.cpg_hip_set_program_placement(hh, in_lds), 'set_program_placement')
 
     # ---- which parameters vary ----------------------------------------------------------------------
-    def set_updated(self, updated_params: Optional[Sequence[str]] = None) -> None:
+    def set_updated(self, updated_params: Optional[Sequence[str]] = None, theta_base: Optional[np.ndarray] = None,
+                    q_setup: Optional[np.ndarray] = None, path: str = 'auto') -> None:
+        """Which user parameters vary across the batch.  Every other parameter is folded into the base
+        vectors at `theta_base` (default: the code-generation-time values theta0 -- what a fresh process of
+        the reference holds; a sequential caller passes the values its workspace holds now).
+        path: 'auto' -- shared factor unless a varying parameter enters P / A or rho adaptation is on;
+        'shared' / 'refactor' force one (a caller that forces 'shared' guarantees that P and A at these
+        values are the family's); q_setup: the unscaled q the workspace held when its matrices were last
+        updated (the cost scaling of OSQP's re-equilibration sees that one)."""
         desc, p, o = self.desc, self.plan, self.plan.osqp
         if updated_params is None:
             updated_params = desc.param_names
@@ -469,38 +521,45 @@ class BatchSolver:
             if nm not in names:
                 names.append(nm)
         names = [q.name for q in desc.params if q.name in names]     # theta order
-        key = tuple(names)
-        if key == self._update_key:
-            return
         dep = desc.user_p_name_to_canon_outdated()
         touched = set()
         for nm in names:
             touched.update(dep[nm])
+        refactor = path == 'refactor' or (path == 'auto' and (bool(touched & {'P', 'A'}) or self.adaptive_rho))
+        if self.adaptive_rho and not refactor:
+            raise ValueError('rho adaptation needs the per-instance factor path')
+        base = desc.theta0 if theta_base is None else np.asarray(theta_base, dtype=np.float64)
+        key = (tuple(names), refactor, None if theta_base is None else base.tobytes(),
+               None if q_setup is None else np.asarray(q_setup, dtype=np.float64).tobytes())
+        if key == self._update_key:
+            return
         cols = np.concatenate([np.arange(desc.param(nm).col, desc.param(nm).col + desc.param(nm).size)
                                for nm in names]).astype(np.int64) if names else np.zeros(0, np.int64)
         NP = desc.NP
         fixed = np.ones(NP + 1, dtype=bool)
         fixed[cols] = False
-        th_fixed = np.where(fixed, desc.theta0, 0.0)
-        if touched & {'P', 'A'}:
-            # a parameter enters P or A: per-instance equilibration + refactorisation path
-            self._set_refactor(cols, th_fixed)
+        th_fixed = np.where(fixed, base, 0.0)
+        self._th_fixed = th_fixed
+        if refactor:
+            # per-instance equilibration + factorisation path
+            self._set_refactor(cols, th_fixed, q_setup)
             self.h = self.h_ref
             self._update_key, self._update_keep = key, []
             self._var_cols, self.np_var = cols, len(cols)
             self._updated_names = names
+            self._q_setup = q_setup
             return
         self.h = self.h_shared
         keep: list = []
 
         def split(pid, scale, order, clip):
             Cm = sp.csr_matrix(desc.maps[pid])
-            base = np.asarray(Cm @ th_fixed).ravel()
+            base_v = np.asarray(Cm @ th_fixed).ravel()
             if clip:
-                base = np.clip(base, -CPG_INF, CPG_INF)
+                base_v = np.clip(base_v, -CPG_INF, CPG_INF)
             Mv = sp.csr_matrix(Cm[:, cols]) if len(cols) else sp.csr_matrix((Cm.shape[0], 0))
             Mv = sp.diags(scale) @ Mv
-            return np.ascontiguousarray((scale * base)[order]), sp.csr_matrix(Mv)[order]
+            return np.ascontiguousarray((scale * base_v)[order]), sp.csr_matrix(Mv)[order]
 
         qb, Mq = split('q', o.scaling.c * o.scaling.D, p.ordx, False)
         ub, Mu = split('u', o.scaling.E, p.ordz, True)
@@ -515,6 +574,7 @@ class BatchSolver:
         self._update_key, self._update_keep = key, keep
         self._var_cols, self.np_var = cols, len(cols)
         self._updated_names = names
+        self._q_setup = q_setup
 
     # ---- adjoint ---------------------------------------------------------------------------------------
     def _set_gradient(self):
@@ -548,8 +608,8 @@ class BatchSolver:
         self._gradient_keep = keep
 
     def gradient(self, params: Dict[str, np.ndarray], sol_x: np.ndarray, sol_y: np.ndarray,
-                 dvars: Dict[str, np.ndarray], updated_params: Optional[Sequence[str]] = None
-                 ) -> Dict[str, np.ndarray]:
+                 dvars: Dict[str, np.ndarray], updated_params: Optional[Sequence[str]] = None,
+                 theta_base: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
         """Batched `cpg_gradient` (templates/cpg_solver.py.jinja2:135-173): given the canonical solution of
         the forward solve and the gradient of a scalar loss w.r.t. the user variables, returns the
         gradient w.r.t. every user parameter (F-order reshaped like the reference's `param.gradient`)."""
@@ -561,12 +621,14 @@ class BatchSolver:
                                for nm in names]).astype(np.int64) if names else np.zeros(0, np.int64)
         fixed = np.ones(desc.NP + 1, dtype=bool)
         fixed[cols] = False
-        key = ('grad',) + tuple(names)
-        if getattr(self, '_grad_key', None) != key:
-            self._set_refactor(cols, np.where(fixed, desc.theta0, 0.0))
+        base = desc.theta0 if theta_base is None else np.asarray(theta_base, dtype=np.float64)
+        before = self._ref_key
+        self._set_refactor(cols, np.where(fixed, base, 0.0), None)     # no-op when these tables are loaded
+        if self._ref_key != before:
+            self._update_key = None          # a following solve must re-select its tables
+        if not self._grad_loaded:
             self._set_gradient()
-            self._grad_key = key
-            self._update_key = None          # the refactor tables were re-uploaded for this set
+            self._grad_loaded = True
         self._updated_names, self._var_cols, self.np_var = names, cols, len(cols)
         tv = self.theta_var(params)
         B = sol_x.shape[0]
@@ -606,8 +668,9 @@ class BatchSolver:
                 B = Bn
             if Bn != B:
                 raise ValueError('inconsistent batch sizes')
-            if v.ndim == 2 and v.shape[1] == up.size and (len(up.shape) != 1 or up.kind != 'dense' or True):
-                # already flattened the way the reference stores it (F-order / diagonal / non-zeros)
+            if v.ndim == 2 and v.shape[1] == up.size:
+                # already flattened the way the reference stores it: F-ORDER for dense matrices
+                # (templates/cpg_solver.py.jinja2:26-34), the diagonal, or the stored non-zeros
                 blocks.append(v.reshape(B, up.size))
             elif up.kind == 'diag' and v.ndim == 3:
                 blocks.append(np.diagonal(v, axis1=1, axis2=2).reshape(B, up.size))
@@ -626,7 +689,10 @@ class BatchSolver:
     # ---- solve ---------------------------------------------------------------------------------------
     def solve(self, params: Optional[Dict[str, np.ndarray]] = None,
               updated_params: Optional[Sequence[str]] = None, B: Optional[int] = None,
-              theta_var: Optional[np.ndarray] = None, **kwargs) -> BatchResult:
+              theta_var: Optional[np.ndarray] = None, state_in: Optional[np.ndarray] = None,
+              return_state: bool = False, **kwargs) -> BatchResult:
+        """state_in / return_state: the workspace a sequential caller carries from solve to solve
+        ([B, n + 2 m + 1]: scaled iterates x | z | y in canonical order, then rho; include/cpg_hip.h)."""
         if not (updated_params is None and theta_var is not None and self._update_key is not None):
             self.set_updated(updated_params)      # None = every parameter, as in the reference
         self.apply_settings(**kwargs)
@@ -636,19 +702,50 @@ class BatchSolver:
         Bn = theta_var.shape[0] if theta_var.ndim == 2 and self.np_var else (B or theta_var.shape[0])
         if self.np_var and theta_var.shape != (Bn, self.np_var):
             raise ValueError(f'theta_var must have shape (B, {self.np_var})')
-        d = self.desc
+        t0 = time.time()
+        out = self._solve_on(self.h, theta_var, Bn, state_in, return_state)
+        t1 = time.time()
+        ms = C.c_float(0)
+        self.lib.L.cpg_hip_last_kernel_ms(self.h, C.byref(ms))
+        self._resolve_class_changes(theta_var, out, state_in)
+        res = self._result(*out[:7], t1 - t0, ms.value)
+        res.state = out[7]
+        return res
+
+    def _solve_on(self, hh, theta_var, Bn, state_in, return_state):
         n_prim, n_dual = self.n_out_prim, self.n_out_dual
         prim = np.empty((Bn, n_prim)); dual = np.empty((Bn, n_dual))
         obj = np.empty(Bn); pri = np.empty(Bn); dua = np.empty(Bn)
         it = np.empty(Bn, dtype=np.int32); st = np.empty(Bn, dtype=np.int32)
-        t0 = time.time()
-        self.lib.check(self.lib.L.cpg_hip_solve_batch(
-            self.h, Bn, _d(theta_var), _d(prim), _d(dual), _d(obj), it.ctypes.data_as(_ip),
-            st.ctypes.data_as(_ip), _d(pri), _d(dua)), 'cpg_hip_solve_batch')
-        t1 = time.time()
-        ms = C.c_float(0)
-        self.lib.L.cpg_hip_last_kernel_ms(self.h, C.byref(ms))
-        return self._result(prim, dual, obj, it, st, pri, dua, t1 - t0, ms.value)
+        slen = self.desc.n_var + 2 * self.desc.m + 1
+        if state_in is not None:
+            state_in = np.ascontiguousarray(state_in, dtype=np.float64)
+            if state_in.shape != (Bn, slen):
+                raise ValueError(f'state_in must have shape (B, {slen})')
+        state_out = np.empty((Bn, slen)) if return_state else None
+        self.lib.check(self.lib.L.cpg_hip_solve_batch_state(
+            hh, Bn, _d(theta_var), None if state_in is None else _d(state_in),
+            None if state_out is None else _d(state_out), _d(prim), _d(dual), _d(obj),
+            it.ctypes.data_as(_ip), st.ctypes.data_as(_ip), _d(pri), _d(dua)), 'cpg_hip_solve_batch_state')
+        return [prim, dual, obj, it, st, pri, dua, state_out]
+
+    def _resolve_class_changes(self, theta_var, out, state_in=None) -> None:
+        """Instances whose parameters moved a constraint row to another class (a bound that became
+        +-infinite or finite again) cannot use the family's shared factor; the reference refactors
+        inside osqp_update_data_vec (update_rho_vec).  They come back from the shared-factor kernel
+        flagged and are solved here through the per-instance factor path, whose kernel classifies the
+        rows of every instance itself."""
+        st = out[4]
+        bad = np.nonzero(st == STATUS_NEEDS_REFACTOR)[0]
+        if not len(bad) or self.h is not self.h_shared:
+            return
+        self._set_refactor(self._var_cols, self._th_fixed, self._q_setup)
+        self._apply_settings_to(self.h_ref)
+        sub = self._solve_on(self.h_ref, np.ascontiguousarray(theta_var[bad]), len(bad),
+                             None if state_in is None else state_in[bad], out[7] is not None)
+        for k in range(8):
+            if out[k] is not None:
+                out[k][bad] = sub[k]
 
     @property
     def n_out_prim(self) -> int:
@@ -693,11 +790,14 @@ class BatchSolver:
 
 class DeviceBatch:
     """Device-resident buffers for `BatchSolver.solve_device`: theta_var in, results out, all in
-    HBM (cpg_hip_malloc), so that a timed solve contains no PCIe traffic."""
+    HBM (cpg_hip_malloc), so that a timed solve contains no PCIe traffic.  Bound to the parameter
+    set that was selected (`set_updated`) when it was created."""
 
     def __init__(self, solver: BatchSolver, B: int):
         self.s, self.B = solver, int(B)
         self.n_prim, self.n_dual = solver.n_out_prim, solver.n_out_dual
+        self.np_var, self._key = solver.np_var, solver._update_key
+        self._theta_host = None
         self._ptrs = {}
         sizes = dict(theta=B * max(solver.np_var, 1) * 8, prim=B * self.n_prim * 8,
                      dual=B * self.n_dual * 8, obj=B * 8, pri=B * 8, dua=B * 8, iter=B * 4, status=B * 4)
@@ -706,8 +806,16 @@ class DeviceBatch:
             solver.lib.check(solver.lib.L.cpg_hip_malloc(solver.h, nbytes, C.byref(p)), 'cpg_hip_malloc')
             self._ptrs[k] = p
 
+    def check_current(self) -> None:
+        if self.s._update_key != self._key or self.s.np_var != self.np_var:
+            raise ValueError('the solver\'s set of updated parameters changed after this DeviceBatch was created')
+
     def upload(self, theta_var: np.ndarray) -> None:
+        self.check_current()
         tv = np.ascontiguousarray(theta_var, dtype=np.float64)
+        if tv.shape != (self.B, self.np_var) and not (self.np_var == 0 and tv.size == 0):
+            raise ValueError(f'theta_var must have shape ({self.B}, {self.np_var}), got {tv.shape}')
+        self._theta_host = tv
         if tv.size:
             self.s.lib.check(self.s.lib.L.cpg_hip_memcpy_h2d(self.s.h, self._ptrs['theta'],
                                                              tv.ctypes.data_as(C.c_void_p), tv.nbytes), 'h2d')
@@ -721,8 +829,12 @@ class DeviceBatch:
             if a.nbytes:
                 s.lib.check(s.lib.L.cpg_hip_memcpy_d2h(s.h, a.ctypes.data_as(C.c_void_p), self._ptrs[k],
                                                        a.nbytes), 'd2h')
-        return s._result(out['prim'], out['dual'], out['obj'], out['iter'], out['status'], out['pri'],
-                         out['dua'], 0.0, s.last_kernel_ms())
+        lst = [out['prim'], out['dual'], out['obj'], out['iter'], out['status'], out['pri'], out['dua'], None]
+        if (out['status'] == STATUS_NEEDS_REFACTOR).any():
+            if self._theta_host is None:
+                raise RuntimeError('row-class changes need the host copy of theta_var (DeviceBatch.upload)')
+            s._resolve_class_changes(self._theta_host, lst)
+        return s._result(*lst[:7], 0.0, s.last_kernel_ms())
 
     def free(self) -> None:
         for p in self._ptrs.values():
@@ -732,6 +844,7 @@ class DeviceBatch:
 
 def _solve_device(self, dev: DeviceBatch) -> None:
     """Asynchronous launch on the solver's stream; pair with synchronize()."""
+    dev.check_current()
     P = dev._ptrs
     self.lib.check(self.lib.L.cpg_hip_solve_batch_device(
         self.h, dev.B, P['theta'], P['prim'], P['dual'], P['obj'], P['iter'], P['status'], P['pri'],

@@ -8,6 +8,7 @@ Runtime behind the generated `cpg_solver.py`: the reference's Python shim
 
 from __future__ import annotations
 
+import json
 import os
 import time
 from typing import Dict, Optional, Sequence
@@ -58,6 +59,11 @@ class GeneratedSolver:
             lib_path = next((c for c in cands if os.path.exists(c)), None)
         self.lib_path = lib_path
         self._bs: Optional[BatchSolver] = None
+        self._ws = None
+        bo = os.path.join(code_dir, 'osqp_build.json')
+        self.build_options = json.load(open(bo)) if os.path.exists(bo) else {}
+        es = os.path.join(code_dir, 'enabled_settings.json')
+        self.enabled_settings = json.load(open(es)) if os.path.exists(es) else []
 
     @property
     def batch_solver(self) -> BatchSolver:
@@ -67,7 +73,7 @@ class GeneratedSolver:
                 self._bs = ConicBatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
             else:
                 self._bs = BatchSolver(self.desc, device=self.device, lib_path=self.lib_path,
-                                       full_output=self.gradient)
+                                       full_output=self.gradient, build_options=self.build_options)
         return self._bs
 
     # ---- batched entry point --------------------------------------------------------------------
@@ -78,6 +84,37 @@ class GeneratedSolver:
         return self.batch_solver.solve(params, updated_params=updated_params, **kwargs)
 
     # ---- the reference's single-instance entry point -------------------------------------------------
+    def _workspace(self):
+        """Host mirror of the state the reference keeps in C static globals between cpg_solve() calls
+        (cvxpygen/utils.py:470-689): cpg_params_vec, the Canon_Outdated flags (all raised at start,
+        utils.py:559-562), and -- inside the OSQP workspace -- the unscaled q, the scaling of the last
+        osqp_update_data_mat, the iterates (warm_starting = 1, solvers/osqp.py:110) and rho."""
+        if self._ws is None:
+            d = self.desc
+            ids = [pid for pid in d.maps if d.changes.get(pid, False)]
+            self._ws = dict(theta=np.array(d.theta0, dtype=np.float64), outdated=set(ids),
+                            q_ws=np.array(d.default_canon()['q'], dtype=np.float64), q_setup=None,
+                            mat_touched=False, state=None)
+        return self._ws
+
+    def _filter_settings(self, kwargs):
+        """settings enabled through `enable_settings` that have no counterpart in the batched kernels:
+        accepted like the reference's `cpg_set_solver_<name>`; polishing itself is not implemented"""
+        out = dict(kwargs)
+        if self.desc.solver == 'OSQP':
+            for name in ('verbose', 'polishing', 'polish_refine_iter', 'delta'):
+                if name in out:
+                    if name not in self.enabled_settings:
+                        raise AttributeError(f'Solver setting "{name}" not available.')
+                    v = out.pop(name)
+                    if name == 'polishing' and int(v):
+                        raise NotImplementedError('solution polishing is not implemented in the HIP backend')
+        return out
+
+    def reset_workspace(self):
+        """back to the code-generation-time workspace (a fresh process of the reference)"""
+        self._ws = None
+
     def cpg_solve(self, prob, updated_params=None, **kwargs):
         desc = self.desc
         if updated_params is None:
@@ -85,18 +122,46 @@ class GeneratedSolver:
         for p in updated_params:
             if p not in desc.param_names:
                 raise AttributeError(f"{p} is not a parameter.")
+        kwargs = self._filter_settings(kwargs)
+        ws = self._workspace()
+        dep = desc.user_p_name_to_canon_outdated()
         param_dict = prob.param_dict
-        vals = {}
+        # cpg_update_<param>: only the listed parameters are read; every other one keeps the value of its
+        # last update (templates/cpg_solver.py.jinja2:44-68, utils.py:904-935)
         for name in updated_params:
-            v = get_param_value(param_dict[name])
-            vals[name] = np.asarray(v, dtype=np.float64).reshape(1, -1)
+            up = desc.param(name)
+            v = np.asarray(get_param_value(param_dict[name]), dtype=np.float64).reshape(-1)
+            ws['theta'][up.col:up.col + up.size] = v
+            ws['outdated'].update(pid for pid in dep[name] if desc.changes.get(pid, False))
+        theta_var = np.ascontiguousarray(ws['theta'][:desc.NP][None, :])
+        bs = self.batch_solver
         t0 = time.time()
-        res = self.batch_solver.solve(vals, updated_params=updated_params, **kwargs)
+        if desc.solver == 'CLARABEL':
+            # new solver per solve in the reference (solvers/clarabel.py:201-204): nothing but theta carries over
+            res = bs.solve(updated_params=None, theta_var=theta_var, B=1, **kwargs)
+        else:
+            if ws['outdated'] & {'P', 'A'}:
+                # osqp_update_data_mat runs before osqp_update_data_vec (solvers/osqp.py:20-59): the
+                # re-equilibration sees the q the workspace held so far
+                ws['q_setup'] = ws['q_ws'].copy()
+                ws['mat_touched'] = True
+            path = 'refactor' if (ws['mat_touched'] or bs.adaptive_rho) else 'shared'
+            bs.set_updated(None, q_setup=ws['q_setup'], path=path)
+            warm = int(kwargs.get('warm_starting', kwargs.get('warm_start', 1)))
+            res = bs.solve(theta_var=theta_var, B=1, state_in=ws['state'] if warm else None,
+                           return_state=True, **kwargs)
+            ws['state'] = res.state
+            if 'q' in ws['outdated']:
+                ws['q_ws'] = np.asarray(desc.canon_at(ws['theta'])['q'], dtype=np.float64)
+        ws['outdated'] = set()
         t1 = time.time()
 
         prob._clear_solution()
-        for v in desc.variables:
-            prob.var_dict[v.name].save_value(np.array(res.prim[v.name][0]).reshape(v.shape, order='A'))
+        k = 0
+        for v in desc.variables:                    # templates/cpg_solver.py.jinja2:76-80
+            sz = int(v.indices.size)
+            prob.var_dict[v.name].save_value(np.array(res.prim_flat[0, k:k + sz]).reshape(v.shape, order='F'))
+            k += sz
         for i, d in enumerate(desc.duals):
             dv = res.dual[d.name][0]
             prob.constraints[i].save_dual_value(np.array(dv).reshape(d.shape) if d.shape else float(dv))
@@ -143,8 +208,10 @@ class GeneratedSolver:
         for v in desc.variables:
             g = prob.var_dict[v.name].gradient
             dvars[v.name] = np.asarray(0.0 if g is None else g, dtype=np.float64).reshape((1,) + tuple(v.shape))
-        vals = {name: np.asarray(get_param_value(prob.param_dict[name]), dtype=np.float64).reshape(1, -1)
-                for name in desc.param_names}
+        # the canonical P / A the adjoint differentiates are those of the workspace, i.e. of the last
+        # cpg_solve (cpg_params_vec), not whatever `prob` holds now (writer.py:233-266)
+        th = self._workspace()['theta']
+        vals = {q.name: th[q.col:q.col + q.size].reshape(1, -1) for q in desc.params}
         out = self.batch_solver.gradient(vals, sx[None, :], sy[None, :], dvars, updated_params=desc.param_names)
         for q in desc.params:
             g = out[q.name][0]

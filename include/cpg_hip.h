@@ -48,7 +48,9 @@ extern "C" {
 #define CPG_STATUS_UNSOLVED 11
 /* a constraint row changed class (equality <-> inequality <-> free) w.r.t. code generation time:
  * the shared KKT factor is not valid for this instance (the reference refactors here,
- * osqp_update_data_vec -> update_rho_vec); the instance must go through the refactor path */
+ * osqp_update_data_vec -> update_rho_vec).  INTERNAL to the two-handle protocol: the host layer
+ * (cvxpygen_amd/runtime.py, BatchSolver._resolve_class_changes) re-solves such instances through the
+ * refactor-mode handle, whose kernel classifies rows per instance; users never see this status. */
 #define CPG_STATUS_NEEDS_REFACTOR (-2)
 
 typedef struct cpg_solver_s *cpg_handle_t;
@@ -110,6 +112,9 @@ typedef struct {
     const int32_t *prim_idx; /* [n_prim] indices into x */
     int32_t n_dual;
     const int32_t *dual_idx; /* [n_dual] indices into y */
+    const int32_t *ord;      /* [n + m] canonical index of the entry at device position i (x entries, then
+                              * rows); NULL = identity.  Only the state buffers of the *_state entry points
+                              * (canonical order) go through it. */
 } cpg_osqp_family_t;
 
 /* Which user parameters vary across the batch and how the canonical VECTORS depend on them
@@ -227,6 +232,13 @@ const char *cpg_hip_status_string(int32_t status);
 int cpg_hip_set_default_settings(cpg_handle_t h);
 int cpg_hip_set_setting(cpg_handle_t h, const char *name, double value);
 int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *value);
+/* Constants of the generated OSQP workspace that the reference can NOT change at solve time (they are
+ * what `osqp.OSQP().setup()` bakes into workspace.c at code generation, cvxpygen/solvers/osqp.py:126-131,
+ * and are not among the settings of osqp.py:102-115): "adaptive_rho" (0/1), "adaptive_rho_interval"
+ * (iterations), "adaptive_rho_tolerance", "check_dualgap" (0/1).  Their values depend on the OSQP release
+ * the reference was generated with; cpg_hip_set_default_settings leaves them alone.
+ * rho adaptation needs a refactor-mode handle (every instance owns its factor). */
+int cpg_hip_set_build_option(cpg_handle_t h, const char *name, double value);
 
 /* ---- which parameters are updated (sticky until changed) -------------------------------------- */
 int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *upd);
@@ -255,6 +267,17 @@ int cpg_hip_solve_batch(cpg_handle_t h, int64_t B, const double *theta_var, doub
 int cpg_hip_solve_batch_device(cpg_handle_t h, int64_t B, const double *d_theta_var, double *d_prim,
                                double *d_dual, double *d_obj, int32_t *d_iter, int32_t *d_status,
                                double *d_pri_res, double *d_dua_res);
+/* Sequential use of one workspace (the reference's static OSQP workspace keeps its iterates and rho
+ * between cpg_solve() calls; warm_starting = 1 is its default, cvxpygen/solvers/osqp.py:110):
+ * state [B][n + 2 m + 1] = scaled iterates x | z | y in canonical order, then rho.  state_in NULL (or
+ * warm_starting = 0) = cold start from the family's rho; state_out NULL = not wanted.  After a solve
+ * without a solution the iterates in state_out are zero (osqp_solve resets them). */
+int cpg_hip_solve_batch_state(cpg_handle_t h, int64_t B, const double *theta_var, const double *state_in,
+                              double *state_out, double *prim, double *dual, double *obj, int32_t *iter,
+                              int32_t *status, double *pri_res, double *dua_res);
+int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_theta_var, const double *d_state_in,
+                                     double *d_state_out, double *d_prim, double *d_dual, double *d_obj,
+                                     int32_t *d_iter, int32_t *d_status, double *d_pri_res, double *d_dua_res);
 int cpg_hip_synchronize(cpg_handle_t h);
 /* duration of the most recent solve kernel on this handle, from HIP events on its stream */
 int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms);

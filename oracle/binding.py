@@ -221,3 +221,48 @@ def qp_adjoint(desc, canon, x, y, dx):
         if desc.changes.get(pid, False):
             dth += sp.csr_matrix(desc.maps[pid]).T @ vec
     return dict(r=r, dq=dq, dl=dl, du=du, dP=dP, dA=dA, dtheta=dth[:desc.NP])
+
+
+class CpgSession:
+    """What ONE process of the reference does over successive `cpg_solve()` calls: a static workspace
+    (cvxpygen/utils.py:470-689) -- cpg_params_vec, Canon_Outdated flags (all raised at start,
+    utils.py:559-562), and the OSQP workspace with its scaling, factor, iterates and rho.
+    `solve(values)` = cpg_update_<param> for the listed parameters, canonicalise what is outdated,
+    osqp_update_data_mat then _vec (solvers/osqp.py:20-59), osqp_solve, cpg_retrieve_info."""
+
+    def __init__(self, desc, **build_settings):
+        from cvxpygen_amd.canon_builder import canon_lu
+        self._canon_lu = canon_lu
+        self.desc = desc
+        c0 = desc.default_canon()
+        l0, u0 = canon_lu(desc, c0)
+        self.build = dict(build_settings)
+        self.oracle = Oracle(desc.P, c0['q'], desc.A, l0, u0, **build_settings)
+        self.theta = np.array(desc.theta0, dtype=np.float64)
+        self.outdated = {pid for pid in desc.maps if desc.changes.get(pid, False)}
+
+    def solve(self, values=None, warm=True, **settings):
+        desc = self.desc
+        dep = desc.user_p_name_to_canon_outdated()
+        for name, v in (values or {}).items():
+            p = desc.param(name)
+            self.theta[p.col:p.col + p.size] = desc.flatten_param(name, v)
+            self.outdated.update(pid for pid in dep[name] if desc.changes.get(pid, False))
+        canon = desc.canon_at(self.theta)
+        # settings: defaults of the generated solver, then the call's (templates/cpg_solver.py.jinja2:55-60)
+        stg = dict(max_iter=4000, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4, eps_dual_inf=1e-4,
+                   scaled_termination=0, check_termination=25)
+        stg.update(settings)
+        self.oracle.set(**stg)
+        od = self.outdated
+        if od & {'P', 'A'}:
+            self.oracle.update_mat(canon['P'] if 'P' in od else None, canon['A'] if 'A' in od else None)
+        if od & {'q', 'l', 'u'}:
+            l, u = self._canon_lu(desc, canon)
+            self.oracle.update_vec(canon['q'] if 'q' in od else None, l if 'l' in od else None, u if 'u' in od else None)
+        self.outdated = set()
+        r = self.oracle.solve(warm=warm)
+        d = float(np.atleast_1d(canon['d'])[0]) if desc.nonzero_d else 0.0
+        ov = r['obj_val'] + d
+        r['obj_val'] = -ov if desc.is_maximization else ov
+        return r
