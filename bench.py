@@ -167,6 +167,9 @@ def main():
     ap.add_argument('--check-termination', type=int, default=0, help='experiments: termination check interval (reference default 25)')
     ap.add_argument('--eps', type=float, default=0.0, help='eps_abs = eps_rel (tight run of SURVEY.md 8(d): 1e-6)')
     ap.add_argument('--adjoint', action='store_true', help='config 5: also time the batched QP adjoint (gradient=True path)')
+    ap.add_argument('--osqp1', action='store_true', help='OSQP >= 1.0 build options: rho adaptation every 50 iterations + duality-gap test (per-instance factor path)')
+    ap.add_argument('--no-gather', action='store_true', help='multi-GPU: leave the final gather out of the timed steps')
+    ap.add_argument('--no-wall', action='store_true', help='skip the PCIe-inclusive pipelined measurement')
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
     args = ap.parse_args()
 
@@ -175,6 +178,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
     if world > 1:
+        # torch.distributed only as the launcher-level plumbing the driver's contract asks for (rendezvous,
+        # barrier, max over ranks of the elapsed time); the data path -- the final gather of the results --
+        # goes through cvxpygen_amd.sharding (RCCL via ctypes on the solver's own stream)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -185,11 +191,14 @@ def main():
     gen = os.path.join(ROOT, 'cvxpygen_amd', 'generated', args.workload, f'libcpg_{args.workload}.so')
     if lib_path is None and not args.generic and os.path.exists(gen):
         lib_path = gen          # what generate_code() builds: executor specialised for this family
+    build_options = {}
+    if args.osqp1:              # the OSQP >= 1.0 reading of the generated workspace
+        build_options = dict(adaptive_rho=1, adaptive_rho_interval=50, adaptive_rho_tolerance=5.0, check_dualgap=1)
     if desc.solver == 'CLARABEL':
         from cvxpygen_amd.conic_runtime import ConicBatchSolver
         solver = ConicBatchSolver(desc, device=local_rank, lib_path=args.lib)
     else:
-        solver = BatchSolver(desc, device=local_rank, lib_path=lib_path)
+        solver = BatchSolver(desc, device=local_rank, lib_path=lib_path, build_options=build_options)
     solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)
     solver.set_program_placement(args.placement)
     B = args.batch
@@ -218,6 +227,17 @@ def main():
     dev = DeviceBatch(solver, B)
     dev.upload(theta)
 
+    # multi-GPU: the job's only exchange is the final gather of every rank's results to the root's device
+    # memory, point-to-point over xGMI (RcclGather); it is part of every timed step
+    gather, gather_kind, gather_ms = None, None, 0.0
+    Btot = world * B
+    if world > 1:
+        from cvxpygen_amd.sharding import RcclGather, result_spec
+        gather = RcclGather(solver, rank, world, key=os.environ.get('MASTER_PORT', '0'))
+        gather_kind = 'rccl ncclSend/ncclRecv to rank 0 (device memory), on the solve stream'
+        spec = result_spec(dev)
+        arrays = [(k, dev._ptrs[k], B, rb) for k, (rb, dt, tail, nm) in spec.items()]
+
     def barrier():
         solver.synchronize()
         if dist is not None:
@@ -225,15 +245,22 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    for _ in range(args.warmup):
+    def step():
         solver.solve_device(dev)
+        if gather is not None and not args.no_gather:
+            gather.enqueue(arrays, Btot)
+        solver.synchronize()
+
+    for _ in range(args.warmup):
+        step()
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        solver.solve_device(dev)
-        solver.synchronize()
+        ts = time.perf_counter()
+        step()
         kernel_ms.append(solver.last_kernel_ms())
+        gather_ms += 1e3 * (time.perf_counter() - ts) - kernel_ms[-1]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -247,15 +274,36 @@ def main():
     solved = int((res.status == 1).sum())
     stats = {'mean_iter': float(iters.mean()), 'max_iter': int(iters.max()), 'solved': solved,
              'not_solved': int(B - solved)}
-    if dist is not None:
-        # the only collective of the job: final gather of the per-instance info (RCCL over xGMI)
-        import torch
-        info = torch.from_numpy(np.stack([res.iter, res.status], axis=1).astype(np.int32)).cuda()
-        outs = [torch.empty_like(info) for _ in range(world)]
-        dist.all_gather(outs, info)
-        alli = torch.cat(outs).cpu().numpy()
-        stats = {'mean_iter': float(alli[:, 0].mean()), 'max_iter': int(alli[:, 0].max()),
-                 'solved': int((alli[:, 1] == 1).sum()), 'not_solved': int((alli[:, 1] != 1).sum())}
+    if gather is not None and not args.no_gather:
+        # what the root holds after the last step: every rank's iteration counts and statuses
+        alli = gather.fetch('iter', dev._ptrs['iter'], 4, Btot, np.int32)
+        alls = gather.fetch('status', dev._ptrs['status'], 4, Btot, np.int32)
+        if rank == 0:
+            stats = {'mean_iter': float(alli.mean()), 'max_iter': int(alli.max()),
+                     'solved': int((alls == 1).sum()), 'not_solved': int((alls != 1).sum())}
+
+    # whole path from host memory (H2D of theta + kernel + D2H of the results), N = 1 only:
+    # page-locked buffers, transfers of batch i +- 1 hidden behind the kernel of batch i
+    wall = None
+    if world == 1 and not args.no_wall and desc.solver == 'OSQP':
+        from cvxpygen_amd.runtime import PinnedStream
+        nb = 4
+        ps = PinnedStream(solver, B, nb)
+        for k in range(nb):
+            ps.theta[k * B:(k + 1) * B] = theta
+        ps.run()                                   # warm-up (first-touch of the pinned pages, buffer allocation)
+        tw = time.perf_counter()
+        ps.run()
+        tw = time.perf_counter() - tw
+        rs = ps.result()
+        same = bool(np.array_equal(rs.iter[:B], res.iter) and np.array_equal(rs.prim_flat[-B:], res.prim_flat))
+        wall = {'value': nb * B / tw, 'unit': 'QP instances/s', 'ms_per_batch': 1e3 * tw / nb, 'batches': nb,
+                'bytes_h2d_per_batch': int(theta.nbytes),
+                'bytes_d2h_per_batch': int(B * (8 * (solver.n_out_prim + solver.n_out_dual) + 32)),
+                'same_results_as_resident_path': same,
+                'what': 'theta in page-locked host memory -> results in page-locked host memory; H2D of batch i+1, '
+                        'kernel of batch i, D2H of batch i-1 on three HIP streams (cpg_hip_solve_batches_pipelined)'}
+        ps.free()
 
     if rank == 0:
         if stats['not_solved'] and args.workload in ('mpc12', 'mpc6', 'adp') and not args.all_params:
@@ -269,16 +317,20 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         traffic = None          # recorded PMC measurement of the same command (profiles/), not re-measured live
         binding = None
+        traffic_src = None
         try:
-            rec = json.load(open(os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json'))).get(args.workload)
-            if rec and rec['instances'] == B and not args.all_params:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')))
+            key = args.workload + ('_all_params' if args.all_params else '') + ('_osqp1' if args.osqp1 else '')
+            rec = tj.get(key)
+            if rec and rec['instances'] == B:
                 traffic = rec['fetch_bytes'] + rec['write_bytes']
                 binding = rec.get('binding_resource')
+                traffic_src = tj.get('_source')
         except (OSError, ValueError, KeyError):
             pass
         rnote = ('compulsory traffic only (theta in, solution out); the iteration state never leaves '
                  'registers/LDS, so this path is latency / LDS bound, not HBM bound (DESIGN.md section 6)')
-        if solver.desc.solver == 'OSQP' and getattr(solver, '_rplan', None) is not None and (args.all_params or args.workload == 'portfolio'):
+        if solver.desc.solver == 'OSQP' and getattr(solver, '_rplan', None) is not None and (args.all_params or args.osqp1 or args.workload == 'portfolio'):
             # per-instance factor: every ADMM iteration streams the substitution coefficients of the
             # instance (8 bytes per entry of the streaming layout) from its buffer in HBM
             sv = 8 * int(solver._rplan.stats['sol_stream_entries'])
@@ -305,6 +357,9 @@ def main():
                                           'all (matrix parameters: per-instance refactorisation)' if args.all_params else ['x_init']),
                        'settings': ('Clarabel defaults of the generated solver (cvxpygen/solvers/clarabel.py:63-119): '
                                     'tol_gap/feas 1e-8, max_iter 200, new solver per instance' if args.workload == 'adp' else
+                                    'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, max_iter=4000, '
+                                    'check_termination=25, cold start; workspace built as OSQP >= 1.0 would: rho adapted every 50 '
+                                    'iterations (tolerance 5), duality-gap test on' if args.osqp1 else
                                     'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
                                     'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start'),
                        'parallelism': f'shard{world}', **stats,
@@ -313,15 +368,23 @@ def main():
                                 for k, v in solver.plan.stats.items()}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_note': 'bytes per launch from rocprofv3 PMC passes recorded in profiles/r1_hbm_traffic.json' if traffic else None,
+                         'traffic_note': (f'REPLAYED, not measured in this run: bytes per launch from the rocprofv3 PMC passes recorded in '
+                                          f'profiles/r2_hbm_traffic.json ({traffic_src})') if traffic else None,
                          'binding_resource': binding,
                          'kernel': ('clarabel_kernel' if args.workload == 'adp' else
-                                    'osqp_refactor_kernel' if (args.all_params or args.workload == 'portfolio')
+                                    'osqp_refactor_kernel' if (args.all_params or args.osqp1 or args.workload == 'portfolio')
                                     else 'osqp_shared_kernel'), 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_instance': bytes_per_inst,
                          'note': rnote},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.all_params:
+        out['config']['value_is'] = ('inputs resident in HBM when the timed region starts, results left in HBM (driver contract); '
+                                     'the PCIe-inclusive whole-path rate of SURVEY.md 8(d) is reported beside it in "wall_pcie"')
+        if wall is not None:
+            out['wall_pcie'] = wall
+        if world > 1:
+            out['config']['gather'] = ('left out of the timed steps (--no-gather)' if args.no_gather else gather_kind)
+            out['config']['gather_ms_per_step_rank0'] = gather_ms / max(1, args.steps)
+        if world == 1 and not args.no_cpu_baseline and not args.all_params and not args.osqp1:
             if args.workload == 'portfolio':
                 out['cpu_baseline'] = cpu_baseline_portfolio(desc, args.cpu_seconds)
             elif args.workload == 'adp':
@@ -362,6 +425,8 @@ def main():
                 'dual_relerr': float(np.abs(do - res.dual_flat[:nchk]).max() / np.abs(do).max())}
         print(json.dumps(out), flush=True)
     dev.free()
+    if gather is not None:
+        gather.close()
     solver.close()
     if dist is not None:
         dist.destroy_process_group()

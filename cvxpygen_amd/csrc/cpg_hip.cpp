@@ -70,6 +70,7 @@ struct cpg_solver_s {
     DevBuf scratch;                     // delta_x / delta_y stash, [waves][G][n + m]
     // staging for the host-pointer entry point
     DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status, s_state_in, s_state_out;
+    struct cpg_pipe_s *pipe = nullptr;  // cpg_hip_solve_batches_pipelined
 };
 
 // ---- runtime primitives -------------------------------------------------------------------------
@@ -609,6 +610,15 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
         {   // dimensions and uniform row classes are literals in the generated kernel
             bool ok = f->n == (int)cpg::GenFam::n && f->m == (int)cpg::GenFam::m && f->n_slots == cpg::GenFam::n_slots;
             for (int i = 0; ok && i < f->m; i++) { const int c = cpg::GenFam::ct(i / 64); if (c != 2 && c != (int)f->ctype[i]) ok = false; }
+            {   // the termination test's row programs carry their chunk table as literals too
+                const cpg_program_t *pr[3] = {&f->A_rows, &f->P_rows, &f->At_rows};
+                const int nn[3] = {CPG_GEN_AROWS_N, CPG_GEN_PROWS_N, CPG_GEN_ATROWS_N};
+                for (int k = 0; ok && k < 3; k++) {
+                    if (pr[k]->n_chunks != nn[k]) ok = false;
+                    for (int c2 = 0; ok && c2 < pr[k]->n_chunks; c2++)
+                        if (pr[k]->hdr[4 * c2] != cpg::GenFam::rows_len(k, c2) || pr[k]->hdr[4 * c2 + 3] != cpg::GenFam::rows_off(k, c2)) ok = false;
+                }
+            }
             if (!ok) { set_error("this library was generated for a different problem family (dimensions / row classes)");
                        cpg_hip_destroy(h); return CPG_E_BADARG; }
         }
@@ -727,6 +737,8 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
 }
 
 static int ensure(DevBuf &b, size_t bytes);
+struct cpg_pipe_s;
+static void free_pipe(cpg_pipe_s *p);
 static void free_list(std::vector<void *> &v) { for (void *p : v) rt_free(p); v.clear(); }
 static void free_buf(DevBuf &b) { if (b.p) rt_free(b.p); b.p = nullptr; b.bytes = 0; }
 
@@ -741,6 +753,7 @@ int cpg_hip_destroy(cpg_handle_t h) {
     free_buf(h->s_theta); free_buf(h->s_prim); free_buf(h->s_dual); free_buf(h->s_obj);
     free_buf(h->s_pri); free_buf(h->s_dua); free_buf(h->s_iter); free_buf(h->s_status);
     free_buf(h->s_state_in); free_buf(h->s_state_out);
+    free_pipe(h->pipe); h->pipe = nullptr;
     if (h->have_events) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1087,6 +1100,12 @@ int cpg_hip_synchronize(cpg_handle_t h) {
     return rt_sync(h);
 }
 
+int cpg_hip_get_stream(cpg_handle_t h, void **stream) {
+    if (!h || !stream) { set_error("null argument"); return CPG_E_BADARG; }
+    *stream = (void *)h->stream;
+    return CPG_OK;
+}
+
 int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms) {
     if (!h || !ms) { set_error("null argument"); return CPG_E_BADARG; }
     RT_CHECK(hipEventSynchronize(h->ev1));
@@ -1137,6 +1156,87 @@ int cpg_hip_solve_batch_state(cpg_handle_t h, int64_t B, const double *theta, co
     if ((rc = rt_d2h(h, iter, h->s_iter.p, b * sizeof(int32_t)))) return rc;
     if ((rc = rt_d2h(h, status, h->s_status.p, b * sizeof(int32_t)))) return rc;
     return rt_sync(h);
+}
+
+// ---- streaming many batches from host memory: transfers hidden behind the solve kernel ----------------
+// Two sets of device buffers; batch i is copied in on `copy_in` while batch i - 1 is being solved on the
+// handle's stream and batch i - 2 is copied out on `copy_out`; events chain the three stages.
+struct PipeSet { DevBuf theta, prim, dual, obj, pri, dua, iter, status; hipEvent_t in_done{}, k_done{}, out_done{}; };
+struct cpg_pipe_s { hipStream_t copy_in{}, copy_out{}; PipeSet set[2]; bool ready = false; };
+static void free_pipe(cpg_pipe_s *p) {
+    if (!p) return;
+    for (auto &s : p->set) {
+        free_buf(s.theta); free_buf(s.prim); free_buf(s.dual); free_buf(s.obj); free_buf(s.pri); free_buf(s.dua);
+        free_buf(s.iter); free_buf(s.status);
+        if (p->ready) { hipEventDestroy(s.in_done); hipEventDestroy(s.k_done); hipEventDestroy(s.out_done); }
+    }
+    if (p->ready) { hipStreamDestroy(p->copy_in); hipStreamDestroy(p->copy_out); }
+    delete p;
+}
+
+int cpg_hip_solve_batches_pipelined(cpg_handle_t h, int64_t B, int32_t n_batches, const double *theta, double *prim,
+                                    double *dual, double *obj, int32_t *iter, int32_t *status, double *pri_res,
+                                    double *dua_res) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    if (!h->have_update) { set_error("cpg_hip_set_update has not been called"); return CPG_E_BADARG; }
+    const size_t npv = (size_t)(h->conic ? h->C.np_var : h->refactor_mode ? h->R.np_var : h->U.np_var);
+    if (B < 0 || n_batches < 0 || !prim || !dual || !obj || !iter || !status || !pri_res || !dua_res || (npv > 0 && !theta)) {
+        set_error("null buffer"); return CPG_E_BADARG; }
+    if (B == 0 || n_batches == 0) return CPG_OK;
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    if (!h->pipe) {
+        h->pipe = new cpg_pipe_s();
+        RT_CHECK(hipStreamCreateWithFlags(&h->pipe->copy_in, hipStreamNonBlocking));
+        RT_CHECK(hipStreamCreateWithFlags(&h->pipe->copy_out, hipStreamNonBlocking));
+        for (auto &s : h->pipe->set) { RT_CHECK(hipEventCreate(&s.in_done)); RT_CHECK(hipEventCreate(&s.k_done)); RT_CHECK(hipEventCreate(&s.out_done)); }
+        h->pipe->ready = true;
+    }
+    cpg_pipe_s &P = *h->pipe;
+    const size_t b = (size_t)B, np_ = (size_t)h->F.n_prim, nd = (size_t)h->F.n_dual;
+    for (auto &s : P.set) {
+        if ((rc = ensure(s.theta, b * npv * 8)) || (rc = ensure(s.prim, b * np_ * 8)) || (rc = ensure(s.dual, b * nd * 8)) ||
+            (rc = ensure(s.obj, b * 8)) || (rc = ensure(s.pri, b * 8)) || (rc = ensure(s.dua, b * 8)) ||
+            (rc = ensure(s.iter, b * 4)) || (rc = ensure(s.status, b * 4))) return rc;
+    }
+    for (int i = 0; i < n_batches; i++) {
+        PipeSet &s = P.set[i & 1];
+        const size_t o = (size_t)i * b;
+        if (i >= 2) RT_CHECK(hipStreamWaitEvent(P.copy_in, s.out_done, 0));     // the set's previous results left the device
+        if (npv) RT_CHECK(hipMemcpyAsync(s.theta.p, theta + o * npv, b * npv * 8, hipMemcpyHostToDevice, P.copy_in));
+        RT_CHECK(hipEventRecord(s.in_done, P.copy_in));
+        RT_CHECK(hipStreamWaitEvent(h->stream, s.in_done, 0));
+        rc = cpg_hip_solve_batch_device_state(h, B, (const double *)s.theta.p, nullptr, nullptr, (double *)s.prim.p, (double *)s.dual.p,
+                                              (double *)s.obj.p, (int32_t *)s.iter.p, (int32_t *)s.status.p, (double *)s.pri.p,
+                                              (double *)s.dua.p);
+        if (rc) return rc;
+        RT_CHECK(hipEventRecord(s.k_done, h->stream));
+        RT_CHECK(hipStreamWaitEvent(P.copy_out, s.k_done, 0));
+        RT_CHECK(hipMemcpyAsync(prim + o * np_, s.prim.p, b * np_ * 8, hipMemcpyDeviceToHost, P.copy_out));
+        RT_CHECK(hipMemcpyAsync(dual + o * nd, s.dual.p, b * nd * 8, hipMemcpyDeviceToHost, P.copy_out));
+        RT_CHECK(hipMemcpyAsync(obj + o, s.obj.p, b * 8, hipMemcpyDeviceToHost, P.copy_out));
+        RT_CHECK(hipMemcpyAsync(pri_res + o, s.pri.p, b * 8, hipMemcpyDeviceToHost, P.copy_out));
+        RT_CHECK(hipMemcpyAsync(dua_res + o, s.dua.p, b * 8, hipMemcpyDeviceToHost, P.copy_out));
+        RT_CHECK(hipMemcpyAsync(iter + o, s.iter.p, b * 4, hipMemcpyDeviceToHost, P.copy_out));
+        RT_CHECK(hipMemcpyAsync(status + o, s.status.p, b * 4, hipMemcpyDeviceToHost, P.copy_out));
+        RT_CHECK(hipEventRecord(s.out_done, P.copy_out));
+    }
+    RT_CHECK(hipStreamSynchronize(P.copy_out));
+    return rt_sync(h);
+}
+
+// page-locked host memory: lets the copies of the pipelined entry point run asynchronously at full PCIe rate
+int cpg_hip_host_malloc(cpg_handle_t h, size_t bytes, void **hptr) {
+    if (!h || !hptr) { set_error("null argument"); return CPG_E_BADARG; }
+    int rc = rt_set_device(h->device);
+    if (rc) return rc;
+    RT_CHECK(hipHostMalloc(hptr, bytes ? bytes : 8, 0));
+    return CPG_OK;
+}
+int cpg_hip_host_free(cpg_handle_t h, void *hptr) {
+    if (!h) { set_error("null handle"); return CPG_E_BADARG; }
+    if (hptr) RT_CHECK(hipHostFree(hptr));
+    return CPG_OK;
 }
 
 int cpg_hip_malloc(cpg_handle_t h, size_t bytes, void **dptr) {

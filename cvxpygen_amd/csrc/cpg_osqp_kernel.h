@@ -409,6 +409,18 @@ struct GenFam {
     static constexpr unsigned n = CPG_GEN_N, m = CPG_GEN_M;
     static constexpr int n_slots = CPG_GEN_NSLOTS;
     static constexpr int ct(int s) { constexpr signed char t[] = CPG_GEN_CT_INIT; return t[s]; }
+    // chunks of the natural-layout row programs of the termination test: {steps, first step}
+    static constexpr int rows_len(int which, int s) {
+        constexpr int a[][2] = CPG_GEN_AROWS; constexpr int p[][2] = CPG_GEN_PROWS; constexpr int t[][2] = CPG_GEN_ATROWS;
+        return which == 0 ? (s < CPG_GEN_AROWS_N ? a[s < CPG_GEN_AROWS_N ? s : 0][0] : 0)
+             : which == 1 ? (s < CPG_GEN_PROWS_N ? p[s < CPG_GEN_PROWS_N ? s : 0][0] : 0)
+                          : (s < CPG_GEN_ATROWS_N ? t[s < CPG_GEN_ATROWS_N ? s : 0][0] : 0);
+    }
+    static constexpr int rows_off(int which, int s) {
+        constexpr int a[][2] = CPG_GEN_AROWS; constexpr int p[][2] = CPG_GEN_PROWS; constexpr int t[][2] = CPG_GEN_ATROWS;
+        return which == 0 ? a[s < CPG_GEN_AROWS_N ? s : 0][1] : which == 1 ? p[s < CPG_GEN_PROWS_N ? s : 0][1]
+                                                                            : t[s < CPG_GEN_ATROWS_N ? s : 0][1];
+    }
 };
 #endif
 #endif
@@ -420,6 +432,38 @@ CPG_DEV double natural_chunk(const DevProgram &P, int s, const double *w, int la
     if (s < P.n_chunks) do_chunk<1, false>(P, s, w, 0, lane, o);
     return o[0];
 }
+
+#ifdef CPG_GEN_N
+// The same with the chunk's step count and first step as literals of the generated family (the loops
+// unroll): the coefficient / offset loads of up to CPG_ROWS_BATCH steps are requested together before the
+// first multiply-add consumes one, so a chunk costs about one L2 round trip instead of one per four steps
+// plus one for its header.  The termination test's three products walk 19 chunks (MPC 12/4/10).
+#ifndef CPG_ROWS_BATCH
+#define CPG_ROWS_BATCH 13
+#endif
+CPG_DEV double natural_chunk_lit(const DevProgram &P, const int len, const int off, const double *w, int lane_in) {
+    // per-call copy of the lane: keeps the optimiser from hoisting the ~330 per-lane load offsets of the
+    // unrolled products out of the instance loop (and spilling them), see cpgw::opaque
+    const int lane = cpgw::opaque(lane_in);
+    const unsigned e0 = (unsigned)off * 64u + (unsigned)lane;
+    double acc = 0.0;
+#pragma unroll
+    for (int t0 = 0; t0 < len; t0 += CPG_ROWS_BATCH) {
+        double v[CPG_ROWS_BATCH];
+        unsigned c[CPG_ROWS_BATCH];
+#pragma unroll
+        for (int t = 0; t < CPG_ROWS_BATCH; t++)
+            if (t0 + t < len) { v[t] = cpgw::gld(P.vals, e0 + 64u * (unsigned)(t0 + t)); c[t] = cpgw::gld(P.cols, e0 + 64u * (unsigned)(t0 + t)); }
+#pragma unroll
+        for (int t = 0; t < CPG_ROWS_BATCH; t++)
+            if (t0 + t < len) acc = fma(v[t], w[c[t]], acc);
+    }
+    return acc;
+}
+#define CPG_NATURAL_ROWS(P, which, s, w, lane) natural_chunk_lit(P, GenFam::rows_len(which, s), GenFam::rows_off(which, s), w, lane)
+#else
+#define CPG_NATURAL_ROWS(P, which, s, w, lane) natural_chunk(P, s, w, lane)
+#endif
 
 // ------------------------------------------------------------------------------------ per-instance state
 template <int NSX, int NSZ, int NV>
@@ -462,9 +506,9 @@ struct SharedCtx {
     CPG_DEV double u(int s, unsigned i) const {
         return s < Inst<NSX, NSZ, NV>::NVZ ? I.uv[s < Inst<NSX, NSZ, NV>::NVZ ? s : 0] : shu[i];
     }
-    CPG_DEV double ax(int s) const { return natural_chunk(F.A_rows, s, w, lane); }     // (A v)_i, v = w[0..n)
-    CPG_DEV double px(int s) const { return natural_chunk(F.P_rows, s, w, lane); }     // (P v)_j
-    CPG_DEV double atx(int s) const { return natural_chunk(F.At_rows, s, w, lane); }   // (A' v)_j, v = w[n..)
+    CPG_DEV double ax(int s) const { return CPG_NATURAL_ROWS(F.A_rows, 0, s, w, lane); }     // (A v)_i, v = w[0..n)
+    CPG_DEV double px(int s) const { return CPG_NATURAL_ROWS(F.P_rows, 1, s, w, lane); }     // (P v)_j
+    CPG_DEV double atx(int s) const { return CPG_NATURAL_ROWS(F.At_rows, 2, s, w, lane); }   // (A' v)_j, v = w[n..)
 };
 
 // cpg_canonicalize_q/l/u/d + osqp_update_data_vec for the parameter-dependent entries; returns

@@ -113,7 +113,8 @@ class CpgLibrary:
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
                'cpg_hip_get_setting', 'cpg_hip_set_build_option', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
                'cpg_hip_solve_batch',
-               'cpg_hip_solve_batch_device', 'cpg_hip_solve_batch_state', 'cpg_hip_solve_batch_device_state', 'cpg_hip_synchronize', 'cpg_hip_last_kernel_ms',
+               'cpg_hip_solve_batch_device', 'cpg_hip_solve_batch_state', 'cpg_hip_solve_batch_device_state', 'cpg_hip_solve_batches_pipelined', 'cpg_hip_host_malloc',
+               'cpg_hip_host_free', 'cpg_hip_synchronize', 'cpg_hip_get_stream', 'cpg_hip_last_kernel_ms',
                'cpg_hip_set_launch', 'cpg_hip_set_program_placement', 'cpg_hip_malloc', 'cpg_hip_free', 'cpg_hip_memcpy_h2d',
                'cpg_hip_memcpy_d2h']
 
@@ -145,6 +146,10 @@ class CpgLibrary:
         L.cpg_hip_solve_batch_state.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
         L.cpg_hip_solve_batch_device_state.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10
         L.cpg_hip_synchronize.argtypes = [C.c_void_p]
+        L.cpg_hip_solve_batches_pipelined.argtypes = [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
+        L.cpg_hip_host_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.cpg_hip_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.cpg_hip_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.cpg_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.cpg_hip_set_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cpg_hip_set_program_placement.argtypes = [C.c_void_p, C.c_int]
@@ -864,3 +869,50 @@ def _last_kernel_ms(self) -> float:
 BatchSolver.solve_device = _solve_device
 BatchSolver.synchronize = _synchronize
 BatchSolver.last_kernel_ms = _last_kernel_ms
+
+
+class PinnedStream:
+    """`n_batches` consecutive batches of B instances in page-locked HOST memory, solved through
+    cpg_hip_solve_batches_pipelined: H2D of batch i + 1, the solve of batch i and D2H of batch i - 1
+    overlap, so that in steady state the PCIe transfers hide behind the kernel -- the whole-path rate of
+    SURVEY.md 8(d) (theta in host memory -> results in host memory)."""
+
+    def __init__(self, solver: BatchSolver, B: int, n_batches: int):
+        self.s, self.B, self.n = solver, int(B), int(n_batches)
+        self._key = solver._update_key
+        tot = self.B * self.n
+        self._raw = []
+
+        def pinned(shape, dtype):
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            p = C.c_void_p()
+            solver.lib.check(solver.lib.L.cpg_hip_host_malloc(solver.h, max(nbytes, 8), C.byref(p)), 'cpg_hip_host_malloc')
+            self._raw.append(p)
+            buf = (C.c_char * max(nbytes, 8)).from_address(p.value)
+            return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self.theta = pinned((tot, max(solver.np_var, 1)), np.float64)[:, :solver.np_var]
+        self.prim = pinned((tot, solver.n_out_prim), np.float64)
+        self.dual = pinned((tot, solver.n_out_dual), np.float64)
+        self.obj, self.pri, self.dua = pinned((tot,), np.float64), pinned((tot,), np.float64), pinned((tot,), np.float64)
+        self.iter, self.status = pinned((tot,), np.int32), pinned((tot,), np.int32)
+
+    def run(self) -> None:
+        s = self.s
+        if s._update_key != self._key:
+            raise ValueError('the solver\'s set of updated parameters changed after this PinnedStream was created')
+        th = self.theta if self.theta.flags['C_CONTIGUOUS'] else np.ascontiguousarray(self.theta)
+        s.lib.check(s.lib.L.cpg_hip_solve_batches_pipelined(
+            s.h, self.B, self.n, _d(th), _d(self.prim), _d(self.dual), _d(self.obj), self.iter.ctypes.data_as(_ip),
+            self.status.ctypes.data_as(_ip), _d(self.pri), _d(self.dua)), 'cpg_hip_solve_batches_pipelined')
+
+    def result(self) -> BatchResult:
+        lst = [np.array(self.prim), np.array(self.dual), np.array(self.obj), np.array(self.iter), np.array(self.status),
+               np.array(self.pri), np.array(self.dua), None]
+        if (lst[4] == STATUS_NEEDS_REFACTOR).any():
+            self.s._resolve_class_changes(np.array(self.theta), lst)
+        return self.s._result(*lst[:7], 0.0, self.s.last_kernel_ms())
+
+    def free(self) -> None:
+        for p in self._raw:
+            self.s.lib.L.cpg_hip_host_free(self.s.h, p)
+        self._raw = []

@@ -278,7 +278,19 @@ int cpg_hip_solve_batch_state(cpg_handle_t h, int64_t B, const double *theta_var
 int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_theta_var, const double *d_state_in,
                                      double *d_state_out, double *d_prim, double *d_dual, double *d_obj,
                                      int32_t *d_iter, int32_t *d_status, double *d_pri_res, double *d_dua_res);
+/* n_batches consecutive batches of B instances each, all in HOST memory (theta_var [n_batches][B][np_var],
+ * outputs likewise): H2D of batch i + 1, the solve of batch i and D2H of batch i - 1 overlap on three HIP
+ * streams over two sets of device buffers, so that in steady state the PCIe transfers hide behind the
+ * kernel.  Buffers from cpg_hip_host_malloc (page-locked) make the copies truly asynchronous. */
+int cpg_hip_solve_batches_pipelined(cpg_handle_t h, int64_t B, int32_t n_batches, const double *theta_var,
+                                    double *prim, double *dual, double *obj, int32_t *iter, int32_t *status,
+                                    double *pri_res, double *dua_res);
+int cpg_hip_host_malloc(cpg_handle_t h, size_t bytes, void **hptr);
+int cpg_hip_host_free(cpg_handle_t h, void *hptr);
 int cpg_hip_synchronize(cpg_handle_t h);
+/* the handle's HIP stream (hipStream_t), for work that must be ordered behind its solves -- the RCCL
+ * sends / receives of the multi-GPU result gather (cvxpygen_amd/sharding.py) */
+int cpg_hip_get_stream(cpg_handle_t h, void **stream);
 /* duration of the most recent solve kernel on this handle, from HIP events on its stream */
 int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms);
 /* launch geometry: waves per block (1..16), instances per wave (1 or 2), blocks per CU; 0 = auto */

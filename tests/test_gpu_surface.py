@@ -1,0 +1,194 @@
+"""GPU tier (-m gpu) for the surface users touch (templates/cpg_solver.py.jinja2:40-212) and for the
+workspace semantics around the hot path, on the real HIP library:
+  * cpg.generate_code(problem, solver='OSQP' | 'CLARABEL', gradient=...) -> prob.solve(method='CPG')
+    -> values against the oracle; cpg_gradient / forward / backward;
+  * successive solves keep the reference's static-workspace state (parameter values, scaling of the
+    last osqp_update_data_mat, warm start);
+  * the OSQP build options (rho adaptation, duality-gap test) against the oracle in the same mode on
+    BASELINE configs 2 and 3; row-class changes are solved, not flagged;
+  * BASELINE config 5 at its full batch size: properties + a 256-instance oracle sample."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from cvxpygen_amd import cpg, families
+from cvxpygen_amd.lite import LiteProblem
+from cvxpygen_amd.runtime import BatchSolver
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-6
+
+
+def _theta(desc, values):
+    B = next(iter(values.values())).shape[0]
+    th = np.tile(desc.theta0, (B, 1))
+    for name, v in values.items():
+        p = desc.param(name)
+        for k in range(B):
+            th[k, p.col:p.col + p.size] = desc.flatten_param(name, v[k])
+    return th
+
+
+def _check(r, o, desc, tol=REL_TOL):
+    prim = np.concatenate([o['sol_x'][:, v.indices] for v in desc.variables], axis=1)
+    dual = np.concatenate([o['sol_y'][:, d.indices] for d in desc.duals], axis=1)
+    assert (r.iter == o['iter']).all(), f'{int((r.iter != o["iter"]).sum())} iteration-count mismatches'
+    assert (r.status == o['status']).all()
+    ok = np.isin(o['status'], (1, 2, 7))
+    assert np.abs(r.prim_flat[ok] - prim[ok]).max() <= tol * np.abs(prim[ok]).max()
+    assert np.abs(r.dual_flat[ok] - dual[ok]).max() <= tol * np.abs(dual[ok]).max()
+    assert np.abs(r.obj_val[ok] - o['obj_val'][ok]).max() <= tol * np.abs(o['obj_val'][ok]).max()
+
+
+def test_generate_code_and_solve_method_cpg_osqp(oracle_lib, tmp_path):
+    """the reference's own workflow on the example of examples/main.py, with gradient=True"""
+    d = families.nonneg_ls()
+    prob = LiteProblem.from_descriptor(d)
+    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'nnls_code'), solver='OSQP', gradient=True, wrapper=True)
+    ses = oracle_lib.CpgSession(d)
+    rng = np.random.default_rng(2)
+    A1, b1, b2 = rng.standard_normal(3), rng.standard_normal(3), rng.standard_normal(3)
+    prob.param_dict['A'].value = A1
+    prob.param_dict['b'].value = b1
+    val = prob.solve(method='CPG', eps_abs=1e-7, eps_rel=1e-7)
+    o = ses.solve({'A': A1, 'b': b1}, eps_abs=1e-7, eps_rel=1e-7)
+    xi = d.variables[0].indices
+    assert prob.status == 'solved' and prob._solution.attr['num_iters'] == o['iter']
+    assert abs(val - o['obj_val']) <= REL_TOL * abs(o['obj_val'])
+    assert np.abs(prob.var_dict['x'].value - o['x'][xi]).max() <= REL_TOL * np.abs(o['x']).max()
+    assert np.abs(prob.constraints[0].dual_value - o['y'][d.duals[0].indices]).max() <= REL_TOL * max(1.0, np.abs(o['y']).max())
+    assert prob._solver_stats.solver_name == 'OSQP' and prob._solution.opt_val == val
+    # second call: only b listed -- A of call 1 stays, warm start from call 1 (static workspace of the reference)
+    prob.param_dict['b'].value = b2
+    val = prob.solve(method='CPG', updated_params=['b'], eps_abs=1e-7, eps_rel=1e-7)
+    o = ses.solve({'b': b2}, eps_abs=1e-7, eps_rel=1e-7)
+    assert prob._solution.attr['num_iters'] == o['iter']
+    assert np.abs(prob.var_dict['x'].value - o['x'][xi]).max() <= REL_TOL * max(1.0, np.abs(o['x']).max())
+    # unknown names raise like the reference (templates/cpg_solver.py.jinja2:48-60)
+    with pytest.raises(AttributeError):
+        prob.solve(method='CPG', updated_params=['nope'])
+    with pytest.raises(AttributeError):
+        prob.solve(method='CPG', not_a_setting=1)
+    # gradient surface: cpg_solve_and_gradient_info + cpg_gradient, then the cvxpylayers protocol
+    val, gp, gd = mod.cpg_solve_and_gradient_info(prob, eps_abs=1e-9, eps_rel=1e-9, warm_start=False)
+    prob.var_dict['x'].gradient = np.array([0.1, 0.1])
+    mod.cpg_gradient(prob, gp, gd)
+    wts = np.zeros(d.n_var); wts[xi] = 0.1
+    th = d.theta0.copy()
+    th[d.param('A').col:d.param('A').col + 3] = A1
+    th[d.param('b').col:d.param('b').col + 3] = b2
+    go = oracle_lib.qp_adjoint(d, d.canon_at(th), np.array(gp), np.array(gd), wts)
+    for nm in ('A', 'b'):
+        p = d.param(nm)
+        ref = go['dtheta'][p.col:p.col + p.size]
+        assert np.abs(np.ravel(prob.param_dict[nm].gradient) - ref).max() <= REL_TOL * np.abs(go['dtheta']).max() + 1e-12
+    for p in prob.parameters():
+        p.id = id(p)
+    ctx = SimpleNamespace(solver_args={'problem': prob}, param_ids=[p.id for p in prob.parameters()],
+                          variables=prob.variables(), info=None)
+    sol, info = mod.forward([p.value for p in prob.parameters()], ctx)
+    ctx.info = info
+    grads, _ = mod.backward([np.array([0.1, 0.1])], ctx)
+    assert len(sol) == 1 and len(grads) == 2 and all(np.isfinite(np.ravel(g)).all() for g in grads)
+
+
+def test_generate_code_and_solve_method_cpg_clarabel(tmp_path):
+    from oracle import clarabel_numpy as cl
+    d = families.adp()
+    prob = LiteProblem.from_descriptor(d)
+    cpg.generate_code(prob, code_dir=str(tmp_path / 'adp_code'), solver='CLARABEL', wrapper=True)
+    vals = families.adp_values(-2 + 4 * np.random.RandomState(5).rand(6))
+    for k, v in vals.items():
+        prob.param_dict[k].value = v
+    val = prob.solve(method='CPG')
+    o = cl.cpg_solve_batch(d, d.theta_from_values(vals)[None, :])
+    assert prob.status.startswith('1 ') and prob._solution.attr['num_iters'] == int(o['iter'][0])
+    assert abs(val - o['obj_val'][0]) <= REL_TOL * max(1.0, abs(o['obj_val'][0]))
+    u = np.concatenate([np.ravel(prob.var_dict[v.name].value, order='F') for v in d.variables])
+    uo = np.concatenate([o['sol_x'][0, v.indices] for v in d.variables])
+    assert np.abs(u - uo).max() <= REL_TOL * np.abs(uo).max()
+
+
+@pytest.mark.parametrize('fam,B', [('mpc6', 256), ('mpc12', 256)])
+@pytest.mark.parametrize('opts', [dict(adaptive_rho=1, adaptive_rho_interval=50, check_dualgap=1),
+                                  dict(adaptive_rho=1, adaptive_rho_interval=25), dict(check_dualgap=1)])
+def test_build_options_vs_oracle_config2(oracle_lib, fam, B, opts):
+    """BASELINE config 2 in the other rho / termination modes of the OSQP build"""
+    d = families.mpc(6, 3, 10) if fam == 'mpc6' else families.mpc(12, 4, 10)
+    x0 = -2 + 4 * np.random.default_rng(17).random((B, d.param('x_init').size))
+    bs = BatchSolver(d, build_options=opts)
+    r = bs.solve({'x_init': x0}, updated_params=['x_init'])
+    o = oracle_lib.cpg_solve_batch(d, _theta(d, {'x_init': x0}), ['x_init'], **opts)
+    _check(r, o, d)
+    assert (r.status == 1).all()
+    bs.close()
+
+
+def test_adaptive_rho_vs_oracle_config3(oracle_lib):
+    """BASELINE config 3 (portfolio: matrix parameters) with rho adaptation and the duality-gap test"""
+    d = families.portfolio(100, 10)
+    B = 48
+    rng = np.random.default_rng(31)
+    sig = np.zeros((B, 10, 10)); sig[:, np.arange(10), np.arange(10)] = rng.random((B, 10))
+    vals = {'a': rng.standard_normal((B, 100)), 'F': np.round(rng.standard_normal((B, 100, 10))),
+            'Sig_f_sqrt': sig, 'd_sqrt': rng.random((B, 100))}
+    opts = dict(adaptive_rho=1, adaptive_rho_interval=50, check_dualgap=1)
+    bs = BatchSolver(d, build_options=opts)
+    r = bs.solve(vals, updated_params=list(vals))
+    o = oracle_lib.cpg_solve_batch(d, _theta(d, vals), list(vals), **opts)
+    _check(r, o, d)
+    bs.close()
+
+
+def test_row_class_changes_are_solved_on_gpu(oracle_lib):
+    d = families.toy_box()
+    B = 300
+    rng = np.random.default_rng(9)
+    th = np.tile(d.theta0, (B, 1))
+    th[:, d.param('a').col] = 3 * rng.standard_normal(B)
+    free = rng.random(B) < 0.25
+    th[free, d.param('ub').col] = 1e30                       # inequality row -> free row
+    infeas = (~free) & (rng.random(B) < 0.2)
+    th[infeas, d.param('lb').col] = 2.0
+    th[infeas, d.param('ub').col] = 1.0
+    bs = BatchSolver(d)
+    vals = {p.name: th[:, p.col:p.col + p.size] for p in d.params}
+    r = bs.solve(vals)
+    o = oracle_lib.cpg_solve_batch(d, th, None)
+    assert (r.status != -2).all() and free.any() and infeas.any()
+    _check(r, o, d, tol=1e-6)
+    bs.close()
+
+
+def test_config5_full_batch_forward_and_adjoint(oracle_lib):
+    """BASELINE config 5: MPC 12/4/10, gradient=True, 100 000 instances -- forward + batched adjoint"""
+    d = families.mpc(12, 4, 10)
+    B = 100000
+    rng = np.random.default_rng(41)
+    x0 = -2 + 4 * rng.random((B, 12))
+    x0[1] = x0[0]
+    bs = BatchSolver(d, full_output=True)
+    r = bs.solve({'x_init': x0}, updated_params=['x_init'])
+    assert (r.status == 1).all()
+    dv = {v.name: 0.1 * np.ones((B,) + tuple(v.shape)) for v in d.variables}    # 0.1 * sol.sum(), tests/test_diff.py:38
+    g = bs.gradient({'x_init': x0}, r.sol_x, r.sol_y, dv, updated_params=['x_init'])
+    dth = g['_flat']
+    assert dth.shape == (B, d.NP) and np.isfinite(dth).all()
+    assert np.array_equal(dth[0], dth[1])                                         # duplicates: identical bits
+    # linearity of the adjoint in the upstream gradient (size-independent property)
+    dv2 = {k: 2.0 * v for k, v in dv.items()}
+    g2 = bs.gradient({'x_init': x0[:2048]}, r.sol_x[:2048], r.sol_y[:2048], {k: v[:2048] for k, v in dv2.items()},
+                     updated_params=['x_init'])
+    assert np.abs(g2['_flat'] - 2.0 * dth[:2048]).max() <= 1e-9 * max(1.0, np.abs(dth[:2048]).max())
+    # oracle sample
+    wts = np.zeros(d.n_var)
+    for v in d.variables:
+        wts[v.indices] = 0.1
+    th = _theta(d, {'x_init': x0[:256]})
+    o = oracle_lib.cpg_solve_batch(d, th, ['x_init'])
+    assert (r.iter[:256] == o['iter']).all()
+    for k in range(0, 256, 8):
+        go = oracle_lib.qp_adjoint(d, d.canon_at(th[k]), r.sol_x[k], r.sol_y[k], wts)
+        assert np.abs(dth[k] - go['dtheta']).max() <= 1e-6 * np.abs(go['dtheta']).max() + 1e-10
+    bs.close()
