@@ -439,11 +439,11 @@ CPG_DEV double natural_chunk(const DevProgram &P, int s, const double *w, int la
 // first multiply-add consumes one, so a chunk costs about one L2 round trip instead of one per four steps
 // plus one for its header.  The termination test's three products walk 19 chunks (MPC 12/4/10).
 #ifndef CPG_ROWS_BATCH
-#define CPG_ROWS_BATCH 13
+#define CPG_ROWS_BATCH 8
 #endif
 CPG_DEV double natural_chunk_lit(const DevProgram &P, const int len, const int off, const double *w, int lane_in) {
     // per-call copy of the lane: keeps the optimiser from hoisting the ~330 per-lane load offsets of the
-    // unrolled products out of the instance loop (and spilling them), see cpgw::opaque
+    // unrolled products out of the enclosing loops (and spilling them), see cpgw::opaque
     const int lane = cpgw::opaque(lane_in);
     const unsigned e0 = (unsigned)off * 64u + (unsigned)lane;
     double acc = 0.0;
@@ -810,7 +810,8 @@ template <int NSX, int NSZ, int NV, int G, bool LDSPROG>
 CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevSettings &S,
                               const DevBatch &Bt, double *lds, int wave_global) {
     typedef Inst<NSX, NSZ, NV> InstT;
-    const int lane = cpgw::lane_id();
+    const int lane0 = cpgw::lane_id();
+    const int lane = lane0;
 #if defined(CPG_GEN_N)
     // family-specialised build: dimensions are literals, so the bounds checks of full slots fold away
     constexpr unsigned n_c = GenFam::n, m_c = GenFam::m;
@@ -889,6 +890,11 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
     }
 
     for (;;) {
+        // per-instance copy of the lane id (see cpgw::opaque): nothing derived from it is invariant across
+        // instances, so the optimiser cannot hoist the dozens of per-lane addresses of the set-up, update and
+        // retrieval code into the kernel prologue and keep them alive (spilled) across the hot loop
+        const int lane = cpgw::opaque(lane0);
+        cpgw::assume((unsigned)lane < 64u);
         unsigned ig = 0;
         if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
         ig = (unsigned)cpgw::read_first_lane((int)ig);
@@ -916,10 +922,10 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
             if (Bt.state_in && S.warm_starting && b < Bt.B)
                 load_state<NSX, NSZ>(F, Bt.state_in + (size_t)b * (size_t)(F.n + 2 * F.m + 1), I[g].x, I[g].z, I[g].y, lane);
             if (__builtin_expect(bad && !I[g].done, 0)) {
-                // a row changed class: the family's factor does not serve this instance (the host layer
-                // sends it through the per-instance factor path, cvxpygen_amd/runtime.py)
-                co[g].status = -2; co[g].obj = NAN;
-                finalize<NSX, NSZ>(F, Bt, I[g].x, I[g].z, I[g].y, I[g].dconst, I[g].b, w + g * ldw, lane, 0, co[g], F.rho);
+                // a row changed class: the family's factor does not serve this instance.  It is only flagged
+                // here (its solution rows stay unwritten); the host layer sends it through the per-instance
+                // factor path and overwrites every output of the row (cvxpygen_amd/runtime.py)
+                if (lane == 0) { Bt.obj[b] = NAN; Bt.iter[b] = 0; Bt.status[b] = -2; Bt.pri_res[b] = 0.0; Bt.dua_res[b] = 0.0; }
                 I[g].done = 1;
             }
             n_open += I[g].done ? 0 : 1;

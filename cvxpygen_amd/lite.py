@@ -30,6 +30,7 @@ class LiteParameter:
         self.attributes = {'diag': up.kind == 'diag', 'sparsity': up.sparsity}
         self._has_dim_reducing_attr = up.kind == 'sparse'
         self._up = up
+        self.id = id(self)
         self.gradient = None
         self.value = value
 

@@ -217,7 +217,7 @@ class FamilyPlan:
 
 
 def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
-                      setup_settings: Optional[Dict[str, float]] = None) -> FamilyPlan:
+                      setup_settings: Optional[Dict[str, float]] = None, bank_layout: bool = True) -> FamilyPlan:
     t0 = time.time()
     n, m, n_eq = desc.n_var, desc.m, desc.n_eq
     # the shared-factor kernel relies on the two row kinds of the reference's OSQP canonical form
@@ -240,8 +240,32 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
     N = n + m
     phases = _sp.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=merge,
                              devpos=devpos)
-    kkt = _sp.pack(phases, N=N)
-    kkt_ragged = _sp.pack_ragged(phases, N, balanced=True)
+    pi = None
+    bank_stats = {}
+    if bank_layout:
+        # bank-aware numbering of the work-vector slots (cvxpygen_amd/slot_layout.py): the entries keep their
+        # region -- x / rows, parameter-dependent first, rows additionally by class so that 64-row slots of
+        # one class stay uniform -- and the spill slots of merged phases are renumbered freely
+        from . import slot_layout as _sl
+        rg0 = _sp.pack_ragged(phases, N, balanced=True)
+        region = np.full(rg0.n_slots, 99, dtype=np.int64)
+        region[:n] = np.where(np.arange(n) < int(vary_q.sum()), 0, 1)
+        ctz = np.asarray(plan.constr_type)[ordz]
+        region[n:N] = np.where(np.arange(m) < int(vary_u.sum()), 10, 20 + (ctz + 1))
+        pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0), region, seed=0)
+        bank_stats = dict(bank_conflict_cycles_natural=int(c0), bank_conflict_cycles=int(c1))
+        # the device ordering follows: the entry at device position p moves to position pi[p]
+        ordx2 = np.empty_like(ordx); ordx2[pi[:n]] = ordx
+        ordz2 = np.empty_like(ordz); ordz2[pi[n:N] - n] = ordz
+        ordx, ordz = ordx2, ordz2
+        posx[ordx] = np.arange(n); posz[ordz] = np.arange(m)
+    kkt = _sp.pack(phases, N=N, slot_perm=pi)
+    kkt_ragged = _sp.pack_ragged(phases, N, balanced=True, slot_perm=pi)
+    if pi is not None:
+        # final_pos is indexed by the logical entry the phases were compiled with (= old device position)
+        fp = np.empty(N, dtype=np.int64); fp[pi[:N]] = kkt.final_pos
+        fr = np.empty(N, dtype=np.int64); fr[pi[:N]] = kkt_ragged.final_pos
+        kkt.final_pos, kkt_ragged.final_pos = fp, fr
     assert kkt_ragged.n_slots == kkt.n_slots and np.array_equal(kkt_ragged.final_pos, kkt.final_pos)
     if kkt.n_slots >= 0xFFFF:
         raise NotImplementedError('problem family too large for 16-bit LDS slot indices')
@@ -259,7 +283,7 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         if desc.duals else np.zeros(0, dtype=np.int32)
     stats = dict(nnzL=len(plan.Li), phases=kkt.n_phases, chunks=kkt.n_chunks, steps=kkt.steps,
                  nnz_program=kkt.nnz, n_slots=kkt.n_slots, lds_program_bytes=kkt_ragged.lds_bytes(),
-                 compile_s=time.time() - t0)
+                 compile_s=time.time() - t0, **bank_stats)
     return FamilyPlan(desc=desc, osqp=plan, ordx=ordx, ordz=ordz, posx=posx, posz=posz,
                       n_vary_x=int(vary_q.sum()), n_vary_z=int(vary_u.sum()), kkt=kkt,
                       kkt_ragged=kkt_ragged, A_rows=A_rows,

@@ -218,21 +218,67 @@ class GeneratedSolver:
             prob.param_dict[q.name].gradient = float(g) if q.kind == 'scalar' else np.array(g)
 
     def forward(self, params, context):
-        """cvxpylayers `custom_method` forward (templates/cpg_solver.py.jinja2:176-193)"""
+        """cvxpylayers `custom_method` forward (templates/cpg_solver.py.jinja2:176-193).  When a parameter
+        value carries a leading batch axis (cvxpylayers hands the whole batch over; the reference's users loop
+        over it one instance at a time, examples/paper_grad/ADP.py:80-88) the batch goes to the GPU as ONE
+        solve: every instance from the code-generation-time workspace, cold start."""
         info = {}
         kwargs = context.solver_args.copy()
         prob = kwargs.pop("problem")
         parameters = prob.parameters()
-        for pid, val in zip(context.param_ids, params):
-            next(p for p in parameters if p.id == pid).value = val
+        plist = [next(p for p in parameters if p.id == pid) for pid in context.param_ids]
+        if any(self._batch_size(p, val) is not None for p, val in zip(plist, params)):
+            return self._forward_batch(plist, params, context, prob, kwargs)
+        for p, val in zip(plist, params):
+            p.value = val
         updated_params = kwargs.pop("updated_params", None)
         _, info["gradient_primal"], info["gradient_dual"] = self.cpg_solve_and_gradient_info(prob, updated_params, **kwargs)
         info["prob"] = prob
         vars_ = prob.variables()
         return [next(v for v in vars_ if v.id == variable.id).value for variable in context.variables], info
 
+    def _batch_size(self, p, val):
+        """leading batch axis of a parameter value: [B, *shape], or [B, size] for values that are already
+        flattened the way the reference stores them (F-order / diagonal / stored non-zeros); None: one instance"""
+        v = np.asarray(val)
+        shape, size = tuple(p.shape), self.desc.param(p.name()).size
+        if v.shape == shape or (v.ndim <= 1 and v.size == size):
+            return None
+        if v.ndim >= 1 and (v.shape[1:] == shape or (v.ndim == 2 and v.shape[1] == size)):
+            return int(v.shape[0])
+        raise ValueError(f'value of parameter {p.name()} has shape {v.shape}, expected {shape} or a leading batch axis')
+
+    def _forward_batch(self, plist, params, context, prob, kwargs):
+        if not self.gradient:
+            raise AttributeError('code was generated with gradient=False')
+        sizes = [self._batch_size(p, val) for p, val in zip(plist, params)]
+        B = max(b for b in sizes if b is not None)
+        vals = {}
+        for p, val, b in zip(plist, params, sizes):
+            v = np.asarray(val, dtype=np.float64)
+            if b is None:                                        # shared by the whole batch
+                v = np.broadcast_to(v, (B,) + v.shape)
+            elif b != B:
+                raise ValueError('inconsistent batch sizes')
+            vals[p.name()] = np.ascontiguousarray(v)
+        kwargs.pop("updated_params", None)
+        kwargs = self._filter_settings(kwargs)
+        kwargs.pop('warm_start', None); kwargs.pop('warm_starting', None)     # independent instances: cold start
+        names = [q.name for q in self.desc.params if q.name in vals]
+        res = self.batch_solver.solve(vals, updated_params=names, **kwargs)
+        info = {"batched": True, "gradient_primal": res.sol_x, "gradient_dual": res.sol_y, "prob": prob,
+                "batch_params": vals, "batch_names": names, "status": res.status, "iter": res.iter}
+        return [res.prim[variable.name()] for variable in context.variables], info
+
     def backward(self, dvars, context):
         prob = context.info["prob"]
+        if context.info.get("batched"):
+            vals, names = context.info["batch_params"], context.info["batch_names"]
+            dv = {variable.name(): np.asarray(g, dtype=np.float64) for variable, g in zip(context.variables, dvars)}
+            out = self.batch_solver.gradient(vals, context.info["gradient_primal"], context.info["gradient_dual"], dv,
+                                             updated_params=names)
+            params = prob.parameters()
+            return [out[next(p for p in params if p.id == pid).name()] for pid in context.param_ids], {}
         vars_ = prob.variables()
         for variable, dv in zip(context.variables, dvars):
             next(v for v in vars_ if v.id == variable.id).gradient = dv

@@ -1,0 +1,103 @@
+"""
+Bank-aware numbering of the LDS work-vector slots of a solve program.
+
+Every multiply-add step of the solve program gathers one 8-byte operand per lane from the work vector
+(`ds_read_b64` with per-lane addresses).  On CDNA4 the LDS services such a read in two groups of 32 lanes;
+inside a group, lanes that address DIFFERENT 8-byte slots on the same pair of banks (slot mod 32) are
+serialised: a group costs as many LDS cycles as the most loaded bank pair has distinct slots
+(MI355X_MICROARCH.md, LDS section).  With the natural numbering the gathers of the MPC 12/4/10 program
+spend 32 % of all LDS cycles on such conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) while the LDS
+pipe is 87 % busy -- the binding resource of the headline kernel.
+
+Which slot a value lives in is free: entries of the KKT right-hand side may be placed in any order inside
+their region (x entries / rows of each class, parameter-dependent ones first: the device ordering of
+cvxpygen_amd/runtime.py is a permutation the host picks), and the spill slots of merged phases are
+arbitrary.  This module picks the numbering by simulated annealing on the exact cost of the generated
+executor's gathers: sum over (step, 32-lane group) of (max distinct slots on one bank pair - 1).
+
+Code-generation time only (numpy); deterministic for a given seed.
+"""
+
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+BANK_PAIRS = 32          # 64 banks x 4 B; an 8-byte slot covers one aligned pair
+GROUP = 32               # lanes serviced together by a ds_read_b64
+
+
+def gather_groups(step_slots: np.ndarray) -> List[np.ndarray]:
+    """step_slots [n_steps, 64]: slot gathered by every lane of every step (what the executor really
+    reads, idle lanes included).  Returns the distinct slots of every (step, 32-lane group)."""
+    out = []
+    for row in step_slots:
+        for g in range(0, row.shape[0], GROUP):
+            out.append(np.unique(row[g:g + GROUP]))
+    return out
+
+
+def conflict_cycles(groups: List[np.ndarray], pi: np.ndarray) -> int:
+    """extra LDS cycles of all gathers under the numbering pi (slot -> position)"""
+    tot = 0
+    for sl in groups:
+        tot += int(np.bincount(pi[sl] % BANK_PAIRS, minlength=BANK_PAIRS).max()) - 1
+    return tot
+
+
+def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed: int = 0
+             ) -> Tuple[np.ndarray, int, int]:
+    """Returns (pi, cost before, cost after).  pi[slot] = new position; pi permutes the slots of every
+    region among themselves (region[slot] = region id; regions are contiguous ranges of positions)."""
+    n = region.shape[0]
+    rng = np.random.default_rng(seed)
+    groups = gather_groups(step_slots)
+    ng = len(groups)
+    pi = np.arange(n, dtype=np.int64)
+    # slot -> groups that contain it
+    occ: List[List[int]] = [[] for _ in range(n)]
+    for gi, sl in enumerate(groups):
+        for s in sl:
+            occ[int(s)].append(gi)
+    occ_arr = [np.asarray(o, dtype=np.int64) for o in occ]
+    cnt = np.zeros((ng, BANK_PAIRS), dtype=np.int32)
+    for gi, sl in enumerate(groups):
+        np.add.at(cnt[gi], pi[sl] % BANK_PAIRS, 1)
+    gmax = cnt.max(axis=1)
+    cost0 = int(gmax.sum() - ng)
+    members = [np.nonzero(region == r)[0] for r in np.unique(region)]
+    members = [m for m in members if len(m) > 1]
+    used = np.array([len(o) > 0 for o in occ])
+    cost = cost0
+    n_moves = sweeps * int(used.sum())
+    T0, T1 = 1.0, 0.05
+    for it in range(n_moves):
+        T = T0 * (T1 / T0) ** (it / max(1, n_moves - 1))
+        m = members[int(rng.integers(len(members)))]
+        a = int(m[int(rng.integers(len(m)))])
+        b = int(m[int(rng.integers(len(m)))])
+        ra, rb = int(pi[a] % BANK_PAIRS), int(pi[b] % BANK_PAIRS)
+        if ra == rb or not (used[a] or used[b]):
+            continue
+        ga, gb = occ_arr[a], occ_arr[b]
+        # groups that contain both are unaffected
+        only_a = np.setdiff1d(ga, gb, assume_unique=True)
+        only_b = np.setdiff1d(gb, ga, assume_unique=True)
+        aff = np.concatenate([only_a, only_b])
+        if not len(aff):
+            pi[a], pi[b] = pi[b], pi[a]
+            continue
+        sub = cnt[aff].copy()
+        na = len(only_a)
+        sub[:na, ra] -= 1; sub[:na, rb] += 1
+        sub[na:, rb] -= 1; sub[na:, ra] += 1
+        new_max = sub.max(axis=1)
+        delta = int(new_max.sum() - gmax[aff].sum())
+        if delta <= 0 or rng.random() < np.exp(-delta / T):
+            cnt[aff] = sub
+            gmax[aff] = new_max
+            pi[a], pi[b] = pi[b], pi[a]
+            cost += delta
+    assert cost == conflict_cycles(groups, pi)
+    return pi, cost0, cost

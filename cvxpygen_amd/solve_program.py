@@ -296,8 +296,9 @@ FLAG_LAST = 2
 NO_ROW = 0xFFFF
 
 
-def assign_slots(phases: List[Phase], N: int):
-    """LDS slot allocation.  Entry i starts in slot i.  A phase whose rows read each other
+def assign_slots(phases: List[Phase], N: int, slot_perm: Optional[np.ndarray] = None):
+    """LDS slot allocation.  Entry i starts in slot i (slot slot_perm[i] when a bank-aware numbering is
+    given, cvxpygen_amd/slot_layout.py: every slot number below is then mapped through it).  A phase whose rows read each other
     (`intra`) writes its results to free slots and releases the slots its rows occupied, so every
     chunk can store immediately; other phases update in place.  Returns (per-phase output slots,
     per-phase column slots, n_slots, final_pos)."""
@@ -321,10 +322,17 @@ def assign_slots(phases: List[Phase], N: int):
         cur[ph.rows] = new
         free.extend(int(v) for v in old[::-1])
         outs.append(new)
+    if slot_perm is not None:
+        sp_ = np.asarray(slot_perm, dtype=np.int64)
+        assert len(sp_) == n_slots and np.array_equal(np.sort(sp_), np.arange(n_slots))
+        outs = [sp_[o] for o in outs]
+        ins = [[sp_[c] for c in ph_in] for ph_in in ins]
+        return outs, ins, n_slots, sp_[cur]
     return outs, ins, n_slots, cur.copy()
 
 
-def pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None) -> PackedProgram:
+def pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None,
+         slot_perm: Optional[np.ndarray] = None) -> PackedProgram:
     """natural=True: chunk c holds rows 64c .. 64c+63, one row per lane (results are consumed in
     registers by the lane that owns the element; nothing is stored to w)."""
     hdr, rows_out, vals_out, cols_out = [], [], [], []
@@ -337,7 +345,7 @@ def pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None) ->
     else:
         if N is None:
             N = int(max(int(ph.rows.max()) for ph in phases)) + 1 if phases else 0
-        outs, ins, n_slots, final_pos = assign_slots(phases, N)
+        outs, ins, n_slots, final_pos = assign_slots(phases, N, slot_perm)
     for ph, out_slots, col_slots in zip(phases, outs, ins):
         lens = [len(c) for c in ph.cols]
         nnz += sum(lens)
@@ -517,7 +525,8 @@ def _balanced_plan(lens: Sequence[int]):
     return best
 
 
-def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0) -> RaggedProgram:
+def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0,
+                slot_perm: Optional[np.ndarray] = None) -> RaggedProgram:
     """balanced=False: rows of a chunk are split over a uniform power-of-two number of lanes;
     balanced=True: variable number of adjacent lanes per row + segmented reduction (fewer steps when
     row lengths are uneven); balanced='auto': per phase whichever of the two the cost model prefers.
@@ -529,10 +538,10 @@ def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float 
         saved = (STAGE_COST, GROUP_STAGE_COST)
         STAGE_COST, GROUP_STAGE_COST = saved[0] * stage_scale, saved[1] * stage_scale
         try:
-            return pack_ragged(phases, N, balanced)
+            return pack_ragged(phases, N, balanced, slot_perm=slot_perm)
         finally:
             STAGE_COST, GROUP_STAGE_COST = saved
-    outs, ins, n_slots, final_pos = assign_slots(phases, N)
+    outs, ins, n_slots, final_pos = assign_slots(phases, N, slot_perm)
     if n_slots * 8 > 0xFFFF:
         raise NotImplementedError('work vector too large for 16-bit byte offsets')
     ctab, desc, vals, cols, chunk_phase = [], [], [], [], []
@@ -668,3 +677,20 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
         ok = R != NO_ROW
         w[R[ok]] = (w[R[ok]] + red[ok]) if accumulate else red[ok]
     return w
+
+
+def gathered_slots(prog: RaggedProgram) -> np.ndarray:
+    """[n_steps, 64]: the slot every lane of every multiply-add step of the GENERATED executor gathers
+    (cvxpygen_amd/codegen.py): lanes past the active prefix of a partial step read the entries that follow
+    in the flat program (their coefficient is then forced to zero), past its end the zero padding (offset 0)."""
+    flat = np.concatenate([prog.cols.astype(np.int64) // 8, np.zeros(2 * LANES, dtype=np.int64)])
+    rows = []
+    for c in range(prog.n_chunks):
+        L, _, first, kind = (int(v) for v in prog.ctab[c])
+        d = prog.desc[c]
+        ln = ((d >> 16) & 0xFFF) if (kind & 1) else (d >> 16)
+        e = first
+        for s_ in range(L):
+            rows.append(flat[e:e + LANES])
+            e += int((ln > s_).sum())
+    return np.asarray(rows, dtype=np.int64).reshape(-1, LANES)

@@ -92,3 +92,40 @@ def test_reference_gradient_surface(sim_lib, oracle_lib, tmp_path):
     ctx.info = info
     grads, _ = mod.backward([np.array([0.1, 0.1])], ctx)
     assert len(grads) == 2 and all(g is not None for g in grads)
+
+
+def test_batched_forward_backward_adapter(sim_lib, oracle_lib, tmp_path):
+    """cvxpylayers protocol with a leading batch axis on the parameters (templates/cpg_solver.py.jinja2:176-212;
+    the reference's users loop over the batch, examples/paper_grad/ADP.py:80-88): ONE batched solve + ONE
+    batched adjoint, equal to the single-instance forward / backward instance by instance"""
+    d = families.nonneg_ls()
+    prob = LiteProblem.from_descriptor(d)
+    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'fb_code'), solver='OSQP', gradient=True, wrapper=True)
+    mod._SOLVER.lib_path = sim_lib
+    B = 3
+    rng = np.random.default_rng(12)
+    Ab, bb = rng.standard_normal((B, 3)), rng.standard_normal((B, 3))
+    ctx = SimpleNamespace(solver_args={'problem': prob, 'eps_abs': 1e-9, 'eps_rel': 1e-9},
+                          param_ids=[p.id for p in prob.parameters()], variables=prob.variables(), info=None)
+    order = [p.name() for p in prob.parameters()]
+    batch_vals = [dict(A=Ab, b=bb)[nm] for nm in order]
+    sol, info = mod.forward(batch_vals, ctx)
+    assert sol[0].shape == (B, 2) and info['batched'] and (info['status'] == 1).all()
+    ctx.info = info
+    up = 0.1 * np.ones((B, 2))
+    grads, _ = mod.backward([up], ctx)
+    assert [g.shape for g in grads] == [(B, 3) if nm == 'A' else (B, 3) for nm in order]
+    wts = np.zeros(d.n_var); wts[d.variables[0].indices] = 0.1
+    for k in range(B):
+        th = d.theta0.copy()
+        th[d.param('A').col:d.param('A').col + 3] = Ab[k]
+        th[d.param('b').col:d.param('b').col + 3] = bb[k]
+        o = oracle_lib.cpg_solve_batch(d, th[None, :], ['A', 'b'], eps_abs=1e-9, eps_rel=1e-9)
+        assert np.abs(sol[0][k] - o['sol_x'][0, d.variables[0].indices]).max() <= 1e-9
+        go = oracle_lib.qp_adjoint(d, d.canon_at(th), info['gradient_primal'][k], info['gradient_dual'][k], wts)
+        for nm, g in zip(order, grads):
+            p = d.param(nm)
+            assert np.abs(np.ravel(g[k]) - go['dtheta'][p.col:p.col + p.size]).max() <= 1e-8 * max(1.0, np.abs(go['dtheta']).max())
+    # a parameter shared by the whole batch may come without the batch axis
+    sol2, _ = mod.forward([dict(A=Ab[0], b=bb)[nm] for nm in order], ctx)
+    assert np.abs(sol2[0][0] - sol[0][0]).max() <= 1e-12
