@@ -984,10 +984,10 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
         const int W = 4;
         const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
         if (lds > h->lds_limit) { set_error("work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
-        long long blocks = (B + W - 1) / W;
         int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : CPG_REFACTOR_WAVES_PER_SIMD;    // workgroups of 4 waves
         if (per_cu > CPG_REFACTOR_WAVES_PER_SIMD) per_cu = CPG_REFACTOR_WAVES_PER_SIMD;
         if ((long long)per_cu * (long long)lds > (long long)h->lds_limit) per_cu = (int)(h->lds_limit / lds);
+        long long blocks = (B + W - 1) / W;
         const long long cap = (long long)h->num_cu * per_cu;
         if (blocks > cap) blocks = cap;
         if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;

@@ -542,11 +542,24 @@ CPG_DEV bool canonicalise(const DevFamily &F, const DevUpdate &U, const double *
     return cpgw::wave_any(bad);
 }
 
-// is_primal_infeasible on delta_y (OSQP paper sec. 3.4); wave-uniform result.  The steps delta_x /
-// delta_y of the checked iteration are handed over in registers (element i on lane i % 64, slot i / 64).
-template <int NSX, int NSZ, typename Ctx>
+// Where the steps delta_x / delta_y of the checked iteration are kept for OSQP's infeasibility tests:
+// registers (element i on lane i % 64, slot i / 64; the shared-factor kernel: nothing leaves the CU) or the
+// wavefront's buffer in global memory (the per-instance factor kernels, whose iterates, q and u already
+// take most of the register budget).
+template <int NS>
+struct RegDelta {
+    const double (&a)[NS];
+    CPG_DEV double operator()(int s, unsigned) const { return a[s]; }
+};
+struct MemDelta {
+    const double *p;
+    CPG_DEV double operator()(int, unsigned i) const { return cpgw::gld(p, i); }
+};
+
+// is_primal_infeasible on delta_y (OSQP paper sec. 3.4); wave-uniform result.
+template <int NSX, int NSZ, typename Ctx, typename DY>
 CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
-                               bool unsc, double eps, double *w, const double (&dy)[NSZ], int lane) {
+                               bool unsc, double eps, double *w, const DY &dy, int lane) {
     double nrm = 0.0, lhs = 0.0;
     double dyp[NSZ];                                   // delta_y projected on the polar of the recession cone of [l, u]
 #pragma unroll
@@ -558,7 +571,7 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
             const bool eq = ct[s] == 1;
             const double ll = eq ? uu : -CPG_INFTY;
             const bool iu = uu > CPG_INFTY * CPG_MIN_SCALING, il = !eq;
-            double d = dy[s];
+            double d = dy(s, i);
             if (iu && il) d = 0.0; else if (iu) d = cpgw::dmin2(d, 0.0); else if (il) d = cpgw::dmax2(d, 0.0);
             dyp[s] = d;
             nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.E, i) * d : d));
@@ -587,15 +600,15 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
 }
 
 // is_dual_infeasible on delta_x; wave-uniform result
-template <int NSX, int NSZ, typename Ctx>
+template <int NSX, int NSZ, typename Ctx, typename DX>
 CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
-                             bool unsc, double eps, double *w, const double (&dx)[NSX], int lane) {
+                             bool unsc, double eps, double *w, const DX &dx, int lane) {
     double nrm = 0.0, qdx = 0.0;
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         if (i < (unsigned)F.n) {
-            const double d = dx[s];
+            const double d = dx(s, i);
             nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.D, i) * d : d));
             qdx += cx.q(s, i) * d;
         }
@@ -606,7 +619,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
     qdx = cpgw::wave_sum(qdx);
     if (!(qdx < -cs * eps * nrm)) return false;
 #pragma unroll
-    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = dx[s]; }
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = dx(s, i); }
     cpgw::lds_order();
     double r = 0.0;
 #pragma unroll
@@ -647,10 +660,10 @@ struct ScaledNorms {
 // update_info + check_termination: residuals in the unscaled space (scaled_termination = 0),
 // optimality / infeasibility decisions.  status stays 11 (unsolved) when nothing triggers.
 // `sn` (optional) receives the scaled norms of the same products.
-template <int NSX, int NSZ, typename Ctx>
+template <int NSX, int NSZ, typename Ctx, typename DX, typename DY>
 CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
                        const DevSettings &S, const double (&Ix)[NSX], const double (&Iz)[NSZ],
-                       const double (&Iy)[NSZ], const double (&dx)[NSX], const double (&dy)[NSZ],
+                       const double (&Iy)[NSZ], const DX &dx, const DY &dy,
                        double *w, int lane, bool approximate, ScaledNorms *sn = nullptr) {
     const bool unsc = !S.scaled_termination;
     CheckOut o;
@@ -722,9 +735,9 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
     bool pc = false, dc = false, pic = false, dic = false, gc = true;
     if (F.m == 0) pc = true;
     else if (rp < ea + er * cpgw::dmax2(nz, na)) pc = true;
-    else pic = primal_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, epi, w, dy, lane);
+    else pic = primal_infeasible<NSX, NSZ, Ctx, DY>(F, cx, ct, unsc, epi, w, dy, lane);
     if (rd < ea + er * dn) dc = true;
-    else dic = dual_infeasible<NSX, NSZ, Ctx>(F, cx, ct, unsc, edi, w, dx, lane);
+    else dic = dual_infeasible<NSX, NSZ, Ctx, DX>(F, cx, ct, unsc, edi, w, dx, lane);
     if (S.check_dualgap) {   // OSQP >= 1.0: |primal - dual objective| against eps_abs + eps_rel max(|primal|, |dual|)
         sup = cpgw::wave_sum(sup);
         const double dual_obj = (-0.5 * quad - sup) * F.cinv, gap = fabs(quad + lin + sup) * F.cinv;
@@ -1052,8 +1065,9 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma nounroll
                 for (int pass = 0; pass < 2; pass++) {
                     if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S,
-                                                                I[g].x, I[g].z, I[g].y, dxr[g], dyr[g], wg, lane, pass == 1);
+                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, RegDelta<NSX>, RegDelta<NSZ>>(
+                        F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S, I[g].x, I[g].z, I[g].y,
+                        RegDelta<NSX>{dxr[g]}, RegDelta<NSZ>{dyr[g]}, wg, lane, pass == 1);
                 }
                 if (o.status == 11 && iter >= S.max_iter) o.status = 7;
                 co[g] = o;

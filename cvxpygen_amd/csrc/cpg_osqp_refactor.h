@@ -97,12 +97,19 @@ struct InstCtx {
     const InstBuf &B;
     const double *w;
     int lane;
+#ifdef CPG_REFACTOR_QU_IN_MEMORY
+    // the instance's scaled q and u are re-read from its buffer where they are needed (experiment: their
+    // 2 (NSX + NSZ) registers against the scratch traffic of the ADMM loop)
+    CPG_DEV double q(int, unsigned i) const { return cpgw::gld((const double *)B.q, i); }
+    CPG_DEV double u(int, unsigned i) const { return cpgw::gld((const double *)B.u, i); }
+#else
     // the instance's scaled q and u stay in registers for the whole ADMM loop (they are read in
     // every iteration; a global load there is a full memory latency on the critical path)
     const double (&qr)[NSX];
     const double (&ur)[NSZ];
     CPG_DEV double q(int s, unsigned) const { return qr[s]; }
     CPG_DEV double u(int s, unsigned) const { return ur[s]; }
+#endif
     template <bool ENT, bool OFFS>
     CPG_DEV double row_dot(const int *ptr, const int *ent, const int *col, const double *val, unsigned r) const {
         double acc = 0.0;
@@ -354,12 +361,16 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         StreamProg ST;
         ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
         ST.n_pairs = R.sol_pairs; ST.dummy = (unsigned)R.sol_nnz / 2u - 1u;
+#ifdef CPG_REFACTOR_QU_IN_MEMORY
+        const InstCtx<NSX, NSZ> cx{F, R, B, w, lane};
+#else
         double qr[NSX], ur[NSZ];
 #pragma unroll
         for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qr[s] = i < n ? cpgw::gld((const double *)B.q, i) : 0.0; }
 #pragma unroll
         for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; ur[s] = i < m ? cpgw::gld((const double *)B.u, i) : 0.0; }
         const InstCtx<NSX, NSZ> cx{F, R, B, w, lane, qr, ur};
+#endif
         double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
         for (int s = 0; s < NSX; s++) x[s] = 0.0;
@@ -434,14 +445,14 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             ScaledNorms sn;
             bool have_info = false;
             if (can_check) {
-                o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, false, &sn);
+                o = check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, w, lane, false, &sn);
                 have_info = true;
                 if (o.status != 11) break;
             }
             if (adapt) {
                 // adapt_rho (OSQP paper sec. 5.2): rho <- rho sqrt(normalised primal / dual residual); a new
                 // factorisation only when it changed by more than adaptive_rho_tolerance
-                if (!have_info) (void)check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, false, &sn);
+                if (!have_info) (void)check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, w, lane, false, &sn);
                 const double pr = sn.prim_res / (cpgw::dmax2(sn.nz, sn.nax) + CPG_DIV_TOL);
                 const double dr = sn.dual_res / (cpgw::dmax2(sn.nq, cpgw::dmax2(sn.naty, sn.npx)) + CPG_DIV_TOL);
                 const double rn = cpgw::dmin2(cpgw::dmax2(rho * sqrt(pr / dr), CPG_RHO_MIN), CPG_RHO_MAX);
@@ -458,8 +469,8 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 }
             }
             if (last) {
-                if (!can_check) o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, false);
-                if (o.status == 11) o = check<NSX, NSZ, InstCtx<NSX, NSZ>>(F, cx, ct, S, x, z, y, dxr, dyr, w, lane, true);
+                if (!can_check) o = check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, w, lane, false);
+                if (o.status == 11) o = check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, w, lane, true);
                 if (o.status == 11) o.status = 7;
             }
         }

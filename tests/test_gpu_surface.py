@@ -192,3 +192,26 @@ def test_config5_full_batch_forward_and_adjoint(oracle_lib):
         go = oracle_lib.qp_adjoint(d, d.canon_at(th[k]), r.sol_x[k], r.sol_y[k], wts)
         assert np.abs(dth[k] - go['dtheta']).max() <= 1e-6 * np.abs(go['dtheta']).max() + 1e-10
     bs.close()
+
+
+@pytest.mark.parametrize('opts', [{}, dict(adaptive_rho=1, adaptive_rho_interval=50, check_dualgap=1)])
+def test_portfolio_family_library_vs_oracle(oracle_lib, opts):
+    """BASELINE config 3 on what generate_code builds for it: the family library (per-instance factor kernel
+    compiled for the family's exact slot class), in both rho modes"""
+    import os
+    from cvxpygen_amd import codegen
+    from cvxpygen_amd.runtime import build_family_plan
+    d = families.portfolio(100, 10)
+    plan = build_family_plan(d)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = codegen.build_family_library(plan, os.path.join(root, 'cvxpygen_amd', 'generated', 'portfolio'), 'portfolio')
+    B = 64
+    rng = np.random.default_rng(77)
+    sig = np.zeros((B, 10, 10)); sig[:, np.arange(10), np.arange(10)] = rng.random((B, 10))
+    vals = {'a': rng.standard_normal((B, 100)), 'F': np.round(rng.standard_normal((B, 100, 10))),
+            'Sig_f_sqrt': sig, 'd_sqrt': rng.random((B, 100))}
+    bs = BatchSolver(d, lib_path=lib, plan=plan, build_options=opts)
+    r = bs.solve(vals, updated_params=list(vals))
+    o = oracle_lib.cpg_solve_batch(d, _theta(d, vals), list(vals), **opts)
+    _check(r, o, d)
+    bs.close()

@@ -198,3 +198,4 @@ def test_refactor_path_parameter_in_P(sim_lib, oracle_lib):
     _assert_parity(r, o, prim, dual)
     assert r.prim['delta_u'].shape == (B, 1, 1) and r.dual['d2'].shape == (B, 1, 1)
     bs.close()
+
