@@ -664,7 +664,12 @@ template <int NSX, int NSZ, typename Ctx, typename DX, typename DY>
 CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
                        const DevSettings &S, const double (&Ix)[NSX], const double (&Iz)[NSZ],
                        const double (&Iy)[NSZ], const DX &dx, const DY &dy,
-                       double *w, int lane, bool approximate, ScaledNorms *sn = nullptr) {
+                       double *w, int lane_in, bool approximate, ScaledNorms *sn = nullptr) {
+    // per-call copy of the lane id (cpgw::opaque): the dozens of per-lane addresses of the test are computed
+    // here and die here, instead of being hoisted out of the caller's loops and kept alive (spilled) across
+    // its hot loop
+    const int lane = cpgw::opaque(lane_in);
+    cpgw::assume((unsigned)lane < 64u);
     const bool unsc = !S.scaled_termination;
     CheckOut o;
 #pragma unroll
@@ -754,8 +759,10 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
 // (reset to zero when there is no solution, as osqp_solve does) and rho.
 template <int NSX, int NSZ>
 CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)[NSX], const double (&Iz)[NSZ],
-                      const double (&Iy)[NSZ], double dconst, long long b, double *w, int lane, int iter,
+                      const double (&Iy)[NSZ], double dconst, long long b, double *w, int lane_in, int iter,
                       const CheckOut &o, double rho) {
+    const int lane = cpgw::opaque(lane_in);                 // see check(): addresses computed here die here
+    cpgw::assume((unsigned)lane < 64u);
     const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
     if (Bt.state_out) {
         double *so = Bt.state_out + (size_t)b * (size_t)(F.n + 2 * F.m + 1);

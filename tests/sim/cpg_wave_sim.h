@@ -1,10 +1,13 @@
 // TEST INFRASTRUCTURE ONLY -- host emulation of the wavefront primitives of
-// cvxpygen_amd/csrc/cpg_wave_gfx950.h: the 64 lanes of a wavefront run as lock-stepped host threads
-// that meet at a barrier in every cross-lane primitive.  tests/sim/build_sim.py force-includes this
-// header in front of the product's cpg_hip.cpp (g++ -include) together with the stand-in
-// <hip/hip_runtime.h> of tests/sim/fake_hip, so the CPU-only test tier executes the product's kernel
-// SOURCES through the real C-ABI.  Defining the include guard of the gfx950 header makes the product
-// sources pick up these definitions; nothing under cvxpygen_amd/ knows about the emulator.
+// cvxpygen_amd/csrc/cpg_wave_gfx950.h: the 64 lanes of a wavefront run lock-stepped and meet at a barrier
+// in every cross-lane primitive.  Every thread of a workgroup is a FIBER (own stack, cooperative switch)
+// and all fibers of one workgroup run on one host thread, so a barrier costs 64 user-space context
+// switches instead of 64 futex waits; different workgroups run on different host threads
+// (fake_hip/hip/hip_runtime.h).  tests/sim/build_sim.py force-includes this header in front of the
+// product's cpg_hip.cpp (g++ -include) together with the stand-in <hip/hip_runtime.h> of
+// tests/sim/fake_hip, so the CPU-only test tier executes the product's kernel SOURCES through the real
+// C-ABI.  Defining the include guard of the gfx950 header makes the product sources pick up these
+// definitions; nothing under cvxpygen_amd/ knows about the emulator.
 #ifndef CPG_WAVE_PRIMITIVES_H
 #define CPG_WAVE_PRIMITIVES_H
 
@@ -12,58 +15,88 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
-#include <pthread.h>
 
 #define CPG_DEV inline
 #define CPG_LANES 64
 
 namespace cpgw {
 
-struct SimWave {                 // shared by the 64 threads of one emulated wavefront
-    pthread_barrier_t bar;
+struct SimBarrier { int count = 0, gen = 0, n = 0; };
+struct SimWave {                 // shared by the 64 fibers of one emulated wavefront
+    SimBarrier bar;
     double xch[64];
     int ixch[64];
 };
-struct SimThread {
+struct SimDim3 { unsigned x, y, z; };
+struct SimThread {               // one fiber = one GPU thread
+    void *sp;                    // saved stack pointer while switched out
     int lane, wave, block, nblocks, waves_per_block;
+    SimDim3 tidx, bidx, bdim, gdim;
     SimWave *wv;
-    pthread_barrier_t *block_bar;
-    char *lds;                   // block-wide dynamic LDS
+    SimBarrier *block_bar;
+    bool done;
+    SimThread *next;             // ring of the workgroup's fibers
 };
-inline thread_local SimThread tls;
+inline thread_local SimThread *cur;
 
-inline void wave_sync() { pthread_barrier_wait(&tls.wv->bar); }
+#if defined(__x86_64__)
+// minimal System-V context switch: callee-saved registers + stack pointer
+extern "C" void cpg_sim_switch(void **save_sp, void *load_sp);
+asm(".text\n.globl cpg_sim_switch\n.type cpg_sim_switch,@function\ncpg_sim_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size cpg_sim_switch,.-cpg_sim_switch\n");
+#else
+#error "the lock-step emulator's fiber switch is written for x86-64 hosts"
+#endif
 
-inline int lane_id() { return tls.lane; }
-inline int wave_in_block() { return tls.wave; }
-inline unsigned thread_in_block() { return (unsigned)(tls.wave * 64 + tls.lane); }
-inline unsigned block_threads() { return (unsigned)(tls.waves_per_block * 64); }
-inline void block_sync() { pthread_barrier_wait(tls.block_bar); }
+// hand the host thread to the next live fiber of the workgroup
+inline void fiber_yield() {
+    SimThread *me = cur, *nx = me->next;
+    while (nx->done) nx = nx->next;
+    if (nx == me) return;
+    cur = nx;
+    cpg_sim_switch(&me->sp, nx->sp);
+}
+inline void bar_wait(SimBarrier *b) {
+    const int g = b->gen;
+    if (++b->count == b->n) { b->count = 0; b->gen = g + 1; return; }
+    while (*(volatile int *)&b->gen == g) fiber_yield();
+}
+
+inline void wave_sync() { bar_wait(&cur->wv->bar); }
+
+inline int lane_id() { return cur->lane; }
+inline int wave_in_block() { return cur->wave; }
+inline unsigned thread_in_block() { return (unsigned)(cur->wave * 64 + cur->lane); }
+inline unsigned block_threads() { return (unsigned)(cur->waves_per_block * 64); }
+inline void block_sync() { bar_wait(cur->block_bar); }
 inline void lds_order() { wave_sync(); }
 
 template <int N>
 inline double row_shl(double v) {
-    SimWave *w = tls.wv;
-    w->xch[tls.lane] = v;
+    SimWave *w = cur->wv;
+    w->xch[cur->lane] = v;
     wave_sync();
-    int src = tls.lane + N;
-    double r = ((src >> 4) == (tls.lane >> 4)) ? w->xch[src] : 0.0;
+    int src = cur->lane + N;
+    double r = ((src >> 4) == (cur->lane >> 4)) ? w->xch[src] : 0.0;
     wave_sync();
     return r;
 }
 inline double read_lane(double v, int lane) {
-    SimWave *w = tls.wv;
-    w->xch[tls.lane] = v;
+    SimWave *w = cur->wv;
+    w->xch[cur->lane] = v;
     wave_sync();
     double r = w->xch[lane];
     wave_sync();
     return r;
 }
 inline double shfl_down(double v, int delta) {
-    SimWave *w = tls.wv;
-    w->xch[tls.lane] = v;
+    SimWave *w = cur->wv;
+    w->xch[cur->lane] = v;
     wave_sync();
-    int src = tls.lane + delta;
+    int src = cur->lane + delta;
     double r = src < 64 ? w->xch[src] : v;
     wave_sync();
     return r;
@@ -71,16 +104,16 @@ inline double shfl_down(double v, int delta) {
 inline double up16(double v) { return shfl_down(v, 16); }
 inline double up32(double v) { return shfl_down(v, 32); }
 inline int read_first_lane(int v) {
-    SimWave *w = tls.wv;
-    w->ixch[tls.lane] = v;
+    SimWave *w = cur->wv;
+    w->ixch[cur->lane] = v;
     wave_sync();
     int r = w->ixch[0];
     wave_sync();
     return r;
 }
 inline bool wave_any(bool p) {
-    SimWave *w = tls.wv;
-    w->ixch[tls.lane] = p ? 1 : 0;
+    SimWave *w = cur->wv;
+    w->ixch[cur->lane] = p ? 1 : 0;
     wave_sync();
     int r = 0;
     for (int i = 0; i < 64; i++) r |= w->ixch[i];
@@ -92,8 +125,8 @@ inline unsigned atomic_next(unsigned *ctr) {
 }
 inline void mem_order() { wave_sync(); }
 inline unsigned long long ballot(bool p) {
-    SimWave *w = tls.wv;
-    w->ixch[tls.lane] = p ? 1 : 0;
+    SimWave *w = cur->wv;
+    w->ixch[cur->lane] = p ? 1 : 0;
     wave_sync();
     unsigned long long m = 0;
     for (int i = 0; i < 64; i++) if (w->ixch[i]) m |= 1ULL << i;
@@ -101,7 +134,7 @@ inline unsigned long long ballot(bool p) {
     return m;
 }
 inline unsigned mbcnt(unsigned long long mask) {
-    return (unsigned)__builtin_popcountll(mask & ((1ULL << tls.lane) - 1ULL));
+    return (unsigned)__builtin_popcountll(mask & ((1ULL << cur->lane) - 1ULL));
 }
 inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
 inline void sched_fence() {}

@@ -1,15 +1,17 @@
 // TEST INFRASTRUCTURE ONLY -- stand-in for <hip/hip_runtime.h> used by the lock-step emulator build
 // (tests/sim/build_sim.py: g++ -I tests/sim/fake_hip -include tests/sim/cpg_wave_sim.h).  It provides
 // just the slice of the HIP runtime API that cvxpygen_amd/csrc/cpg_hip.cpp calls, on host memory:
-// device buffers are malloc'ed, copies are memcpy, a kernel launch runs the workgroups one after the
-// other, each as blockDim.x host threads (64 per emulated wavefront, see cpg_wave_sim.h).
+// device buffers are malloc'ed, copies are memcpy, a kernel launch runs every workgroup on a host thread
+// as blockDim.x cooperatively scheduled fibers (64 per emulated wavefront, see cpg_wave_sim.h).
 #pragma once
 
-#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
+#include <atomic>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -35,20 +37,22 @@ struct dim3 {
 #define __global__
 #define __device__
 #define __forceinline__ inline
-#define __shared__
+#define __shared__ __thread
 #define __launch_bounds__(...)
 
-// per-thread launch coordinates and the (single, blocks run one at a time) dynamic LDS window
-struct SimDim { unsigned x, y, z; };
-inline thread_local SimDim threadIdx, blockIdx, blockDim, gridDim;
-alignas(16) inline double cpg_lds[(160 * 1024) / 8 + 16];
+// launch coordinates of the running fiber; the dynamic LDS window is per host thread = per running workgroup
+#define threadIdx (cpgw::cur->tidx)
+#define blockIdx (cpgw::cur->bidx)
+#define blockDim (cpgw::cur->bdim)
+#define gridDim (cpgw::cur->gdim)
+alignas(16) inline __thread double cpg_lds[(160 * 1024) / 8 + 16];
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulator error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
-    p->multiProcessorCount = 2;                      // keeps the emulated grids small
+    p->multiProcessorCount = 4;                      // keeps the emulated grids small
     p->sharedMemPerBlock = 160 * 1024;
     strcpy(p->gcnArchName, "gfx950-emulated");
     return hipSuccess;
@@ -74,26 +78,85 @@ inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { ret
 inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned = 0) { return hipMalloc(p, bytes); }
 inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 
+namespace cpgsim {
+constexpr size_t STACK_BYTES = 2u << 20;          // per fiber; mmap'ed, touched pages only
+struct Block {                                    // the fibers of one workgroup, run by one host thread
+    std::vector<cpgw::SimThread> th;
+    std::vector<cpgw::SimWave> wv;
+    cpgw::SimBarrier block_bar;
+    std::function<void()> body;
+    void *main_sp = nullptr;
+    int live = 0;
+};
+inline thread_local Block *running;
+
+// first frame of every fiber: run the kernel, then leave the ring for good
+inline void fiber_main() {
+    Block *blk = running;
+    blk->body();
+    cpgw::SimThread *me = cpgw::cur;
+    me->done = true;
+    void *dummy;
+    if (--blk->live == 0) { cpgw::cpg_sim_switch(&dummy, blk->main_sp); }
+    cpgw::SimThread *nx = me->next;
+    while (nx->done) nx = nx->next;
+    cpgw::cur = nx;
+    cpgw::cpg_sim_switch(&dummy, nx->sp);
+    abort();
+}
+
+inline void run_block(unsigned b, unsigned nblocks, unsigned nthreads, size_t lds_bytes, std::function<void()> body) {
+    Block blk;
+    const int waves = (int)(nthreads / 64);
+    blk.th.resize(nthreads);
+    blk.wv.resize(waves);
+    for (auto &w : blk.wv) w.bar.n = 64;
+    blk.block_bar.n = (int)nthreads;
+    blk.body = std::move(body);
+    blk.live = (int)nthreads;
+    memset(cpg_lds, 0, lds_bytes + 64 <= sizeof(cpg_lds) ? lds_bytes + 64 : sizeof(cpg_lds));
+    char *stacks = (char *)mmap(nullptr, STACK_BYTES * nthreads, PROT_READ | PROT_WRITE,
+                                MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == (char *)MAP_FAILED) abort();
+    for (unsigned t = 0; t < nthreads; t++) {
+        cpgw::SimThread &f = blk.th[t];
+        f.lane = (int)(t & 63); f.wave = (int)(t >> 6); f.block = (int)b; f.nblocks = (int)nblocks;
+        f.waves_per_block = waves;
+        f.tidx = {t, 0, 0}; f.bidx = {b, 0, 0}; f.bdim = {nthreads, 1, 1}; f.gdim = {nblocks, 1, 1};
+        f.wv = &blk.wv[t >> 6]; f.block_bar = &blk.block_bar; f.done = false;
+        f.next = &blk.th[(t + 1) % nthreads];
+        // initial frame for cpg_sim_switch: six callee-saved registers, then the entry point as return address
+        uintptr_t top = ((uintptr_t)(stacks + STACK_BYTES * (t + 1))) & ~(uintptr_t)15;
+        void **sp = (void **)top;
+        *--sp = nullptr;                           // fake return address of fiber_main (never returns)
+        *--sp = (void *)&fiber_main;
+        for (int r = 0; r < 6; r++) *--sp = nullptr;
+        f.sp = (void *)sp;
+    }
+    running = &blk;
+    cpgw::cur = &blk.th[0];
+    cpgw::cpg_sim_switch(&blk.main_sp, blk.th[0].sp);
+    cpgw::cur = nullptr;
+    running = nullptr;
+    munmap(stacks, STACK_BYTES * nthreads);
+}
+}  // namespace cpgsim
+
 template <class Kern, class... Args>
 inline void hipLaunchKernelGGL(Kern kern, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t, Args... args) {
-    const int waves = (int)(block.x / 64);
-    for (unsigned b = 0; b < grid.x; b++) {
-        memset(cpg_lds, 0, lds_bytes + 64 <= sizeof(cpg_lds) ? lds_bytes + 64 : sizeof(cpg_lds));
-        std::vector<cpgw::SimWave> wv(waves);
-        for (auto &w : wv) pthread_barrier_init(&w.bar, nullptr, 64);
-        pthread_barrier_t block_bar;
-        pthread_barrier_init(&block_bar, nullptr, block.x);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < block.x; t++)
-            th.emplace_back([&, t]() {
-                threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; blockDim = {block.x, 1, 1}; gridDim = {grid.x, 1, 1};
-                cpgw::tls.lane = (int)(t & 63); cpgw::tls.wave = (int)(t >> 6); cpgw::tls.block = (int)b;
-                cpgw::tls.nblocks = (int)grid.x; cpgw::tls.waves_per_block = waves;
-                cpgw::tls.wv = &wv[t >> 6]; cpgw::tls.lds = (char *)cpg_lds; cpgw::tls.block_bar = &block_bar;
-                kern(args...);
-            });
-        for (auto &t : th) t.join();
-        for (auto &w : wv) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&block_bar);
-    }
+    // workgroups are independent: one host thread each, at most the host's core count at a time
+    unsigned par = std::thread::hardware_concurrency();
+    if (par == 0) par = 1;
+    std::atomic<unsigned> next_block{0};
+    auto worker = [&]() {
+        for (;;) {
+            unsigned b = next_block.fetch_add(1);
+            if (b >= grid.x) return;
+            cpgsim::run_block(b, grid.x, block.x, lds_bytes, [&]() { kern(args...); });
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < par && i < grid.x; i++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
 }

@@ -71,7 +71,8 @@ def test_reference_gradient_surface(sim_lib, oracle_lib, tmp_path):
     """generate_code(gradient=True) -> cpg_solve_and_gradient_info / cpg_gradient / forward / backward"""
     d = families.nonneg_ls()                                      # examples/main.py family
     prob = LiteProblem.from_descriptor(d)
-    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'grad_code'), solver='OSQP', gradient=True, wrapper=True)
+    cpg.generate_code(prob, code_dir=str(tmp_path / 'grad_code'), solver='OSQP', gradient=True, wrapper=False)   # (no hipcc step: the emulator library is injected)
+    mod = cpg.load_generated(str(tmp_path / 'grad_code'), prob)
     mod._SOLVER.lib_path = sim_lib
     val, gp, gd = mod.cpg_solve_and_gradient_info(prob, eps_abs=1e-9, eps_rel=1e-9)
     assert len(gp) == d.n_var and len(gd) == d.m and prob.status == 'solved'
@@ -100,7 +101,8 @@ def test_batched_forward_backward_adapter(sim_lib, oracle_lib, tmp_path):
     batched adjoint, equal to the single-instance forward / backward instance by instance"""
     d = families.nonneg_ls()
     prob = LiteProblem.from_descriptor(d)
-    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'fb_code'), solver='OSQP', gradient=True, wrapper=True)
+    cpg.generate_code(prob, code_dir=str(tmp_path / 'fb_code'), solver='OSQP', gradient=True, wrapper=False)   # (no hipcc step: the emulator library is injected)
+    mod = cpg.load_generated(str(tmp_path / 'fb_code'), prob)
     mod._SOLVER.lib_path = sim_lib
     B = 3
     rng = np.random.default_rng(12)

@@ -104,7 +104,8 @@ def test_row_class_change_is_solved_not_flagged(sim_lib, oracle_lib):
 def test_drop_in_keeps_the_reference_workspace_between_calls(sim_lib, oracle_lib, tmp_path):
     d = families.nonneg_ls()                                       # parameters A (sparse) and b
     prob = LiteProblem.from_descriptor(d)
-    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'seq_code'), solver='OSQP', wrapper=True)
+    cpg.generate_code(prob, code_dir=str(tmp_path / 'seq_code'), solver='OSQP', wrapper=False)   # (no hipcc step: the emulator library is injected)
+    mod = cpg.load_generated(str(tmp_path / 'seq_code'), prob)
     mod._SOLVER.lib_path = sim_lib
     ses = oracle_lib.CpgSession(d)
     rng = np.random.default_rng(21)
@@ -145,7 +146,8 @@ def test_drop_in_sequence_on_a_vector_only_family(sim_lib, oracle_lib, tmp_path)
     """only vector parameters (q, l, u): shared factor in every call, warm start from the previous solution"""
     d = families.toy_box()
     prob = LiteProblem.from_descriptor(d)
-    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'seq_box'), solver='OSQP', wrapper=True)
+    cpg.generate_code(prob, code_dir=str(tmp_path / 'seq_box'), solver='OSQP', wrapper=False)   # (no hipcc step: the emulator library is injected)
+    mod = cpg.load_generated(str(tmp_path / 'seq_box'), prob)
     mod._SOLVER.lib_path = sim_lib
     ses = oracle_lib.CpgSession(d)
     rng = np.random.default_rng(4)
