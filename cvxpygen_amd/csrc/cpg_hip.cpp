@@ -569,7 +569,7 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
             }
         }
     }
-    F.kkt_ragged.dict = nullptr; F.kkt_ragged.words = nullptr; F.kkt_ragged.n_dict = 0;
+    F.kkt_ragged.dict = nullptr; F.kkt_ragged.words = nullptr; F.kkt_ragged.n_dict = 0; F.kkt_ragged.cols_padded = nullptr;
 #ifdef CPG_GEN_COMPRESSED
     if (f->kkt_ragged.n_chunks > 0) {
         // dictionary of the distinct coefficients (bit patterns, sorted) and one word per entry
@@ -621,6 +621,29 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
             }
             if (!ok) { set_error("this library was generated for a different problem family (dimensions / row classes)");
                        cpg_hip_destroy(h); return CPG_E_BADARG; }
+        }
+#endif
+#ifdef CPG_GEN_PADDED_OFFSETS
+        {   // operand offsets of all 64 lanes of every step, in the executor's order; idle lanes read the zero slot
+            static const int steps[][2] = CPG_GEN_STEPS;        // {first entry, active lanes}
+            const unsigned zero_off = (unsigned)(f->n_slots + CPG_GEN_DUMMY_SLOTS) * 8u;
+            std::vector<unsigned short> cp((size_t)((CPG_GEN_PADDED_OFFSETS + 3) & ~3) * 64, (unsigned short)zero_off);
+            bool ok = zero_off <= 0xFFFFu;
+            for (int k = 0; ok && k < CPG_GEN_PADDED_OFFSETS; k++) {
+                const int e = steps[k][0], cnt = steps[k][1];
+                if (e < 0 || cnt < 0 || cnt > 64 || e + cnt > rg.nnz) { ok = false; break; }
+                for (int t = 0; t < 64; t++) {
+                    const unsigned short v = t < cnt ? rg.cols[e + t] : (unsigned short)zero_off;
+#ifdef CPG_GEN_GROUPED_OFFSETS      // 2 or 4 consecutive steps of a lane side by side: one LDS read serves them all
+                    cp[((size_t)(k / CPG_GEN_GROUPED_OFFSETS) * 64 + t) * CPG_GEN_GROUPED_OFFSETS + (k % CPG_GEN_GROUPED_OFFSETS)] = v;
+#else
+                    cp[(size_t)k * 64 + t] = v;
+#endif
+                }
+            }
+            if (!ok) { set_error("generated step table does not match the solve program"); cpg_hip_destroy(h); return CPG_E_BADARG; }
+            TRY(upload<unsigned short>(h, h->owned, cp.data(), cp.size(), &F.kkt_ragged.cols_padded));
+            TRY(rt_sync(h));      // `cp` is a stack-lifetime buffer
         }
 #endif
         h->program_in_lds = 1;
@@ -1008,7 +1031,7 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
     const int G = h->inst_per_wave;
     const size_t N = (size_t)(h->F.n + h->F.m);
 #if defined(CPG_GEN_HEADER) && defined(CPG_GEN_N)
-    const size_t per_wave = (size_t)G * (h->F.n_slots + CPG_GEN_DUMMY_SLOTS) * sizeof(double);
+    const size_t per_wave = (size_t)G * (h->F.n_slots + CPG_GEN_EXTRA_SLOTS) * sizeof(double);
 #else
     const size_t per_wave = (size_t)G * h->F.n_slots * sizeof(double);
 #endif
@@ -1027,7 +1050,12 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
 #ifdef CPG_GEN_COMPRESSED
     const size_t prog_bytes = R.n_chunks > 0 ? ((size_t)R.n_dict + (nnzp + 1) / 2 + tab_doubles) * 8 : 0;
 #else
-    const size_t prog_bytes = R.n_chunks > 0 ? (nnzp + (nnzp + 3) / 4 + tab_doubles) * 8 : 0;
+#ifdef CPG_GEN_PADDED_OFFSETS
+    const size_t n_off = (size_t)64 * ((CPG_GEN_PADDED_OFFSETS + 3) & ~3);    // operand offsets of all 64 lanes of every step
+#else
+    const size_t n_off = nnzp;
+#endif
+    const size_t prog_bytes = R.n_chunks > 0 ? (nnzp + (n_off + 3) / 4 + tab_doubles) * 8 : 0;
 #endif
     bool in_lds = false;
     int W = h->waves_per_block;

@@ -55,6 +55,9 @@ struct DevRagged {
     const double *vals;         // [nnz]
     const unsigned short *cols; // [nnz]
     int n_chunks, nnz;
+    // generated executor with CPG_GEN_PADDED_OFFSETS: operand offsets of all 64 lanes of every step, in
+    // execution order (idle lanes: the zero slot); built by cpg_hip_create_osqp from the header's step table
+    const unsigned short *cols_padded;
     // dictionary-compressed form (family libraries built with CPG_GEN_COMPRESSED): the distinct
     // coefficients and, per entry, operand byte offset | dictionary byte offset << 16
     const double *dict;
@@ -196,6 +199,7 @@ CPG_DEV void run_program(const DevProgram &P, double *w, int ldw, int lane) {
 // order as run_program_lds<1>; idle lanes read the trailing zero pair.
 struct StreamPairD { double a, b; };
 struct StreamPairU { unsigned a, b; };
+struct alignas(8) OffsetQuad { unsigned a, b; };     // operand offsets of four steps (generated executor)
 CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double *w) {
     const int stages = (int)(f & 7u);
     // segmented chunks: all three stages, branch-free (the mask of an unused stage is zero)
@@ -347,7 +351,8 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
 // One multiply-add step in three separately scheduled parts (software pipeline, see codegen.py):
 // offset + coefficient loads with literal LDS offsets, the gather from the work vector, the FMA.
 // In a partial step lanes >= CNT load like everybody else (they hit later entries of the program, or
-// the zero padding behind it) and get their coefficient replaced by zero: no address arithmetic.
+// the zero padding behind it: no address arithmetic) and get their coefficient replaced by zero -- or, when the
+// offsets are stored for all 64 lanes of a step, find 0.0 as their operand and need no special treatment.
 #define CPG_GEN_PAD 64
 #ifdef CPG_GEN_COMPRESSED
 // Dictionary-compressed program: structured families repeat their coefficients (MPC 12/4/10: 1 739
@@ -369,6 +374,28 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
 #define CPG_GEN_LOAD_CV(ID, E)                                                                     \
     const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
     const unsigned co##ID = *(const unsigned short *)(cb + (E) * 2u);
+// offsets stored for all 64 lanes of every step (the header defines CPG_GEN_PADDED_OFFSETS): step K of the
+// execution order finds them at [K][lane]
+#define CPG_GEN_LOAD_CVP(ID, E, K)                                                                 \
+    const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
+    const unsigned co##ID = *(const unsigned short *)(cb + (K) * 128u);
+// ... and with CPG_GEN_GROUPED_OFFSETS 2 the offsets of steps 2k and 2k + 1 share one 32-bit word at [k][lane]:
+// one LDS read serves two steps
+#define CPG_GEN_LOAD_CVP2A(ID, E, K)                                                               \
+    const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
+    const unsigned cp##ID = *(const unsigned *)(cb + (unsigned)lane * 2u + ((K) >> 1) * 256u);     \
+    const unsigned co##ID = cp##ID & 0xFFFFu;
+#define CPG_GEN_LOAD_CVP2B(ID, E, PREV)                                                            \
+    const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
+    const unsigned co##ID = cp##PREV >> 16;
+// ... and with CPG_GEN_GROUPED_OFFSETS 4 the offsets of steps 4k .. 4k + 3 share one 64-bit word at [k][lane]
+#define CPG_GEN_LOAD_CVP4A(ID, E, K)                                                               \
+    const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
+    const OffsetQuad cq##ID = *(const OffsetQuad *)(cb + (unsigned)lane * 6u + ((K) >> 2) * 512u);          \
+    const unsigned co##ID = cq##ID.a & 0xFFFFu;
+#define CPG_GEN_LOAD_CVP4B(ID, E, FIRST, J)                                                        \
+    const double vl##ID = *(const double *)(vb + (E) * 8u);                                        \
+    const unsigned co##ID = (J) == 1 ? cq##FIRST.a >> 16 : (J) == 2 ? (cq##FIRST.b & 0xFFFFu) : cq##FIRST.b >> 16;
 #define CPG_GEN_LOAD_W(ID)                                                                         \
     double x##ID[G];                                                                               \
     _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) x##ID[g_] = *(const double *)(wb + (unsigned)g_ * ldwb + co##ID);
@@ -381,10 +408,13 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = fma(v_, x##ID[g_], A[g_]);        \
     }
 // per (chunk, lane) table entry: output slot (13 bits) | segmented-reduction mask << 13.  Lanes that
-// own no row store to a private dummy slot behind the work vector (n_slots + lane): the store is
-// unconditional and the whole program stays one basic block.
+// own no row store to a dummy slot behind the work vector (n_slots + lane % 16: one per lane of the 16-lane
+// groups a ds_write_b64 is served in, so they never collide): the store is unconditional and the whole
+// program stays one basic block.  One more slot behind them always holds 0.0: the operand of idle lanes
+// when the offsets are stored for all 64 lanes of a step (CPG_GEN_PADDED_OFFSETS).
 #define CPG_GEN_SLOT_MASK 0x1FFFu
-#define CPG_GEN_DUMMY_SLOTS 64
+#define CPG_GEN_DUMMY_SLOTS 16
+#define CPG_GEN_EXTRA_SLOTS (CPG_GEN_DUMMY_SLOTS + 1)
 #define CPG_GEN_REDUCE_STORE(A, LG, C)                                                             \
     {                                                                                              \
         const unsigned row_ = rows[(C) * 64u + (unsigned)lane] & CPG_GEN_SLOT_MASK;                \
@@ -650,6 +680,29 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
     return res;
 }
 
+// OSQP runs is_primal_infeasible / is_dual_infeasible inside check_termination, and only when the matching
+// residual test has failed.  They are pure functions of (delta_y, delta_x, problem data, eps), so the kernels
+// evaluate them right after the checked iteration -- while the steps are still in the registers that
+// iteration produced them in -- and hand check() the verdicts, which it uses under OSQP's conditions.  The
+// steps (13 registers per lane on the MPC 12/4/10 family) are then dead before the register-hungry residual
+// products of check() start; kept alive across them (for the tests, and for the second, approximate pass at
+// max_iter) they were spilled to scratch at every check: 2.9 GB of writes per 100 000 instances.
+struct InfeasVerdict { bool primal, dual; };
+
+template <int NSX, int NSZ, typename Ctx, typename DX, typename DY>
+CPG_DEV InfeasVerdict infeasibility_tests(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
+                                          const DevSettings &S, const DX &dx, const DY &dy,
+                                          double *w, int lane_in, bool approximate) {
+    const int lane = cpgw::opaque(lane_in);                 // per-call copy of the lane id, see check()
+    cpgw::assume((unsigned)lane < 64u);
+    const bool unsc = !S.scaled_termination;
+    const double mult = approximate ? 10.0 : 1.0;
+    InfeasVerdict v;
+    v.primal = F.m != 0 && primal_infeasible<NSX, NSZ, Ctx, DY>(F, cx, ct, unsc, S.eps_prim_inf * mult, w, dy, lane);
+    v.dual = dual_infeasible<NSX, NSZ, Ctx, DX>(F, cx, ct, unsc, S.eps_dual_inf * mult, w, dx, lane);
+    return v;
+}
+
 // The three sparse products of update_info on the staged iterates (w = [x | y]) and the SCALED norms
 // OSQP's compute_rho_estimate needs; shared by the termination test and the rho adaptation.
 struct ScaledNorms {
@@ -660,10 +713,10 @@ struct ScaledNorms {
 // update_info + check_termination: residuals in the unscaled space (scaled_termination = 0),
 // optimality / infeasibility decisions.  status stays 11 (unsolved) when nothing triggers.
 // `sn` (optional) receives the scaled norms of the same products.
-template <int NSX, int NSZ, typename Ctx, typename DX, typename DY>
+template <int NSX, int NSZ, typename Ctx>
 CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
                        const DevSettings &S, const double (&Ix)[NSX], const double (&Iz)[NSZ],
-                       const double (&Iy)[NSZ], const DX &dx, const DY &dy,
+                       const double (&Iy)[NSZ], InfeasVerdict iv,
                        double *w, int lane_in, bool approximate, ScaledNorms *sn = nullptr) {
     // per-call copy of the lane id (cpgw::opaque): the dozens of per-lane addresses of the test are computed
     // here and die here, instead of being hoisted out of the caller's loops and kept alive (spilled) across
@@ -671,6 +724,8 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
     const int lane = cpgw::opaque(lane_in);
     cpgw::assume((unsigned)lane < 64u);
     const bool unsc = !S.scaled_termination;
+    const double mult = approximate ? 10.0 : 1.0;
+    const double ea = S.eps_abs * mult, er = S.eps_rel * mult;
     CheckOut o;
 #pragma unroll
     for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = Ix[s]; }
@@ -732,17 +787,14 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
         sn->naty = cpgw::wave_max_nonneg(s_nat); sn->npx = cpgw::wave_max_nonneg(s_npx);
     }
 
-    const double mult = approximate ? 10.0 : 1.0;
-    const double ea = S.eps_abs * mult, er = S.eps_rel * mult;
-    const double epi = S.eps_prim_inf * mult, edi = S.eps_dual_inf * mult;
     o.status = 11;
     if (rp > CPG_INFTY || rd > CPG_INFTY) { o.status = 9; o.obj = NAN; return o; }
     bool pc = false, dc = false, pic = false, dic = false, gc = true;
     if (F.m == 0) pc = true;
     else if (rp < ea + er * cpgw::dmax2(nz, na)) pc = true;
-    else pic = primal_infeasible<NSX, NSZ, Ctx, DY>(F, cx, ct, unsc, epi, w, dy, lane);
+    else pic = iv.primal;
     if (rd < ea + er * dn) dc = true;
-    else dic = dual_infeasible<NSX, NSZ, Ctx, DX>(F, cx, ct, unsc, edi, w, dx, lane);
+    else dic = iv.dual;
     if (S.check_dualgap) {   // OSQP >= 1.0: |primal - dual objective| against eps_abs + eps_rel max(|primal|, |dual|)
         sup = cpgw::wave_sum(sup);
         const double dual_obj = (-0.5 * quad - sup) * F.cinv, gap = fabs(quad + lin + sup) * F.cinv;
@@ -835,7 +887,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #if defined(CPG_GEN_N)
     // family-specialised build: dimensions are literals, so the bounds checks of full slots fold away
     constexpr unsigned n_c = GenFam::n, m_c = GenFam::m;
-    constexpr int ldw = GenFam::n_slots + CPG_GEN_DUMMY_SLOTS;   // + one dummy store target per lane
+    constexpr int ldw = GenFam::n_slots + CPG_GEN_EXTRA_SLOTS;   // + dummy store targets and the zero slot
     static_assert(!LDSPROG || ((n_c + 63) / 64 == (unsigned)NSX && (m_c + 63) / 64 == (unsigned)NSZ), "slot class of the generated family");
 #else
     const unsigned n_c = (unsigned)F.n, m_c = (unsigned)F.m;
@@ -866,11 +918,18 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
         const unsigned short *lc = (const unsigned short *)lw;
 #else
         double *lv = lds + lds_off;                         lds_off += (size_t)nnzp;
+#ifdef CPG_GEN_PADDED_OFFSETS
+        constexpr unsigned n_off = 64u * ((CPG_GEN_PADDED_OFFSETS + 3u) & ~3u);
+        unsigned short *lc = (unsigned short *)(lds + lds_off); lds_off += (size_t)((n_off + 3) / 4);
+        for (unsigned t = t0; t < nnzp; t += nt) lv[t] = t < (unsigned)R.nnz ? cpgw::gld(R.vals, t) : 0.0;
+        for (unsigned t = t0; t < n_off; t += nt) lc[t] = cpgw::gld(R.cols_padded, t);
+#else
         unsigned short *lc = (unsigned short *)(lds + lds_off); lds_off += (size_t)((nnzp + 3) / 4);
         for (unsigned t = t0; t < nnzp; t += nt) {
             const bool in = t < (unsigned)R.nnz;
             lv[t] = in ? cpgw::gld(R.vals, t) : 0.0; lc[t] = in ? cpgw::gld(R.cols, t) : (unsigned short)0;
         }
+#endif
 #endif
         LP.vals = lv; LP.cols = lc; LP.n_chunks = R.n_chunks; LP.dummy = (unsigned)R.nnz - 1u;
 #ifdef CPG_GEN_HEADER
@@ -879,7 +938,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
         unsigned short *lr = (unsigned short *)(lds + lds_off); lds_off += (size_t)R.n_chunks * 16;
         for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) {
             const unsigned d = cpgw::gld(R.desc, t);
-            const unsigned slot = (d & 0xFFFFu) == CPG_NO_ROW ? (unsigned)F.n_slots + (t & 63u) : (d & 0xFFFFu);
+            const unsigned slot = (d & 0xFFFFu) == CPG_NO_ROW ? (unsigned)F.n_slots + (t & (CPG_GEN_DUMMY_SLOTS - 1u)) : (d & 0xFFFFu);
             lr[t] = (unsigned short)(slot | ((d >> 28) << 13));
         }
         LP.rows16 = lr; LP.ctab = nullptr; LP.desc = nullptr;
@@ -1064,6 +1123,18 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                 }
             }
             // ---- termination test / bookkeeping
+            InfeasVerdict iv[G][2];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                iv[g][0] = iv[g][1] = InfeasVerdict{false, false};
+                if (I[g].done) continue;
+                double *wg = w + g * ldw;
+#pragma nounroll
+                for (int pass = 0; pass < (iter >= S.max_iter ? 2 : 1); pass++)
+                    iv[g][pass] = infeasibility_tests<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, RegDelta<NSX>, RegDelta<NSZ>>(
+                        F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S,
+                        RegDelta<NSX>{dxr[g]}, RegDelta<NSZ>{dyr[g]}, wg, lane, pass == 1);
+            }
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (I[g].done) continue;
@@ -1072,9 +1143,9 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma nounroll
                 for (int pass = 0; pass < 2; pass++) {
                     if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, RegDelta<NSX>, RegDelta<NSZ>>(
+                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(
                         F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S, I[g].x, I[g].z, I[g].y,
-                        RegDelta<NSX>{dxr[g]}, RegDelta<NSZ>{dyr[g]}, wg, lane, pass == 1);
+                        iv[g][pass], wg, lane, pass == 1);
                 }
                 if (o.status == 11 && iter >= S.max_iter) o.status = 7;
                 co[g] = o;

@@ -248,11 +248,14 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         # one class stay uniform -- and the spill slots of merged phases are renumbered freely
         from . import slot_layout as _sl
         rg0 = _sp.pack_ragged(phases, N, balanced=True)
-        region = np.full(rg0.n_slots, 99, dtype=np.int64)
+        pad0 = _sp.padded_offsets_fit(rg0, N)
+        region = np.full(rg0.n_slots + (_sp.GEN_EXTRA_SLOTS if pad0 else 0), 99, dtype=np.int64)
+        region[rg0.n_slots:] = 1000 + np.arange(len(region) - rg0.n_slots)      # dummy / zero slots stay put
         region[:n] = np.where(np.arange(n) < int(vary_q.sum()), 0, 1)
         ctz = np.asarray(plan.constr_type)[ordz]
         region[n:N] = np.where(np.arange(m) < int(vary_u.sum()), 10, 20 + (ctz + 1))
-        pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0), region, seed=0)
+        pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0, idle_zero=pad0), region, seed=0)
+        pi = pi[:rg0.n_slots]
         bank_stats = dict(bank_conflict_cycles_natural=int(c0), bank_conflict_cycles=int(c1))
         # the device ordering follows: the entry at device position p moves to position pi[p]
         ordx2 = np.empty_like(ordx); ordx2[pi[:n]] = ordx

@@ -679,10 +679,55 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
     return w
 
 
-def gathered_slots(prog: RaggedProgram) -> np.ndarray:
+GEN_DUMMY_SLOTS = 16        # generated executor: store targets of lanes without a row (one per lane of a 16-lane store group)
+GEN_EXTRA_SLOTS = GEN_DUMMY_SLOTS + 1     # ... and one slot that always holds 0.0 (operand of idle lanes)
+
+
+def execution_steps(prog: RaggedProgram):
+    """The multiply-add steps of the GENERATED executor in the order it runs them (cvxpygen_amd/codegen.py):
+    phase by phase, round-robin over the chunks of a phase.  [(phase index, chunk, first entry, active lanes)]"""
+    lens_all = np.where((prog.ctab[:, 3:4] & 1) == 1, (prog.desc >> 16) & 0xFFF, prog.desc >> 16)
+    phases = {}
+    for c in range(prog.n_chunks):
+        phases.setdefault(int(prog.chunk_phase[c]), []).append(c)
+    steps = []
+    for pi_, p in enumerate(sorted(phases)):
+        per_chunk = []
+        for c in phases[p]:
+            L, first = int(prog.ctab[c, 0]), int(prog.ctab[c, 2])
+            e, lst = first, []
+            for s_ in range(L):
+                cnt = int((lens_all[c] > s_).sum())
+                lst.append((pi_, c, e, cnt))
+                e += cnt
+            per_chunk.append(lst)
+        for s_ in range(max(len(l) for l in per_chunk)):
+            for lst in per_chunk:
+                if s_ < len(lst):
+                    steps.append(lst[s_])
+    return steps
+
+
+def padded_offsets_fit(prog: RaggedProgram, N: int, waves: int = 8, lds_bytes: int = 160 * 1024) -> bool:
+    """Should the generated executor store the operand offsets for all 64 lanes of every step (idle lanes point
+    at the zero slot: no masking of partial steps)?  Yes when that costs no resident wavefront (of at most
+    `waves`) against the ragged layout.  Same arithmetic as cpg_hip.cpp / cpg_osqp_kernel.h."""
+    n_steps = int(prog.ctab[:, 0].sum())
+    nnzp = prog.nnz + 64
+    per_wave = 8 * (prog.n_slots + GEN_EXTRA_SLOTS)
+
+    def fit(n_off):
+        fixed = 8 * N + 8 * (nnzp + (n_off + 3) // 4 + 16 * prog.n_chunks)
+        return max(0, min(waves, (lds_bytes - fixed) // per_wave))
+    return fit(64 * ((n_steps + 3) & ~3)) >= max(1, fit(nnzp))
+
+
+def gathered_slots(prog: RaggedProgram, idle_zero: bool = False) -> np.ndarray:
     """[n_steps, 64]: the slot every lane of every multiply-add step of the GENERATED executor gathers
-    (cvxpygen_amd/codegen.py): lanes past the active prefix of a partial step read the entries that follow
-    in the flat program (their coefficient is then forced to zero), past its end the zero padding (offset 0)."""
+    (cvxpygen_amd/codegen.py).  Lanes past the active prefix of a partial step read either the zero slot
+    behind the work vector (idle_zero: offsets stored for all 64 lanes) or, in the ragged layout, the entries
+    that follow in the flat program (their lanes then sit out the multiply-add), past its end the zero padding
+    (offset 0)."""
     flat = np.concatenate([prog.cols.astype(np.int64) // 8, np.zeros(2 * LANES, dtype=np.int64)])
     rows = []
     for c in range(prog.n_chunks):
@@ -691,6 +736,10 @@ def gathered_slots(prog: RaggedProgram) -> np.ndarray:
         ln = ((d >> 16) & 0xFFF) if (kind & 1) else (d >> 16)
         e = first
         for s_ in range(L):
-            rows.append(flat[e:e + LANES])
-            e += int((ln > s_).sum())
+            cnt = int((ln > s_).sum())
+            row = flat[e:e + LANES].copy()
+            if idle_zero:
+                row[cnt:] = prog.n_slots + GEN_DUMMY_SLOTS
+            rows.append(row)
+            e += cnt
     return np.asarray(rows, dtype=np.int64).reshape(-1, LANES)

@@ -106,8 +106,10 @@ def test_settings_and_errors(sim_lib):
     bs.close()
 
 
-@pytest.mark.parametrize('fam,G', [('nnls', 1), ('nnls', 2), ('mpc6', 1)])
-def test_generated_executor_parity(oracle_lib, tmp_path, fam, G):
+@pytest.mark.parametrize('fam,G,gen', [('nnls', 1, {}), ('nnls', 2, {}), ('mpc6', 1, {}),
+                                       ('mpc6', 1, dict(cross=0, pad_offsets=False)),
+                                       ('nnls', 2, dict(cross=9, depth=3, group_offsets=2)), ('mpc6', 1, dict(group_offsets=1, batch=2))])
+def test_generated_executor_parity(oracle_lib, tmp_path, fam, G, gen):
     """cvxpygen_amd.codegen: the family-specialised straight-line executor (emulator build of the
     generated source) gives the oracle's results; a library generated for one family refuses another."""
     from cvxpygen_amd.runtime import build_family_plan
@@ -117,8 +119,8 @@ def test_generated_executor_parity(oracle_lib, tmp_path, fam, G):
     else:
         d, name, vals = families.mpc(6, 3, 10), 'x_init', -2 + 4 * np.random.default_rng(1).random((3, 6))
     plan = build_family_plan(d)
-    lib = build_sim.build_family(plan, str(tmp_path), fam)
-    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    lib = build_sim.build_family(plan, str(tmp_path), fam, **gen)   # gen: pipeline options of the
+    bs = BatchSolver(d, lib_path=lib, plan=plan)                    # generated executor
     bs.set_launch(waves_per_block=2, inst_per_wave=G)
     r = bs.solve({name: vals}, updated_params=[name])
     o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, name, vals), [name])
