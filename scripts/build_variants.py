@@ -21,9 +21,9 @@ def main():
         kw = {}
         for item in filter(None, opts.split(',')):
             k, v = item.split('=')
-            kw[k] = int(v)
+            kw[k] = int(v) if v.lstrip('-').isdigit() else v
         waves = kw.pop('waves', None)
-        flags = [f'-D{k}=1' for k in list(kw) if k.startswith('CPG_') and kw.pop(k)]
+        flags = [f'-D{k}={kw.pop(k)}' for k in list(kw) if k.startswith('CPG_')]
         out = os.path.join(ROOT, 'cvxpygen_amd', 'generated', 'variants', tag)
         return codegen.build_family_library(plan, out, fam, g_list=(1,), waves={1: waves or 8}, verbose=False, extra_flags=flags, **kw)
     with ThreadPoolExecutor(max_workers=6) as ex:

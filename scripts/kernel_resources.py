@@ -13,7 +13,7 @@ FAMS = {'mpc12': lambda: families.mpc(12, 4, 10), 'mpc6': lambda: families.mpc(6
 
 def main(name):
     out = os.path.join(ROOT, 'cvxpygen_amd', 'generated', name)
-    kw = {k: int(v) for k, v in (it.split('=') for it in filter(None, os.environ.get('GEN_OPTS', '').split(',')))}
+    kw = {k: (int(v) if v.lstrip('-').isdigit() else v) for k, v in (it.split('=') for it in filter(None, os.environ.get('GEN_OPTS', '').split(',')))}
     if kw:
         out = os.path.join(out, '..', 'variants', 'tmp')
     hdr, defs = codegen.family_library_defs(build_family_plan(FAMS[name]()), out, name, **kw)
