@@ -116,8 +116,13 @@ def descriptor_from_reduced(name: str, solver: str, n_var: int, n_eq: int, n_ine
 
 def descriptor_from_cvxpy(problem, solver: str = 'OSQP', solver_opts=None, name: str = 'problem') -> FamilyDescriptor:
     """`Canonicalizer._extract` (`canonicalizer.py:86-122`) for the OSQP and CLARABEL forms."""
+    import warnings
     import cvxpy as cp
     from cvxpy.reductions.solvers.conic_solvers.conic_solver import ConicSolver
+    warnings.warn('cvxpygen_amd: the cvxpy front door has not been exercised against a cvxpy installation '
+                  '(none in the build image); what it unpacks from get_problem_data is checked only through '
+                  'hand-canonicalised descriptors and the reference\'s own post-processing (tests/test_ref_fixtures.py). '
+                  'Compare the first solve with prob.solve(solver=...) before relying on it.', RuntimeWarning, stacklevel=2)
     from cvxpy.reductions import InverseData
     try:
         from cvxpy.reductions.solvers.solving_chain import SolverInverseData

@@ -47,7 +47,7 @@ LANES = 64
 PHASE_COST = float(_os.environ.get('CPG_PHASE_COST', 14.0))      # fixed cost of a phase
 CHUNK_COST = float(_os.environ.get('CPG_CHUNK_COST', 3.0))       # fixed cost of one more chunk inside a phase
 GROUP_STAGE_COST = float(_os.environ.get('CPG_GROUP_STAGE_COST', 1.5))   # one stage of a power-of-two group reduction
-MAX_GROUP_ROWS = 128
+MAX_GROUP_ROWS = int(_os.environ.get('CPG_MAX_GROUP_ROWS', 128))     # rows of a merged phase (its inverse fills in)
 
 
 @dataclass
