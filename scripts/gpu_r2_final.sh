@@ -3,7 +3,7 @@
 # passes (SQ, instruction mix, FETCH_SIZE, WRITE_SIZE -- separate passes) of the headline workload.
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd $R
-OUT=gpurun_out/r2final; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=gpurun_out/${CPG_OUT:-r2final}; mkdir -p $OUT; export TMPDIR=/tmp
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $OUT/pytest_gpu.txt
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt
 P="import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), d['config'].get('mean_iter'), d['config'].get('solved'), d.get('wall_pcie',{}).get('value'), (d.get('cpu_baseline') or {}).get('value'), d.get('adjoint'))"
