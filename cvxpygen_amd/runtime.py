@@ -254,9 +254,11 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         region[:n] = np.where(np.arange(n) < int(vary_q.sum()), 0, 1)
         ctz = np.asarray(plan.constr_type)[ordz]
         region[n:N] = np.where(np.arange(m) < int(vary_u.sum()), 10, 20 + (ctz + 1))
-        pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0, idle_zero=pad0), region, seed=0)
+        stores = _sl.store_groups((rg0.desc & 0xFFFF).astype(np.int64), 0xFFFF)
+        pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0, idle_zero=pad0), region, seed=0, stores=stores,
+                                  sweeps=int(os.environ.get('CPG_BANK_SWEEPS', 60)))
         pi = pi[:rg0.n_slots]
-        bank_stats = dict(bank_conflict_cycles_natural=int(c0), bank_conflict_cycles=int(c1))
+        bank_stats = dict(bank_conflict_cycles_natural=int(c0), bank_conflict_cycles=int(c1))   # gathers + reduce-stores
         # the device ordering follows: the entry at device position p moves to position pi[p]
         ordx2 = np.empty_like(ordx); ordx2[pi[:n]] = ordx
         ordz2 = np.empty_like(ordz); ordz2[pi[n:N] - n] = ordz

@@ -5,7 +5,10 @@ Every multiply-add step of the solve program gathers one 8-byte operand per lane
 (`ds_read_b64` with per-lane addresses).  On CDNA4 the LDS services such a read in two groups of 32 lanes;
 inside a group, lanes that address DIFFERENT 8-byte slots on the same pair of banks (slot mod 32) are
 serialised: a group costs as many LDS cycles as the most loaded bank pair has distinct slots
-(MI355X_MICROARCH.md, LDS section).  With the natural numbering the gathers of the MPC 12/4/10 program
+(MI355X_MICROARCH.md, LDS section; calibrated with scripts/micro/lds_conflicts.hip: the measured cycles of a
+gather are exactly that count).  The reduce-stores at the phase ends are scattered too: a `ds_write_b64` is served
+in four groups of 16 lanes over 32 four-byte banks, so 8-byte slots of one group collide modulo 16.
+With the natural numbering the gathers of the MPC 12/4/10 program
 spend 32 % of all LDS cycles on such conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) while the LDS
 pipe is 87 % busy -- the binding resource of the headline kernel.
 
@@ -38,21 +41,46 @@ def gather_groups(step_slots: np.ndarray) -> List[np.ndarray]:
     return out
 
 
-def conflict_cycles(groups: List[np.ndarray], pi: np.ndarray) -> int:
-    """extra LDS cycles of all gathers under the numbering pi (slot -> position)"""
+def conflict_cycles(groups: List[np.ndarray], pi: np.ndarray, mods=None) -> int:
+    """extra LDS cycles of all gathers (and stores, modulus 16) under the numbering pi (slot -> position)"""
     tot = 0
-    for sl in groups:
-        tot += int(np.bincount(pi[sl] % BANK_PAIRS, minlength=BANK_PAIRS).max()) - 1
+    for gi, sl in enumerate(groups):
+        m = BANK_PAIRS if mods is None else int(mods[gi])
+        tot += int(np.bincount(pi[sl] % m, minlength=m).max()) - 1
     return tot
 
 
-def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed: int = 0
-             ) -> Tuple[np.ndarray, int, int]:
+STORE_GROUP = 16         # lanes served together by a ds_write_b64 (four groups per wavefront) ...
+STORE_BANK_PAIRS = 16    # ... over 32 four-byte banks: 8-byte slots collide modulo 16
+
+
+def store_groups(out_slots: np.ndarray, no_row: int) -> List[np.ndarray]:
+    """out_slots [n_chunks, 64]: slot every lane of a chunk's reduce-store writes (no_row: none, the lane
+    writes a dummy slot).  Returns the distinct real slots of every (chunk, 16-lane group) with more than one."""
+    out = []
+    for row in out_slots:
+        for g in range(0, row.shape[0], STORE_GROUP):
+            sl = np.unique(row[g:g + STORE_GROUP])
+            sl = sl[sl != no_row]
+            if len(sl) > 1:
+                out.append(sl.astype(np.int64))
+    return out
+
+
+def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed: int = 0,
+             stores: List[np.ndarray] = ()) -> Tuple[np.ndarray, int, int]:
     """Returns (pi, cost before, cost after).  pi[slot] = new position; pi permutes the slots of every
-    region among themselves (region[slot] = region id; regions are contiguous ranges of positions)."""
+    region among themselves (region[slot] = region id; regions are contiguous ranges of positions).
+    stores: groups of slots written by one 16-lane group of a reduce-store (`store_groups`); they are charged
+    with the store's banking (8-byte slots collide modulo 16), measured like the gathers' with
+    scripts/micro/lds_conflicts.hip: a ds_write_b64 costs the sum over its four lane groups of the largest number
+    of distinct slots on one bank pair."""
     n = region.shape[0]
     rng = np.random.default_rng(seed)
     groups = gather_groups(step_slots)
+    mods = [BANK_PAIRS] * len(groups) + [STORE_BANK_PAIRS] * len(stores)
+    groups = groups + [np.asarray(g_, dtype=np.int64) for g_ in stores]
+    mods = np.asarray(mods, dtype=np.int64)
     ng = len(groups)
     pi = np.arange(n, dtype=np.int64)
     # slot -> groups that contain it
@@ -63,7 +91,7 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
     occ_arr = [np.asarray(o, dtype=np.int64) for o in occ]
     cnt = np.zeros((ng, BANK_PAIRS), dtype=np.int32)
     for gi, sl in enumerate(groups):
-        np.add.at(cnt[gi], pi[sl] % BANK_PAIRS, 1)
+        np.add.at(cnt[gi], pi[sl] % mods[gi], 1)
     gmax = cnt.max(axis=1)
     cost0 = int(gmax.sum() - ng)
     members = [np.nonzero(region == r)[0] for r in np.unique(region)]
@@ -77,8 +105,7 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
         m = members[int(rng.integers(len(members)))]
         a = int(m[int(rng.integers(len(m)))])
         b = int(m[int(rng.integers(len(m)))])
-        ra, rb = int(pi[a] % BANK_PAIRS), int(pi[b] % BANK_PAIRS)
-        if ra == rb or not (used[a] or used[b]):
+        if pi[a] % BANK_PAIRS == pi[b] % BANK_PAIRS or not (used[a] or used[b]):
             continue
         ga, gb = occ_arr[a], occ_arr[b]
         # groups that contain both are unaffected
@@ -90,8 +117,10 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
             continue
         sub = cnt[aff].copy()
         na = len(only_a)
-        sub[:na, ra] -= 1; sub[:na, rb] += 1
-        sub[na:, rb] -= 1; sub[na:, ra] += 1
+        ra, rb = pi[a] % mods[aff], pi[b] % mods[aff]      # residues under every affected group's banking
+        ia, ib = np.arange(na), np.arange(na, len(aff))
+        np.subtract.at(sub, (ia, ra[:na]), 1); np.add.at(sub, (ia, rb[:na]), 1)
+        np.subtract.at(sub, (ib, rb[na:]), 1); np.add.at(sub, (ib, ra[na:]), 1)
         new_max = sub.max(axis=1)
         delta = int(new_max.sum() - gmax[aff].sum())
         if delta <= 0 or rng.random() < np.exp(-delta / T):
@@ -99,5 +128,5 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
             gmax[aff] = new_max
             pi[a], pi[b] = pi[b], pi[a]
             cost += delta
-    assert cost == conflict_cycles(groups, pi)
+    assert cost == conflict_cycles(groups, pi, mods)
     return pi, cost0, cost

@@ -6,7 +6,7 @@
 #include <stdlib.h>
 #include <vector>
 
-__global__ void __launch_bounds__(512) probe(const unsigned short *pat, int npat, int reps, unsigned long long *cyc, double *sink) {
+__global__ void __launch_bounds__(512) probe(const unsigned short *pat, int npat, int reps, unsigned long long *cyc, double *sink, int write_mode) {
     __shared__ double w[4096];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 4096; i += 512) w[i] = (double)i;
@@ -18,6 +18,14 @@ __global__ void __launch_bounds__(512) probe(const unsigned short *pat, int npat
         __syncthreads();
         const unsigned long long t0 = __builtin_readcyclecounter();
         for (int r = 0; r < reps; r++) {
+            if (write_mode) {
+                const unsigned aw = (unsigned)(unsigned long long)wb + off;
+                const double d = acc + (double)r;
+                asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %1\n\tds_write_b64 %0, %1\n\tds_write_b64 %0, %1\n\t"
+                             "ds_write_b64 %0, %1\n\tds_write_b64 %0, %1\n\tds_write_b64 %0, %1\n\tds_write_b64 %0, %1\n\t"
+                             "s_waitcnt lgkmcnt(0)" :: "v"(aw), "v"(d) : "memory");
+                continue;
+            }
             double v0, v1, v2, v3, v4, v5, v6, v7;
             const unsigned a = (unsigned)(unsigned long long)wb + off;     // LDS byte address
             asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8\n\tds_read_b64 %2, %8\n\tds_read_b64 %3, %8\n\t"
@@ -42,7 +50,7 @@ int main(int argc, char **argv) {
     unsigned short *dp; unsigned long long *dc; double *ds;
     hipMalloc(&dp, pat.size() * 2); hipMalloc(&dc, npat * 8); hipMalloc(&ds, 64 * 8);
     hipMemcpy(dp, pat.data(), pat.size() * 2, hipMemcpyHostToDevice);
-    for (int it = 0; it < 2; it++) hipLaunchKernelGGL(probe, dim3(1), dim3(512), 0, 0, dp, npat, reps, dc, ds);
+    for (int it = 0; it < 2; it++) hipLaunchKernelGGL(probe, dim3(1), dim3(512), 0, 0, dp, npat, reps, dc, ds, argc > 1 && argv[1][0] == 'w');
     hipDeviceSynchronize();
     std::vector<unsigned long long> c(npat);
     hipMemcpy(c.data(), dc, npat * 8, hipMemcpyDeviceToHost);
