@@ -525,6 +525,7 @@ CPG_DEV double csr_row(const DevCsr &mp, unsigned row, const double *theta, doub
 // products through the family's natural-layout row programs.
 template <int NSX, int NSZ, int NV>
 struct SharedCtx {
+    static constexpr bool kTestsFirst = true;      // check(): verdicts of infeasibility_tests() are passed in
     const DevFamily &F;
     const double *sh, *shu;       // base q / base u (block-shared LDS copy, or the global arrays)
     const Inst<NSX, NSZ, NV> &I;
@@ -584,6 +585,9 @@ struct RegDelta {
 struct MemDelta {
     const double *p;
     CPG_DEV double operator()(int, unsigned i) const { return cpgw::gld(p, i); }
+};
+struct NoDelta {      // check() of a kernel that ran the infeasibility tests itself
+    CPG_DEV double operator()(int, unsigned) const { return 0.0; }
 };
 
 // is_primal_infeasible on delta_y (OSQP paper sec. 3.4); wave-uniform result.
@@ -713,15 +717,20 @@ struct ScaledNorms {
 // update_info + check_termination: residuals in the unscaled space (scaled_termination = 0),
 // optimality / infeasibility decisions.  status stays 11 (unsolved) when nothing triggers.
 // `sn` (optional) receives the scaled norms of the same products.
-template <int NSX, int NSZ, typename Ctx>
+//
+// Two forms, chosen by the context type, because this code is inlined into kernels whose register allocation
+// around their hot loops reacts to it (both measured):
+//   Ctx::kTestsFirst  (shared-factor kernel)  the caller has run infeasibility_tests() right after the iteration
+//                     and passes the verdicts `iv`; the lane id is re-derived per call (cpgw::opaque) so that the
+//                     dozens of per-lane addresses of the test are computed here and die here;
+//   otherwise         (per-instance factor kernels)  OSQP's own order: the tests run in here, on dx / dy, when
+//                     the matching residual test has failed; the caller's lane id is used as it is.
+template <int NSX, int NSZ, typename Ctx, typename DX, typename DY>
 CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
                        const DevSettings &S, const double (&Ix)[NSX], const double (&Iz)[NSZ],
-                       const double (&Iy)[NSZ], InfeasVerdict iv,
+                       const double (&Iy)[NSZ], const DX &dx, const DY &dy, InfeasVerdict iv,
                        double *w, int lane_in, bool approximate, ScaledNorms *sn = nullptr) {
-    // per-call copy of the lane id (cpgw::opaque): the dozens of per-lane addresses of the test are computed
-    // here and die here, instead of being hoisted out of the caller's loops and kept alive (spilled) across
-    // its hot loop
-    const int lane = cpgw::opaque(lane_in);
+    const int lane = Ctx::kTestsFirst ? cpgw::opaque(lane_in) : lane_in;
     cpgw::assume((unsigned)lane < 64u);
     const bool unsc = !S.scaled_termination;
     const double mult = approximate ? 10.0 : 1.0;
@@ -792,9 +801,9 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
     bool pc = false, dc = false, pic = false, dic = false, gc = true;
     if (F.m == 0) pc = true;
     else if (rp < ea + er * cpgw::dmax2(nz, na)) pc = true;
-    else pic = iv.primal;
+    else pic = Ctx::kTestsFirst ? iv.primal : primal_infeasible<NSX, NSZ, Ctx, DY>(F, cx, ct, unsc, S.eps_prim_inf * mult, w, dy, lane);
     if (rd < ea + er * dn) dc = true;
-    else dic = iv.dual;
+    else dic = Ctx::kTestsFirst ? iv.dual : dual_infeasible<NSX, NSZ, Ctx, DX>(F, cx, ct, unsc, S.eps_dual_inf * mult, w, dx, lane);
     if (S.check_dualgap) {   // OSQP >= 1.0: |primal - dual objective| against eps_abs + eps_rel max(|primal|, |dual|)
         sup = cpgw::wave_sum(sup);
         const double dual_obj = (-0.5 * quad - sup) * F.cinv, gap = fabs(quad + lin + sup) * F.cinv;
@@ -809,11 +818,11 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
 // store_solution + cpg_retrieve_*: unscale, gather the user-facing entries, write the info scalars;
 // with Bt.state_out also the workspace a sequential caller carries to its next solve: the scaled iterates
 // (reset to zero when there is no solution, as osqp_solve does) and rho.
-template <int NSX, int NSZ>
+template <int NSX, int NSZ, bool OPAQUE_LANE = true>
 CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)[NSX], const double (&Iz)[NSZ],
                       const double (&Iy)[NSZ], double dconst, long long b, double *w, int lane_in, int iter,
                       const CheckOut &o, double rho) {
-    const int lane = cpgw::opaque(lane_in);                 // see check(): addresses computed here die here
+    const int lane = OPAQUE_LANE ? cpgw::opaque(lane_in) : lane_in;     // see check(): addresses computed here die here
     cpgw::assume((unsigned)lane < 64u);
     const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
     if (Bt.state_out) {
@@ -1143,9 +1152,9 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #pragma nounroll
                 for (int pass = 0; pass < 2; pass++) {
                     if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>>(
+                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, NoDelta, NoDelta>(
                         F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S, I[g].x, I[g].z, I[g].y,
-                        iv[g][pass], wg, lane, pass == 1);
+                        NoDelta{}, NoDelta{}, iv[g][pass], wg, lane, pass == 1);
                 }
                 if (o.status == 11 && iter >= S.max_iter) o.status = 7;
                 co[g] = o;
