@@ -110,8 +110,8 @@ class ConicBatchSolver(BatchSolver):
             self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h, in_lds), 'set_program_placement')
 
     def gradient(self, *a, **k):
-        raise NotImplementedError('differentiation is available for OSQP families only '
-                                  '(the reference needs a second, OSQP-form canonicalisation: cvxpygen/generator.py:76-80)')
+        raise NotImplementedError('a conic family is differentiated through its OSQP form '
+                                  '(cvxpygen/generator.py:76-80): cvxpygen_amd.two_stage.TwoStageBatchSolver')
 
     def set_updated(self, updated_params: Optional[Sequence[str]] = None) -> None:
         """(Re)creates the device handle for this set of per-instance parameters: every other

@@ -51,12 +51,14 @@ class GeneratedSolver:
         if gradient is None:
             gradient = os.path.exists(os.path.join(code_dir, 'GRADIENT'))
         self.gradient = bool(gradient)
+        # gradient_two_stage (cvxpygen/generator.py:76-80): conic solve, OSQP-form adjoint (cvxpygen_amd/two_stage.py)
+        self.two_stage = os.path.exists(os.path.join(code_dir, 'TWO_STAGE'))
         self.device = device
         if lib_path is None:
             # the library generate_code compiled for this family, else the generic table-driven one
             tag = ''.join(ch if ch.isalnum() else '_' for ch in self.desc.name)
             cands = [os.path.join(code_dir, f'libcpg_{tag}.so'), os.path.join(code_dir, f'libcpg_{tag}_streamed.so')]
-            lib_path = next((c for c in cands if os.path.exists(c)), None)
+            lib_path = None if self.two_stage else next((c for c in cands if os.path.exists(c)), None)
         self.lib_path = lib_path
         self._bs: Optional[BatchSolver] = None
         self._ws = None
@@ -68,7 +70,10 @@ class GeneratedSolver:
     @property
     def batch_solver(self) -> BatchSolver:
         if self._bs is None:
-            if self.desc.solver == 'CLARABEL':
+            if self.two_stage:
+                from .two_stage import TwoStageBatchSolver
+                self._bs = TwoStageBatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
+            elif self.desc.solver == 'CLARABEL':
                 from .conic_runtime import ConicBatchSolver
                 self._bs = ConicBatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
             else:
@@ -101,7 +106,7 @@ class GeneratedSolver:
         """settings enabled through `enable_settings` that have no counterpart in the batched kernels:
         accepted like the reference's `cpg_set_solver_<name>`; polishing itself is not implemented"""
         out = dict(kwargs)
-        if self.desc.solver == 'OSQP':
+        if self.desc.solver == 'OSQP' and not self.two_stage:
             for name in ('verbose', 'polishing', 'polish_refine_iter', 'delta'):
                 if name in out:
                     if name not in self.enabled_settings:
@@ -136,7 +141,8 @@ class GeneratedSolver:
         theta_var = np.ascontiguousarray(ws['theta'][:desc.NP][None, :])
         bs = self.batch_solver
         t0 = time.time()
-        if desc.solver == 'CLARABEL':
+        conic = desc.solver == 'CLARABEL' or self.two_stage
+        if conic:
             # new solver per solve in the reference (solvers/clarabel.py:201-204): nothing but theta carries over
             res = bs.solve(updated_params=None, theta_var=theta_var, B=1, **kwargs)
         else:
@@ -165,7 +171,7 @@ class GeneratedSolver:
         for i, d in enumerate(desc.duals):
             dv = res.dual[d.name][0]
             prob.constraints[i].save_dual_value(np.array(dv).reshape(d.shape) if d.shape else float(dv))
-        if desc.solver == 'CLARABEL':
+        if conic:
             # integer status, formatted as the reference does (cvxpygen/utils.py:1598-1601)
             status = '%d (for description visit https://oxfordcontrol.github.io/ClarabelDocs/)' % int(res.status[0])
         else:
@@ -183,7 +189,7 @@ class GeneratedSolver:
         prob._solution = make_solution(prob.status, prob.value, primal_vars, dual_vars, attr)
         prob._solver_stats = make_solver_stats({'solver_specific_stats': solver_specific_stats,
                                                 'num_iters': int(res.iter[0]),
-                                                'solve_time': t1 - t0}, desc.solver)
+                                                'solve_time': t1 - t0}, 'CLARABEL' if conic else desc.solver)
         self._last = (res.sol_x[0].copy(), res.sol_y[0].copy()) if res.sol_x is not None else None
         return prob.value
 
