@@ -41,7 +41,8 @@ CPG_INF = 1e30
 
 CANON_IDS_QP = ('P', 'q', 'd', 'A', 'l', 'u')
 CANON_IDS_CONIC = ('P', 'q', 'd', 'A', 'b')
-CANON_IDS_ALL = ('P', 'q', 'd', 'A', 'l', 'u', 'b')
+CANON_IDS_ECOS = ('c', 'd', 'A', 'b', 'G', 'h')          # cvxpygen/solvers/ecos.py:20
+CANON_IDS_ALL = ('P', 'q', 'd', 'A', 'l', 'u', 'b', 'c', 'G', 'h')
 
 
 @dataclass

@@ -343,6 +343,35 @@ def adp(name: str = 'ADP') -> FamilyDescriptor:
     return cb.build(adp_values(state), solver='CLARABEL')
 
 
+def adp_norm(name: str = 'ADP_norm', tie: bool = True) -> FamilyDescriptor:
+    """Test family for the ECOS form (cvxpygen/solvers/ecos.py; no quadratic objective): the ADP problem of
+    `tests/test_E2E_SOCP.py:15-35` with plain norms,  minimise ||f + G u_0|| + ||Rsqrt u_0||  s.t. ||u_i|| <= 0.1,
+    as cvxpy hands it to a solver without quadratic objective: epigraph variables s1, s2 with
+    (s1, f + G u_0) in SOC(7), (s2, Rsqrt u_0) in SOC(4), (tn_i, u_i) in SOC(4), tn_i <= 0.1; `tie` adds the
+    equality rows u_1 = u_0 / 2 (so that the A x = b block of the ECOS form is not empty).  Returned in the
+    stacked conic form with P = 0; `cvxpygen_amd.ecos_front.ecos_from_conic` splits it."""
+    cb = CanonBuilder(name)
+    n, m = 6, 3
+    Rsqrt = cb.param('Rsqrt', (m, m), kind='diag')
+    f = cb.param('f', (n,))
+    G = cb.param('G', (n, m))
+    u = cb.var('u', (2, m))
+    s12, tn = cb.aux(2), cb.aux(2)
+    cb.lin(s12[0], 1.0)
+    cb.lin(s12[1], 1.0)
+    eqs = [cb.eq([(u[1, j], 1.0), (u[0, j], -0.5)], 0.0) for j in range(m)] if tie else []
+    rows = [cb.ineq([(tn[i], 1.0)], 0.1) for i in range(2)]
+    cb.soc([([(s12[0], -1.0)], 0.0)] + [([(u[0, j], cmul(G[i, j], -1.0)) for j in range(m)], f[i]) for i in range(n)])
+    cb.soc([([(s12[1], -1.0)], 0.0)] + [([(u[0, i], cmul(Rsqrt[i, i], -1.0))], 0.0) for i in range(m)])
+    for i in range(2):
+        cb.soc([([(tn[i], -1.0)], 0.0)] + [([(u[i, j], -1.0)], 0.0) for j in range(m)])
+    cb.dual('d0', rows, (2,))
+    if tie:
+        cb.dual('d1', eqs, (m,))
+    state = -2.0 + 4.0 * np.random.RandomState(0).rand(6)
+    return cb.build(adp_values(state), solver='CLARABEL')
+
+
 def toy_qa(n: int = 3, name: str = 'toy_qa') -> FamilyDescriptor:
     """minimise ||G x - h||^2 + c'x  s.t. 0 <= x <= 1 (test family: q AND A parameter-dependent, so
     osqp_update_data_mat and osqp_update_data_vec both fire; cvxpygen/solvers/osqp.py:20-59)"""
@@ -367,4 +396,4 @@ def toy_qa(n: int = 3, name: str = 'toy_qa') -> FamilyDescriptor:
 
 
 FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio, 'toy_box': toy_box,
-            'toy_lp': toy_lp, 'toy_qa': toy_qa, 'ADP': adp, 'actuator': actuator}
+            'toy_lp': toy_lp, 'toy_qa': toy_qa, 'ADP': adp, 'ADP_norm': adp_norm, 'actuator': actuator}

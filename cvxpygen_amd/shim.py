@@ -73,6 +73,9 @@ class GeneratedSolver:
             if self.two_stage:
                 from .two_stage import TwoStageBatchSolver
                 self._bs = TwoStageBatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
+            elif self.desc.solver == 'ECOS':
+                from .ecos_front import EcosBatchSolver
+                self._bs = EcosBatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
             elif self.desc.solver == 'CLARABEL':
                 from .conic_runtime import ConicBatchSolver
                 self._bs = ConicBatchSolver(self.desc, device=self.device, lib_path=self.lib_path)
@@ -98,7 +101,7 @@ class GeneratedSolver:
             d = self.desc
             ids = [pid for pid in d.maps if d.changes.get(pid, False)]
             self._ws = dict(theta=np.array(d.theta0, dtype=np.float64), outdated=set(ids),
-                            q_ws=np.array(d.default_canon()['q'], dtype=np.float64), q_setup=None,
+                            q_ws=np.array(d.default_canon().get('q', np.zeros(0)), dtype=np.float64), q_setup=None,
                             mat_touched=False, state=None)
         return self._ws
 
@@ -141,7 +144,7 @@ class GeneratedSolver:
         theta_var = np.ascontiguousarray(ws['theta'][:desc.NP][None, :])
         bs = self.batch_solver
         t0 = time.time()
-        conic = desc.solver == 'CLARABEL' or self.two_stage
+        conic = desc.solver in ('CLARABEL', 'ECOS') or self.two_stage
         if conic:
             # new solver per solve in the reference (solvers/clarabel.py:201-204): nothing but theta carries over
             res = bs.solve(updated_params=None, theta_var=theta_var, B=1, **kwargs)
@@ -173,7 +176,8 @@ class GeneratedSolver:
             prob.constraints[i].save_dual_value(np.array(dv).reshape(d.shape) if d.shape else float(dv))
         if conic:
             # integer status, formatted as the reference does (cvxpygen/utils.py:1598-1601)
-            status = '%d (for description visit https://oxfordcontrol.github.io/ClarabelDocs/)' % int(res.status[0])
+            docu = 'https://github.com/embotech/ecos/wiki/Usage-from-C' if desc.solver == 'ECOS' else 'https://oxfordcontrol.github.io/ClarabelDocs/'
+            status = '%d (for description visit %s)' % (int(res.status[0]), docu)
         else:
             status = STATUS_STRINGS.get(int(res.status[0]), 'unknown')
         prob._status = status
@@ -189,7 +193,7 @@ class GeneratedSolver:
         prob._solution = make_solution(prob.status, prob.value, primal_vars, dual_vars, attr)
         prob._solver_stats = make_solver_stats({'solver_specific_stats': solver_specific_stats,
                                                 'num_iters': int(res.iter[0]),
-                                                'solve_time': t1 - t0}, 'CLARABEL' if conic else desc.solver)
+                                                'solve_time': t1 - t0}, 'CLARABEL' if self.two_stage else desc.solver)
         self._last = (res.sol_x[0].copy(), res.sol_y[0].copy()) if res.sol_x is not None else None
         return prob.value
 
