@@ -569,7 +569,7 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
             }
         }
     }
-    F.kkt_ragged.dict = nullptr; F.kkt_ragged.words = nullptr; F.kkt_ragged.n_dict = 0; F.kkt_ragged.cols_padded = nullptr;
+    F.kkt_ragged.dict = nullptr; F.kkt_ragged.words = nullptr; F.kkt_ragged.n_dict = 0; F.kkt_ragged.cols_padded = nullptr; F.kkt_ragged.rows_gen = nullptr;
 #ifdef CPG_GEN_COMPRESSED
     if (f->kkt_ragged.n_chunks > 0) {
         // dictionary of the distinct coefficients (bit patterns, sorted) and one word per entry
@@ -623,6 +623,30 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
                        cpg_hip_destroy(h); return CPG_E_BADARG; }
         }
 #endif
+        {   // output-slot table of the generated executor: [chunk / 4][lane][chunk % 4], slot | segment mask << 13
+            const int nch4 = (rg.n_chunks + 3) & ~3;
+            std::vector<unsigned short> rt((size_t)nch4 * 64, (unsigned short)f->n_slots);
+            for (int c = 0; c < rg.n_chunks; c++)
+                for (int g0 = 0; g0 < 64; g0 += 16) {
+                    // a ds_write_b64 is served in 16-lane groups whose 8-byte slots collide modulo 16: idle lanes
+                    // take, in order, the dummy slots whose residue no row of the group uses
+                    bool used[16] = {false};
+                    for (int t = g0; t < g0 + 16; t++) { const unsigned d = rg.desc[(size_t)c * 64 + t]; if ((d & 0xFFFFu) != 0xFFFFu) used[(d & 0xFFFFu) % 16u] = true; }
+                    int nxt = 0;
+                    for (int t = g0; t < g0 + 16; t++) {
+                        const unsigned d = rg.desc[(size_t)c * 64 + t];
+                        unsigned slot = d & 0xFFFFu;
+                        if (slot == 0xFFFFu) {
+                            while (nxt < CPG_GEN_DUMMY_SLOTS && used[(unsigned)(f->n_slots + nxt) % 16u]) nxt++;
+                            const int j = nxt < CPG_GEN_DUMMY_SLOTS ? nxt++ : (t & (CPG_GEN_DUMMY_SLOTS - 1));
+                            slot = (unsigned)(f->n_slots + j);
+                        }
+                        rt[((size_t)(c >> 2) * 64 + t) * 4 + (c & 3)] = (unsigned short)(slot | ((d >> 28) << 13));
+                    }
+                }
+            TRY(upload<unsigned short>(h, h->owned, rt.data(), rt.size(), &F.kkt_ragged.rows_gen));
+            TRY(rt_sync(h));      // `rt` is a stack-lifetime buffer
+        }
 #ifdef CPG_GEN_PADDED_OFFSETS
         {   // operand offsets of all 64 lanes of every step, in the executor's order; idle lanes read the zero slot
             static const int steps[][2] = CPG_GEN_STEPS;        // {first entry, active lanes}
@@ -1038,7 +1062,7 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
     // LDS-resident program: one workgroup per CU, as many waves as fit next to the program
     const cpg::DevRagged &R = h->F.kkt_ragged;
 #ifdef CPG_GEN_HEADER
-    const size_t tab_doubles = (size_t)R.n_chunks * 16;     // 16-bit output-slot table
+    const size_t tab_doubles = (size_t)((R.n_chunks + 3) & ~3) * 16;     // 16-bit output-slot table, four chunks per entry group
 #else
     const size_t tab_doubles = (size_t)R.n_chunks * 34;     // desc (u32 x 64) + ctab (int x 4)
 #endif

@@ -58,6 +58,10 @@ struct DevRagged {
     // generated executor with CPG_GEN_PADDED_OFFSETS: operand offsets of all 64 lanes of every step, in
     // execution order (idle lanes: the zero slot); built by cpg_hip_create_osqp from the header's step table
     const unsigned short *cols_padded;
+    // generated executor: output slot | segment mask << 13 of every (chunk, lane), four chunks of a lane side by
+    // side ([chunk / 4][lane][chunk % 4]); lanes without a row get a dummy slot whose bank pair no row of their
+    // 16-lane store group uses (cpg_hip_create_osqp builds it)
+    const unsigned short *rows_gen;
     // dictionary-compressed form (family libraries built with CPG_GEN_COMPRESSED): the distinct
     // coefficients and, per entry, operand byte offset | dictionary byte offset << 16
     const double *dict;
@@ -408,22 +412,27 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = fma(v_, x##ID[g_], A[g_]);        \
     }
 // per (chunk, lane) table entry: output slot (13 bits) | segmented-reduction mask << 13.  Lanes that
-// own no row store to a dummy slot behind the work vector (n_slots + lane % 16: one per lane of the 16-lane
-// groups a ds_write_b64 is served in, so they never collide): the store is unconditional and the whole
+// own no row store to one of 16 dummy slots behind the work vector (a ds_write_b64 is served in 16-lane groups
+// whose 8-byte slots collide modulo 16: every idle lane of a group gets a dummy no row of the group collides
+// with): the store is unconditional and the whole
 // program stays one basic block.  One more slot behind them always holds 0.0: the operand of idle lanes
 // when the offsets are stored for all 64 lanes of a step (CPG_GEN_PADDED_OFFSETS).
 #define CPG_GEN_SLOT_MASK 0x1FFFu
 #define CPG_GEN_DUMMY_SLOTS 16
 #define CPG_GEN_EXTRA_SLOTS (CPG_GEN_DUMMY_SLOTS + 1)
-#define CPG_GEN_REDUCE_STORE(A, LG, C)                                                             \
+// the table entries of four chunks come with one LDS read (CPG_GEN_LOAD_ROWS, issued when the phase of the first
+// of them opens); CPG_GEN_ROW picks chunk C's
+#define CPG_GEN_LOAD_ROWS(Q) const OffsetQuad rq##Q = *(const OffsetQuad *)((const char *)rows + (unsigned)lane * 8u + (Q) * 512u);
+#define CPG_GEN_ROW(Q, J) ((J) == 0 ? (rq##Q.a & 0xFFFFu) : (J) == 1 ? (rq##Q.a >> 16) : (J) == 2 ? (rq##Q.b & 0xFFFFu) : (rq##Q.b >> 16))
+#define CPG_GEN_REDUCE_STORE(A, LG, Q, J)                                                          \
     {                                                                                              \
-        const unsigned row_ = rows[(C) * 64u + (unsigned)lane] & CPG_GEN_SLOT_MASK;                \
+        const unsigned row_ = CPG_GEN_ROW(Q, J) & CPG_GEN_SLOT_MASK;                               \
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
             w[(unsigned)(g_ * ldw) + row_] = cpgw::group_sum_first<LG>(A[g_]);                     \
     }
-#define CPG_GEN_SEGREDUCE_STORE(A, S, C)                                                           \
+#define CPG_GEN_SEGREDUCE_STORE(A, S, Q, J)                                                        \
     {                                                                                              \
-        const unsigned e_ = rows[(C) * 64u + (unsigned)lane];                                      \
+        const unsigned e_ = CPG_GEN_ROW(Q, J);                                                     \
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
             w[(unsigned)(g_ * ldw) + (e_ & CPG_GEN_SLOT_MASK)] = cpgw::seg_sum_first<S>(A[g_], e_ >> 13); \
     }
@@ -944,12 +953,9 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
 #ifdef CPG_GEN_HEADER
         // the generated executor has every count / offset baked in; it only needs the per-lane
         // output slots as a 16-bit table
-        unsigned short *lr = (unsigned short *)(lds + lds_off); lds_off += (size_t)R.n_chunks * 16;
-        for (unsigned t = t0; t < (unsigned)R.n_chunks * 64u; t += nt) {
-            const unsigned d = cpgw::gld(R.desc, t);
-            const unsigned slot = (d & 0xFFFFu) == CPG_NO_ROW ? (unsigned)F.n_slots + (t & (CPG_GEN_DUMMY_SLOTS - 1u)) : (d & 0xFFFFu);
-            lr[t] = (unsigned short)(slot | ((d >> 28) << 13));
-        }
+        const unsigned n_rows16 = (((unsigned)R.n_chunks + 3u) & ~3u) * 64u;
+        unsigned short *lr = (unsigned short *)(lds + lds_off); lds_off += (size_t)(n_rows16 / 4u);
+        for (unsigned t = t0; t < n_rows16; t += nt) lr[t] = cpgw::gld(R.rows_gen, t);
         LP.rows16 = lr; LP.ctab = nullptr; LP.desc = nullptr;
 #else
         unsigned *ld = (unsigned *)(lds + lds_off);         lds_off += (size_t)R.n_chunks * 32;

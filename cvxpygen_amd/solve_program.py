@@ -717,7 +717,7 @@ def padded_offsets_fit(prog: RaggedProgram, N: int, waves: int = 8, lds_bytes: i
     per_wave = 8 * (prog.n_slots + GEN_EXTRA_SLOTS)
 
     def fit(n_off):
-        fixed = 8 * N + 8 * (nnzp + (n_off + 3) // 4 + 16 * prog.n_chunks)
+        fixed = 8 * N + 8 * (nnzp + (n_off + 3) // 4 + 16 * ((prog.n_chunks + 3) & ~3))
         return max(0, min(waves, (lds_bytes - fixed) // per_wave))
     return fit(64 * ((n_steps + 3) & ~3)) >= max(1, fit(nnzp))
 
