@@ -164,6 +164,32 @@ def test_generated_family_library_vs_oracle(oracle_lib, tmp_path):
     bs.close()
 
 
+@pytest.mark.parametrize('name', ['mpc8', 'nnls40'])
+def test_generated_executor_other_shapes(oracle_lib, tmp_path, name):
+    """two more families through the generated executor (libraries built by __graft_entry__.build): step and chunk
+    counts that are not multiples of four (grouped offsets / output-slot table padding), other phase structures"""
+    from cvxpygen_amd import codegen
+    from cvxpygen_amd.runtime import build_family_plan
+    rng = np.random.default_rng(31)
+    if name == 'mpc8':
+        d = families.mpc(8, 3, 7)
+        pname, vals = 'x_init', -2 + 4 * rng.random((300, 8))
+    else:
+        d = families.nonneg_ls(40, 20, sparsity=None, seed=1)
+        pname, vals = 'b', d.theta0[d.param('b').col:d.param('b').col + 40] * (1 + 0.3 * rng.standard_normal((300, 40)))
+    plan = build_family_plan(d)
+    pre = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'cvxpygen_amd', 'generated', name,
+                       f'libcpg_{name}.so')
+    lib = pre if os.path.exists(pre) else codegen.build_family_library(plan, str(tmp_path), name)
+    o = oracle_lib.cpg_solve_batch(d, _theta(d, pname, vals), [pname])
+    for G in (1, 2):
+        bs = BatchSolver(d, lib_path=lib, plan=plan)
+        bs.set_launch(0, G, 0)
+        r = bs.solve({pname: vals}, updated_params=[pname])
+        _check(r, o, d)
+        bs.close()
+
+
 @pytest.mark.parametrize('make,B', [(lambda: families.nonneg_ls(10, 5, sparsity=None, seed=0), 200),
                                     (lambda: families.mpc(6, 3, 10, sparse_params=True, terminal_index=9, const=1.0), 96),
                                     (lambda: families.mpc(6, 3, 10), 64),
