@@ -1138,17 +1138,20 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                 }
             }
             // ---- termination test / bookkeeping
-            InfeasVerdict iv[G][2];
+            // (verdicts in named variables selected by value: a local array indexed by `pass` would live in scratch)
+            InfeasVerdict iv_exact[G], iv_approx[G];
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                iv[g][0] = iv[g][1] = InfeasVerdict{false, false};
+                iv_exact[g] = iv_approx[g] = InfeasVerdict{false, false};
                 if (I[g].done) continue;
                 double *wg = w + g * ldw;
 #pragma nounroll
-                for (int pass = 0; pass < (iter >= S.max_iter ? 2 : 1); pass++)
-                    iv[g][pass] = infeasibility_tests<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, RegDelta<NSX>, RegDelta<NSZ>>(
+                for (int pass = 0; pass < (iter >= S.max_iter ? 2 : 1); pass++) {
+                    const InfeasVerdict v = infeasibility_tests<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, RegDelta<NSX>, RegDelta<NSZ>>(
                         F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S,
                         RegDelta<NSX>{dxr[g]}, RegDelta<NSZ>{dyr[g]}, wg, lane, pass == 1);
+                    if (pass == 0) iv_exact[g] = v; else iv_approx[g] = v;
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -1160,7 +1163,7 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                     if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
                     o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, NoDelta, NoDelta>(
                         F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S, I[g].x, I[g].z, I[g].y,
-                        NoDelta{}, NoDelta{}, iv[g][pass], wg, lane, pass == 1);
+                        NoDelta{}, NoDelta{}, pass == 0 ? iv_exact[g] : iv_approx[g], wg, lane, pass == 1);
                 }
                 if (o.status == 11 && iter >= S.max_iter) o.status = 7;
                 co[g] = o;
