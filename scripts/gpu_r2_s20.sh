@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round 2, GPU session 20: time split of the per-instance factor kernel in the MID-ROUND build (commit 4f6d55e checked out
+# as a git worktree under tmp_old/, its portfolio library built there) -- the counterpart of gpu_r2_s15.sh
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd $R/tmp_old
 python -c "import __graft_entry__" 2>/dev/null
