@@ -107,8 +107,8 @@ def test_settings_and_errors(sim_lib):
 
 
 @pytest.mark.parametrize('fam,G,gen', [('nnls', 1, {}), ('nnls', 2, {}), ('mpc6', 1, {}),
-                                       ('mpc6', 1, dict(cross=0, pad_offsets=False)),
-                                       ('nnls', 2, dict(cross=9, depth=3, group_offsets=2)), ('mpc6', 1, dict(group_offsets=1, batch=2))])
+                                       ('mpc6', 1, dict(cross=0, pad_offsets=False, early=0)),
+                                       ('nnls', 2, dict(cross=9, depth=3, group_offsets=2, early=9)), ('mpc6', 1, dict(group_offsets=1, batch=2))])
 def test_generated_executor_parity(oracle_lib, tmp_path, fam, G, gen):
     """cvxpygen_amd.codegen: the family-specialised straight-line executor (emulator build of the
     generated source) gives the oracle's results; a library generated for one family refuses another."""
