@@ -287,7 +287,7 @@ def main():
     wall = None
     if world == 1 and not args.no_wall and desc.solver == 'OSQP':
         from cvxpygen_amd.runtime import PinnedStream
-        nb = 4
+        nb = 8                                     # fill and drain of the pipeline (first H2D, last D2H) over eight batches
         ps = PinnedStream(solver, B, nb)
         for k in range(nb):
             ps.theta[k * B:(k + 1) * B] = theta
