@@ -884,7 +884,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     if ((rc = upload_csr(h, own, r->map_q, &R.map_q))) return rc;
     if ((rc = upload_csr(h, own, r->map_u, &R.map_u))) return rc;
     if ((rc = upload_csr(h, own, r->map_d, &R.map_d))) return rc;
-    R.buf_doubles = (long long)(r->nnzP + r->nnzA + 3 * n + 4 * m + r->nnzL + 2 * N + R.sol_nnz + 64);   // see carve()
+    R.buf_doubles = (long long)(r->nnzP + 2 * r->nnzA + 3 * n + 4 * m + r->nnzL + 2 * N + R.sol_nnz + 64);   // see carve()
     if ((rc = rt_sync(h))) return rc;
     h->refactor_mode = true;
     h->have_update = true;

@@ -54,6 +54,7 @@ CPG_DEV double lim_scaling(double v) { v = v < 1e-4 ? 1.0 : v; return v > 1e4 ? 
 // per-wavefront buffer layout (doubles)
 struct InstBuf {
     double *P, *A, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *Lx, *Dg, *Dginv, *sv;
+    double *Ar;     // the entries of A once more in ROW order (row walks then need no entry-number indirection)
 };
 CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
     InstBuf o;
@@ -63,7 +64,22 @@ CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
     o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
     o.Lx = b; b += R.nnzL; o.Dg = b; b += N; o.Dginv = b; b += N;
     o.sv = b; b += R.sol_nnz;
+    o.Ar = b; b += R.nnzA;
     return o;
+}
+
+// CPG_REFACTOR_ROW_COPY (family libraries of families with long rows of A, codegen.family_library_defs): the row
+// walks of the equilibration sweeps and of the termination test read a ROW-ordered copy of A's entries instead of
+// going through the entry numbers -- one dependent memory round trip per four entries instead of two; a
+// 101-entry row (portfolio family) is 26 such groups long and everything else of its 64-row slot waits for it.
+// Portfolio: 105.2 -> 101.6 ms per 20 000; families with short rows only pay for the copy (MPC 12/4/10 with every
+// parameter: 176 -> 182 ms), so the generic library and their family libraries leave it off.
+// B.Ar[k] = B.A[entry number of the k-th entry in row order]: one coalesced pass per instance and scaling state
+CPG_DEV void refresh_row_copy(const DevRefactor &R, const InstBuf &B, int lane) {
+    cpgw::mem_order();
+    for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u)
+        cpgw::gst(B.Ar, k, cpgw::gld((const double *)B.A, (unsigned)cpgw::gld(R.Aent, k)));
+    cpgw::mem_order();
 }
 
 // Walks row r of a sparse pattern (ptr / optional entry numbers / columns) over the instance's values
@@ -124,7 +140,11 @@ struct InstCtx {
     }
     CPG_DEV double ax(int s) const {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+#ifdef CPG_REFACTOR_ROW_COPY
+        return i < (unsigned)F.m ? row_dot<false, false>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i) : 0.0;
+#else
         return i < (unsigned)F.m ? row_dot<true, false>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i) : 0.0;
+#endif
     }
     CPG_DEV double px(int s) const {
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
@@ -272,6 +292,9 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         for (unsigned i = (unsigned)lane; i < m; i += 64u) cpgw::gst(B.u, i, csr_row(R.map_u, i, theta, cpgw::gld(R.u_base, i)));
         const double dconst = csr_row(R.map_d, 0, theta, R.d_base);
         cpgw::mem_order();
+#ifdef CPG_REFACTOR_ROW_COPY
+        refresh_row_copy(R, B, lane);            // unscaled A in row order: the row walks of the equilibration sweeps
+#endif
 
         // ---- 2. Ruiz equilibration from scratch (D in w[0..n), E in w[n..N), cumulative form)
         double cs = 1.0;
@@ -299,7 +322,11 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 double acc = 0.0;
                 if (i < m) {
                     const double ei = w[n + i];
+#ifdef CPG_REFACTOR_ROW_COPY
+                    for_row_entries<false>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i,
+#else
                     for_row_entries<true>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i,
+#endif
                                           [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(ei * v * w[c])); });
                 }
                 en[s] = acc;
@@ -339,6 +366,9 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             a = (unsigned)cpgw::gld(R.Pp, j); e = (unsigned)cpgw::gld(R.Pp, j + 1u);
             for (unsigned k = a; k < e; k++) cpgw::gst(B.P, k, cs * w[(unsigned)cpgw::gld(R.Pi, k)] * cpgw::gld((const double *)B.P, k) * dj);
         }
+#ifdef CPG_REFACTOR_ROW_COPY
+        refresh_row_copy(R, B, lane);            // scaled A in row order: the termination test's A x
+#endif
         signed char ct[NSZ];
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
