@@ -75,6 +75,9 @@ CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
 // Portfolio: 105.2 -> 101.6 ms per 20 000; families with short rows only pay for the copy (MPC 12/4/10 with every
 // parameter: 176 -> 182 ms), so the generic library and their family libraries leave it off.
 // B.Ar[k] = B.A[entry number of the k-th entry in row order]: one coalesced pass per instance and scaling state
+#ifndef CPG_ROW_COPY_BATCH
+#define CPG_ROW_COPY_BATCH 8      // entries of a row requested together where the row-ordered copy is walked (4: 101.4, 8: 99.6 ms; 16 spills in the ADMM loop)
+#endif
 CPG_DEV void refresh_row_copy(const DevRefactor &R, const InstBuf &B, int lane) {
     cpgw::mem_order();
     for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u)
@@ -85,22 +88,22 @@ CPG_DEV void refresh_row_copy(const DevRefactor &R, const InstBuf &B, int lane) 
 // Walks row r of a sparse pattern (ptr / optional entry numbers / columns) over the instance's values
 // and calls f(value, column) for every entry in storage order.  An entry costs a chain of dependent
 // loads (entry number -> value), so four entries are requested together before f consumes them.
-template <bool ENT, class Fn>
+template <bool ENT, int NB = 4, class Fn>
 CPG_DEV void for_row_entries(const int *ptr, const int *ent, const int *col, const double *val, unsigned r, Fn f) {
     const unsigned a = (unsigned)cpgw::gld(ptr, r), e = (unsigned)cpgw::gld(ptr, r + 1u);
-    for (unsigned k = a; k < e; k += 4u) {
-        unsigned en[4], co[4];
+    for (unsigned k = a; k < e; k += (unsigned)NB) {
+        unsigned en[NB], co[NB];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < NB; t++) {
             const unsigned kk = k + (unsigned)t < e ? k + (unsigned)t : a;
             en[t] = ENT ? (unsigned)cpgw::gld(ent, kk) : kk;
             co[t] = (unsigned)cpgw::gld(col, kk);
         }
-        double av[4];
+        double av[NB];
 #pragma unroll
-        for (int t = 0; t < 4; t++) av[t] = cpgw::gld(val, en[t]);
+        for (int t = 0; t < NB; t++) av[t] = cpgw::gld(val, en[t]);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NB; t++)
             if (k + (unsigned)t < e) f(av[t], co[t]);
     }
 }
@@ -131,17 +134,17 @@ struct InstCtx {
     CPG_DEV double q(int s, unsigned) const { return qr[s]; }
     CPG_DEV double u(int s, unsigned) const { return ur[s]; }
 #endif
-    template <bool ENT, bool OFFS>
+    template <bool ENT, bool OFFS, int NB = 4>
     CPG_DEV double row_dot(const int *ptr, const int *ent, const int *col, const double *val, unsigned r) const {
         double acc = 0.0;
         const double *wv = w + (OFFS ? (unsigned)F.n : 0u);
-        for_row_entries<ENT>(ptr, ent, col, val, r, [&](double v, unsigned c) { acc = fma(v, wv[c], acc); });
+        for_row_entries<ENT, NB>(ptr, ent, col, val, r, [&](double v, unsigned c) { acc = fma(v, wv[c], acc); });
         return acc;
     }
     CPG_DEV double ax(int s) const {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
 #ifdef CPG_REFACTOR_ROW_COPY
-        return i < (unsigned)F.m ? row_dot<false, false>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i) : 0.0;
+        return i < (unsigned)F.m ? row_dot<false, false, CPG_ROW_COPY_BATCH>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i) : 0.0;
 #else
         return i < (unsigned)F.m ? row_dot<true, false>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i) : 0.0;
 #endif
@@ -323,7 +326,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 if (i < m) {
                     const double ei = w[n + i];
 #ifdef CPG_REFACTOR_ROW_COPY
-                    for_row_entries<false>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i,
+                    for_row_entries<false, CPG_ROW_COPY_BATCH>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i,
 #else
                     for_row_entries<true>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i,
 #endif
