@@ -88,7 +88,10 @@ CPG_DEV void refresh_row_copy(const DevRefactor &R, const InstBuf &B, int lane) 
 // Walks row r of a sparse pattern (ptr / optional entry numbers / columns) over the instance's values
 // and calls f(value, column) for every entry in storage order.  An entry costs a chain of dependent
 // loads (entry number -> value), so four entries are requested together before f consumes them.
-template <bool ENT, int NB = 4, class Fn>
+#ifndef CPG_ROW_WALK_BATCH
+#define CPG_ROW_WALK_BATCH 4       // entries requested together in every other row / column walk
+#endif
+template <bool ENT, int NB = CPG_ROW_WALK_BATCH, class Fn>
 CPG_DEV void for_row_entries(const int *ptr, const int *ent, const int *col, const double *val, unsigned r, Fn f) {
     const unsigned a = (unsigned)cpgw::gld(ptr, r), e = (unsigned)cpgw::gld(ptr, r + 1u);
     for (unsigned k = a; k < e; k += (unsigned)NB) {
@@ -134,7 +137,7 @@ struct InstCtx {
     CPG_DEV double q(int s, unsigned) const { return qr[s]; }
     CPG_DEV double u(int s, unsigned) const { return ur[s]; }
 #endif
-    template <bool ENT, bool OFFS, int NB = 4>
+    template <bool ENT, bool OFFS, int NB = CPG_ROW_WALK_BATCH>
     CPG_DEV double row_dot(const int *ptr, const int *ent, const int *col, const double *val, unsigned r) const {
         double acc = 0.0;
         const double *wv = w + (OFFS ? (unsigned)F.n : 0u);
