@@ -227,3 +227,66 @@ def test_bank_aware_slot_numbering():
     pa, pb = build_family_plan(d, bank_layout=True), build_family_plan(d, bank_layout=False)
     assert pa.stats['bank_conflict_cycles'] <= pa.stats['bank_conflict_cycles_natural']
     assert pa.kkt_ragged.nnz == pb.kkt_ragged.nnz and pa.kkt_ragged.n_slots == pb.kkt_ragged.n_slots
+
+
+@pytest.mark.parametrize('opts', [{}, dict(batch=2, early=9, cross=9, depth=3), dict(pad_offsets=False, early=0, cross=0),
+                                  dict(group_offsets=2), dict(group_offsets=1, depth=1)])
+def test_generated_executor_schedule_invariants(opts):
+    """cvxpygen_amd/codegen.emit_program_header, without compiling anything: every step's offset / coefficient load,
+    gather and multiply-add appear exactly once and in that order; multiply-adds of a chunk keep their order; a
+    gather that reads what the previous phase stores comes after that phase's reduce / store, every other gather
+    may come before (`early`); every chunk is stored exactly once, after its last multiply-add"""
+    import re
+    from cvxpygen_amd import codegen
+    d = families.mpc(6, 3, 10)
+    plan = build_family_plan(d)
+    rp = plan.kkt_ragged
+    text = codegen.emit_program_header(rp, 'mpc6', plan, pad_offsets=opts.pop('pad_offsets', True), **opts)
+    steps = SP.execution_steps(rp)
+    T = len(steps)
+    body = text[text.index('run_program_gen'):]
+    ev = []                                    # (kind, id) in program order
+    for ln in body.splitlines():
+        m = re.match(r'\s*CPG_GEN_LOAD_CV\w*\((\d+),', ln)
+        if m: ev.append(('C', int(m.group(1)))); continue
+        m = re.match(r'\s*CPG_GEN_LOAD_W\((\d+)\)', ln)
+        if m: ev.append(('W', int(m.group(1)))); continue
+        m = re.match(r'\s*CPG_GEN_FMA_\w+\(a(\d+), (\d+)', ln)
+        if m: ev.append(('F', int(m.group(2)), int(m.group(1)))); continue
+        m = re.match(r'\s*CPG_GEN_(?:SEG)?REDUCE_STORE\(a(\d+),', ln)
+        if m: ev.append(('S', int(m.group(1))))
+    pos = {}
+    for k, e in enumerate(ev):
+        assert (e[0], e[1]) not in pos, e
+        pos[(e[0], e[1])] = k
+    assert all(('C', t) in pos and ('W', t) in pos and ('F', t) in pos for t in range(T))
+    assert all(pos[('C', t)] < pos[('W', t)] < pos[('F', t)] for t in range(T))
+    assert all(('S', c) in pos for c in range(rp.n_chunks))
+    fma_order = [e[1] for e in ev if e[0] == 'F']
+    assert fma_order == sorted(fma_order)                       # multiply-adds in execution order
+    assert [e[1] for e in ev if e[0] == 'W'] == list(range(T))  # gathers too
+    chunk_of = {t: st[1] for t, st in enumerate(steps)}
+    for e in ev:
+        if e[0] == 'F':
+            assert e[2] == chunk_of[e[1]] and pos[('F', e[1])] < pos[('S', e[2])]
+    # dependences through the work vector
+    outs = {}
+    for c in range(rp.n_chunks):
+        outs.setdefault(int(rp.chunk_phase[c]), set()).update(int(x) for x in (rp.desc[c] & 0xFFFF) if int(x) != 0xFFFF)
+    phase_ids = sorted(outs)
+    n_early = 0
+    for t, (pi_, c, e0, cnt) in enumerate(steps):
+        if pi_ == 0:
+            continue
+        prev_chunks = [c2 for c2 in range(rp.n_chunks) if phase_ids.index(int(rp.chunk_phase[c2])) == pi_ - 1]
+        prev_end = max(pos[('S', c2)] for c2 in prev_chunks)
+        reads_prev = any(int(x) // 8 in outs[phase_ids[pi_ - 1]] for x in rp.cols[e0:e0 + cnt])
+        if reads_prev:
+            assert pos[('W', t)] > prev_end
+        elif pos[('W', t)] < prev_end:
+            n_early += 1
+        # never earlier than the phase before the previous one has stored
+        if pi_ >= 2:
+            pp = [c2 for c2 in range(rp.n_chunks) if phase_ids.index(int(rp.chunk_phase[c2])) == pi_ - 2]
+            assert pos[('W', t)] > max(pos[('S', c2)] for c2 in pp)
+    assert (n_early > 0) == bool(opts.get('early', 4))
