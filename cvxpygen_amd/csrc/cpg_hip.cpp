@@ -71,6 +71,16 @@ struct cpg_solver_s {
     // staging for the host-pointer entry point
     DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status, s_state_in, s_state_out;
     struct cpg_pipe_s *pipe = nullptr;  // cpg_hip_solve_batches_pipelined
+    // OSQP library defaults the generated shim has no setter for (cpg_hip_set_build_option); restored, like the
+    // others, by cpg_hip_set_default_settings
+    int opt_adaptive_rho = 1, opt_adaptive_rho_interval = 50, opt_check_dualgap = 1;
+    double opt_adaptive_rho_tolerance = 5.0;
+    // hybrid execution of rho adaptation (cpg_hip_set_handover): instances of this shared-factor handle whose
+    // rho changes continue on `linked`'s per-instance factor kernel, launched behind on this handle's stream
+    cpg_solver_s *linked = nullptr;
+    DevBuf ho_state, ho_list;
+    rt_event_t ev_mid{};
+    bool two_phase_last = false;
 };
 
 // ---- runtime primitives -------------------------------------------------------------------------
@@ -250,11 +260,11 @@ osqp_refactor_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, c
     cpg::osqp_refactor_body<NSX, NSZ>(F, R, S, Bt, cpg_lds, wave_global);
 }
 template <int NSX, int NSZ>
-static int launch_refactor_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+static int launch_refactor_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
     auto kern = osqp_refactor_kernel<NSX, NSZ>;
     if (lds > 48 * 1024)
         RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->F, h->R, h->S, Bt);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, stream, h->F, h->R, S, Bt);
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
@@ -285,9 +295,11 @@ static int launch_gradient(cpg_handle_t h, const cpg::DevGradBatch &Bt, int bloc
     set_error("problem family larger than the largest compiled slot class");
     return CPG_E_UNSUPPORTED;
 }
-static int launch_refactor(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+// (stream and settings are the caller's: the hand-over launch of a linked handle runs on the shared-factor
+// handle's stream with that handle's settings)
+static int launch_refactor(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
     const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
-#define Z(a, b) if (nsx <= a && nsz <= b) return launch_refactor_t<a, b>(h, Bt, blocks, waves, lds);
+#define Z(a, b) if (nsx <= a && nsz <= b) return launch_refactor_t<a, b>(h, stream, S, Bt, blocks, waves, lds);
     CPG_KERNELS_REFACTOR(Z)
 #undef Z
     set_error("problem family larger than the largest compiled slot class");
@@ -450,8 +462,14 @@ int cpg_hip_set_default_settings(cpg_handle_t h) {
     h->S.max_iter = 4000; h->S.eps_abs = 1e-3; h->S.eps_rel = 1e-3; h->S.eps_prim_inf = 1e-4;
     h->S.eps_dual_inf = 1e-4; h->S.scaled_termination = 0; h->S.check_termination = 25;
     h->S.warm_starting = 1;
-    // (the build options -- adaptive_rho*, check_dualgap -- are workspace constants of the generated code,
-    // not settings the reference resets: cpg_hip_set_build_option)
+    // ... and every other OSQP setting goes back to the linked library's default as well: the generated
+    // cpg_set_solver_default_settings IS osqp_set_default_settings(solver.settings) (solvers/osqp.py:101,
+    // utils.py:1071-1073).  For OSQP >= 1.0 -- the only API the reference's emitted calls compile against
+    // (osqp_update_data_mat / _vec, OSQPSolver; pyproject.toml:26) -- that means rho adaptation every 50 iterations
+    // with tolerance 5 and the duality-gap term in the termination test.  cpg_hip_set_build_option replaces these
+    // four (e.g. adaptive_rho 0, check_dualgap 0 for a solver generated against an OSQP that never adapts).
+    h->S.adaptive_rho = h->opt_adaptive_rho; h->S.adaptive_rho_interval = h->opt_adaptive_rho_interval;
+    h->S.adaptive_rho_tolerance = h->opt_adaptive_rho_tolerance; h->S.check_dualgap = h->opt_check_dualgap;
     return CPG_OK;
 }
 
@@ -479,10 +497,10 @@ int cpg_hip_set_build_option(cpg_handle_t h, const char *name, double v) {
     if (!h || !name) { set_error("null argument"); return CPG_E_BADARG; }
     if (h->conic) { set_error("not available for a conic (interior-point) handle"); return CPG_E_BADARG; }
     std::string s(name);
-    if (s == "adaptive_rho") h->S.adaptive_rho = (int)v;
-    else if (s == "adaptive_rho_interval") h->S.adaptive_rho_interval = (int)v;
-    else if (s == "adaptive_rho_tolerance") h->S.adaptive_rho_tolerance = v;
-    else if (s == "check_dualgap") h->S.check_dualgap = (int)v;
+    if (s == "adaptive_rho") h->S.adaptive_rho = h->opt_adaptive_rho = (int)v;
+    else if (s == "adaptive_rho_interval") h->S.adaptive_rho_interval = h->opt_adaptive_rho_interval = (int)v;
+    else if (s == "adaptive_rho_tolerance") h->S.adaptive_rho_tolerance = h->opt_adaptive_rho_tolerance = v;
+    else if (s == "check_dualgap") h->S.check_dualgap = h->opt_check_dualgap = (int)v;
     else { set_error("Build option \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
 }
@@ -527,7 +545,7 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
         if (h->lds_limit < 160 * 1024 && strstr(prop.gcnArchName, "gfx950")) h->lds_limit = 160 * 1024;
         e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); delete h; return CPG_E_HIP; }
-        hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); h->have_events = true;
+        hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); hipEventCreate(&h->ev_mid); h->have_events = true;
     }
     cpg::DevFamily &F = h->F;
     F.n = f->n; F.m = f->m; F.n_eq = f->n_eq; F.is_max = f->is_maximization;
@@ -686,8 +704,6 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     TRY(rt_sync(h));   // Dinv / Einv are stack-lifetime buffers
 #undef TRY
     cpg_hip_set_default_settings(h);
-    // build options: fixed rho, no duality-gap test; cpg_hip_set_build_option
-    h->S.adaptive_rho = 0; h->S.adaptive_rho_interval = 50; h->S.adaptive_rho_tolerance = 5.0; h->S.check_dualgap = 0;
     *out = h;
     return CPG_OK;
 }
@@ -703,7 +719,7 @@ static int open_device(cpg_handle_t h, int device) {
     if (h->lds_limit < 160 * 1024 && strstr(prop.gcnArchName, "gfx950")) h->lds_limit = 160 * 1024;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); return CPG_E_HIP; }
-    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); h->have_events = true;
+    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1); hipEventCreate(&h->ev_mid); h->have_events = true;
     return CPG_OK;
 }
 
@@ -800,8 +816,9 @@ int cpg_hip_destroy(cpg_handle_t h) {
     free_buf(h->s_theta); free_buf(h->s_prim); free_buf(h->s_dual); free_buf(h->s_obj);
     free_buf(h->s_pri); free_buf(h->s_dua); free_buf(h->s_iter); free_buf(h->s_status);
     free_buf(h->s_state_in); free_buf(h->s_state_out);
+    free_buf(h->ho_state); free_buf(h->ho_list);
     free_pipe(h->pipe); h->pipe = nullptr;
-    if (h->have_events) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
+    if (h->have_events) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); hipEventDestroy(h->ev_mid); }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return CPG_OK;
@@ -885,9 +902,50 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     if ((rc = upload_csr(h, own, r->map_u, &R.map_u))) return rc;
     if ((rc = upload_csr(h, own, r->map_d, &R.map_d))) return rc;
     R.buf_doubles = (long long)(r->nnzP + 2 * r->nnzA + 3 * n + 4 * m + r->nnzL + 2 * N + R.sol_nnz + 64);   // see carve()
+    R.shared_mats = r->shared_mats ? 1 : 0; R.cs = 1.0;
+    R.Ps = R.As = R.Ars = R.Ds = R.Dinvs = R.Es = R.Einvs = nullptr;
+    std::vector<double> ars, dinv, einv;                          // alive until the sync below
+    if (r->shared_mats) {
+        if (!r->Ps || !r->As || !r->D || !r->E || !(r->c > 0.0)) { set_error("shared-matrix mode needs Ps, As, D, E, c"); return CPG_E_BADARG; }
+        ars.resize((size_t)r->nnzA); dinv.resize(n); einv.resize(m);
+        for (int k = 0; k < r->nnzA; k++) ars[k] = r->As[r->Aent[k]];               // row-ordered copy (CPG_REFACTOR_ROW_COPY builds)
+        for (size_t i = 0; i < n; i++) dinv[i] = 1.0 / r->D[i];
+        for (size_t i = 0; i < m; i++) einv[i] = 1.0 / r->E[i];
+        R.cs = r->c;
+        if ((rc = upload<double>(h, own, r->Ps, (size_t)r->nnzP, &R.Ps))) return rc;
+        if ((rc = upload<double>(h, own, r->As, (size_t)r->nnzA, &R.As))) return rc;
+        if ((rc = upload<double>(h, own, ars.data(), ars.size(), &R.Ars))) return rc;
+        if ((rc = upload<double>(h, own, r->D, n, &R.Ds))) return rc;
+        if ((rc = upload<double>(h, own, dinv.data(), n, &R.Dinvs))) return rc;
+        if ((rc = upload<double>(h, own, r->E, m, &R.Es))) return rc;
+        if ((rc = upload<double>(h, own, einv.data(), m, &R.Einvs))) return rc;
+    }
     if ((rc = rt_sync(h))) return rc;
     h->refactor_mode = true;
     h->have_update = true;
+    return CPG_OK;
+}
+
+int cpg_hip_set_handover(cpg_handle_t h, cpg_handle_t per_instance) {
+    if (!h || h->conic || (per_instance && per_instance->conic)) { set_error("cpg_hip_set_handover: OSQP handles only"); return CPG_E_BADARG; }
+    if (per_instance && (per_instance->device != h->device || per_instance->F.n != h->F.n || per_instance->F.m != h->F.m ||
+                         per_instance->F.n_prim != h->F.n_prim || per_instance->F.n_dual != h->F.n_dual)) {
+        set_error("cpg_hip_set_handover: the two handles must describe the same family on the same device"); return CPG_E_BADARG; }
+    h->linked = per_instance;
+    return CPG_OK;
+}
+
+int cpg_hip_last_phase_ms(cpg_handle_t h, float *ms_shared, float *ms_per_instance, int64_t *n_handed_over) {
+    if (!h || !ms_shared || !ms_per_instance || !n_handed_over) { set_error("null argument"); return CPG_E_BADARG; }
+    RT_CHECK(hipEventSynchronize(h->ev1));
+    *ms_per_instance = 0.f; *n_handed_over = 0;
+    if (!h->two_phase_last) { RT_CHECK(hipEventElapsedTime(ms_shared, h->ev0, h->ev1)); return CPG_OK; }
+    RT_CHECK(hipEventElapsedTime(ms_shared, h->ev0, h->ev_mid));
+    RT_CHECK(hipEventElapsedTime(ms_per_instance, h->ev_mid, h->ev1));
+    unsigned cnt = 0;
+    RT_CHECK(hipMemcpyAsync(&cnt, h->d_counter + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    RT_CHECK(hipStreamSynchronize(h->stream));
+    *n_handed_over = (int64_t)cnt;
     return CPG_OK;
 }
 
@@ -985,6 +1043,33 @@ int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds) {
     return CPG_OK;
 }
 
+static cpg::DevBatch make_batch(int64_t B, const double *d_theta, const double *d_state_in, double *d_state_out, double *d_prim,
+                                double *d_dual, double *d_obj, int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
+    cpg::DevBatch Bt;
+    Bt.scratch = nullptr; Bt.state_in = d_state_in; Bt.state_out = d_state_out;
+    Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
+    Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = nullptr;
+    Bt.ho_list = nullptr; Bt.ho_count = nullptr; Bt.ho_state = nullptr; Bt.list = nullptr; Bt.list_count = nullptr; Bt.resume = 0;
+    return Bt;
+}
+
+// per-instance factor kernel of handle `h` (its tables, its scratch) on `stream` with settings `S`
+static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, cpg::DevBatch &Bt) {
+    const int W = 4;
+    const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
+    if (lds > h->lds_limit) { set_error("work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
+    int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : CPG_REFACTOR_WAVES_PER_SIMD;    // workgroups of 4 waves
+    if (per_cu > CPG_REFACTOR_WAVES_PER_SIMD) per_cu = CPG_REFACTOR_WAVES_PER_SIMD;
+    if ((long long)per_cu * (long long)lds > (long long)h->lds_limit) per_cu = (int)(h->lds_limit / lds);
+    long long blocks = (Bt.B + W - 1) / W;
+    const long long cap = (long long)h->num_cu * per_cu;
+    if (blocks > cap) blocks = cap;
+    int rc;
+    if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
+    Bt.scratch = (double *)h->scratch.p;
+    return launch_refactor(h, stream, S, Bt, (int)blocks, W, lds);
+}
+
 int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_theta, const double *d_state_in,
                                      double *d_state_out, double *d_prim, double *d_dual, double *d_obj,
                                      int32_t *d_iter, int32_t *d_status, double *d_pri, double *d_dua) {
@@ -1016,10 +1101,8 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
         if (per_cu < 1) per_cu = 1;
         const long long cap = (long long)h->num_cu * per_cu;
         if (blocks > cap) blocks = cap;
-        cpg::DevBatch Bt;
-        Bt.scratch = nullptr; Bt.state_in = nullptr; Bt.state_out = nullptr;
-        Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
-        Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
+        cpg::DevBatch Bt = make_batch(B, d_theta, nullptr, nullptr, d_prim, d_dual, d_obj, d_iter, d_status, d_pri, d_dua);
+        Bt.counter = h->d_counter;
         RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
         RT_CHECK(hipEventRecord(h->ev0, h->stream));
         rc = launch_conic(h, Bt, (int)blocks, W, lds, tables_in_lds);
@@ -1028,30 +1111,21 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
         return CPG_OK;
     }
     if (h->refactor_mode) {
-        const int W = 4;
-        const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
-        if (lds > h->lds_limit) { set_error("work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
-        int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : CPG_REFACTOR_WAVES_PER_SIMD;    // workgroups of 4 waves
-        if (per_cu > CPG_REFACTOR_WAVES_PER_SIMD) per_cu = CPG_REFACTOR_WAVES_PER_SIMD;
-        if ((long long)per_cu * (long long)lds > (long long)h->lds_limit) per_cu = (int)(h->lds_limit / lds);
-        long long blocks = (B + W - 1) / W;
-        const long long cap = (long long)h->num_cu * per_cu;
-        if (blocks > cap) blocks = cap;
-        if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
-        cpg::DevBatch Bt;
-        Bt.scratch = (double *)h->scratch.p; Bt.state_in = d_state_in; Bt.state_out = d_state_out;
-        Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
-        Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
-        RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
+        cpg::DevBatch Bt = make_batch(B, d_theta, d_state_in, d_state_out, d_prim, d_dual, d_obj, d_iter, d_status, d_pri, d_dua);
+        Bt.counter = h->d_counter;
+        RT_CHECK(hipMemsetAsync(h->d_counter, 0, 4 * sizeof(unsigned), h->stream));
         RT_CHECK(hipEventRecord(h->ev0, h->stream));
-        rc = launch_refactor(h, Bt, (int)blocks, W, lds);
+        rc = launch_per_instance(h, h->stream, h->S, Bt);
         if (rc) return rc;
         RT_CHECK(hipEventRecord(h->ev1, h->stream));
+        h->two_phase_last = false;
         return CPG_OK;
     }
-    if (h->S.adaptive_rho && h->S.adaptive_rho_interval > 0) {
-        // rho adaptation gives every instance its own factor: only the per-instance factor path serves it
-        set_error("adaptive_rho needs the per-instance factor path (cpg_hip_set_refactor)"); return CPG_E_UNSUPPORTED; }
+    // rho adaptation on the shared factor: hybrid execution when a per-instance factor handle is linked
+    // (cpg_hip_set_handover); without one the kernel flags the instances whose rho changes (status -2) and the
+    // host layer re-solves them through the per-instance factor path
+    const bool two_phase = h->S.adaptive_rho && h->S.adaptive_rho_interval > 0 && h->linked != nullptr;
+    if (two_phase && !h->linked->refactor_mode) { set_error("linked handle has no per-instance factor tables (cpg_hip_set_refactor)"); return CPG_E_BADARG; }
     const int G = h->inst_per_wave;
     const size_t N = (size_t)(h->F.n + h->F.m);
 #if defined(CPG_GEN_HEADER) && defined(CPG_GEN_N)
@@ -1128,14 +1202,29 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
     long long blocks = (ngroups + W - 1) / W;
     const long long cap = (long long)h->num_cu * per_cu;
     if (blocks > cap) blocks = cap;
-    cpg::DevBatch Bt;
-    Bt.scratch = nullptr; Bt.state_in = d_state_in; Bt.state_out = d_state_out;
-    Bt.B = B; Bt.theta = d_theta; Bt.prim = d_prim; Bt.dual = d_dual; Bt.obj = d_obj; Bt.pri_res = d_pri;
-    Bt.dua_res = d_dua; Bt.iter = d_iter; Bt.status = d_status; Bt.counter = h->d_counter;
-    RT_CHECK(hipMemsetAsync(h->d_counter, 0, sizeof(unsigned), h->stream));
+    cpg::DevBatch Bt = make_batch(B, d_theta, d_state_in, d_state_out, d_prim, d_dual, d_obj, d_iter, d_status, d_pri, d_dua);
+    Bt.counter = h->d_counter;
+    const size_t state_bytes = (size_t)B * ((size_t)h->F.n + 2 * (size_t)h->F.m + 1) * sizeof(double);
+    if (two_phase) {
+        // hand-over buffers: the workspace of every instance whose rho changes (the caller's state_out rows serve
+        // when it gave a buffer: the continuing kernel overwrites them with the final workspace) and their numbers
+        if (!d_state_out) { if ((rc = ensure(h->ho_state, state_bytes))) return rc; }
+        if ((rc = ensure(h->ho_list, (size_t)B * sizeof(int)))) return rc;
+        Bt.ho_state = d_state_out ? d_state_out : (double *)h->ho_state.p;
+        Bt.ho_list = (int *)h->ho_list.p; Bt.ho_count = h->d_counter + 1;
+    }
+    RT_CHECK(hipMemsetAsync(h->d_counter, 0, 4 * sizeof(unsigned), h->stream));
     RT_CHECK(hipEventRecord(h->ev0, h->stream));
     rc = launch(h, Bt, (int)blocks, W, G, lds, in_lds);
     if (rc) return rc;
+    h->two_phase_last = two_phase;
+    if (two_phase) {
+        RT_CHECK(hipEventRecord(h->ev_mid, h->stream));
+        cpg::DevBatch B2 = make_batch(B, d_theta, Bt.ho_state, d_state_out, d_prim, d_dual, d_obj, d_iter, d_status, d_pri, d_dua);
+        B2.counter = h->d_counter + 2; B2.list = Bt.ho_list; B2.list_count = h->d_counter + 1; B2.resume = 1;
+        rc = launch_per_instance(h->linked, h->stream, h->S, B2);
+        if (rc) return rc;
+    }
     RT_CHECK(hipEventRecord(h->ev1, h->stream));
     return CPG_OK;
 }

@@ -110,10 +110,12 @@ struct DevUpdate {
 struct DevSettings {
     int max_iter, check_termination, scaled_termination;
     double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
-    // what `osqp.OSQP().setup()` bakes into the generated workspace and the reference never touches
-    // again (not among the settings of cvxpygen/solvers/osqp.py:102-115): version dependent, see DESIGN.md
+    // OSQP library defaults that `osqp_set_default_settings(solver.settings)` restores on every cpg_solve of the
+    // reference (cvxpygen/solvers/osqp.py:100-101, utils.py:1071-1073) and the generated shim offers no setter for:
+    // OSQP >= 1.0 (what the reference's API requires, pyproject.toml:26): adaptive_rho 1, interval 50, tolerance 5,
+    // check_dualgap 1.  cpg_hip_set_default_settings restores the same; cpg_hip_set_build_option overrides.
     int check_dualgap;            // duality-gap term of OSQP >= 1.0's termination test
-    int adaptive_rho, adaptive_rho_interval;   // rho adaptation every `interval` iterations (per-instance factor path only)
+    int adaptive_rho, adaptive_rho_interval;   // rho adaptation every `interval` iterations
     double adaptive_rho_tolerance;
     int warm_starting;            // 1: start from DevBatch::state_in when it is given
 };
@@ -128,6 +130,17 @@ struct DevBatch {
     // [B][n + 2 m + 1] = scaled iterates x | z | y in CANONICAL order, then rho.  Null: cold start / not wanted.
     const double *state_in;
     double *state_out;
+    // ---- hybrid execution of rho adaptation on a shared-factor batch ----
+    // The shared-factor kernel serves an instance until its rho changes (OSQP's adapt_rho gives it a KKT
+    // matrix of its own); it then writes the instance's workspace to ho_state (layout of state_out, rho = the
+    // new value), its iteration count to iter[], and appends its number to ho_list.  A per-instance factor
+    // kernel launched behind it on the same stream continues those instances (`list`, `resume`).
+    int *ho_list;
+    unsigned *ho_count;
+    double *ho_state;
+    const int *list;              // instances to process (null: 0 .. B - 1) ...
+    const unsigned *list_count;   // ... and how many (device memory, written by the kernel in front)
+    int resume;                   // 1: continue at iteration iter[b] from state_in[b] (x | z | y | rho), whatever warm_starting says
 };
 
 template <int A, int B> struct MinI { static const int v = A < B ? A : B; };
@@ -824,6 +837,35 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
     return o;
 }
 
+// The workspace of an instance in the layout of DevBatch::state_out: scaled iterates x | z | y in canonical
+// order (zeros when `keep` is false), then rho.
+template <int NSX, int NSZ>
+CPG_DEV void store_state(const DevFamily &F, double *so, const double (&Ix)[NSX], const double (&Iz)[NSZ],
+                         const double (&Iy)[NSZ], bool keep, double rho, int lane) {
+#pragma unroll
+    for (int s = 0; s < NSX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        if (i < (unsigned)F.n) cpgw::gst(so, F.ord ? (unsigned)cpgw::gld(F.ord, i) : i, keep ? Ix[s] : 0.0);
+    }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        if (i < (unsigned)F.m) {
+            const unsigned c = F.ord ? (unsigned)cpgw::gld(F.ord, (unsigned)F.n + i) : i;
+            cpgw::gst(so, (unsigned)F.n + c, keep ? Iz[s] : 0.0);
+            cpgw::gst(so, (unsigned)(F.n + F.m) + c, keep ? Iy[s] : 0.0);
+        }
+    }
+    if (lane == 0) so[F.n + 2 * F.m] = rho;
+}
+
+// OSQP's compute_rho_estimate on the scaled norms of update_info: rho sqrt(normalised primal / dual residual)
+CPG_DEV double rho_estimate(const ScaledNorms &sn, double rho_settings) {
+    const double pr = sn.prim_res / (cpgw::dmax2(sn.nz, sn.nax) + CPG_DIV_TOL);
+    const double dr = sn.dual_res / (cpgw::dmax2(sn.nq, cpgw::dmax2(sn.naty, sn.npx)) + CPG_DIV_TOL);
+    return cpgw::dmin2(cpgw::dmax2(rho_settings * sqrt(pr / dr), CPG_RHO_MIN), CPG_RHO_MAX);
+}
+
 // store_solution + cpg_retrieve_*: unscale, gather the user-facing entries, write the info scalars;
 // with Bt.state_out also the workspace a sequential caller carries to its next solve: the scaled iterates
 // (reset to zero when there is no solution, as osqp_solve does) and rho.
@@ -834,24 +876,7 @@ CPG_DEV void finalize(const DevFamily &F, const DevBatch &Bt, const double (&Ix)
     const int lane = OPAQUE_LANE ? cpgw::opaque(lane_in) : lane_in;     // see check(): addresses computed here die here
     cpgw::assume((unsigned)lane < 64u);
     const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
-    if (Bt.state_out) {
-        double *so = Bt.state_out + (size_t)b * (size_t)(F.n + 2 * F.m + 1);
-#pragma unroll
-        for (int s = 0; s < NSX; s++) {
-            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-            if (i < (unsigned)F.n) cpgw::gst(so, F.ord ? (unsigned)cpgw::gld(F.ord, i) : i, has_sol ? Ix[s] : 0.0);
-        }
-#pragma unroll
-        for (int s = 0; s < NSZ; s++) {
-            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-            if (i < (unsigned)F.m) {
-                const unsigned c = F.ord ? (unsigned)cpgw::gld(F.ord, (unsigned)F.n + i) : i;
-                cpgw::gst(so, (unsigned)F.n + c, has_sol ? Iz[s] : 0.0);
-                cpgw::gst(so, (unsigned)(F.n + F.m) + c, has_sol ? Iy[s] : 0.0);
-            }
-        }
-        if (lane == 0) so[F.n + 2 * F.m] = rho;
-    }
+    if (Bt.state_out) store_state<NSX, NSZ>(F, Bt.state_out + (size_t)b * (size_t)(F.n + 2 * F.m + 1), Ix, Iz, Iy, has_sol, rho, lane);
 #pragma unroll
     for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = has_sol ? cpgw::gld(F.D, i) * Ix[s] : NAN; }
 #pragma unroll
@@ -885,6 +910,26 @@ CPG_DEV void load_state(const DevFamily &F, const double *si, double (&Ix)[NSX],
             const unsigned c = F.ord ? (unsigned)cpgw::gld(F.ord, (unsigned)F.n + i) : i;
             Iz[s] = cpgw::gld(si, (unsigned)F.n + c); Iy[s] = cpgw::gld(si, (unsigned)(F.n + F.m) + c);
         }
+    }
+}
+
+// Hand-over of an instance whose rho changed to the per-instance factor kernel behind this one (DevBatch):
+// workspace (iterates + the new rho), iteration count, and its number in the list; status -3 marks the row
+// until that kernel has written its results.
+#define CPG_STATUS_HANDED_OVER (-3)
+template <int NSX, int NSZ>
+CPG_DEV void hand_over(const DevFamily &F, const DevBatch &Bt, const double (&Ix)[NSX], const double (&Iz)[NSZ],
+                       const double (&Iy)[NSZ], long long b, int lane_in, int iter, double rho_new) {
+    const int lane = cpgw::opaque(lane_in);
+    cpgw::assume((unsigned)lane < 64u);
+    if (!Bt.ho_state || !Bt.ho_list) {      // no kernel behind this one: report it (the host layer re-solves the row)
+        if (lane == 0) { Bt.obj[b] = NAN; Bt.iter[b] = iter; Bt.status[b] = -2; Bt.pri_res[b] = 0.0; Bt.dua_res[b] = 0.0; }
+        return;
+    }
+    store_state<NSX, NSZ>(F, Bt.ho_state + (size_t)b * (size_t)(F.n + 2 * F.m + 1), Ix, Iz, Iy, true, rho_new, lane);
+    if (lane == 0) {
+        Bt.iter[b] = iter; Bt.status[b] = CPG_STATUS_HANDED_OVER;
+        Bt.ho_list[cpgw::atomic_next(Bt.ho_count)] = (int)b;
     }
 }
 
@@ -1015,6 +1060,15 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
             const bool bad = canonicalise<NSX, NSZ, NV>(F, U, theta, I[g], lane);
             if (Bt.state_in && S.warm_starting && b < Bt.B)
                 load_state<NSX, NSZ>(F, Bt.state_in + (size_t)b * (size_t)(F.n + 2 * F.m + 1), I[g].x, I[g].z, I[g].y, lane);
+            if (Bt.state_in && b < Bt.B && !bad) {
+                // the workspace of a sequential caller keeps the rho its last adapt_rho left (and the factor that
+                // goes with it); this kernel's factor only serves the family's rho
+                const double rho_in = cpgw::gld(Bt.state_in + (size_t)b * (size_t)(F.n + 2 * F.m + 1), (unsigned)(F.n + 2 * F.m));
+                if (__builtin_expect(cpgw::dmin2(cpgw::dmax2(rho_in, CPG_RHO_MIN), CPG_RHO_MAX) != F.rho, 0)) {
+                    hand_over<NSX, NSZ>(F, Bt, I[g].x, I[g].z, I[g].y, b, lane, 0, rho_in);
+                    I[g].done = 1;
+                }
+            }
             if (__builtin_expect(bad && !I[g].done, 0)) {
                 // a row changed class: the family's factor does not serve this instance.  It is only flagged
                 // here (its solution rows stay unwritten); the host layer sends it through the per-instance
@@ -1108,23 +1162,24 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
             }
             cpgw::lds_order();
         };
+        // events: the multiples of check_termination (termination test), the multiples of adaptive_rho_interval
+        // (OSQP >= 1.0's adapt_rho) and max_iter (osqp_solve)
+        const int chk_int = S.check_termination;
+        const int ad_int = (S.adaptive_rho && S.adaptive_rho_interval > 0) ? S.adaptive_rho_interval : 0;
 #pragma nounroll
         while (n_open > 0) {
             double dxr[G][NSX], dyr[G][NSZ];
             if (iter < S.max_iter) {
-                // checked iterations: the multiples of check_termination, and max_iter (osqp_solve)
-                int next_chk = S.max_iter;
-                if (S.check_termination > 0) {
-                    const int c = (iter / S.check_termination + 1) * S.check_termination;
-                    if (c < next_chk) next_chk = c;
-                }
+                int next_ev = S.max_iter;
+                if (chk_int > 0) { const int c = (iter / chk_int + 1) * chk_int; if (c < next_ev) next_ev = c; }
+                if (ad_int > 0) { const int c = (iter / ad_int + 1) * ad_int; if (c < next_ev) next_ev = c; }
                 // plain iterations in their own loop: the termination test, its products and their
                 // register demand stay outside the hot code
 #pragma nounroll
                 for (;;) {
                     iter++;
                     rhs_and_solve();
-                    if (iter >= next_chk) break;
+                    if (iter >= next_ev) break;
                     update(std::false_type{}, dxr, dyr);
                 }
                 update(std::true_type{}, dxr, dyr);
@@ -1137,16 +1192,19 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                     for (int s = 0; s < NSZ; s++) dyr[g][s] = 0.0;
                 }
             }
+            const bool last = iter >= S.max_iter;
+            const bool can_check = last || (chk_int > 0 && iter % chk_int == 0);
+            const bool adapt = ad_int > 0 && iter > 0 && iter % ad_int == 0;
             // ---- termination test / bookkeeping
             // (verdicts in named variables selected by value: a local array indexed by `pass` would live in scratch)
             InfeasVerdict iv_exact[G], iv_approx[G];
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 iv_exact[g] = iv_approx[g] = InfeasVerdict{false, false};
-                if (I[g].done) continue;
+                if (I[g].done || !can_check) continue;
                 double *wg = w + g * ldw;
 #pragma nounroll
-                for (int pass = 0; pass < (iter >= S.max_iter ? 2 : 1); pass++) {
+                for (int pass = 0; pass < (last ? 2 : 1); pass++) {
                     const InfeasVerdict v = infeasibility_tests<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, RegDelta<NSX>, RegDelta<NSZ>>(
                         F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S,
                         RegDelta<NSX>{dxr[g]}, RegDelta<NSZ>{dyr[g]}, wg, lane, pass == 1);
@@ -1158,17 +1216,33 @@ CPG_DEV void osqp_shared_body(const DevFamily &F, const DevUpdate &U, const DevS
                 if (I[g].done) continue;
                 CheckOut o = co[g];
                 double *wg = w + g * ldw;
+                ScaledNorms sn;
+                double rho_ws = F.rho;          // rho of the workspace this instance leaves behind
+                bool rho_changed = false;
 #pragma nounroll
                 for (int pass = 0; pass < 2; pass++) {
-                    if (pass == 1 && !(o.status == 11 && iter >= S.max_iter)) break;
-                    o = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, NoDelta, NoDelta>(
+                    if (pass == 1 && !(o.status == 11 && last)) break;
+                    // update_info (+ check_termination): at an adaptation point that is not a checked iteration
+                    // only the norms are used (osqp_solve updates the info for adapt_rho, no test)
+                    const CheckOut oc = check<NSX, NSZ, SharedCtx<NSX, NSZ, NV>, NoDelta, NoDelta>(
                         F, SharedCtx<NSX, NSZ, NV>{F, sh, shu, I[g], wg, lane}, ct_reg, S, I[g].x, I[g].z, I[g].y,
-                        NoDelta{}, NoDelta{}, pass == 0 ? iv_exact[g] : iv_approx[g], wg, lane, pass == 1);
+                        NoDelta{}, NoDelta{}, pass == 0 ? iv_exact[g] : iv_approx[g], wg, lane, pass == 1,
+                        (pass == 0 && adapt) ? &sn : nullptr);
+                    if (can_check) o = oc;
+                    if (pass == 0 && adapt && o.status == 11) {
+                        // adapt_rho: this kernel's factor belongs to the family's rho -- an instance whose estimate
+                        // leaves [rho / tolerance, rho * tolerance] continues on a factor of its own (hand-over)
+                        const double rn = rho_estimate(sn, F.rho);
+                        if (rn > F.rho * S.adaptive_rho_tolerance || rn < F.rho / S.adaptive_rho_tolerance) { rho_ws = rn; rho_changed = true; }
+                    }
                 }
-                if (o.status == 11 && iter >= S.max_iter) o.status = 7;
+                if (o.status == 11 && last) o.status = 7;
                 co[g] = o;
                 if (o.status != 11) {
-                    finalize<NSX, NSZ>(F, Bt, I[g].x, I[g].z, I[g].y, I[g].dconst, I[g].b, wg, lane, iter, o, F.rho);
+                    finalize<NSX, NSZ>(F, Bt, I[g].x, I[g].z, I[g].y, I[g].dconst, I[g].b, wg, lane, iter, o, rho_ws);
+                    I[g].done = 1; n_open--;
+                } else if (rho_changed) {
+                    hand_over<NSX, NSZ>(F, Bt, I[g].x, I[g].z, I[g].y, I[g].b, lane, iter, rho_ws);
                     I[g].done = 1; n_open--;
                 }
             }

@@ -41,6 +41,13 @@ struct DevRefactor {
     double d_base;
     DevCsr map_P, map_A, map_q, map_u, map_d;
     long long buf_doubles;   // per-wavefront buffer length
+    // Shared-matrix mode (no varying parameter enters P or A; the instances own a factor only because their rho
+    // differs -- OSQP's adapt_rho, or a row that changed class): the family's equilibrated matrices and scaling
+    // vectors, canonical order; q_base / u_base / map_q / map_u are then pre-scaled (c D q, E u) like
+    // DevUpdate's and steps 1 - 3 of the kernel (canonicalise P / A, Ruiz sweeps) are skipped.
+    int shared_mats;
+    const double *Ps, *As, *Ars, *Ds, *Dinvs, *Es, *Einvs;
+    double cs;
 };
 
 #define CPG_K_NONE 0
@@ -268,7 +275,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
     const unsigned n = (unsigned)F0.n, m = (unsigned)F0.m, N = n + m;
     const int ldw = R.sol_slots;
     double *w = lds + (size_t)cpgw::wave_in_block() * ldw;
-    const InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F0, R);
+    InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F0, R);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
     const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
     unsigned short fpx[NSX], fpz[NSZ];
@@ -277,113 +284,134 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 #pragma unroll
     for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; fpz[s] = i < m ? cpgw::gld(R.sol_fpos, n + i) : 0; }
 
+    const unsigned n_work = Bt.list_count ? cpgw::sld(Bt.list_count, 0u) : 0u;   // written by the kernel in front of this one
+    if (R.shared_mats) {     // the family's matrices serve every instance
+        B.P = const_cast<double *>(R.Ps); B.A = const_cast<double *>(R.As); B.Ar = const_cast<double *>(R.Ars);
+        B.D = const_cast<double *>(R.Ds); B.Dinv = const_cast<double *>(R.Dinvs);
+        B.E = const_cast<double *>(R.Es); B.Einv = const_cast<double *>(R.Einvs);
+    }
+
     for (;;) {
         unsigned ig = 0;
         if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
         ig = (unsigned)cpgw::read_first_lane((int)ig);
-        if ((long long)ig >= Bt.B) break;
-        const long long b = (long long)ig;
+        long long b = (long long)ig;
+        if (Bt.list) {
+            if (ig >= n_work) break;
+            b = (long long)cpgw::read_first_lane(cpgw::gld(Bt.list, ig));
+        } else if (b >= Bt.B) break;
         const double *theta = Bt.theta + (size_t)b * R.np_var;
-        // rho of this instance: the family's, or what a sequential caller's previous solve left (rho
-        // adaptation is workspace state in OSQP); osqp_solve clamps it
-        const double *state_in = (Bt.state_in && S.warm_starting) ? Bt.state_in + (size_t)b * state_len : nullptr;
-        double rho = state_in ? cpgw::gld(state_in, n + 2u * m) : F0.rho;
+        // rho of this instance's WORKSPACE (its factor): the family's, or what a sequential caller's previous solve
+        // left (rho adaptation is workspace state in OSQP), or what the kernel in front handed over; clamped as
+        // osqp_solve does.  rho of the SETTINGS (what compute_rho_estimate scales): every cpg_solve of the
+        // reference resets it to the library default (osqp_set_default_settings, solvers/osqp.py:100-101) without
+        // touching the workspace; adapt_rho (osqp_update_rho) then sets both.
+        const double *state_in = (Bt.state_in && (S.warm_starting || Bt.resume)) ? Bt.state_in + (size_t)b * state_len : nullptr;
+        double rho = Bt.state_in ? cpgw::gld(Bt.state_in + (size_t)b * state_len, n + 2u * m) : F0.rho;     // (osqp_cold_start resets the iterates only)
         rho = cpgw::dmin2(cpgw::dmax2(rho, CPG_RHO_MIN), CPG_RHO_MAX);
+        double rho_stg = F0.rho;        // (a resumed instance: see where `iter` starts)
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
-        // ---- 1. canonicalise (unscaled): P, A values, q, u, d
-        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) cpgw::gst(B.A, k, csr_row(R.map_A, k, theta, cpgw::gld(R.A_base, k)));
-        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) cpgw::gst(B.P, k, csr_row(R.map_P, k, theta, cpgw::gld(R.P_base, k)));
+        // ---- 1. canonicalise (unscaled; scaled in shared-matrix mode): P, A values, q, u, d
+        if (!R.shared_mats) {
+            for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) cpgw::gst(B.A, k, csr_row(R.map_A, k, theta, cpgw::gld(R.A_base, k)));
+            for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) cpgw::gst(B.P, k, csr_row(R.map_P, k, theta, cpgw::gld(R.P_base, k)));
+        }
         for (unsigned i = (unsigned)lane; i < n; i += 64u) cpgw::gst(B.q, i, csr_row(R.map_q, i, theta, cpgw::gld(R.q_base, i)));
         for (unsigned i = (unsigned)lane; i < m; i += 64u) cpgw::gst(B.u, i, csr_row(R.map_u, i, theta, cpgw::gld(R.u_base, i)));
         const double dconst = csr_row(R.map_d, 0, theta, R.d_base);
         cpgw::mem_order();
+        double cs = R.shared_mats ? R.cs : 1.0;
+        if (!R.shared_mats) {
 #ifdef CPG_REFACTOR_ROW_COPY
-        refresh_row_copy(R, B, lane);            // unscaled A in row order: the row walks of the equilibration sweeps
+            refresh_row_copy(R, B, lane);            // unscaled A in row order: the row walks of the equilibration sweeps
 #endif
 
-        // ---- 2. Ruiz equilibration from scratch (D in w[0..n), E in w[n..N), cumulative form)
-        double cs = 1.0;
-        for (unsigned i = (unsigned)lane; i < N; i += 64u) w[i] = 1.0;
-        cpgw::lds_order();
+            // ---- 2. Ruiz equilibration from scratch (D in w[0..n), E in w[n..N), cumulative form)
+            for (unsigned i = (unsigned)lane; i < N; i += 64u) w[i] = 1.0;
+            cpgw::lds_order();
 #pragma nounroll
-        for (int it = 0; it < R.scaling_iters; it++) {
-            double dn[NSX], en[NSZ];
+            for (int it = 0; it < R.scaling_iters; it++) {
+                double dn[NSX], en[NSZ];
 #pragma unroll
-            for (int s = 0; s < NSX; s++) {
-                const unsigned j = (unsigned)lane + 64u * (unsigned)s;
-                double acc = 0.0;
-                if (j < n) {
-                    const double dj = w[j];
-                    for_row_entries<true>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j,
-                                          [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(cs * dj * v * w[c])); });
-                    for_row_entries<false>(R.Ap, nullptr, R.Ai, (const double *)B.A, j,
-                                           [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(w[n + c] * v * dj)); });
-                }
-                dn[s] = acc;
-            }
-#pragma unroll
-            for (int s = 0; s < NSZ; s++) {
-                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                double acc = 0.0;
-                if (i < m) {
-                    const double ei = w[n + i];
-#ifdef CPG_REFACTOR_ROW_COPY
-                    for_row_entries<false, CPG_ROW_COPY_BATCH>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i,
-#else
-                    for_row_entries<true>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i,
-#endif
-                                          [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(ei * v * w[c])); });
-                }
-                en[s] = acc;
-            }
-            cpgw::lds_order();
-#pragma unroll
-            for (int s = 0; s < NSX; s++) { const unsigned j = (unsigned)lane + 64u * (unsigned)s; if (j < n) w[j] = w[j] * (1.0 / sqrt(lim_scaling(dn[s]))); }
-#pragma unroll
-            for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < m) w[n + i] = w[n + i] * (1.0 / sqrt(lim_scaling(en[s]))); }
-            cpgw::lds_order();
-            // cost scaling: mean column norm of the scaled P against ||q||_inf
-            double psum = 0.0, qn = 0.0;
-#pragma unroll
-            for (int s = 0; s < NSX; s++) {
-                const unsigned j = (unsigned)lane + 64u * (unsigned)s;
-                if (j < n) {
-                    const double dj = w[j];
+                for (int s = 0; s < NSX; s++) {
+                    const unsigned j = (unsigned)lane + 64u * (unsigned)s;
                     double acc = 0.0;
-                    for_row_entries<true>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j,
-                                          [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(cs * dj * v * w[c])); });
-                    psum += acc;
-                    qn = cpgw::dmax2(qn, fabs(cs * dj * cpgw::gld(R.q_setup, j)));   // update_mat runs before update_vec
+                    if (j < n) {
+                        const double dj = w[j];
+                        for_row_entries<true>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j,
+                                              [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(cs * dj * v * w[c])); });
+                        for_row_entries<false>(R.Ap, nullptr, R.Ai, (const double *)B.A, j,
+                                               [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(w[n + c] * v * dj)); });
+                    }
+                    dn[s] = acc;
                 }
-            }
-            psum = cpgw::wave_sum(psum);
-            qn = lim_scaling(cpgw::wave_max_nonneg(qn));
-            const double cm = n ? psum / (double)n : 0.0;
-            cs = cs * (1.0 / lim_scaling(cpgw::dmax2(cm, qn)));
-        }
-        // ---- 3. scaled data, row classes, step sizes
-        for (unsigned j = (unsigned)lane; j < n; j += 64u) {
-            const double dj = w[j];
-            cpgw::gst(B.D, j, dj); cpgw::gst(B.Dinv, j, 1.0 / dj);
-            cpgw::gst(B.q, j, cs * dj * cpgw::gld((const double *)B.q, j));
-            unsigned a = (unsigned)cpgw::gld(R.Ap, j), e = (unsigned)cpgw::gld(R.Ap, j + 1u);
-            for (unsigned k = a; k < e; k++) cpgw::gst(B.A, k, w[n + (unsigned)cpgw::gld(R.Ai, k)] * cpgw::gld((const double *)B.A, k) * dj);
-            a = (unsigned)cpgw::gld(R.Pp, j); e = (unsigned)cpgw::gld(R.Pp, j + 1u);
-            for (unsigned k = a; k < e; k++) cpgw::gst(B.P, k, cs * w[(unsigned)cpgw::gld(R.Pi, k)] * cpgw::gld((const double *)B.P, k) * dj);
-        }
+#pragma unroll
+                for (int s = 0; s < NSZ; s++) {
+                    const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                    double acc = 0.0;
+                    if (i < m) {
+                        const double ei = w[n + i];
 #ifdef CPG_REFACTOR_ROW_COPY
-        refresh_row_copy(R, B, lane);            // scaled A in row order: the termination test's A x
+                        for_row_entries<false, CPG_ROW_COPY_BATCH>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i,
+#else
+                        for_row_entries<true>(R.Arp, R.Aent, R.Acol, (const double *)B.A, i,
 #endif
+                                              [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(ei * v * w[c])); });
+                    }
+                    en[s] = acc;
+                }
+                cpgw::lds_order();
+#pragma unroll
+                for (int s = 0; s < NSX; s++) { const unsigned j = (unsigned)lane + 64u * (unsigned)s; if (j < n) w[j] = w[j] * (1.0 / sqrt(lim_scaling(dn[s]))); }
+#pragma unroll
+                for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < m) w[n + i] = w[n + i] * (1.0 / sqrt(lim_scaling(en[s]))); }
+                cpgw::lds_order();
+                // cost scaling: mean column norm of the scaled P against ||q||_inf
+                double psum = 0.0, qn = 0.0;
+#pragma unroll
+                for (int s = 0; s < NSX; s++) {
+                    const unsigned j = (unsigned)lane + 64u * (unsigned)s;
+                    if (j < n) {
+                        const double dj = w[j];
+                        double acc = 0.0;
+                        for_row_entries<true>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j,
+                                              [&](double v, unsigned c) { acc = cpgw::dmax2(acc, fabs(cs * dj * v * w[c])); });
+                        psum += acc;
+                        qn = cpgw::dmax2(qn, fabs(cs * dj * cpgw::gld(R.q_setup, j)));   // update_mat runs before update_vec
+                    }
+                }
+                psum = cpgw::wave_sum(psum);
+                qn = lim_scaling(cpgw::wave_max_nonneg(qn));
+                const double cm = n ? psum / (double)n : 0.0;
+                cs = cs * (1.0 / lim_scaling(cpgw::dmax2(cm, qn)));
+            }
+            // ---- 3. scaled data, row classes, step sizes
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                const double dj = w[j];
+                cpgw::gst(B.D, j, dj); cpgw::gst(B.Dinv, j, 1.0 / dj);
+                cpgw::gst(B.q, j, cs * dj * cpgw::gld((const double *)B.q, j));
+                unsigned a = (unsigned)cpgw::gld(R.Ap, j), e = (unsigned)cpgw::gld(R.Ap, j + 1u);
+                for (unsigned k = a; k < e; k++) cpgw::gst(B.A, k, w[n + (unsigned)cpgw::gld(R.Ai, k)] * cpgw::gld((const double *)B.A, k) * dj);
+                a = (unsigned)cpgw::gld(R.Pp, j); e = (unsigned)cpgw::gld(R.Pp, j + 1u);
+                for (unsigned k = a; k < e; k++) cpgw::gst(B.P, k, cs * w[(unsigned)cpgw::gld(R.Pi, k)] * cpgw::gld((const double *)B.P, k) * dj);
+            }
+#ifdef CPG_REFACTOR_ROW_COPY
+            refresh_row_copy(R, B, lane);            // scaled A in row order: the termination test's A x
+#endif
+        }
         signed char ct[NSZ];
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
             ct[s] = 0;
             if (i < m) {
-                const double ei = w[n + i];
-                const double uu = ei * cpgw::gld((const double *)B.u, i);
-                cpgw::gst(B.E, i, ei); cpgw::gst(B.Einv, i, 1.0 / ei); cpgw::gst(B.u, i, uu);
+                double uu = cpgw::gld((const double *)B.u, i);      // shared-matrix mode: already E u
+                if (!R.shared_mats) {
+                    const double ei = w[n + i];
+                    uu = ei * uu;
+                    cpgw::gst(B.E, i, ei); cpgw::gst(B.Einv, i, 1.0 / ei); cpgw::gst(B.u, i, uu);
+                }
                 // equality rows (l = u) are the first n_eq rows of the canonical form
                 ct[s] = i < (unsigned)R.n_eq ? 1 : (uu > CPG_INFTY * CPG_MIN_SCALING ? -1 : 0);
                 cpgw::gst(B.rinv, i, ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr));
@@ -420,7 +448,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         if (state_in) load_state<NSX, NSZ>(F, state_in, x, z, y, lane);
         CheckOut o;
         o.prim_res = 0; o.dual_res = 0; o.obj = 0; o.status = 11;
-        int iter = 0;
+        int iter = Bt.resume ? cpgw::read_first_lane(cpgw::gld((const int *)Bt.iter, (unsigned)b)) : 0;
+        // handed over after an adapt_rho of this solve (osqp_update_rho wrote settings and workspace); at iteration 0
+        // the workspace merely arrived with another rho than the family's
+        if (iter > 0) rho_stg = rho;
         double dxr[NSX], dyr[NSZ];      // steps of the last checked iteration (infeasibility tests)
 #pragma unroll
         for (int s = 0; s < NSX; s++) dxr[s] = 0.0;
@@ -494,11 +525,9 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 // adapt_rho (OSQP paper sec. 5.2): rho <- rho sqrt(normalised primal / dual residual); a new
                 // factorisation only when it changed by more than adaptive_rho_tolerance
                 if (!have_info) (void)check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
-                const double pr = sn.prim_res / (cpgw::dmax2(sn.nz, sn.nax) + CPG_DIV_TOL);
-                const double dr = sn.dual_res / (cpgw::dmax2(sn.nq, cpgw::dmax2(sn.naty, sn.npx)) + CPG_DIV_TOL);
-                const double rn = cpgw::dmin2(cpgw::dmax2(rho * sqrt(pr / dr), CPG_RHO_MIN), CPG_RHO_MAX);
-                if (rn > rho * S.adaptive_rho_tolerance || rn < rho / S.adaptive_rho_tolerance) {
-                    rho = rn; rho_eq = 1e3 * rho; rho_in = rho; ri_eq = 1.0 / rho_eq; ri_in = 1.0 / rho_in;
+                const double rn = rho_estimate(sn, rho_stg);
+                if (rn > rho_stg * S.adaptive_rho_tolerance || rn < rho_stg / S.adaptive_rho_tolerance) {
+                    rho = rn; rho_stg = rn; rho_eq = 1e3 * rho; rho_in = rho; ri_eq = 1.0 / rho_eq; ri_in = 1.0 / rho_in;
 #pragma unroll
                     for (int s = 0; s < NSZ; s++) {
                         const unsigned i = (unsigned)lane + 64u * (unsigned)s;

@@ -39,9 +39,14 @@ STATUS_STRINGS = {1: 'solved', 2: 'solved inaccurate', 3: 'primal infeasible',
                   9: 'problem non convex', 11: 'unsolved', -2: 'needs refactorization'}
 STATUS_NEEDS_REFACTOR = -2
 
-# constants of the generated OSQP workspace (what osqp.OSQP().setup() bakes in at code generation,
-# cvxpygen/solvers/osqp.py:126-131); version dependent, see DESIGN.md section 2
+# OSQP settings the generated shim has no setter for: the defaults of the OSQP library the solver is linked
+# with, restored by every cpg_solve (osqp_set_default_settings, cvxpygen/solvers/osqp.py:100-101).  The reference
+# requires osqp >= 1.0 (pyproject.toml:26; its emitted calls are the 1.0 API): rho adapted every 50 iterations,
+# tolerance 5, duality-gap test.  `build_options` / generate_code(solver_opts=...) override.
 BUILD_OPTIONS = ('adaptive_rho', 'adaptive_rho_interval', 'adaptive_rho_tolerance', 'check_dualgap')
+BUILD_OPTION_DEFAULTS = {'adaptive_rho': 1, 'adaptive_rho_interval': 50, 'adaptive_rho_tolerance': 5.0, 'check_dualgap': 1}
+# the other reading of the reference's default (a solver generated against an OSQP whose codegen never adapts rho)
+BUILD_OPTIONS_FIXED_RHO = {'adaptive_rho': 0, 'check_dualgap': 0}
 
 # cvxpy-style aliases of the reference (`stgs_translation`, cvxpygen/solvers/osqp.py:110,
 # cvxpygen/solvers/_interface.py:196-199)
@@ -89,7 +94,8 @@ class _Refactor(C.Structure):
                 ('np_var', C.c_int32), ('P_base', _dp), ('A_base', _dp), ('q_base', _dp), ('u_base', _dp),
                 ('d_base', C.c_double),
                 ('map_P', _Csr), ('map_A', _Csr), ('map_q', _Csr), ('map_u', _Csr), ('map_d', _Csr),
-                ('q_setup', _dp)]
+                ('q_setup', _dp),
+                ('shared_mats', C.c_int32), ('Ps', _dp), ('As', _dp), ('D', _dp), ('E', _dp), ('c', C.c_double)]
 
 
 class _Gradient(C.Structure):
@@ -111,7 +117,7 @@ class CpgLibrary:
 
     SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_create_clarabel', 'cpg_hip_destroy', 'cpg_hip_last_error',
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
-               'cpg_hip_get_setting', 'cpg_hip_set_build_option', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
+               'cpg_hip_get_setting', 'cpg_hip_set_build_option', 'cpg_hip_set_handover', 'cpg_hip_last_phase_ms', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
                'cpg_hip_solve_batch',
                'cpg_hip_solve_batch_device', 'cpg_hip_solve_batch_state', 'cpg_hip_solve_batch_device_state', 'cpg_hip_solve_batches_pipelined', 'cpg_hip_host_malloc',
                'cpg_hip_host_free', 'cpg_hip_synchronize', 'cpg_hip_get_stream', 'cpg_hip_last_kernel_ms',
@@ -137,6 +143,8 @@ class CpgLibrary:
         L.cpg_hip_set_setting.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.cpg_hip_get_setting.argtypes = [C.c_void_p, C.c_char_p, _dp]
         L.cpg_hip_set_build_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.cpg_hip_set_handover.argtypes = [C.c_void_p, C.c_void_p]
+        L.cpg_hip_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.cpg_hip_set_update.argtypes = [C.c_void_p, C.POINTER(_Update)]
         L.cpg_hip_set_refactor.argtypes = [C.c_void_p, C.POINTER(_Refactor)]
         L.cpg_hip_set_gradient.argtypes = [C.c_void_p, C.POINTER(_Gradient)]
@@ -326,8 +334,9 @@ class BatchSolver:
                  build_options: Optional[Dict[str, float]] = None):
         """full_output: return the complete canonical solution (sol_x, sol_y) -- what the reference's
         `cpg_solve_and_gradient_info` hands to `cpg_gradient` (templates/cpg_solver.py.jinja2:122-173).
-        build_options: constants of the generated OSQP workspace (BUILD_OPTIONS), e.g.
-        {'adaptive_rho': 1, 'adaptive_rho_interval': 50, 'check_dualgap': 1} for an OSQP >= 1.0 build."""
+        build_options: OSQP settings without a setter in the generated shim (BUILD_OPTIONS); default = the
+        OSQP >= 1.0 library defaults (BUILD_OPTION_DEFAULTS), BUILD_OPTIONS_FIXED_RHO for a solver that never
+        adapts rho."""
         self.full_output = full_output
         self.build_options = dict(build_options or {})
         for k in self.build_options:
@@ -444,33 +453,44 @@ class BatchSolver:
 
     @property
     def adaptive_rho(self) -> bool:
-        bo = self.build_options
-        return bool(bo.get('adaptive_rho', 0)) and int(bo.get('adaptive_rho_interval', 50)) > 0
+        bo = {**BUILD_OPTION_DEFAULTS, **self.build_options}
+        return bool(bo['adaptive_rho']) and int(bo['adaptive_rho_interval']) > 0
 
-    def _set_refactor(self, cols: np.ndarray, th_fixed: np.ndarray, q_setup: Optional[np.ndarray] = None):
+    def _set_refactor(self, cols: np.ndarray, th_fixed: np.ndarray, q_setup: Optional[np.ndarray] = None,
+                      shared_mats: bool = False):
         """tables of the per-instance factor path for this column subset; solve and gradient share them,
-        one signature (cols, fixed part of theta, q of the workspace) decides whether they are current"""
+        one signature (cols, fixed part of theta, q of the workspace, mode) decides whether they are current.
+        shared_mats: no varying parameter enters P or A -- the workspace's equilibrated matrices serve every
+        instance (pre-scaled q / u maps, no re-equilibration in the kernel): the instances handed over by the
+        shared-factor kernel after a rho change, and rows that changed class."""
         self._ensure_refactor_handle()
         desc, rp, o = self.desc, self._rplan, self.plan.osqp
         if q_setup is None:
             q_setup = desc.default_canon()['q']
         q_setup = np.ascontiguousarray(q_setup, dtype=np.float64)
-        key = (np.asarray(cols).tobytes(), np.asarray(th_fixed).tobytes(), q_setup.tobytes())
+        key = (np.asarray(cols).tobytes(), np.asarray(th_fixed).tobytes(), q_setup.tobytes(), bool(shared_mats))
         if key == self._ref_key:
             return
         keep: list = []
 
-        def split(pid, clip=False):
+        def split(pid, clip=False, scale=None):
             Cm = sp.csr_matrix(desc.maps[pid])
             base = np.asarray(Cm @ th_fixed).ravel()
             if clip:
                 base = np.clip(base, -CPG_INF, CPG_INF)
             Mv = sp.csr_matrix(Cm[:, cols]) if len(cols) else sp.csr_matrix((Cm.shape[0], 0))
+            if scale is not None:
+                base, Mv = scale * base, sp.csr_matrix(sp.diags(scale) @ Mv)
             base = np.ascontiguousarray(base)
             keep.append(base)
             return base, _csr_struct(Mv, keep)
 
-        Pb, MP = split('P'); Ab, MA = split('A'); qb, Mq = split('q'); ub, Mu = split('u', clip=True)
+        Pb, MP = split('P'); Ab, MA = split('A')
+        qb, Mq = split('q', scale=(o.scaling.c * o.scaling.D) if shared_mats else None)
+        ub, Mu = split('u', clip=True, scale=o.scaling.E if shared_mats else None)
+        Ps = np.ascontiguousarray(o.Px, dtype=np.float64); As = np.ascontiguousarray(o.Ax, dtype=np.float64)
+        Dv = np.ascontiguousarray(o.scaling.D, dtype=np.float64); Ev = np.ascontiguousarray(o.scaling.E, dtype=np.float64)
+        keep += [Ps, As, Dv, Ev]
         keep.append(q_setup)
         Cd = sp.csr_matrix(desc.maps['d'])
         d_base = float((Cd @ th_fixed)[0]) if desc.nonzero_d else 0.0
@@ -496,7 +516,8 @@ class BatchSolver:
             sol_ctab=i32(rp.sol.ctab), sol_desc=u32(rp.sol.desc), sol_cols=u16(rp.sol.cols),
             sol_kind=i32(rp.sol_kind), sol_idx=i32(rp.sol_idx), sol_fpos=u16(rp.sol.final_pos),
             np_var=len(cols), P_base=_d(Pb), A_base=_d(Ab), q_base=_d(qb), u_base=_d(ub), d_base=d_base,
-            map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md, q_setup=_d(q_setup))
+            map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md, q_setup=_d(q_setup),
+            shared_mats=int(bool(shared_mats)), Ps=_d(Ps), As=_d(As), D=_d(Dv), E=_d(Ev), c=float(o.scaling.c))
         self.lib.check(self.lib.L.cpg_hip_set_refactor(self.h_ref, C.byref(rf)), 'cpg_hip_set_refactor')
         self._refactor_keep = keep
         self._ref_key = key
@@ -542,9 +563,11 @@ class BatchSolver:
         """Which user parameters vary across the batch.  Every other parameter is folded into the base
         vectors at `theta_base` (default: the code-generation-time values theta0 -- what a fresh process of
         the reference holds; a sequential caller passes the values its workspace holds now).
-        path: 'auto' -- shared factor unless a varying parameter enters P / A or rho adaptation is on;
-        'shared' / 'refactor' force one (a caller that forces 'shared' guarantees that P and A at these
-        values are the family's); q_setup: the unscaled q the workspace held when its matrices were last
+        path: 'auto' -- shared factor unless a varying parameter enters P / A; with rho adaptation on (the
+        default) the shared-factor kernel then hands instances whose rho changes to the per-instance factor
+        kernel in shared-matrix mode ("hybrid": two kernels per solve, cpg_hip_set_handover);
+        'shared' / 'refactor' force one kernel (a caller that forces 'shared' guarantees that P and A at these
+        values are the family's; 'refactor' = every instance equilibrates and factors from iteration 0); q_setup: the unscaled q the workspace held when its matrices were last
         updated (the cost scaling of OSQP's re-equilibration sees that one)."""
         desc, p, o = self.desc, self.plan, self.plan.osqp
         if updated_params is None:
@@ -559,11 +582,10 @@ class BatchSolver:
         touched = set()
         for nm in names:
             touched.update(dep[nm])
-        refactor = path == 'refactor' or (path == 'auto' and (bool(touched & {'P', 'A'}) or self.adaptive_rho))
-        if self.adaptive_rho and not refactor:
-            raise ValueError('rho adaptation needs the per-instance factor path')
+        refactor = path == 'refactor' or (path == 'auto' and bool(touched & {'P', 'A'}))
+        hybrid = (not refactor) and self.adaptive_rho
         base = desc.theta0 if theta_base is None else np.asarray(theta_base, dtype=np.float64)
-        key = (tuple(names), refactor, None if theta_base is None else base.tobytes(),
+        key = (tuple(names), refactor, hybrid, None if theta_base is None else base.tobytes(),
                None if q_setup is None else np.asarray(q_setup, dtype=np.float64).tobytes())
         if key == self._update_key:
             return
@@ -605,6 +627,13 @@ class BatchSolver:
                       map_q=_csr_struct(Mq, keep), map_u=_csr_struct(Mu, keep),
                       map_d=_csr_struct(Md, keep))
         self.lib.check(self.lib.L.cpg_hip_set_update(self.h, C.byref(upd)), 'cpg_hip_set_update')
+        if hybrid:
+            # rho adaptation: instances whose rho changes continue on their own factor of the SAME matrices
+            self._set_refactor(cols, th_fixed, q_setup, shared_mats=True)
+            self.lib.check(self.lib.L.cpg_hip_set_handover(self.h_shared, self.h_ref), 'cpg_hip_set_handover')
+        elif self.h_ref.value:
+            self.lib.check(self.lib.L.cpg_hip_set_handover(self.h_shared, None), 'cpg_hip_set_handover')
+        self._hybrid = hybrid
         self._update_key, self._update_keep = key, keep
         self._var_cols, self.np_var = cols, len(cols)
         self._updated_names = names
@@ -663,8 +692,7 @@ class BatchSolver:
         if not self._grad_loaded:
             self._set_gradient()
             self._grad_loaded = True
-        self._updated_names, self._var_cols, self.np_var = names, cols, len(cols)
-        tv = self.theta_var(params)
+        tv = self.theta_var(params, names=names)      # (the solve-side selection -- _updated_names, _var_cols -- stays as it is)
         B = sol_x.shape[0]
         dx = np.zeros((B, desc.n_var))
         for v in desc.variables:
@@ -687,10 +715,13 @@ class BatchSolver:
             out[q.name] = blk
         return out
 
-    def theta_var(self, params: Dict[str, np.ndarray], B: Optional[int] = None) -> np.ndarray:
+    def theta_var(self, params: Dict[str, np.ndarray], B: Optional[int] = None,
+                  names: Optional[Sequence[str]] = None) -> np.ndarray:
         """[B, np_var] C-contiguous array of the updated parameters, each flattened as the reference's
-        `get_param_value` does (F-order / diagonal / stored non-zeros), instance-major."""
-        names = self._updated_names
+        `get_param_value` does (F-order / diagonal / stored non-zeros), instance-major.
+        names: parameter set in theta order (default: the one selected by set_updated)."""
+        if names is None:
+            names = self._updated_names
         blocks = []
         for nm in names:
             if nm not in params:
@@ -773,7 +804,9 @@ class BatchSolver:
         bad = np.nonzero(st == STATUS_NEEDS_REFACTOR)[0]
         if not len(bad) or self.h is not self.h_shared:
             return
-        self._set_refactor(self._var_cols, self._th_fixed, self._q_setup)
+        # the reference keeps its scaling when a bound moves a row to another class (osqp_update_data_vec ->
+        # update_rho_vec refactors K, nothing else): the workspace's matrices, a factor per instance
+        self._set_refactor(self._var_cols, self._th_fixed, self._q_setup, shared_mats=True)
         self._apply_settings_to(self.h_ref)
         sub = self._solve_on(self.h_ref, np.ascontiguousarray(theta_var[bad]), len(bad),
                              None if state_in is None else state_in[bad], out[7] is not None)
@@ -895,6 +928,15 @@ def _last_kernel_ms(self) -> float:
     return float(ms.value)
 
 
+def _last_phase_ms(self):
+    """(ms of the shared-factor kernel, ms of the per-instance factor kernel behind it, instances handed over)
+    of the most recent solve on the current handle"""
+    a, b, n = C.c_float(0), C.c_float(0), C.c_int64(0)
+    self.lib.check(self.lib.L.cpg_hip_last_phase_ms(self.h, C.byref(a), C.byref(b), C.byref(n)), 'cpg_hip_last_phase_ms')
+    return float(a.value), float(b.value), int(n.value)
+
+
+BatchSolver.last_phase_ms = _last_phase_ms
 BatchSolver.solve_device = _solve_device
 BatchSolver.synchronize = _synchronize
 BatchSolver.last_kernel_ms = _last_kernel_ms

@@ -154,11 +154,13 @@ class GeneratedSolver:
                 # re-equilibration sees the q the workspace held so far
                 ws['q_setup'] = ws['q_ws'].copy()
                 ws['mat_touched'] = True
-            path = 'refactor' if (ws['mat_touched'] or bs.adaptive_rho) else 'shared'
+            # matrices never updated: the workspace's P, A are the family's -- shared factor, and with rho
+            # adaptation (the default) the per-instance factor kernel behind it (hybrid execution)
+            path = 'refactor' if ws['mat_touched'] else 'shared'
             bs.set_updated(None, q_setup=ws['q_setup'], path=path)
-            warm = int(kwargs.get('warm_starting', kwargs.get('warm_start', 1)))
-            res = bs.solve(theta_var=theta_var, B=1, state_in=ws['state'] if warm else None,
-                           return_state=True, **kwargs)
+            # the workspace always goes in: warm_starting = 0 (osqp_cold_start) zeroes the iterates only, the rho
+            # its last adapt_rho left -- and the factor that goes with it -- stay (the kernels read the setting)
+            res = bs.solve(theta_var=theta_var, B=1, state_in=ws['state'], return_state=True, **kwargs)
             ws['state'] = res.state
             if 'q' in ws['outdated']:
                 ws['q_ws'] = np.asarray(desc.canon_at(ws['theta'])['q'], dtype=np.float64)

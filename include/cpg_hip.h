@@ -46,6 +46,9 @@ extern "C" {
 #define CPG_STATUS_MAX_ITER_REACHED 7
 #define CPG_STATUS_NON_CVX 9
 #define CPG_STATUS_UNSOLVED 11
+/* INTERNAL: set by the shared-factor kernel on an instance it handed to the per-instance factor kernel queued
+ * behind it (cpg_hip_set_handover); that kernel overwrites it before the stream is idle again */
+#define CPG_STATUS_HANDED_OVER (-3)
 /* a constraint row changed class (equality <-> inequality <-> free) w.r.t. code generation time:
  * the shared KKT factor is not valid for this instance (the reference refactors here,
  * osqp_update_data_vec -> update_rho_vec).  INTERNAL to the two-handle protocol: the host layer
@@ -165,6 +168,14 @@ typedef struct {
      * osqp_update_data_mat BEFORE osqp_update_data_vec (cvxpygen/solvers/osqp.py:20-59), so the
      * cost scaling of the re-equilibration sees the old q, never the instance's new one */
     const double *q_setup;
+    /* Shared-matrix mode (no varying parameter enters P or A; instances own a factor only because their rho differs:
+     * OSQP's adapt_rho, or a row that changed class): the workspace's equilibrated matrices and scaling -- Ps [nnzP],
+     * As [nnzA] (c D P D, E A D), D [n], E [m], c -- in canonical order; q_base / u_base / map_q / map_u are then
+     * PRE-SCALED (c D q, E u) as in cpg_osqp_update_t and the kernel skips canonicalise-P/A and the re-equilibration
+     * (there was no osqp_update_data_mat). */
+    int32_t shared_mats;
+    const double *Ps, *As, *D, *E;
+    double c;
 } cpg_osqp_refactor_t;
 
 /* QP adjoint (gradient=True in the reference): transposed canonical maps over ALL user parameters.
@@ -232,13 +243,23 @@ const char *cpg_hip_status_string(int32_t status);
 int cpg_hip_set_default_settings(cpg_handle_t h);
 int cpg_hip_set_setting(cpg_handle_t h, const char *name, double value);
 int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *value);
-/* Constants of the generated OSQP workspace that the reference can NOT change at solve time (they are
- * what `osqp.OSQP().setup()` bakes into workspace.c at code generation, cvxpygen/solvers/osqp.py:126-131,
- * and are not among the settings of osqp.py:102-115): "adaptive_rho" (0/1), "adaptive_rho_interval"
- * (iterations), "adaptive_rho_tolerance", "check_dualgap" (0/1).  Their values depend on the OSQP release
- * the reference was generated with; cpg_hip_set_default_settings leaves them alone.
- * rho adaptation needs a refactor-mode handle (every instance owns its factor). */
+/* OSQP settings the generated shim offers no setter for (they are not among cvxpygen/solvers/osqp.py:102-115):
+ * "adaptive_rho" (0/1), "adaptive_rho_interval" (iterations), "adaptive_rho_tolerance", "check_dualgap" (0/1).
+ * Their values are the defaults of the OSQP library the generated code is linked with.  Defaults = OSQP >= 1.0 (1, 50, 5.0, 1): like every other
+ * OSQP setting they are what osqp_set_default_settings restores on each cpg_solve of the reference
+ * (solvers/osqp.py:100-101), so cpg_hip_set_default_settings restores the values given here. */
 int cpg_hip_set_build_option(cpg_handle_t h, const char *name, double value);
+/* Hybrid execution of rho adaptation for a family whose matrices do not vary across the batch.  `h` is a
+ * shared-factor handle (cpg_hip_set_update), `per_instance` a handle of the same family carrying per-instance
+ * factor tables in shared-matrix mode (cpg_hip_set_refactor).  A solve on `h` with adaptive_rho on then runs
+ * TWO kernels back to back on h's stream: the shared-factor kernel serves every instance until OSQP's adapt_rho
+ * changes its rho (iterations 1 .. interval always; for as long as the estimate stays inside [rho / tolerance,
+ * rho * tolerance] after that) and hands the others -- workspace, iteration count -- to the per-instance factor
+ * kernel, which refactors K for the new rho and continues.  per_instance == NULL unlinks. */
+int cpg_hip_set_handover(cpg_handle_t h, cpg_handle_t per_instance);
+/* split of the most recent solve on `h`: kernel time of the two phases and the number of instances handed over
+ * (0 / 0 when the solve ran one kernel) */
+int cpg_hip_last_phase_ms(cpg_handle_t h, float *ms_shared, float *ms_per_instance, int64_t *n_handed_over);
 
 /* ---- which parameters are updated (sticky until changed) -------------------------------------- */
 int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *upd);

@@ -31,8 +31,8 @@ STATUS = {1: 'solved', 2: 'solved inaccurate', 3: 'primal infeasible',
 
 DEFAULTS = dict(rho=0.1, sigma=1e-6, alpha=1.6, scaling=10, max_iter=4000, eps_abs=1e-3,
                 eps_rel=1e-3, eps_prim_inf=1e-4, eps_dual_inf=1e-4, scaled_termination=0,
-                check_termination=25, adaptive_rho=0, adaptive_rho_interval=50,
-                adaptive_rho_tolerance=5.0, check_dualgap=0)
+                check_termination=25, adaptive_rho=1, adaptive_rho_interval=50,
+                adaptive_rho_tolerance=5.0, check_dualgap=1)     # OSQP >= 1.0 library defaults
 
 
 def _limit(v):

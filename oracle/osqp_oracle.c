@@ -161,20 +161,27 @@ static void scale_data(OracleWS *w) {
 }
 
 /* ------------------------------------------------------------------ rho vector */
-/* returns 1 when a constraint changed class (equality / inequality / free) */
+/* OSQP's update_rho_vec: re-classify the rows; returns 1 when a constraint changed class (equality /
+ * inequality / free).  Only then is rho_vec rebuilt -- from settings->rho (w->stg[S_RHO]), which every
+ * cpg_solve of the reference has reset to the library default (osqp_set_default_settings writes the settings
+ * struct only, cvxpygen/solvers/osqp.py:100-101), not from the rho the workspace's last adapt_rho left
+ * (w->rho, what rho_vec and the factor carry until then). */
 static int set_rho_vec(OracleWS *w) {
     int changed = 0;
-    w->rho = dmin(dmax(w->rho, ORC_RHO_MIN), ORC_RHO_MAX);
     for (int i = 0; i < w->m; i++) {
-        int t; double r;
-        if (w->l[i] < -ORC_INFTY * ORC_MIN_SCALING && w->u[i] > ORC_INFTY * ORC_MIN_SCALING) {
-            t = -1; r = ORC_RHO_MIN;
-        } else if (w->u[i] - w->l[i] < ORC_RHO_TOL) { t = 1; r = ORC_RHO_EQ_OVER_INEQ * w->rho;
-        } else { t = 0; r = w->rho; }
+        int t;
+        if (w->l[i] < -ORC_INFTY * ORC_MIN_SCALING && w->u[i] > ORC_INFTY * ORC_MIN_SCALING) t = -1;
+        else if (w->u[i] - w->l[i] < ORC_RHO_TOL) t = 1;
+        else t = 0;
         if (t != w->ctype[i]) changed = 1;
-        w->ctype[i] = t; w->rho_vec[i] = r; w->rho_inv[i] = 1.0 / r;
+        w->ctype[i] = t;
     }
-    return changed;
+    if (!changed) return 0;
+    w->rho = w->stg[S_RHO] = dmin(dmax(w->stg[S_RHO], ORC_RHO_MIN), ORC_RHO_MAX);
+    for (int i = 0; i < w->m; i++) {
+        w->rho_vec[i] = w->ctype[i] == -1 ? ORC_RHO_MIN : (w->ctype[i] == 1 ? ORC_RHO_EQ_OVER_INEQ * w->rho : w->rho);
+        w->rho_inv[i] = 1.0 / w->rho_vec[i]; }
+    return 1;
 }
 
 /* ------------------------------------------------------------------ ordering */
@@ -304,8 +311,10 @@ static int refactor(OracleWS *w) { fill_kkt(w); w->n_refactor++; return ldl_fact
 void oracle_default_settings(double *s) {
     s[S_RHO] = 0.1; s[S_SIGMA] = 1e-6; s[S_ALPHA] = 1.6; s[S_SCALING] = 10; s[S_MAX_ITER] = 4000;
     s[S_EPS_ABS] = 1e-3; s[S_EPS_REL] = 1e-3; s[S_EPS_PINF] = 1e-4; s[S_EPS_DINF] = 1e-4;
-    s[S_SCALED_TERM] = 0; s[S_CHECK_TERM] = 25; s[S_WARM] = 1; s[S_ADAPT_RHO] = 0; s[S_ADAPT_INT] = 50;
-    s[S_ADAPT_TOL] = 5.0; s[S_CHECK_GAP] = 0;
+    /* OSQP >= 1.0 library defaults (what the reference's generated code is linked with, pyproject.toml:26):
+     * rho adapted every 50 iterations when the estimate leaves [rho / 5, 5 rho], duality-gap test */
+    s[S_SCALED_TERM] = 0; s[S_CHECK_TERM] = 25; s[S_WARM] = 1; s[S_ADAPT_RHO] = 1; s[S_ADAPT_INT] = 50;
+    s[S_ADAPT_TOL] = 5.0; s[S_CHECK_GAP] = 1;
 }
 
 static void alloc_common(OracleWS *w) {
@@ -415,8 +424,9 @@ int oracle_update_mat(OracleWS *w, const double *Px, const double *Ax) {
     else { memcpy(w->Px, w->P0, sizeof(double) * w->nnzP); memcpy(w->Ax, w->A0, sizeof(double) * w->nnzA); }
     return refactor(w);
 }
+/* osqp_update_rho: settings->rho and the workspace (rho_vec, factor) */
 static int update_rho(OracleWS *w, double rho_new) {
-    w->rho = dmin(dmax(rho_new, ORC_RHO_MIN), ORC_RHO_MAX);
+    w->rho = w->stg[S_RHO] = dmin(dmax(rho_new, ORC_RHO_MIN), ORC_RHO_MAX);
     for (int i = 0; i < w->m; i++) {
         w->rho_vec[i] = w->ctype[i] == -1 ? ORC_RHO_MIN : (w->ctype[i] == 1 ? ORC_RHO_EQ_OVER_INEQ * w->rho : w->rho);
         w->rho_inv[i] = 1.0 / w->rho_vec[i]; }
@@ -497,7 +507,8 @@ static double rho_estimate(const OracleWS *w) {
     double pn = dmax(norm_inf(w->z, w->m), norm_inf(w->tAx, w->m));
     double dn = dmax(norm_inf(w->q, w->n), dmax(norm_inf(w->tAty, w->n), norm_inf(w->tPx, w->n)));
     double pr = w->sc_prim_res / (pn + ORC_DIV_TOL), dr = w->sc_dual_res / (dn + ORC_DIV_TOL);
-    return dmin(dmax(w->rho * sqrt(pr / dr), ORC_RHO_MIN), ORC_RHO_MAX);
+    /* compute_rho_estimate scales settings->rho, not the rho of the workspace */
+    return dmin(dmax(w->stg[S_RHO] * sqrt(pr / dr), ORC_RHO_MIN), ORC_RHO_MAX);
 }
 
 /* ------------------------------------------------------------------ public: solve */
@@ -515,7 +526,7 @@ int oracle_solve(OracleWS *w, double *sol_x, double *sol_y) {
     int max_iter = (int)w->stg[S_MAX_ITER], chk = (int)w->stg[S_CHECK_TERM];
     int ad = (int)w->stg[S_ADAPT_RHO], adi = (int)w->stg[S_ADAPT_INT];
     if (!(int)w->stg[S_WARM]) { memset(w->x, 0, sizeof(double) * n); memset(w->z, 0, sizeof(double) * m); memset(w->y, 0, sizeof(double) * m); }
-    w->status = ST_UNSOLVED; w->rho = dmin(dmax(w->rho, ORC_RHO_MIN), ORC_RHO_MAX);
+    w->status = ST_UNSOLVED;
     int iter, can_check = 0, done = 0;
     for (iter = 1; iter <= max_iter; iter++) {
         { double *t = w->x; w->x = w->x_prev; w->x_prev = t; t = w->z; w->z = w->z_prev; w->z_prev = t; }
@@ -536,7 +547,7 @@ int oracle_solve(OracleWS *w, double *sol_x, double *sol_y) {
         if (ad && adi && (iter % adi == 0)) {
             if (!can_check) update_info(w, iter);
             double rn = rho_estimate(w), tol = w->stg[S_ADAPT_TOL];
-            if (rn > w->rho * tol || rn < w->rho / tol) if (update_rho(w, rn)) return -1;
+            if (rn > w->stg[S_RHO] * tol || rn < w->stg[S_RHO] / tol) if (update_rho(w, rn)) return -1;
         }
     }
     if (!done) { iter = max_iter; if (!can_check) update_info(w, iter);

@@ -39,11 +39,13 @@ def _parity(r, o, desc, tol=1e-9):
     assert np.abs(r.obj_val[ok] - o['obj_val'][ok]).max() <= tol * max(1.0, np.abs(o['obj_val'][ok]).max())
 
 
-@pytest.mark.parametrize('opts', [dict(adaptive_rho=1, adaptive_rho_interval=10),
+@pytest.mark.parametrize('opts', [dict(adaptive_rho=1, adaptive_rho_interval=10, check_dualgap=0),
                                   dict(adaptive_rho=1, adaptive_rho_interval=25, check_dualgap=1),
-                                  dict(check_dualgap=1)])
+                                  dict(adaptive_rho=1, adaptive_rho_interval=35),        # not a multiple of check_termination
+                                  dict(adaptive_rho=0, check_dualgap=1), dict(adaptive_rho=0, check_dualgap=0), {}])
 def test_build_options_vs_oracle_vector_parameters(sim_lib, oracle_lib, opts):
-    """only q / l / u vary: with rho adaptation every instance still needs its own factor"""
+    """only q / l / u vary: the shared-factor kernel serves every instance until its rho changes, the per-instance
+    factor kernel behind it the rest (hybrid execution); without rho adaptation one kernel"""
     d = families.nonneg_ls()
     rng = np.random.default_rng(3)
     vals = {'b': 3.0 * rng.standard_normal((5, 3))}
@@ -52,7 +54,7 @@ def test_build_options_vs_oracle_vector_parameters(sim_lib, oracle_lib, opts):
         r = bs.solve(vals, updated_params=['b'], **stg)
         o = oracle_lib.cpg_solve_batch(d, _theta(d, vals), ['b'], **opts, **stg)
         _parity(r, o, d)
-    assert (bs.h is bs.h_ref) == bool(opts.get('adaptive_rho'))
+    assert bs.h is bs.h_shared and bs._hybrid == bool(opts.get('adaptive_rho', 1))     # default: OSQP >= 1.0, rho adapted
     bs.close()
 
 
@@ -65,7 +67,7 @@ def test_adaptive_rho_vs_oracle_mpc_and_matrix_parameters(sim_lib, oracle_lib):
     r = bs.solve({'x_init': x0}, updated_params=['x_init'])
     o = oracle_lib.cpg_solve_batch(d, _theta(d, {'x_init': x0}), ['x_init'], **opts)
     _parity(r, o, d)
-    o_fixed = oracle_lib.cpg_solve_batch(d, _theta(d, {'x_init': x0}), ['x_init'])
+    o_fixed = oracle_lib.cpg_solve_batch(d, _theta(d, {'x_init': x0}), ['x_init'], adaptive_rho=0, check_dualgap=0)
     assert o['iter'].tolist() != o_fixed['iter'].tolist()      # the mode matters on this family
     bs.close()
     d2 = families.nonneg_ls()                                    # A is a parameter: osqp_update_data_mat path

@@ -193,11 +193,13 @@ def test_refactor_path_parameter_in_P(sim_lib, oracle_lib):
     th[:, d.param('lamb_sm').col] = rng.random(B)                     # np.random.rand() per seed in the reference test
     th[:, d.param('w').col:d.param('w').col + 3] += rng.standard_normal((B, 3))
     bs = BatchSolver(d, lib_path=sim_lib)
-    # (this family needs > 2000 ADMM iterations at the default tolerances: three checks are enough here)
+    # (three checks and one rho adaptation are enough here; the cut-off exercises the approximate second test too)
     r = bs.solve({p.name: th[:, p.col:p.col + p.size] for p in d.params}, max_iter=75)
     o, prim, dual = _oracle_flat(oracle_lib, d, th, None, max_iter=75)
-    assert (o['status'] == 7).all()
-    _assert_parity(r, o, prim, dual)
+    assert np.isin(o['status'], (2, 7)).all() and (o['status'] == 7).any()
+    # (slow family, cut off far from its solution right after a rho change: rounding differences of the two
+    # factorisations show at 1e-9; the contract is 1e-6)
+    _assert_parity(r, o, prim, dual, tol=1e-8)
     assert r.prim['delta_u'].shape == (B, 1, 1) and r.dual['d2'].shape == (B, 1, 1)
     bs.close()
 
