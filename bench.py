@@ -4,7 +4,10 @@ bench.py -- QP instances solved per second by the MI355X batched-solve backend o
 BASELINE.json's metric is quoted on: config 2, the MPC QP of examples/MPC.ipynb at
 n_x = 12, n_u = 4, horizon 10, OSQP backend, 100 000 instances per GPU, x_init varying per
 instance (tests/test_E2E_QP.py:146: x_init = -2 + 4 * rand), cold start, default OSQP settings
-(cvxpygen/solvers/osqp.py:102-115).
+(cvxpygen/solvers/osqp.py:102-115) on top of the OSQP >= 1.0 library defaults that every cpg_solve of the
+reference restores (osqp_set_default_settings, osqp.py:100-101): rho adapted every 50 iterations, duality-gap
+test.  `value` is measured in THAT mode (two kernels per step: shared factor until an instance's rho changes,
+per-instance factor behind it); the fixed-rho fork of the same workload is printed beside it as `fixed_rho`.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -29,13 +32,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from cvxpygen_amd import families                      # noqa: E402
-from cvxpygen_amd.runtime import BatchSolver, DeviceBatch   # noqa: E402
+from cvxpygen_amd.runtime import BatchSolver, DeviceBatch, BUILD_OPTIONS_FIXED_RHO   # noqa: E402
 
 def C_float():
     return ctypes.c_float(0)
 
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def source_fingerprint() -> str:
+    """sha256 over the kernel sources and the generators of the family libraries: what a recorded PMC
+    measurement must have been taken on to be replayed next to a live timing"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, 'cvxpygen_amd')
+    for f in sorted(os.listdir(os.path.join(base, 'csrc'))):
+        if f.endswith(('.h', '.cpp')):
+            h.update(open(os.path.join(base, 'csrc', f), 'rb').read())
+    for f in ('codegen.py', 'solve_program.py', 'refactor_plan.py', 'slot_layout.py'):
+        h.update(open(os.path.join(base, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def make_workload(name: str):
@@ -84,9 +101,9 @@ def make_theta(desc, B: int, seed: int) -> np.ndarray:
     return -2.0 + 4.0 * rng.random((B, p.size))
 
 
-def cpu_baseline(desc, target_seconds: float = 12.0):
+def cpu_baseline(desc, target_seconds: float = 12.0, **mode):
     """Oracle (scalar-C restatement of the generated solver, oracle/osqp_oracle.c) on all host cores;
-    bounded sample of the same workload."""
+    bounded sample of the same workload, same mode (mode: oracle settings, e.g. adaptive_rho=0)."""
     from oracle import binding as ob
     ob.build()
     cores = ob.lib().oracle_num_threads()
@@ -96,7 +113,7 @@ def cpu_baseline(desc, target_seconds: float = 12.0):
         th = np.tile(desc.theta0, (B, 1))
         th[:, p.col:p.col + p.size] = make_theta(desc, B, seed)
         t0 = time.time()
-        ob.cpg_solve_batch(desc, th, ['x_init'], nthreads=cores)
+        ob.cpg_solve_batch(desc, th, ['x_init'], nthreads=cores, **mode)
         return time.time() - t0
 
     t_probe = run(8 * cores, 1)
@@ -108,7 +125,7 @@ def cpu_baseline(desc, target_seconds: float = 12.0):
                       f'OpenMP static over instances, {t:.1f} s wall'}
 
 
-def cpu_baseline_portfolio(desc, target_seconds: float = 12.0):
+def cpu_baseline_portfolio(desc, target_seconds: float = 12.0, **mode):
     """config 3 on the host: the C oracle with per-instance osqp_update_data_mat, all host cores"""
     from oracle import binding as ob
     ob.build()
@@ -122,7 +139,7 @@ def cpu_baseline_portfolio(desc, target_seconds: float = 12.0):
             for k in range(B):
                 th[k, p.col:p.col + p.size] = desc.flatten_param(nm, v[k])
         t0 = time.time()
-        ob.cpg_solve_batch(desc, th, list(pv.keys()), nthreads=cores)
+        ob.cpg_solve_batch(desc, th, list(pv.keys()), nthreads=cores, **mode)
         return time.time() - t0
 
     t_probe = run(2 * cores, 1)
@@ -167,7 +184,9 @@ def main():
     ap.add_argument('--check-termination', type=int, default=0, help='experiments: termination check interval (reference default 25)')
     ap.add_argument('--eps', type=float, default=0.0, help='eps_abs = eps_rel (tight run of SURVEY.md 8(d): 1e-6)')
     ap.add_argument('--adjoint', action='store_true', help='config 5: also time the batched QP adjoint (gradient=True path)')
-    ap.add_argument('--osqp1', action='store_true', help='OSQP >= 1.0 build options: rho adaptation every 50 iterations + duality-gap test (per-instance factor path)')
+    ap.add_argument('--osqp1', action='store_true', help='(default now; kept for old command lines) OSQP >= 1.0 library defaults')
+    ap.add_argument('--fixed-rho', action='store_true', help='the other fork: a solver that never adapts rho, no duality-gap test (OSQP 0.6-style codegen)')
+    ap.add_argument('--no-fixed-rho-leg', action='store_true', help='skip the short fixed-rho measurement printed beside the default mode')
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: leave the final gather out of the timed steps')
     ap.add_argument('--no-wall', action='store_true', help='skip the PCIe-inclusive pipelined measurement')
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
@@ -191,9 +210,10 @@ def main():
     gen = os.path.join(ROOT, 'cvxpygen_amd', 'generated', args.workload, f'libcpg_{args.workload}.so')
     if lib_path is None and not args.generic and os.path.exists(gen):
         lib_path = gen          # what generate_code() builds: executor specialised for this family
-    build_options = {}
-    if args.osqp1:              # the OSQP >= 1.0 reading of the generated workspace
-        build_options = dict(adaptive_rho=1, adaptive_rho_interval=50, adaptive_rho_tolerance=5.0, check_dualgap=1)
+    # default: OSQP >= 1.0 library defaults (rho adaptation every 50 iterations, tolerance 5, duality-gap test)
+    build_options = dict(BUILD_OPTIONS_FIXED_RHO) if args.fixed_rho else {}
+    args.osqp1 = not args.fixed_rho
+    oracle_mode = dict(adaptive_rho=0, check_dualgap=0) if args.fixed_rho else {}
     if desc.solver == 'CLARABEL':
         from cvxpygen_amd.conic_runtime import ConicBatchSolver
         solver = ConicBatchSolver(desc, device=local_rank, lib_path=args.lib)
@@ -269,6 +289,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    hybrid = desc.solver == 'OSQP' and bool(getattr(solver, '_hybrid', False)) and solver.h is solver.h_shared
+    phase = solver.last_phase_ms() if hybrid else None      # split of the last step: (ms shared, ms per-instance, handed over)
     res = dev.download()
     iters = res.iter
     solved = int((res.status == 1).sum())
@@ -318,26 +340,60 @@ def main():
         traffic = None          # recorded PMC measurement of the same command (profiles/), not re-measured live
         binding = None
         traffic_src = None
+        traffic_stale = None
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')))
-            key = args.workload + ('_all_params' if args.all_params else '') + ('_osqp1' if args.osqp1 else '')
+            # records are stamped with the fingerprint of the kernel sources and name their kernel: a record taken on
+            # other kernels is refused instead of silently replayed (scripts/record_traffic.py writes them)
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r3_hbm_traffic.json')))
+            key = args.workload + ('_all_params' if args.all_params else '') + ('_fixed_rho' if args.fixed_rho else '')
             rec = tj.get(key)
             if rec and rec['instances'] == B:
-                traffic = rec['fetch_bytes'] + rec['write_bytes']
-                binding = rec.get('binding_resource')
-                traffic_src = tj.get('_source')
+                if rec.get('source_fingerprint') == source_fingerprint():
+                    traffic = rec['fetch_bytes'] + rec['write_bytes']
+                    binding = rec.get('binding_resource')
+                    traffic_src = f"{rec.get('source')}; kernel {rec.get('kernel')}"
+                else:
+                    traffic_stale = f"record {key} of profiles/r3_hbm_traffic.json was taken on other kernel sources ({rec.get('source_fingerprint')}): refused"
         except (OSError, ValueError, KeyError):
             pass
         rnote = ('compulsory traffic only (theta in, solution out); the iteration state never leaves '
                  'registers/LDS, so this path is latency / LDS bound, not HBM bound (DESIGN.md section 6)')
-        if solver.desc.solver == 'OSQP' and getattr(solver, '_rplan', None) is not None and (args.all_params or args.osqp1 or args.workload == 'portfolio'):
+        per_instance_kernel = desc.solver == 'OSQP' and solver.h is solver.h_ref
+        kernel_name = ('clarabel_kernel' if args.workload == 'adp' else 'osqp_refactor_kernel' if per_instance_kernel else 'osqp_shared_kernel')
+        units = B
+        stream = None
+        sv = 8 * int(solver._rplan.stats['sol_stream_entries']) if getattr(solver, '_rplan', None) is not None else 0
+        phases = None
+        if hybrid:
+            # two kernels per step; the roofline object describes the one that takes longer
+            ms1, ms2, n_ho = phase
+            it = res.iter.astype(np.int64)
+            ad = 50
+            it1 = np.minimum(it, ad)          # iterations served by the shared-factor kernel (every instance hands over at its first rho change)
+            ho = it > ad                       # (instances whose estimate stayed inside the tolerance band continue on the shared factor: counted there)
+            phases = {'shared_factor': {'kernel': 'osqp_shared_kernel', 'ms': ms1, 'instances': B,
+                                        'iterations': int(it1.sum())},
+                      'per_instance_factor': {'kernel': 'osqp_refactor_kernel', 'ms': ms2, 'instances': n_ho,
+                                              'iterations': int((it - it1)[ho].sum()),
+                                              'note': 'instances handed over after a rho change: numeric LDL\' for the new rho, then ADMM with their own factor'}}
+            if ms2 > ms1:
+                kernel_name, units, k_ms = 'osqp_refactor_kernel', n_ho, ms2
+                # the hand-over adds the workspace (n + 2m + 1 doubles) written by the kernel in front and read here
+                it2 = float((it - it1)[ho].mean()) if ho.any() else 0.0
+                stream = {'bytes_per_instance': int(it2 * sv), 'what': f'{it2:.1f} iterations x {sv} B of per-instance substitution coefficients',
+                          'achieved': it2 * sv * n_ho / (ms2 * 1e-3) / 1e9}
+                rnote = ('dominant kernel of the two-kernel step: per-instance factor phase of the instances whose rho changed; `achieved` prices SURVEY.md 8(d) '
+                         'bytes per instance it serves, `stream` the coefficients it actually streams from HBM per iteration (DESIGN.md section 4.5)')
+            else:
+                k_ms = ms1
+        elif per_instance_kernel:
             # per-instance factor: every ADMM iteration streams the substitution coefficients of the
             # instance (8 bytes per entry of the streaming layout) from its buffer in HBM
-            sv = 8 * int(solver._rplan.stats['sol_stream_entries'])
-            bytes_per_inst = int(bytes_per_inst + stats['mean_iter'] * sv)
-            rnote = (f'compulsory traffic + mean_iter x {sv} B of per-instance substitution coefficients streamed '
-                     'from HBM in every ADMM iteration (DESIGN.md section 4.2); the shared index tables stay in L2')
-        achieved = bytes_per_inst * B / (k_ms * 1e-3) / 1e9
+            stream = {'bytes_per_instance': int(stats['mean_iter'] * sv), 'what': f"{stats['mean_iter']:.1f} iterations x {sv} B of per-instance substitution coefficients",
+                      'achieved': stats['mean_iter'] * sv * B / (k_ms * 1e-3) / 1e9}
+            rnote = ('`achieved` prices SURVEY.md 8(d) bytes per instance; `stream` the per-instance substitution coefficients read from HBM in every ADMM '
+                     'iteration (DESIGN.md section 4.2); the shared index tables stay in L2')
+        achieved = bytes_per_inst * units / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = world * B * args.steps / elapsed
         out = {
             'metric': ('SOCP instances solved/sec (batched ADP, conic interior point)' if args.workload == 'adp'
@@ -358,8 +414,8 @@ def main():
                        'settings': ('Clarabel defaults of the generated solver (cvxpygen/solvers/clarabel.py:63-119): '
                                     'tol_gap/feas 1e-8, max_iter 200, new solver per instance' if args.workload == 'adp' else
                                     'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, max_iter=4000, '
-                                    'check_termination=25, cold start; workspace built as OSQP >= 1.0 would: rho adapted every 50 '
-                                    'iterations (tolerance 5), duality-gap test on' if args.osqp1 else
+                                    'check_termination=25, cold start; OSQP >= 1.0 library defaults restored by every cpg_solve: rho adapted '
+                                    'every 50 iterations (tolerance 5), duality-gap test on' if args.osqp1 else
                                     'OSQP defaults of the generated solver: eps_abs=eps_rel=1e-3, '
                                     'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start'),
                        'parallelism': f'shard{world}', **stats,
@@ -368,32 +424,57 @@ def main():
                                 for k, v in solver.plan.stats.items()}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_note': (f'REPLAYED, not measured in this run: bytes per launch from the rocprofv3 PMC passes recorded in '
-                                          f'profiles/r2_hbm_traffic.json ({traffic_src})') if traffic else None,
+                         'traffic_note': (f'REPLAYED, not measured in this run: bytes per step (all kernels of the step) from the rocprofv3 PMC '
+                                          f'passes recorded in profiles/r3_hbm_traffic.json ({traffic_src})') if traffic else traffic_stale,
                          'binding_resource': binding,
-                         'kernel': ('clarabel_kernel' if args.workload == 'adp' else
-                                    'osqp_refactor_kernel' if (args.all_params or args.osqp1 or args.workload == 'portfolio')
-                                    else 'osqp_shared_kernel'), 'kernel_ms': k_ms,
-                         'algorithmic_bytes_per_instance': bytes_per_inst,
+                         'kernel': kernel_name, 'kernel_ms': k_ms, 'units_per_launch': int(units),
+                         'algorithmic_bytes_per_instance': bytes_per_inst, 'stream': stream,
                          'note': rnote},
         }
         out['config']['value_is'] = ('inputs resident in HBM when the timed region starts, results left in HBM (driver contract); '
                                      'the PCIe-inclusive whole-path rate of SURVEY.md 8(d) is reported beside it in "wall_pcie"')
+        if phases is not None:
+            out['phases'] = phases
         if wall is not None:
             out['wall_pcie'] = wall
         if world > 1:
             out['config']['gather'] = ('left out of the timed steps (--no-gather)' if args.no_gather else gather_kind)
             out['config']['gather_ms_per_step_rank0'] = gather_ms / max(1, args.steps)
-        if world == 1 and not args.no_cpu_baseline and not args.all_params and not args.osqp1:
+        if world == 1 and not args.no_cpu_baseline and not args.all_params:
             if args.workload == 'portfolio':
-                out['cpu_baseline'] = cpu_baseline_portfolio(desc, args.cpu_seconds)
+                out['cpu_baseline'] = cpu_baseline_portfolio(desc, args.cpu_seconds, **oracle_mode)
             elif args.workload == 'adp':
                 out['cpu_baseline'] = cpu_baseline_adp(desc, min(args.cpu_seconds, 10.0))
             else:
-                out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds)
+                out['cpu_baseline'] = cpu_baseline(desc, args.cpu_seconds, **oracle_mode)
+            if desc.solver == 'OSQP':
+                out['cpu_baseline']['mode'] = 'fixed rho, no duality-gap test' if args.fixed_rho else 'OSQP >= 1.0 defaults (same mode as value)'
+        if (world == 1 and desc.solver == 'OSQP' and not args.fixed_rho and not args.no_fixed_rho_leg and not args.all_params
+                and args.workload in ('mpc12', 'mpc6')):
+            # the other fork of the reference's default, same workload and batch: one shared-factor kernel
+            fs = BatchSolver(desc, device=local_rank, lib_path=lib_path, build_options=dict(BUILD_OPTIONS_FIXED_RHO))
+            fs.set_launch(args.waves, args.ipw, args.blocks_per_cu)
+            fs.set_program_placement(args.placement)
+            fs.set_updated(['x_init'])
+            fs.apply_settings(**stg)
+            fdev = DeviceBatch(fs, B)
+            fdev.upload(theta)
+            for _ in range(2):
+                fs.solve_device(fdev); fs.synchronize()
+            nf = max(3, min(args.steps, 10))
+            tf = time.perf_counter()
+            for _ in range(nf):
+                fs.solve_device(fdev); fs.synchronize()
+            tf = time.perf_counter() - tf
+            fr = fdev.download()
+            out['fixed_rho'] = {'value': B * nf / tf, 'unit': 'QP instances/s', 'steps': nf, 'ms_per_step': 1e3 * tf / nf,
+                                'kernel_ms': fs.last_kernel_ms(), 'mean_iter': float(fr.iter.mean()), 'solved': int((fr.status == 1).sum()),
+                                'what': 'same workload with build options adaptive_rho=0, check_dualgap=0 (a solver whose OSQP never adapts rho): '
+                                        'one shared-factor kernel; NOT the mode `value` is quoted in'}
+            fdev.free(); fs.close()
         if args.adjoint and desc.solver == 'OSQP':
             # config 5: forward as above, then the adjoint with upstream dX = dU = 0.1
-            gs = BatchSolver(desc, device=local_rank, lib_path=lib_path, full_output=True)
+            gs = BatchSolver(desc, device=local_rank, lib_path=lib_path, full_output=True, build_options=build_options)
             Bg = min(B, 20000)
             x0 = make_theta(desc, Bg, seed=77)
             fw = gs.solve({'x_init': x0}, updated_params=['x_init'])
@@ -416,7 +497,7 @@ def main():
             p = desc.param('x_init')
             th = np.tile(desc.theta0, (nchk, 1))
             th[:, p.col:p.col + p.size] = theta[:nchk]
-            o = ob.cpg_solve_batch(desc, th, ['x_init'])
+            o = ob.cpg_solve_batch(desc, th, ['x_init'], **oracle_mode)
             po = np.concatenate([o['sol_x'][:, v.indices] for v in desc.variables], axis=1)
             do = np.concatenate([o['sol_y'][:, d.indices] for d in desc.duals], axis=1)
             out['check'] = {
