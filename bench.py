@@ -190,7 +190,20 @@ def main():
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: leave the final gather out of the timed steps')
     ap.add_argument('--no-wall', action='store_true', help='skip the PCIe-inclusive pipelined measurement')
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
+    ap.add_argument('--rccl-lib', default='librccl.so', help='RCCL library of the result gather (CPU tier: the recording stand-in of tests/sim/fake_rccl)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher -- one rank per GPU through the same
+        # torch.distributed.run command line the driver uses; rank 0's JSON line is this process's output
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -198,12 +211,15 @@ def main():
     dist = None
     if world > 1:
         # torch.distributed only as the launcher-level plumbing the driver's contract asks for (rendezvous,
-        # barrier, max over ranks of the elapsed time); the data path -- the final gather of the results --
-        # goes through cvxpygen_amd.sharding (RCCL via ctypes on the solver's own stream)
+        # barrier, max over ranks of the elapsed time) -- on its CPU backend, so that the process holds exactly ONE
+        # RCCL runtime and ONE communicator: the one of the data path, the final gather of the results
+        # (cvxpygen_amd.sharding.RcclGather: librccl through ctypes on the solver's own stream)
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group('gloo')
 
     desc, label = make_workload(args.workload)
     lib_path = args.lib
@@ -253,7 +269,11 @@ def main():
     Btot = world * B
     if world > 1:
         from cvxpygen_amd.sharding import RcclGather, result_spec
-        gather = RcclGather(solver, rank, world, key=os.environ.get('MASTER_PORT', '0'))
+        def bcast_uid(raw):        # the RCCL unique id rides on the launcher's process group: no rendezvous file to go stale
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        gather = RcclGather(solver, rank, world, key=os.environ.get('MASTER_PORT', '0'), lib=args.rccl_lib, uid_exchange=bcast_uid)
         gather_kind = 'rccl ncclSend/ncclRecv to rank 0 (device memory), on the solve stream'
         spec = result_spec(dev)
         arrays = [(k, dev._ptrs[k], B, rb) for k, (rb, dt, tail, nm) in spec.items()]
@@ -262,7 +282,8 @@ def main():
         solver.synchronize()
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
             dist.barrier()
 
     def step():
@@ -285,7 +306,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

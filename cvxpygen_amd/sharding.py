@@ -12,9 +12,12 @@ consumer (rank `root`), for which this module has two transports, neither of the
                array that the root reads -- no collective at all; the realistic case when the consumer
                is numpy on the host, and the transport the CPU test tier can run.
 
-Both are single-node (the scope of BASELINE.json: the 8 GPUs of one node) and rendezvous through
-/dev/shm files keyed by `key` (e.g. MASTER_PORT of the launcher).  The reference has no counterpart
-(single process, single thread).
+Both are single-node (the scope of BASELINE.json: the 8 GPUs of one node).  Rendezvous: the RCCL unique id
+travels through whatever the launcher already has (`uid_exchange`, e.g. a broadcast over its process group:
+bench.py) or, by default, through a /dev/shm file keyed by `key`, which must be unique per JOB
+(`job_key()`: the launcher's port plus the pid of the launcher process every rank is a child of) -- a key
+reused by a later job would let its ranks read the id a crashed run left behind.  The reference has no
+counterpart (single process, single thread).
 """
 
 from __future__ import annotations
@@ -34,6 +37,12 @@ def shard_bounds(B: int, rank: int, world: int) -> Tuple[int, int]:
     lo = rank * base + min(rank, rem)
     hi = lo + base + (1 if rank < rem else 0)
     return lo, hi
+
+
+def job_key(port=None) -> str:
+    """rendezvous key of this job: MASTER_PORT of the launcher + the pid of the parent process (the launcher's
+    agent, the same for all ranks of one job and different for the next job on the same port)"""
+    return f"{port if port is not None else os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
 
 
 def _wait_for(path: str, timeout: float = 120.0) -> None:
@@ -66,7 +75,16 @@ class HostGather:
         self._seq += 1
         ready = f'/dev/shm/{name}.ready'
         if self.rank == self.root:
-            shm = shared_memory.SharedMemory(name=name, create=True, size=hdr + max(1, B * row_bytes))
+            try:
+                shm = shared_memory.SharedMemory(name=name, create=True, size=hdr + max(1, B * row_bytes))
+            except FileExistsError:
+                # a segment a killed run left under the same key: nobody of THIS job can be attached yet (the
+                # ready file is written after the segment exists), so it is safe to replace
+                if os.path.exists(ready):
+                    os.remove(ready)
+                stale = shared_memory.SharedMemory(name=name)
+                stale.close(); stale.unlink()
+                shm = shared_memory.SharedMemory(name=name, create=True, size=hdr + max(1, B * row_bytes))
             shm.buf[:hdr] = bytes(hdr)
             open(ready, 'w').close()
         else:
@@ -108,7 +126,10 @@ class RcclGather:
 
     NCCL_UINT8 = 1
 
-    def __init__(self, solver, rank: int, world: int, key: str, root: int = 0, lib: str = 'librccl.so'):
+    def __init__(self, solver, rank: int, world: int, key: str, root: int = 0, lib: str = 'librccl.so',
+                 uid_exchange=None):
+        """uid_exchange(raw: bytes | None) -> bytes: delivers the root's 128-byte RCCL unique id to every rank (the
+        root passes it, the others pass None); default: a /dev/shm file keyed by `key` (see job_key)."""
         self.rank, self.world, self.root, self.key = rank, world, root, str(key)
         self.s = solver
         self.name = 'rccl'
@@ -125,16 +146,22 @@ class RcclGather:
         self.stream = stream
         uid = _NcclUniqueId()
         path = f'/dev/shm/cpg_rccl_{self.key}.id'
+        self._id_path = None
         if rank == root:
             self._ck(L.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+        if uid_exchange is not None:
+            raw = uid_exchange(C.string_at(C.byref(uid), 128) if rank == root else None)     # (all 128 bytes: a c_char field would stop at a NUL)
+            if rank != root:
+                C.memmove(C.byref(uid), raw, min(128, len(raw)))
+        elif rank == root:
             with open(path + '.tmp', 'wb') as f:
-                f.write(bytes(uid.internal))
-            os.replace(path + '.tmp', path)
+                f.write(C.string_at(C.byref(uid), 128))
+            os.replace(path + '.tmp', path)          # atomic: a reader never sees a partial id
+            self._id_path = path
         else:
             _wait_for(path)
             raw = open(path, 'rb').read()
-            C.memmove(C.byref(uid), raw, 128)
-        self._id_path = path
+            C.memmove(C.byref(uid), raw, min(128, len(raw)))
         self.comm = C.c_void_p()
         self._ck(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), 'ncclCommInitRank')
         self._gbufs: Dict[str, list] = {}      # root: one device gather buffer per named array [ptr, bytes]
@@ -208,7 +235,7 @@ class RcclGather:
         if self.comm.value:
             self.L.ncclCommDestroy(self.comm)
             self.comm = C.c_void_p()
-        if self.rank == self.root and os.path.exists(self._id_path):
+        if self._id_path and os.path.exists(self._id_path):
             os.remove(self._id_path)
 
 

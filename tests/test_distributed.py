@@ -87,3 +87,47 @@ def test_package_does_not_import_torch():
             if fn.endswith('.py'):
                 txt = open(os.path.join(dp, fn)).read()
                 assert 'import torch' not in txt and 'from torch' not in txt, fn
+
+
+def _fake_rccl():
+    """builds tests/sim/fake_rccl/libfake_rccl.so (recording stand-in for librccl.so, transfers through /dev/shm files)"""
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'sim', 'fake_rccl')
+    so, src = os.path.join(d, 'libfake_rccl.so'), os.path.join(d, 'fake_rccl.c')
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['gcc', '-O1', '-shared', '-fPIC', '-w', '-o', so, src])
+    return so
+
+
+def test_bench_gpus_2_starts_two_ranks_and_gathers_over_one_rccl(sim_lib, tmp_path):
+    """`python bench.py --gpus 2` (no launcher around it, as the driver calls --gpus 1) must start two ranks by
+    itself, report n_gpus 2, and move every rank's results to the root through ONE communicator: checked on the
+    emulator library with the recording RCCL stand-in (send / receive schedule of RcclGather.enqueue)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = tmp_path / 'rccl.log'
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['CPG_FAKE_RCCL_LOG'] = str(log)
+    B, steps = 6, 2
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', str(steps), '--warmup', '1',
+                        '--workload', 'mpc6', '--batch', str(B), '--lib', sim_lib, '--rccl-lib', _fake_rccl(), '--generic'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['instances_per_gpu'] == B and out['scaling'] == 'weak'
+    assert out['config']['solved'] == 2 * B                  # the root saw both shards' statuses through the gather
+    assert out['value'] > 0 and abs(out['ms_per_step'] * steps * out['value'] / 1e3 - 2 * B * steps) < 1e-6 * B
+    txt = log.read_text().splitlines()
+    assert sum(ln.startswith('getuid') for ln in txt) == 1 and sum(ln.startswith('init') for ln in txt) == 2   # one id, one communicator per rank
+    # per step one group per rank: rank 1 sends its 7 result arrays to rank 0, rank 0 posts the 7 matching receives
+    row_bytes = sorted([8 * 96, 8 * 96, 8, 4, 4, 8, 8])      # prim, dual (MPC 6/3/10: 96 user entries each), obj, iter, status, pri, dua
+    sends = [ln for ln in txt if ln.startswith('send')]
+    recvs = [ln for ln in txt if ln.startswith('recv')]
+    assert len(sends) == len(recvs) == 7 * (steps + 1)
+    assert all('rank=1 peer=0' in ln for ln in sends) and all('rank=0 peer=1' in ln for ln in recvs)
+    first = sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in sends[:7])
+    assert first == [B * rb for rb in row_bytes]
+    assert sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in recvs[:7]) == first
