@@ -380,10 +380,11 @@ def main():
         rnote = ('compulsory traffic only (theta in, solution out); the iteration state never leaves '
                  'registers/LDS, so this path is latency / LDS bound, not HBM bound (DESIGN.md section 6)')
         per_instance_kernel = desc.solver == 'OSQP' and solver.h is solver.h_ref
+        rpl = (getattr(solver, '_rplan_s', None) if hybrid else getattr(solver, '_rplan', None)) if desc.solver == 'OSQP' else None
         kernel_name = ('clarabel_kernel' if args.workload == 'adp' else 'osqp_refactor_kernel' if per_instance_kernel else 'osqp_shared_kernel')
         units = B
         stream = None
-        sv = 8 * int(solver._rplan.stats['sol_stream_entries']) if getattr(solver, '_rplan', None) is not None else 0
+        sv = 8 * int(rpl.stats['sol_stream_entries']) if rpl is not None else 0
         phases = None
         if hybrid:
             # two kernels per step; the roofline object describes the one that takes longer

@@ -247,10 +247,30 @@ class OsqpPlan:
     Lx: np.ndarray
     D: np.ndarray
     etree: np.ndarray
+    # setup(prune=True): positions (in P.data / A.data order) of the entries the KKT pattern was built from --
+    # the numerically non-zero ones; None: every stored entry
+    keepP: Optional[np.ndarray] = None
+    keepA: Optional[np.ndarray] = None
 
     @property
     def N(self):
         return self.n + self.m
+
+    def pruned(self, P: sp.csc_matrix, A: sp.csc_matrix):
+        """(P, A) SCALED, on the pattern the KKT matrix of this plan was built from"""
+        Ps = sp.csc_matrix((self.Px, P.indices, P.indptr), shape=P.shape)
+        As = sp.csc_matrix((self.Ax, A.indices, A.indptr), shape=A.shape)
+        if self.keepP is not None:
+            Ps, As = _keep_entries(Ps, self.keepP), _keep_entries(As, self.keepA)
+        return Ps, As
+
+
+def _keep_entries(M: sp.csc_matrix, keep: np.ndarray) -> sp.csc_matrix:
+    """M restricted to the stored entries `keep` (positions in M.data), same column order"""
+    cols = np.repeat(np.arange(M.shape[1]), np.diff(M.indptr))[keep]
+    indptr = np.zeros(M.shape[1] + 1, dtype=np.int64)
+    np.add.at(indptr, cols + 1, 1)
+    return sp.csc_matrix((M.data[keep], M.indices[keep], np.cumsum(indptr).astype(np.int32)), shape=M.shape)
 
 
 def choose_ordering(K: sp.csc_matrix, method: str = 'auto') -> np.ndarray:
@@ -275,7 +295,13 @@ def choose_ordering(K: sp.csc_matrix, method: str = 'auto') -> np.ndarray:
 
 
 def setup(P: sp.csc_matrix, q: np.ndarray, A: sp.csc_matrix, l: np.ndarray, u: np.ndarray,
-          settings: Optional[Dict[str, float]] = None, ordering: str = 'auto') -> OsqpPlan:
+          settings: Optional[Dict[str, float]] = None, ordering: str = 'auto', prune: bool = False) -> OsqpPlan:
+    """prune: build the KKT pattern, the ordering and the factor from the numerically NON-ZERO entries of P and A
+    only.  A parametrised matrix carries every position a parameter can reach (MPC 12/4/10: 4 168 stored entries of
+    A, 896 of them non-zero at the code-generation-time values); as long as no varying parameter enters P or A the
+    others are exact zeros in every instance, and a factorisation that skips them computes the same numbers from
+    a fraction of the fill (nnz(L) 6 314 -> 1 110, elimination-tree height 242 -> 35 on that family).  Px / Ax
+    keep the full stored order; keepP / keepA name the entries that were used."""
     stg = dict(DEFAULT_SETTINGS)
     if settings:
         stg.update(settings)
@@ -290,6 +316,10 @@ def setup(P: sp.csc_matrix, q: np.ndarray, A: sp.csc_matrix, l: np.ndarray, u: n
     rho_vec, ctype = compute_rho_vec(ls, us, stg['rho'])
     Ps = sp.csc_matrix((Px, P.indices, P.indptr), shape=P.shape)
     As = sp.csc_matrix((Ax, A.indices, A.indptr), shape=A.shape)
+    keepP = keepA = None
+    if prune:
+        keepP, keepA = np.nonzero(Px != 0.0)[0], np.nonzero(Ax != 0.0)[0]
+        Ps, As = _keep_entries(Ps, keepP), _keep_entries(As, keepA)
     K, K_idx = kkt_upper(Ps, As, stg['sigma'], rho_vec)
     perm = choose_ordering(K, ordering)
     Kp, Kp_src = permute_upper(K, perm)
@@ -297,7 +327,7 @@ def setup(P: sp.csc_matrix, q: np.ndarray, A: sp.csc_matrix, l: np.ndarray, u: n
     Lx, D = numeric_ldl(Kp, Lp, Li)
     return OsqpPlan(n=n, m=m, settings=stg, scaling=sc, Px=Px, Ax=Ax, q=qs, l=ls, u=us,
                     rho_vec=rho_vec, constr_type=ctype, K=K, K_idx=K_idx, perm=perm,
-                    Kp_src=Kp_src, Kp=Kp, Lp=Lp, Li=Li, Lx=Lx, D=D, etree=etree)
+                    Kp_src=Kp_src, Kp=Kp, Lp=Lp, Li=Li, Lx=Lx, D=D, etree=etree, keepP=keepP, keepA=keepA)
 
 
 def ldl_solve(plan: OsqpPlan, b: np.ndarray) -> np.ndarray:

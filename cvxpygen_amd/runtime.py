@@ -207,7 +207,7 @@ class FamilyPlan:
     """Code-generation-time product for one OSQP problem family: scaling, factor, solve program
     and the device ordering (entries depending on user parameters first)."""
     desc: FamilyDescriptor
-    osqp: _setup.OsqpPlan
+    osqp: _setup.OsqpPlan   # scaling, row classes and the factor on the STRUCTURAL pattern (per-instance matrix parameters)
     ordx: np.ndarray        # device position -> canonical x index
     ordz: np.ndarray        # device position -> canonical row
     posx: np.ndarray        # canonical x index -> device position
@@ -222,6 +222,10 @@ class FamilyPlan:
     prim_idx: np.ndarray
     dual_idx: np.ndarray
     stats: Dict[str, float] = field(default_factory=dict)
+    # the same workspace factored on the numerically non-zero pattern (osqp_setup.setup(prune=True)): what every
+    # path uses whose matrices are the code-generation-time ones -- the shared solve program and the
+    # per-instance factors of shared-matrix mode (rho adaptation, rows that changed class)
+    osqp_shared: Optional[_setup.OsqpPlan] = None
 
 
 def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
@@ -237,6 +241,9 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
     l0, u0 = canon_lu(desc, canon0)
     plan = _setup.setup(desc.P, canon0['q'], desc.A, l0, u0, settings=setup_settings,
                         ordering=ordering)
+    prune = os.environ.get('CPG_PRUNE', '1') != '0'
+    splan = _setup.setup(desc.P, canon0['q'], desc.A, l0, u0, settings=setup_settings, ordering=ordering, prune=True) \
+        if prune and ((plan.Ax == 0.0).any() or (plan.Px == 0.0).any()) else plan
     NP = desc.NP
     vary_q = np.diff(sp.csr_matrix(desc.maps['q'])[:, :NP].tocsr().indptr) > 0
     vary_u = np.diff(Mu[:, :NP].tocsr().indptr) > 0
@@ -246,7 +253,7 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
     posz = np.empty(m, dtype=np.int64); posz[ordz] = np.arange(m)
     devpos = np.concatenate([posx, n + posz])
     N = n + m
-    phases = _sp.compile_ldl(N, plan.Lp, plan.Li, plan.Lx, plan.D, plan.perm, merge=merge,
+    phases = _sp.compile_ldl(N, splan.Lp, splan.Li, splan.Lx, splan.D, splan.perm, merge=merge,
                              devpos=devpos)
     pi = None
     bank_stats = {}
@@ -282,8 +289,7 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
     assert kkt_ragged.n_slots == kkt.n_slots and np.array_equal(kkt_ragged.final_pos, kkt.final_pos)
     if kkt.n_slots >= 0xFFFF:
         raise NotImplementedError('problem family too large for 16-bit LDS slot indices')
-    As = sp.csc_matrix((plan.Ax, desc.A.indices, desc.A.indptr), shape=desc.A.shape)
-    Pu = sp.csc_matrix((plan.Px, desc.P.indices, desc.P.indptr), shape=desc.P.shape)
+    Pu, As = splan.pruned(desc.P, desc.A)          # (the termination test's products skip the exact zeros too)
     Pf = Pu + sp.triu(Pu, 1).T
     A_dev = sp.csr_matrix(As)[ordz][:, ordx]
     P_dev = sp.csr_matrix(Pf)[ordx][:, ordx]
@@ -294,14 +300,15 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         if desc.variables else np.zeros(0, dtype=np.int32)
     dual_idx = np.concatenate([posz[d.indices] for d in desc.duals]).astype(np.int32) \
         if desc.duals else np.zeros(0, dtype=np.int32)
-    stats = dict(nnzL=len(plan.Li), phases=kkt.n_phases, chunks=kkt.n_chunks, steps=kkt.steps,
+    stats = dict(nnzL=len(splan.Li), nnzL_structural=len(plan.Li), nnzA=int(As.nnz), nnzA_structural=int(desc.A.nnz),
+                 phases=kkt.n_phases, chunks=kkt.n_chunks, steps=kkt.steps,
                  nnz_program=kkt.nnz, n_slots=kkt.n_slots, lds_program_bytes=kkt_ragged.lds_bytes(),
                  compile_s=time.time() - t0, **bank_stats)
     return FamilyPlan(desc=desc, osqp=plan, ordx=ordx, ordz=ordz, posx=posx, posz=posz,
                       n_vary_x=int(vary_q.sum()), n_vary_z=int(vary_u.sum()), kkt=kkt,
                       kkt_ragged=kkt_ragged, A_rows=A_rows,
                       P_rows=P_rows, At_rows=At_rows, prim_idx=prim_idx, dual_idx=dual_idx,
-                      stats=stats)
+                      stats=stats, osqp_shared=splan)
 
 
 @dataclass
@@ -396,32 +403,46 @@ class BatchSolver:
         self._apply_build_options(self.h)
         self.device = device
         self.h_shared = self.h
-        self.h_ref = C.c_void_p()          # canonical-order handle of the refactorisation path
+        self.h_ref = C.c_void_p()          # canonical-order handle of the refactorisation path (structural pattern)
         self._rplan = None
+        self.h_rs = C.c_void_p()           # ... and of shared-matrix mode (numerically non-zero pattern, plan.osqp_shared)
+        self._rplan_s = None
+        self._rs_key = None
+        self._hybrid = False
         self.np_var = 0
         self._var_cols = np.zeros(0, dtype=np.int64)
 
     def close(self):
-        for name in ('h_shared', 'h_ref'):
+        for name in ('h_shared', 'h_ref', 'h_rs'):
             hh = getattr(self, name, None)
             if hh is not None and hh.value:
                 self.lib.L.cpg_hip_destroy(hh)
                 setattr(self, name, C.c_void_p())
         self.h = C.c_void_p()
 
-    def _ensure_refactor_handle(self):
-        """second handle in canonical ordering (no device permutation) carrying the structural
-        tables of the per-instance refactorisation path"""
-        if self.h_ref.value:
+    def _ensure_refactor_handle(self, shared_mats: bool = False):
+        """second / third handle in canonical ordering (no device permutation) carrying the structural tables of a
+        per-instance factor path: on the stored pattern of P and A (parameters entering the matrices; the adjoint),
+        or -- shared_mats -- on the numerically non-zero pattern of the code-generation-time workspace"""
+        attr = 'h_rs' if shared_mats else 'h_ref'
+        if getattr(self, attr).value:
             return
         from . import refactor_plan as _rp
-        desc, o = self.desc, self.plan.osqp
-        self._rplan = _rp.build_refactor_plan(desc.P, desc.A, o)
+        desc = self.desc
+        if shared_mats:
+            o = self.plan.osqp_shared or self.plan.osqp
+            Ps, As = o.pruned(desc.P, desc.A)
+            rplan = _rp.build_refactor_plan(Ps, As, o)
+            self._rplan_s = rplan
+        else:
+            o = self.plan.osqp
+            rplan = _rp.build_refactor_plan(desc.P, desc.A, o)
+            self._rplan = rplan
         keep = self._keep
         n, m = desc.n_var, desc.m
         ones_n, ones_m = np.ones(n), np.ones(m)
         ctype = np.ascontiguousarray(o.constr_type, dtype=np.int8)
-        fpos = np.ascontiguousarray(self._rplan.sol.final_pos, dtype=np.uint16)
+        fpos = np.ascontiguousarray(rplan.sol.final_pos, dtype=np.uint16)
         prim_idx = np.ascontiguousarray(np.concatenate([v.indices for v in desc.variables]), dtype=np.int32) \
             if desc.variables else np.zeros(0, dtype=np.int32)
         dual_idx = np.ascontiguousarray(np.concatenate([d.indices for d in desc.duals]), dtype=np.int32) \
@@ -434,18 +455,20 @@ class BatchSolver:
             n=n, m=m, n_eq=desc.n_eq, is_maximization=int(desc.is_maximization),
             sigma=o.settings['sigma'], alpha=o.settings['alpha'], rho=o.settings['rho'],
             D=_d(ones_n), E=_d(ones_m), c=1.0, ctype=ctype.ctypes.data_as(_i8p),
-            n_slots=self._rplan.sol.n_slots, fpos=fpos.ctypes.data_as(_u16p), n_vary_x=n, n_vary_z=m,
+            n_slots=rplan.sol.n_slots, fpos=fpos.ctypes.data_as(_u16p), n_vary_x=n, n_vary_z=m,
             kkt=empty, A_rows=empty, P_rows=empty, At_rows=empty,
             kkt_ragged=_Ragged(0, 0, None, None, None, None),
             n_prim=len(prim_idx), prim_idx=prim_idx.ctypes.data_as(_ip),
             n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip), ord=None)
-        self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), self.device, C.byref(self.h_ref)),
-                       'cpg_hip_create_osqp (refactor handle)')
-        self._apply_build_options(self.h_ref)
+        hh = C.c_void_p()
+        self.lib.check(self.lib.L.cpg_hip_create_osqp(C.byref(fam), self.device, C.byref(hh)),
+                       'cpg_hip_create_osqp (per-instance factor handle)')
+        setattr(self, attr, hh)
+        self._apply_build_options(hh)
         if getattr(self, '_launch', None):
-            self.lib.check(self.lib.L.cpg_hip_set_launch(self.h_ref, *self._launch), 'set_launch')
+            self.lib.check(self.lib.L.cpg_hip_set_launch(hh, *self._launch), 'set_launch')
         if getattr(self, '_placement', None) is not None:
-            self.lib.check(self.lib.L.cpg_hip_set_program_placement(self.h_ref, self._placement), 'set_program_placement')
+            self.lib.check(self.lib.L.cpg_hip_set_program_placement(hh, self._placement), 'set_program_placement')
 
     def _apply_build_options(self, hh) -> None:
         for k, v in self.build_options.items():
@@ -463,13 +486,16 @@ class BatchSolver:
         shared_mats: no varying parameter enters P or A -- the workspace's equilibrated matrices serve every
         instance (pre-scaled q / u maps, no re-equilibration in the kernel): the instances handed over by the
         shared-factor kernel after a rho change, and rows that changed class."""
-        self._ensure_refactor_handle()
-        desc, rp, o = self.desc, self._rplan, self.plan.osqp
+        self._ensure_refactor_handle(shared_mats)
+        desc = self.desc
+        rp = self._rplan_s if shared_mats else self._rplan
+        o = (self.plan.osqp_shared or self.plan.osqp) if shared_mats else self.plan.osqp
+        hh = self.h_rs if shared_mats else self.h_ref
         if q_setup is None:
             q_setup = desc.default_canon()['q']
         q_setup = np.ascontiguousarray(q_setup, dtype=np.float64)
-        key = (np.asarray(cols).tobytes(), np.asarray(th_fixed).tobytes(), q_setup.tobytes(), bool(shared_mats))
-        if key == self._ref_key:
+        key = (np.asarray(cols).tobytes(), np.asarray(th_fixed).tobytes(), q_setup.tobytes())
+        if key == (self._rs_key if shared_mats else self._ref_key):
             return
         keep: list = []
 
@@ -485,10 +511,18 @@ class BatchSolver:
             keep.append(base)
             return base, _csr_struct(Mv, keep)
 
-        Pb, MP = split('P'); Ab, MA = split('A')
+        if shared_mats:
+            # the matrices are the workspace's: equilibrated values on the pattern of this plan, no maps
+            Psm, Asm = o.pruned(desc.P, desc.A)
+            Ps = np.ascontiguousarray(Psm.data, dtype=np.float64); As = np.ascontiguousarray(Asm.data, dtype=np.float64)
+            Pb, Ab = np.zeros(max(1, rp.nnzP)), np.zeros(max(1, rp.nnzA))
+            MP = _csr_struct(sp.csr_matrix((rp.nnzP, len(cols))), keep); MA = _csr_struct(sp.csr_matrix((rp.nnzA, len(cols))), keep)
+            keep += [Pb, Ab]
+        else:
+            Pb, MP = split('P'); Ab, MA = split('A')
+            Ps = np.ascontiguousarray(o.Px, dtype=np.float64); As = np.ascontiguousarray(o.Ax, dtype=np.float64)
         qb, Mq = split('q', scale=(o.scaling.c * o.scaling.D) if shared_mats else None)
         ub, Mu = split('u', clip=True, scale=o.scaling.E if shared_mats else None)
-        Ps = np.ascontiguousarray(o.Px, dtype=np.float64); As = np.ascontiguousarray(o.Ax, dtype=np.float64)
         Dv = np.ascontiguousarray(o.scaling.D, dtype=np.float64); Ev = np.ascontiguousarray(o.scaling.E, dtype=np.float64)
         keep += [Ps, As, Dv, Ev]
         keep.append(q_setup)
@@ -518,9 +552,11 @@ class BatchSolver:
             np_var=len(cols), P_base=_d(Pb), A_base=_d(Ab), q_base=_d(qb), u_base=_d(ub), d_base=d_base,
             map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md, q_setup=_d(q_setup),
             shared_mats=int(bool(shared_mats)), Ps=_d(Ps), As=_d(As), D=_d(Dv), E=_d(Ev), c=float(o.scaling.c))
-        self.lib.check(self.lib.L.cpg_hip_set_refactor(self.h_ref, C.byref(rf)), 'cpg_hip_set_refactor')
-        self._refactor_keep = keep
-        self._ref_key = key
+        self.lib.check(self.lib.L.cpg_hip_set_refactor(hh, C.byref(rf)), 'cpg_hip_set_refactor')
+        if shared_mats:
+            self._rs_keep, self._rs_key = keep, key
+        else:
+            self._refactor_keep, self._ref_key = keep, key
 
     def __del__(self):
         try:
@@ -546,14 +582,14 @@ class BatchSolver:
     def set_launch(self, waves_per_block=0, inst_per_wave=0, blocks_per_cu=0):
         """launch geometry of both handles (shared-factor and refactorisation path)"""
         self._launch = (waves_per_block, inst_per_wave, blocks_per_cu)
-        for hh in (self.h_shared, self.h_ref):
+        for hh in (self.h_shared, self.h_ref, self.h_rs):
             if hh is not None and hh.value:
                 self.lib.check(self.lib.L.cpg_hip_set_launch(hh, *self._launch), 'set_launch')
 
     def set_program_placement(self, in_lds: int = -1):
         """-1 automatic, 0 stream the solve program from L2/HBM, 1 keep it resident in LDS"""
         self._placement = in_lds
-        for hh in (self.h_shared, self.h_ref):
+        for hh in (self.h_shared, self.h_ref, self.h_rs):
             if hh is not None and hh.value:
                 self.lib.check(self.lib.L.cpg_hip_set_program_placement(hh, in_lds), 'set_program_placement')
 
@@ -630,8 +666,8 @@ class BatchSolver:
         if hybrid:
             # rho adaptation: instances whose rho changes continue on their own factor of the SAME matrices
             self._set_refactor(cols, th_fixed, q_setup, shared_mats=True)
-            self.lib.check(self.lib.L.cpg_hip_set_handover(self.h_shared, self.h_ref), 'cpg_hip_set_handover')
-        elif self.h_ref.value:
+            self.lib.check(self.lib.L.cpg_hip_set_handover(self.h_shared, self.h_rs), 'cpg_hip_set_handover')
+        else:
             self.lib.check(self.lib.L.cpg_hip_set_handover(self.h_shared, None), 'cpg_hip_set_handover')
         self._hybrid = hybrid
         self._update_key, self._update_keep = key, keep
@@ -807,8 +843,8 @@ class BatchSolver:
         # the reference keeps its scaling when a bound moves a row to another class (osqp_update_data_vec ->
         # update_rho_vec refactors K, nothing else): the workspace's matrices, a factor per instance
         self._set_refactor(self._var_cols, self._th_fixed, self._q_setup, shared_mats=True)
-        self._apply_settings_to(self.h_ref)
-        sub = self._solve_on(self.h_ref, np.ascontiguousarray(theta_var[bad]), len(bad),
+        self._apply_settings_to(self.h_rs)
+        sub = self._solve_on(self.h_rs, np.ascontiguousarray(theta_var[bad]), len(bad),
                              None if state_in is None else state_in[bad], out[7] is not None)
         for k in range(8):
             if out[k] is not None:
