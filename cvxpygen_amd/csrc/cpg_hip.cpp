@@ -268,6 +268,26 @@ static int launch_refactor_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevS
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
+#ifdef CPG_GENI_HEADER
+// the same body with the generated instance executor: a lane keeps its CPG_GENI_NSTEPS coefficients in registers
+// for the whole ADMM loop, so the budget is the 256 VGPRs of two wavefronts per SIMD
+template <int NSX, int NSZ>
+__global__ void __launch_bounds__(256, 2)
+osqp_instance_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cpg::osqp_refactor_body<NSX, NSZ, true>(F, R, S, Bt, cpg_lds, wave_global);
+}
+template <int NSX, int NSZ>
+static int launch_instance_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = osqp_instance_kernel<NSX, NSZ>;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, stream, h->F, h->R, S, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#endif
 #ifndef CPG_KERNELS_REFACTOR
 #define CPG_KERNELS_REFACTOR(Z) Z(1, 1) Z(4, 4) Z(8, 8) Z(16, 16)
 #endif
@@ -525,6 +545,8 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     else if (s == "adaptive_rho_interval") *v = h->S.adaptive_rho_interval;
     else if (s == "adaptive_rho_tolerance") *v = h->S.adaptive_rho_tolerance;
     else if (s == "check_dualgap") *v = h->S.check_dualgap;
+    // (read-only facts about the handle) 1: per-instance solves of this handle run the generated instance executor
+    else if (s == "generated_instance_executor") *v = (h->refactor_mode && h->R.gi_ok && h->program_in_lds != 0) ? 1.0 : 0.0;
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
 }
@@ -920,6 +942,61 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if ((rc = upload<double>(h, own, r->E, m, &R.Es))) return rc;
         if ((rc = upload<double>(h, own, einv.data(), m, &R.Einvs))) return rc;
     }
+    R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr;
+#ifdef CPG_GENI_HEADER
+    std::vector<unsigned short> gcols, grows;                     // alive until the sync below
+    std::vector<unsigned> gsrc;
+    if (r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
+        unsigned hsh = 0x811C9DC5u;
+        auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = (const unsigned char *)p;
+            for (size_t i = 0; i < nbytes; i++) hsh = (hsh ^ b[i]) * 0x01000193u; };
+        mix(r->sol_ctab, (size_t)r->sol_chunks * 16); mix(r->sol_desc, (size_t)r->sol_chunks * 256); mix(r->sol_cols, (size_t)r->sol_nnz * 2);
+        static const int steps[][2] = CPG_GENI_STEPS;             // {first entry, active lanes} in execution order
+        bool ok = hsh == CPG_GENI_FINGERPRINT;
+        const unsigned zero_off = (unsigned)(r->sol_slots + CPG_GEN_DUMMY_SLOTS) * 8u;
+        if (zero_off > 0xFFFFu || r->sol_slots + CPG_GEN_EXTRA_SLOTS > 0x1FFF) ok = false;
+        if (ok) {
+            const int T4 = (CPG_GENI_NSTEPS + 3) & ~3, C4 = (CPG_GENI_NCHUNKS + 3) & ~3;
+            gcols.assign((size_t)T4 * 64, (unsigned short)zero_off);
+            gsrc.assign((size_t)CPG_GENI_NSTEPS * 64, 0u);
+            for (int t = 0; ok && t < CPG_GENI_NSTEPS; t++) {
+                const int e = steps[t][0], cnt = steps[t][1];
+                if (e < 0 || cnt < 0 || cnt > 64 || e + cnt > r->sol_nnz) { ok = false; break; }
+                for (int l = 0; l < cnt; l++) {
+                    gcols[((size_t)(t / 4) * 64 + l) * 4 + (t % 4)] = r->sol_cols[e + l];
+                    const int kind = r->sol_kind[e + l], idx = r->sol_idx[e + l];
+                    if (kind < 0 || kind > 3 || idx < 0 || idx >= (1 << 28)) { ok = false; break; }
+                    gsrc[(size_t)t * 64 + l] = ((unsigned)kind << 28) | (unsigned)idx;
+                }
+            }
+            grows.assign((size_t)C4 * 64, (unsigned short)r->sol_slots);
+            for (int c = 0; ok && c < r->sol_chunks; c++) {
+                const bool seg = r->sol_ctab[4 * c + 3] & 1;
+                for (int g0 = 0; g0 < 64; g0 += 16) {            // dummy targets per 16-lane store group, as for the shared program
+                    bool used[16] = {false};
+                    for (int t = g0; t < g0 + 16; t++) { const unsigned d = r->sol_desc[(size_t)c * 64 + t]; if ((d & 0xFFFFu) != 0xFFFFu) used[(d & 0xFFFFu) % 16u] = true; }
+                    int nxt = 0;
+                    for (int t = g0; t < g0 + 16; t++) {
+                        const unsigned d = r->sol_desc[(size_t)c * 64 + t];
+                        unsigned slot = d & 0xFFFFu;
+                        if (slot == 0xFFFFu) {
+                            while (nxt < CPG_GEN_DUMMY_SLOTS && used[(unsigned)(r->sol_slots + nxt) % 16u]) nxt++;
+                            const int j = nxt < CPG_GEN_DUMMY_SLOTS ? nxt++ : (t & (CPG_GEN_DUMMY_SLOTS - 1));
+                            slot = (unsigned)(r->sol_slots + j);
+                        }
+                        grows[((size_t)(c >> 2) * 64 + t) * 4 + (c & 3)] = (unsigned short)(slot | ((seg ? (d >> 28) : 0u) << 13));
+                    }
+                }
+            }
+        }
+        if (ok) {
+            if ((rc = upload<unsigned short>(h, own, gcols.data(), gcols.size(), &R.gi_cols))) return rc;
+            if ((rc = upload<unsigned short>(h, own, grows.data(), grows.size(), &R.gi_rows))) return rc;
+            if ((rc = upload<unsigned>(h, own, gsrc.data(), gsrc.size(), &R.gi_src))) return rc;
+            R.gi_ok = 1;
+        }
+    }
+#endif
     if ((rc = rt_sync(h))) return rc;
     h->refactor_mode = true;
     h->have_update = true;
@@ -1056,6 +1133,28 @@ static cpg::DevBatch make_batch(int64_t B, const double *d_theta, const double *
 // per-instance factor kernel of handle `h` (its tables, its scratch) on `stream` with settings `S`
 static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, cpg::DevBatch &Bt) {
     const int W = 4;
+#ifdef CPG_GENI_HEADER
+    if (h->R.gi_ok && h->program_in_lds != 0) {       // generated instance executor (cpg_hip_set_program_placement(0): the streaming one)
+        const size_t tab = (size_t)(((CPG_GENI_NSTEPS + 3) / 4) * 256 + ((CPG_GENI_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
+        const size_t nq = (size_t)(h->F.n + h->F.m), per_wave = (size_t)(CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS) + nq + (nq & 1);   // work vector | q | u
+        const size_t lds = tab + (size_t)W * per_wave * sizeof(double);
+        if (lds <= h->lds_limit) {
+            int per_cu = 2;                            // 8 wavefronts per CU: the register budget of the kernel
+            if (h->blocks_per_cu > 0 && h->blocks_per_cu < per_cu) per_cu = h->blocks_per_cu;
+            if ((size_t)per_cu * lds > h->lds_limit) per_cu = (int)(h->lds_limit / lds);
+            long long blocks = (Bt.B + W - 1) / W;
+            const long long cap = (long long)h->num_cu * per_cu;
+            if (blocks > cap) blocks = cap;
+            int rc;
+            if ((rc = ensure(h->scratch, (size_t)blocks * W * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
+            Bt.scratch = (double *)h->scratch.p;
+            const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
+#define Z(a, b) if (nsx <= a && nsz <= b) return launch_instance_t<a, b>(h, stream, S, Bt, (int)blocks, W, lds);
+            CPG_KERNELS_REFACTOR(Z)
+#undef Z
+        }
+    }
+#endif
     const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
     if (lds > h->lds_limit) { set_error("work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
     int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : CPG_REFACTOR_WAVES_PER_SIMD;    // workgroups of 4 waves

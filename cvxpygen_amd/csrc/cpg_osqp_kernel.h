@@ -362,6 +362,11 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
     }
 }
 
+// work-vector slots behind the program's own that the generated executors use (see the table macros below):
+// 16 dummy store targets and one slot that always holds 0.0
+#define CPG_GEN_SLOT_MASK 0x1FFFu
+#define CPG_GEN_DUMMY_SLOTS 16
+#define CPG_GEN_EXTRA_SLOTS (CPG_GEN_DUMMY_SLOTS + 1)
 #ifdef CPG_GEN_HEADER
 // ---- family-specialised executor generated by cvxpygen_amd/codegen.py ---------------------------
 #define CPG_GEN_ZERO(A) _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) A[g_] = 0.0
@@ -430,9 +435,6 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
 // with): the store is unconditional and the whole
 // program stays one basic block.  One more slot behind them always holds 0.0: the operand of idle lanes
 // when the offsets are stored for all 64 lanes of a step (CPG_GEN_PADDED_OFFSETS).
-#define CPG_GEN_SLOT_MASK 0x1FFFu
-#define CPG_GEN_DUMMY_SLOTS 16
-#define CPG_GEN_EXTRA_SLOTS (CPG_GEN_DUMMY_SLOTS + 1)
 // the table entries of four chunks come with one LDS read (CPG_GEN_LOAD_ROWS, issued when the phase of the first
 // of them opens); CPG_GEN_ROW picks chunk C's
 #define CPG_GEN_LOAD_ROWS(Q) const OffsetQuad rq##Q = *(const OffsetQuad *)((const char *)rows + (unsigned)lane * 8u + (Q) * 512u);

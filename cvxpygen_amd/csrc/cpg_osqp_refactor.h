@@ -17,6 +17,12 @@
 
 #include "cpg_osqp_kernel.h"
 
+#ifdef CPG_GENI_HEADER
+// straight-line executor of the family's per-instance substitution program in shared-matrix mode, coefficients in
+// registers (cvxpygen_amd/codegen.py::emit_instance_program)
+#include CPG_GENI_HEADER
+#endif
+
 namespace cpg {
 
 struct DevRefactor {
@@ -48,6 +54,14 @@ struct DevRefactor {
     int shared_mats;
     const double *Ps, *As, *Ars, *Ds, *Dinvs, *Es, *Einvs;
     double cs;
+    // Generated instance executor (family libraries, shared-matrix mode; cpg_hip_set_refactor checks that the
+    // uploaded program is the one the library was generated for): operand byte offsets of all 64 lanes of every
+    // step, four steps side by side ([step / 4][lane][4]; idle lanes: the zero slot), output slot | segment mask << 13
+    // of every (chunk, lane), four chunks side by side, and per (step, lane) where the coefficient comes from
+    // (kind << 28 | index; kind 1: 1.0, 2: -L[index], 3: 1 / d[index], 0: none).
+    int gi_ok;
+    const unsigned short *gi_cols, *gi_rows;
+    const unsigned *gi_src;
 };
 
 #define CPG_K_NONE 0
@@ -119,7 +133,7 @@ CPG_DEV void for_row_entries(const int *ptr, const int *ent, const int *col, con
 }
 
 // row products with the instance's own scaled matrices (values gathered from the buffer)
-template <int NSX, int NSZ>
+template <int NSX, int NSZ, bool QUMEM = false>
 struct InstCtx {
     // check() runs the infeasibility tests itself, in OSQP's order, with the caller's lane id: on this kernel the
     // form that keeps the shared-factor kernel spill-free costs the ADMM loop its register allocation
@@ -131,19 +145,14 @@ struct InstCtx {
     const InstBuf &B;
     const double *w;
     int lane;
-#ifdef CPG_REFACTOR_QU_IN_MEMORY
-    // the instance's scaled q and u are re-read from its buffer where they are needed (experiment: their
-    // 2 (NSX + NSZ) registers against the scratch traffic of the ADMM loop)
-    CPG_DEV double q(int, unsigned i) const { return cpgw::gld((const double *)B.q, i); }
-    CPG_DEV double u(int, unsigned i) const { return cpgw::gld((const double *)B.u, i); }
-#else
-    // the instance's scaled q and u stay in registers for the whole ADMM loop (they are read in
-    // every iteration; a global load there is a full memory latency on the critical path)
+    // the instance's scaled q and u stay in registers for the whole ADMM loop (they are read in every iteration;
+    // a global load there is a full memory latency on the critical path) -- or, QUMEM, in the wavefront's LDS slice
+    // (the generated instance executor keeps its coefficients in registers and needs these 2 (NSX + NSZ) back)
     const double (&qr)[NSX];
     const double (&ur)[NSZ];
-    CPG_DEV double q(int s, unsigned) const { return qr[s]; }
-    CPG_DEV double u(int s, unsigned) const { return ur[s]; }
-#endif
+    const double *qm, *um;
+    CPG_DEV double q(int s, unsigned i) const { return QUMEM ? qm[i] : qr[s]; }
+    CPG_DEV double u(int s, unsigned i) const { return QUMEM ? um[i] : ur[s]; }
     template <bool ENT, bool OFFS, int NB = CPG_ROW_WALK_BATCH>
     CPG_DEV double row_dot(const int *ptr, const int *ent, const int *col, const double *val, unsigned r) const {
         double acc = 0.0;
@@ -268,13 +277,51 @@ CPG_DEV void substitution_values(const DevRefactor &R, const InstBuf &B, int lan
     cpgw::mem_order();
 }
 
-template <int NSX, int NSZ>
+#ifdef CPG_GENI_HEADER
+// the instance's coefficients of the generated executor, from its factor (one gather per step and lane, once per
+// factorisation: the ADMM loop then reads none)
+CPG_DEV void load_instance_coefficients(const DevRefactor &R, const InstBuf &B, double (&cf)[CPG_GENI_NSTEPS], int lane) {
+#pragma unroll
+    for (int t = 0; t < CPG_GENI_NSTEPS; t++) {
+        const unsigned code = cpgw::gld(R.gi_src, (unsigned)t * 64u + (unsigned)lane);
+        const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
+        double v = 0.0;
+        if (kind == 1u) v = 1.0;
+        else if (kind == 2u) v = -cpgw::gld((const double *)B.Lx, idx);
+        else if (kind == 3u) v = cpgw::gld((const double *)B.Dginv, idx);
+        cf[t] = v;
+    }
+}
+#endif
+
+// GENI: the substitution runs through the generated instance executor (register-resident coefficients) instead of
+// the streaming one; the launch code selects it for shared-matrix handles of a family library (R.gi_ok)
+template <int NSX, int NSZ, bool GENI = false>
 CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const DevSettings &S,
                                 const DevBatch &Bt, double *lds, int wave_global) {
     const int lane = cpgw::lane_id();
     const unsigned n = (unsigned)F0.n, m = (unsigned)F0.m, N = n + m;
+#ifdef CPG_GENI_HEADER
+    const int ldw = GENI ? CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS : R.sol_slots;
+    // block-shared copies of the executor's offset / output-slot tables in front of the work vectors
+    constexpr unsigned gi_ncols = ((CPG_GENI_NSTEPS + 3u) / 4u) * 256u, gi_nrows = ((CPG_GENI_NCHUNKS + 3u) / 4u) * 256u;
+    const unsigned short *gi_lc = nullptr, *gi_lr = nullptr;
+    if (GENI) {
+        unsigned short *lc = (unsigned short *)lds, *lr = lc + gi_ncols;
+        for (unsigned t = cpgw::thread_in_block(); t < gi_ncols; t += cpgw::block_threads()) lc[t] = cpgw::gld(R.gi_cols, t);
+        for (unsigned t = cpgw::thread_in_block(); t < gi_nrows; t += cpgw::block_threads()) lr[t] = cpgw::gld(R.gi_rows, t);
+        cpgw::block_sync();
+        gi_lc = lc; gi_lr = lr;
+        lds += (gi_ncols + gi_nrows) / 4u;
+    }
+#else
     const int ldw = R.sol_slots;
-    double *w = lds + (size_t)cpgw::wave_in_block() * ldw;
+#endif
+    // per wavefront: the work vector, and with the generated executor the instance's q and u behind it
+    const size_t per_wave = (size_t)ldw + (GENI ? (size_t)(N + (N & 1u)) : 0u);
+    double *w = lds + (size_t)cpgw::wave_in_block() * per_wave;
+    double *qs = w + ldw, *us = qs + n;
+    const bool shared = GENI || R.shared_mats != 0;      // (a literal in the generated-executor build: its kernel serves shared-matrix handles only)
     InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F0, R);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
     const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
@@ -285,7 +332,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
     for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; fpz[s] = i < m ? cpgw::gld(R.sol_fpos, n + i) : 0; }
 
     const unsigned n_work = Bt.list_count ? cpgw::sld(Bt.list_count, 0u) : 0u;   // written by the kernel in front of this one
-    if (R.shared_mats) {     // the family's matrices serve every instance
+    if (shared) {     // the family's matrices serve every instance
         B.P = const_cast<double *>(R.Ps); B.A = const_cast<double *>(R.As); B.Ar = const_cast<double *>(R.Ars);
         B.D = const_cast<double *>(R.Ds); B.Dinv = const_cast<double *>(R.Dinvs);
         B.E = const_cast<double *>(R.Es); B.Einv = const_cast<double *>(R.Einvs);
@@ -313,7 +360,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
         // ---- 1. canonicalise (unscaled; scaled in shared-matrix mode): P, A values, q, u, d
-        if (!R.shared_mats) {
+        if (!shared) {
             for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) cpgw::gst(B.A, k, csr_row(R.map_A, k, theta, cpgw::gld(R.A_base, k)));
             for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) cpgw::gst(B.P, k, csr_row(R.map_P, k, theta, cpgw::gld(R.P_base, k)));
         }
@@ -321,8 +368,8 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         for (unsigned i = (unsigned)lane; i < m; i += 64u) cpgw::gst(B.u, i, csr_row(R.map_u, i, theta, cpgw::gld(R.u_base, i)));
         const double dconst = csr_row(R.map_d, 0, theta, R.d_base);
         cpgw::mem_order();
-        double cs = R.shared_mats ? R.cs : 1.0;
-        if (!R.shared_mats) {
+        double cs = shared ? R.cs : 1.0;
+        if (!shared) {
 #ifdef CPG_REFACTOR_ROW_COPY
             refresh_row_copy(R, B, lane);            // unscaled A in row order: the row walks of the equilibration sweeps
 #endif
@@ -407,7 +454,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             ct[s] = 0;
             if (i < m) {
                 double uu = cpgw::gld((const double *)B.u, i);      // shared-matrix mode: already E u
-                if (!R.shared_mats) {
+                if (!shared) {
                     const double ei = w[n + i];
                     uu = ei * uu;
                     cpgw::gst(B.E, i, ei); cpgw::gst(B.Einv, i, 1.0 / ei); cpgw::gst(B.u, i, uu);
@@ -422,6 +469,17 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 
         // ---- 4. numeric LDL' through the dot-product schedule, 5. coefficients of the substitution program
         numeric_ldl(R, B, F0.sigma, lane);
+#ifdef CPG_GENI_HEADER
+        double cf[CPG_GENI_NSTEPS];          // (dead, hence free, in the streaming instantiation)
+        if (GENI) {
+            cpgw::mem_order();
+            load_instance_coefficients(R, B, cf, lane);
+            // idle lanes of a step gather the zero slot, idle lanes of a chunk store to the dummy slots behind the
+            // program's own: everything starts finite
+            for (unsigned t = (unsigned)lane; t < (unsigned)ldw; t += 64u) w[t] = 0.0;
+            cpgw::lds_order();
+        } else
+#endif
         substitution_values(R, B, lane);
 
         // ---- 6. ADMM from cold start with the instance's own factor
@@ -430,16 +488,22 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         StreamProg ST;
         ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
         ST.n_pairs = R.sol_pairs; ST.dummy = (unsigned)R.sol_nnz / 2u - 1u;
-#ifdef CPG_REFACTOR_QU_IN_MEMORY
-        const InstCtx<NSX, NSZ> cx{F, R, B, w, lane};
-#else
+        typedef InstCtx<NSX, NSZ, GENI> CtxT;
         double qr[NSX], ur[NSZ];
 #pragma unroll
-        for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qr[s] = i < n ? cpgw::gld((const double *)B.q, i) : 0.0; }
+        for (int s = 0; s < NSX; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            qr[s] = i < n ? cpgw::gld((const double *)B.q, i) : 0.0;
+            if (GENI && i < n) qs[i] = qr[s];
+        }
 #pragma unroll
-        for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; ur[s] = i < m ? cpgw::gld((const double *)B.u, i) : 0.0; }
-        const InstCtx<NSX, NSZ> cx{F, R, B, w, lane, qr, ur};
-#endif
+        for (int s = 0; s < NSZ; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            ur[s] = i < m ? cpgw::gld((const double *)B.u, i) : 0.0;
+            if (GENI && i < m) us[i] = ur[s];
+        }
+        cpgw::lds_order();
+        const CtxT cx{F, R, B, w, lane, qr, ur, qs, us};
         double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
         for (int s = 0; s < NSX; s++) x[s] = 0.0;
@@ -468,12 +532,16 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 if (i < m) w[n + i] = z[s] - ri * y[s];
             }
             cpgw::lds_order();
+#ifdef CPG_GENI_HEADER
+            if (GENI) run_program_inst(cf, gi_lc, gi_lr, w, lane);
+            else
+#endif
             run_program_stream(ST, w, lane);
 #pragma unroll
             for (int s = 0; s < NSX; s++) {
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;
                 if (i < n) {
-                    const double xn = F.alpha * w[fpx[s]] + (1.0 - F.alpha) * x[s];
+                    const double xn = F.alpha * w[GENI ? i : (unsigned)fpx[s]] + (1.0 - F.alpha) * x[s];     // (generated program: solved in place)
                     if (chk) dxr[s] = xn - x[s];
                     x[s] = xn;
                 }
@@ -485,7 +553,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                     const double rv = ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr);
                     const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
                     const double zp = z[s], yp = y[s];
-                    const double zt = (zp - ri * yp) + ri * w[fpz[s]];
+                    const double zt = (zp - ri * yp) + ri * w[GENI ? n + i : (unsigned)fpz[s]];
                     const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
                     const double uu = cx.u(s, i);
                     const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
@@ -517,14 +585,14 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             ScaledNorms sn;
             bool have_info = false;
             if (can_check) {
-                o = check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
+                o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
                 have_info = true;
                 if (o.status != 11) break;
             }
             if (adapt) {
                 // adapt_rho (OSQP paper sec. 5.2): rho <- rho sqrt(normalised primal / dual residual); a new
                 // factorisation only when it changed by more than adaptive_rho_tolerance
-                if (!have_info) (void)check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
+                if (!have_info) (void)check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
                 const double rn = rho_estimate(sn, rho_stg);
                 if (rn > rho_stg * S.adaptive_rho_tolerance || rn < rho_stg / S.adaptive_rho_tolerance) {
                     rho = rn; rho_stg = rn; rho_eq = 1e3 * rho; rho_in = rho; ri_eq = 1.0 / rho_eq; ri_in = 1.0 / rho_in;
@@ -535,12 +603,16 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                     }
                     cpgw::mem_order();
                     numeric_ldl(R, B, F0.sigma, lane);
+#ifdef CPG_GENI_HEADER
+                    if (GENI) { cpgw::mem_order(); load_instance_coefficients(R, B, cf, lane); }
+                    else
+#endif
                     substitution_values(R, B, lane);
                 }
             }
             if (last) {
-                if (!can_check) o = check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false);
-                if (o.status == 11) o = check<NSX, NSZ, InstCtx<NSX, NSZ>, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, true);
+                if (!can_check) o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false);
+                if (o.status == 11) o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, true);
                 if (o.status == 11) o.status = 7;
             }
         }
