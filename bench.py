@@ -190,6 +190,8 @@ def main():
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: leave the final gather out of the timed steps')
     ap.add_argument('--no-wall', action='store_true', help='skip the PCIe-inclusive pipelined measurement')
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
+    ap.add_argument('--instance-executor', choices=['auto', 'stream', 'generated'], default='auto',
+                    help='experiments: executor of the per-instance factor kernel behind the shared-factor one (family libraries)')
     ap.add_argument('--rccl-lib', default='librccl.so', help='RCCL library of the result gather (CPU tier: the recording stand-in of tests/sim/fake_rccl)')
     args = ap.parse_args()
 
@@ -252,6 +254,8 @@ def main():
     else:
         solver.set_updated(['x_init'])
         theta = make_theta(desc, B, seed=1000 + rank)
+    if args.instance_executor == 'stream' and desc.solver == 'OSQP' and getattr(solver, 'h_rs', None) is not None and solver.h_rs.value:
+        solver.lib.check(solver.lib.L.cpg_hip_set_program_placement(solver.h_rs, 0), 'set_program_placement')
     stg = {}
     if args.max_iter:
         stg['max_iter'] = args.max_iter

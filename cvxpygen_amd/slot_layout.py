@@ -76,6 +76,24 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
     scripts/micro/lds_conflicts.hip: a ds_write_b64 costs the sum over its four lane groups of the largest number
     of distinct slots on one bank pair."""
     n = region.shape[0]
+    # the result is a pure function of the arguments: cached on disk (next to the generated family libraries), so
+    # that constructing a solver for a family that was laid out before does not anneal again
+    import hashlib
+    import os
+    hsh = hashlib.sha256()
+    for a_ in (np.ascontiguousarray(step_slots, dtype=np.int64), np.ascontiguousarray(region, dtype=np.int64),
+               np.asarray([sweeps, seed, BANK_PAIRS, STORE_BANK_PAIRS], dtype=np.int64),
+               *[np.ascontiguousarray(g_, dtype=np.int64) for g_ in stores]):
+        hsh.update(a_.tobytes()); hsh.update(b'|')
+    cdir = os.environ.get('CPG_LAYOUT_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'generated', '.layout_cache'))
+    cfile = os.path.join(cdir, hsh.hexdigest()[:32] + '.npy')
+    if os.path.exists(cfile):
+        try:
+            rec = np.load(cfile)
+            if rec.shape == (n + 2,):
+                return rec[2:].astype(np.int64), int(rec[0]), int(rec[1])
+        except (OSError, ValueError):
+            pass
     rng = np.random.default_rng(seed)
     groups = gather_groups(step_slots)
     mods = [BANK_PAIRS] * len(groups) + [STORE_BANK_PAIRS] * len(stores)
@@ -98,6 +116,7 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
     members = [m for m in members if len(m) > 1]
     used = np.array([len(o) > 0 for o in occ])
     cost = cost0
+    best_cost, best_pi = cost0, pi.copy()        # the annealer wanders: what it returns is the best numbering it SAW
     n_moves = sweeps * int(used.sum())
     T0, T1 = 1.0, 0.05
     for it in range(n_moves):
@@ -128,5 +147,16 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
             gmax[aff] = new_max
             pi[a], pi[b] = pi[b], pi[a]
             cost += delta
+            if cost < best_cost:
+                best_cost, best_pi = cost, pi.copy()
     assert cost == conflict_cycles(groups, pi, mods)
-    return pi, cost0, cost
+    # never worse than the natural numbering (identity when nothing better was seen)
+    assert best_cost == conflict_cycles(groups, best_pi, mods) and best_cost <= cost0
+    try:
+        os.makedirs(cdir, exist_ok=True)
+        tmp = cfile + f'.{os.getpid()}.tmp.npy'
+        np.save(tmp, np.concatenate([[cost0, best_cost], best_pi]).astype(np.int64))
+        os.replace(tmp, cfile)
+    except OSError:
+        pass
+    return best_pi, cost0, best_cost

@@ -90,7 +90,62 @@ def test_generate_code_and_solve_method_cpg_osqp(oracle_lib, tmp_path):
     sol, info = mod.forward([p.value for p in prob.parameters()], ctx)
     ctx.info = info
     grads, _ = mod.backward([np.array([0.1, 0.1])], ctx)
-    assert len(sol) == 1 and len(grads) == 2 and all(np.isfinite(np.ravel(g)).all() for g in grads)
+    assert len(sol) == 1 and len(grads) == 2
+    # forward = one more cpg_solve on the static workspace (warm start from the previous call); backward = the
+    # adjoint at THAT solution, checked against the oracle's adjoint like cpg_gradient above
+    go2 = oracle_lib.qp_adjoint(d, d.canon_at(th), np.array(info['gradient_primal']), np.array(info['gradient_dual']), wts)
+    for p_, g in zip(prob.parameters(), grads):
+        q = d.param(p_.name())
+        ref = go2['dtheta'][q.col:q.col + q.size]
+        assert np.abs(np.ravel(g) - ref).max() <= REL_TOL * np.abs(go2['dtheta']).max() + 1e-12
+    assert np.abs(np.asarray(sol[0]) - np.asarray(info['gradient_primal'])[xi]).max() == 0.0
+
+
+@pytest.mark.parametrize('fam,B', [('nonneg_LS', 300), ('mpc6', 256)])
+def test_batched_forward_backward_on_gpu(oracle_lib, tmp_path, fam, B):
+    """row (f)3: cvxpylayers' custom_method protocol (templates/cpg_solver.py.jinja2:176-212) with a leading batch
+    axis on the parameters -- ONE batched solve and ONE batched adjoint on the GPU against the oracle, instance
+    by instance: forward = oracle.cpg_solve_batch, backward = oracle.qp_adjoint at that solution"""
+    d = families.nonneg_ls() if fam == 'nonneg_LS' else families.mpc(6, 3, 10)
+    prob = LiteProblem.from_descriptor(d)
+    mod = cpg.generate_code(prob, code_dir=str(tmp_path / f'fb_{fam}'), solver='OSQP', gradient=True, wrapper=True)
+    rng = np.random.default_rng(55)
+    if fam == 'nonneg_LS':
+        vals = {'A': rng.standard_normal((B, 3)), 'b': rng.standard_normal((B, 3))}
+        stg = dict(eps_abs=1e-9, eps_rel=1e-9)
+    else:
+        vals = {'x_init': -2 + 4 * rng.random((B, 6))}
+        stg = dict(eps_abs=1e-7, eps_rel=1e-7)
+    for p_ in prob.parameters():
+        p_.id = id(p_)
+    plist = [p_ for p_ in prob.parameters() if p_.name() in vals]
+    ctx = SimpleNamespace(solver_args={'problem': prob, **stg}, param_ids=[p_.id for p_ in plist],
+                          variables=prob.variables(), info=None)
+    sol, info = mod.forward([vals[p_.name()] for p_ in plist], ctx)
+    assert info['batched'] and (info['status'] == 1).all()
+    th = np.tile(d.theta0, (B, 1))
+    for nm, v in vals.items():
+        q = d.param(nm)
+        th[:, q.col:q.col + q.size] = v
+    o = oracle_lib.cpg_solve_batch(d, th, list(vals), **stg)
+    assert info['iter'].tolist() == o['iter'].tolist()
+    for var, sv in zip(ctx.variables, sol):
+        v = next(x for x in d.variables if x.name == var.name())
+        ref = o['sol_x'][:, v.indices]
+        got = np.asarray(sv).reshape(B, -1) if len(v.shape) <= 1 else np.asarray(sv).transpose(0, 2, 1).reshape(B, -1)
+        assert np.abs(got - ref).max() <= REL_TOL * np.abs(ref).max()
+    ctx.info = info
+    ups = [0.1 * np.ones((B,) + tuple(var.shape)) for var in ctx.variables]       # 0.1 * sol.sum(), tests/test_diff.py:38
+    grads, _ = mod.backward(ups, ctx)
+    wts = np.zeros(d.n_var)
+    for v in d.variables:
+        wts[v.indices] = 0.1
+    for k in range(0, B, 16):
+        go = oracle_lib.qp_adjoint(d, d.canon_at(th[k]), info['gradient_primal'][k], info['gradient_dual'][k], wts)
+        for p_, g in zip(plist, grads):
+            q = d.param(p_.name())
+            ref = go['dtheta'][q.col:q.col + q.size]
+            assert np.abs(np.ravel(g[k]) - ref).max() <= REL_TOL * np.abs(go['dtheta']).max() + 1e-12, (fam, k, p_.name())
 
 
 def test_generate_code_and_solve_method_cpg_clarabel(tmp_path):
