@@ -942,10 +942,12 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if ((rc = upload<double>(h, own, r->E, m, &R.Es))) return rc;
         if ((rc = upload<double>(h, own, einv.data(), m, &R.Einvs))) return rc;
     }
-    R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr;
+    R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_lcol = nullptr; R.fac_kc = nullptr; R.fac_krow = nullptr;
 #ifdef CPG_GENI_HEADER
-    std::vector<unsigned short> gcols, grows;                     // alive until the sync below
+    std::vector<unsigned short> gcols, grows, glcol;              // alive until the sync below
     std::vector<unsigned> gsrc;
+    std::vector<double> fkc;
+    std::vector<int> fkrow;
     if (r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
         unsigned hsh = 0x811C9DC5u;
         auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = (const unsigned char *)p;
@@ -959,6 +961,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
             const int T4 = (CPG_GENI_NSTEPS + 3) & ~3, C4 = (CPG_GENI_NCHUNKS + 3) & ~3;
             gcols.assign((size_t)T4 * 64, (unsigned short)zero_off);
             gsrc.assign((size_t)CPG_GENI_NSTEPS * 64, 0u);
+            glcol.assign((size_t)CPG_GENI_NSTEPS * 64, (unsigned short)0);
             for (int t = 0; ok && t < CPG_GENI_NSTEPS; t++) {
                 const int e = steps[t][0], cnt = steps[t][1];
                 if (e < 0 || cnt < 0 || cnt > 64 || e + cnt > r->sol_nnz) { ok = false; break; }
@@ -967,6 +970,10 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                     const int kind = r->sol_kind[e + l], idx = r->sol_idx[e + l];
                     if (kind < 0 || kind > 3 || idx < 0 || idx >= (1 << 28)) { ok = false; break; }
                     gsrc[(size_t)t * 64 + l] = ((unsigned)kind << 28) | (unsigned)idx;
+                    if (kind == 2) {
+                        if (idx >= r->nnzL || r->Lcol[idx] < 0 || r->Lcol[idx] > 0xFFFF) { ok = false; break; }
+                        glcol[(size_t)t * 64 + l] = (unsigned short)r->Lcol[idx];
+                    }
                 }
             }
             grows.assign((size_t)C4 * 64, (unsigned short)r->sol_slots);
@@ -989,7 +996,23 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                 }
             }
         }
+        if (ok) {   // KKT values of the factorisation's destinations: constants of the family, except -1 / rho_vec
+            const size_t nd = (size_t)r->nnzL + N;
+            fkc.assign(nd, 0.0); fkrow.assign(nd, -1);
+            for (size_t d = 0; ok && d < nd; d++) {
+                const int kind = r->ksrc_kind[d], idx = r->ksrc_idx[d];
+                const bool piv = d >= (size_t)r->nnzL;
+                if (kind == CPG_K_P) { if (idx < 0 || idx >= r->nnzP) ok = false; else fkc[d] = r->Ps[idx] + (piv ? h->F.sigma : 0.0); }
+                else if (kind == CPG_K_A) { if (idx < 0 || idx >= r->nnzA) ok = false; else fkc[d] = r->As[idx]; }
+                else if (kind == CPG_K_SIGMA) fkc[d] = h->F.sigma;
+                else if (kind == CPG_K_RHO) { if (idx < 0 || (size_t)idx >= m) ok = false; else fkrow[d] = idx; }
+                else if (kind != CPG_K_NONE) ok = false;
+            }
+        }
         if (ok) {
+            if ((rc = upload<double>(h, own, fkc.data(), fkc.size(), &R.fac_kc))) return rc;
+            if ((rc = upload<int>(h, own, fkrow.data(), fkrow.size(), &R.fac_krow))) return rc;
+            if ((rc = upload<unsigned short>(h, own, glcol.data(), glcol.size(), &R.gi_lcol))) return rc;
             if ((rc = upload<unsigned short>(h, own, gcols.data(), gcols.size(), &R.gi_cols))) return rc;
             if ((rc = upload<unsigned short>(h, own, grows.data(), grows.size(), &R.gi_rows))) return rc;
             if ((rc = upload<unsigned>(h, own, gsrc.data(), gsrc.size(), &R.gi_src))) return rc;
@@ -1136,7 +1159,10 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
 #ifdef CPG_GENI_HEADER
     if (h->R.gi_ok && h->program_in_lds != 0) {       // generated instance executor (cpg_hip_set_program_placement(0): the streaming one)
         const size_t tab = (size_t)(((CPG_GENI_NSTEPS + 3) / 4) * 256 + ((CPG_GENI_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
-        const size_t nq = (size_t)(h->F.n + h->F.m), per_wave = (size_t)(CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS) + nq + (nq & 1);   // work vector | q | u
+        const size_t nq = (size_t)(h->F.n + h->F.m);
+        size_t per_wave = (size_t)(CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS) + nq + (nq & 1);   // work vector | q | u ...
+        const size_t fac = (size_t)h->R.nnzL + nq;                                            // ... or the factor while it is computed
+        if (per_wave < fac) per_wave = fac + (fac & 1);
         const size_t lds = tab + (size_t)W * per_wave * sizeof(double);
         if (lds <= h->lds_limit) {
             int per_cu = 2;                            // 8 wavefronts per CU: the register budget of the kernel
@@ -1426,11 +1452,27 @@ int cpg_hip_solve_batches_pipelined(cpg_handle_t h, int64_t B, int32_t n_batches
     int rc = rt_set_device(h->device);
     if (rc) return rc;
     if (!h->pipe) {
-        h->pipe = new cpg_pipe_s();
-        RT_CHECK(hipStreamCreateWithFlags(&h->pipe->copy_in, hipStreamNonBlocking));
-        RT_CHECK(hipStreamCreateWithFlags(&h->pipe->copy_out, hipStreamNonBlocking));
-        for (auto &s : h->pipe->set) { RT_CHECK(hipEventCreate(&s.in_done)); RT_CHECK(hipEventCreate(&s.k_done)); RT_CHECK(hipEventCreate(&s.out_done)); }
-        h->pipe->ready = true;
+        // built aside and published only when every stream / event exists: a failed create must not leave a
+        // half-initialised pipe behind for the next call
+        cpg_pipe_s *np_ = new cpg_pipe_s();
+        bool ok = hipStreamCreateWithFlags(&np_->copy_in, hipStreamNonBlocking) == hipSuccess;
+        const bool in_ok = ok;
+        const bool out_ok = ok && hipStreamCreateWithFlags(&np_->copy_out, hipStreamNonBlocking) == hipSuccess;
+        ok = out_ok;
+        int n_ev = 0;
+        hipEvent_t *evs[6] = {&np_->set[0].in_done, &np_->set[0].k_done, &np_->set[0].out_done,
+                              &np_->set[1].in_done, &np_->set[1].k_done, &np_->set[1].out_done};
+        for (; ok && n_ev < 6; n_ev++) ok = hipEventCreate(evs[n_ev]) == hipSuccess;
+        if (!ok) {
+            for (int k = 0; k < n_ev - 1; k++) hipEventDestroy(*evs[k]);
+            if (out_ok) hipStreamDestroy(np_->copy_out);
+            if (in_ok) hipStreamDestroy(np_->copy_in);
+            delete np_;
+            set_error("cpg_hip_solve_batches_pipelined: could not create the copy streams / events");
+            return CPG_E_HIP;
+        }
+        np_->ready = true;
+        h->pipe = np_;
     }
     cpg_pipe_s &P = *h->pipe;
     const size_t b = (size_t)B, np_ = (size_t)h->F.n_prim, nd = (size_t)h->F.n_dual;
@@ -1449,7 +1491,10 @@ int cpg_hip_solve_batches_pipelined(cpg_handle_t h, int64_t B, int32_t n_batches
         rc = cpg_hip_solve_batch_device_state(h, B, (const double *)s.theta.p, nullptr, nullptr, (double *)s.prim.p, (double *)s.dual.p,
                                               (double *)s.obj.p, (int32_t *)s.iter.p, (int32_t *)s.status.p, (double *)s.pri.p,
                                               (double *)s.dua.p);
-        if (rc) return rc;
+        if (rc) {   // batches already queued copy into the caller's buffers: let them finish before handing the error back
+            hipStreamSynchronize(P.copy_in); hipStreamSynchronize(h->stream); hipStreamSynchronize(P.copy_out);
+            return rc;
+        }
         RT_CHECK(hipEventRecord(s.k_done, h->stream));
         RT_CHECK(hipStreamWaitEvent(P.copy_out, s.k_done, 0));
         RT_CHECK(hipMemcpyAsync(prim + o * np_, s.prim.p, b * np_ * 8, hipMemcpyDeviceToHost, P.copy_out));

@@ -62,6 +62,11 @@ struct DevRefactor {
     int gi_ok;
     const unsigned short *gi_cols, *gi_rows;
     const unsigned *gi_src;
+    const unsigned short *gi_lcol;      // [step][lane] column of the L entry behind a kind-2 coefficient
+    // shared-matrix mode: the KKT value of every destination of the factorisation is a family constant (fac_kc; sigma
+    // included on the pivots) except the -1 / rho_vec of the (2,2) diagonal: fac_krow = its row, -1 elsewhere
+    const double *fac_kc;
+    const int *fac_krow;
 };
 
 #define CPG_K_NONE 0
@@ -278,17 +283,84 @@ CPG_DEV void substitution_values(const DevRefactor &R, const InstBuf &B, int lan
 }
 
 #ifdef CPG_GENI_HEADER
-// the instance's coefficients of the generated executor, from its factor (one gather per step and lane, once per
-// factorisation: the ADMM loop then reads none)
-CPG_DEV void load_instance_coefficients(const DevRefactor &R, const InstBuf &B, double (&cf)[CPG_GENI_NSTEPS], int lane) {
+// Numeric LDL' of shared-matrix mode with the factor in the wavefront's LDS slice (Ml [nnzL] | Dil [N]): the same
+// dot-product schedule as numeric_ldl, in the form that needs ONE dependent step per level of the elimination tree
+// instead of two -- the entries of a column are kept UNDIVIDED (M_ij = l_ij d_j = K_ij - sum_k M_ik M_jk / d_k), so
+// they do not wait for their column's pivot; what is stored per pivot is 1 / d_j.  Every operand of the dependent
+// chain is an LDS read; the schedule's index tables (shared, L2) and the constant part of the KKT values do not
+// depend on the factor and are requested one batch / one chunk ahead.  The instances of a shared-matrix batch
+// differ in rho only: this is the whole per-instance cost of a rho change (config 2: ~ 9 of the 14 ms the
+// per-instance phase spent outside its iterations were the global-memory round trips of the generic version).
+CPG_DEV void numeric_ldl_lds(const DevRefactor &R, double *Ml, double *Dil, const double *rinv, int lane) {
+    constexpr int NB = CPG_LDL_BATCH;
+    // header of the first chunk; the next one is requested while a chunk runs
+    int hL = cpgw::gld(R.fac_ctab, 0u), hlast = cpgw::gld(R.fac_ctab, 1u), hbase = cpgw::gld(R.fac_ctab, 2u), hlg = cpgw::gld(R.fac_ctab, 3u);
+    unsigned htask = cpgw::gld(R.fac_task, (unsigned)lane), hlw = cpgw::gld(R.fac_len, (unsigned)lane);
+#pragma nounroll
+    for (int c = 0; c < R.fac_chunks; c++) {
+        const int L = cpgw::read_first_lane(hL), last = cpgw::read_first_lane(hlast), lg = cpgw::read_first_lane(hlg);
+        unsigned base = (unsigned)cpgw::read_first_lane(hbase);
+        const unsigned task = htask, lw = hlw;
+        if (c + 1 < R.fac_chunks) {
+            const unsigned c1 = (unsigned)(c + 1);
+            hL = cpgw::gld(R.fac_ctab, 4u * c1); hlast = cpgw::gld(R.fac_ctab, 4u * c1 + 1u);
+            hbase = cpgw::gld(R.fac_ctab, 4u * c1 + 2u); hlg = cpgw::gld(R.fac_ctab, 4u * c1 + 3u);
+            htask = cpgw::gld(R.fac_task, c1 * 64u + (unsigned)lane); hlw = cpgw::gld(R.fac_len, c1 * 64u + (unsigned)lane);
+        }
+        // KKT value of this lane's destination: constant part + the instance's -1 / rho_vec where it enters
+        const bool has = task != 0xFFFFFFFFu;
+        const double kc = has ? cpgw::gld(R.fac_kc, task) : 0.0;
+        const int krow = has ? cpgw::gld(R.fac_krow, task) : -1;
+        const double kr = krow >= 0 ? cpgw::gld(rinv, (unsigned)krow) : 0.0;
+        const int len = (int)(lw & 0xFFFFu), rlen = (int)(lw >> 16);
+        double acc = 0.0;
+        unsigned ia[NB], ib[NB], ik[NB];
+        auto load_indices = [&](int s0, unsigned (&xa)[NB], unsigned (&xb)[NB], unsigned (&xk)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+                const bool on = s0 + t < len;
+                const unsigned e = on ? base + (unsigned)lane : 0u;
+                base += cpgw::popc64(cpgw::ballot(on));
+                xa[t] = cpgw::gld(R.fac_a, e); xb[t] = cpgw::gld(R.fac_b, e); xk[t] = cpgw::gld(R.fac_k, e);
+            }
+        };
+        load_indices(0, ia, ib, ik);
+#pragma nounroll
+        for (int s = 0; s < L; s += NB) {
+            double la[NB], lb[NB], dk[NB];
+#pragma unroll
+            for (int t = 0; t < NB; t++) { la[t] = Ml[ia[t]]; lb[t] = Ml[ib[t]]; dk[t] = Dil[ik[t]]; }
+            unsigned na[NB], nb[NB], nk[NB];
+            if (s + NB < L) load_indices(s + NB, na, nb, nk);   // uniform
+#pragma unroll
+            for (int t = 0; t < NB; t++)
+                if (s + t < rlen) acc = fma(la[t] * dk[t], lb[t], acc);
+#pragma unroll
+            for (int t = 0; t < NB; t++) { ia[t] = na[t]; ib[t] = nb[t]; ik[t] = nk[t]; }
+        }
+        acc = cpgw::group_sum_first_dyn(acc, lg);
+        if (has) {
+            const double v = (kc - kr) - acc;
+            if (task >= (unsigned)R.nnzL) Dil[task - (unsigned)R.nnzL] = 1.0 / v;
+            else Ml[task] = v;
+        }
+        if (last) cpgw::lds_order();     // level complete: the next one reads what this one stored
+    }
+    cpgw::lds_order();
+}
+
+// the instance's coefficients of the generated executor, from its factor in LDS (one gather per step and lane, once
+// per factorisation: the ADMM loop then reads none): -l_ij = -M_ij / d_j, 1 / d_i, or 1
+CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, const double *Dil, double (&cf)[CPG_GENI_NSTEPS], int lane) {
 #pragma unroll
     for (int t = 0; t < CPG_GENI_NSTEPS; t++) {
         const unsigned code = cpgw::gld(R.gi_src, (unsigned)t * 64u + (unsigned)lane);
+        const unsigned col = cpgw::gld(R.gi_lcol, (unsigned)t * 64u + (unsigned)lane);
         const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
         double v = 0.0;
         if (kind == 1u) v = 1.0;
-        else if (kind == 2u) v = -cpgw::gld((const double *)B.Lx, idx);
-        else if (kind == 3u) v = cpgw::gld((const double *)B.Dginv, idx);
+        else if (kind == 2u) v = -(Ml[idx] * Dil[col]);
+        else if (kind == 3u) v = Dil[idx];
         cf[t] = v;
     }
 }
@@ -317,8 +389,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 #else
     const int ldw = R.sol_slots;
 #endif
-    // per wavefront: the work vector, and with the generated executor the instance's q and u behind it
-    const size_t per_wave = (size_t)ldw + (GENI ? (size_t)(N + (N & 1u)) : 0u);
+    // per wavefront: the work vector, and with the generated executor the instance's q and u behind it; the same
+    // slice holds the factor (M [nnzL] | 1 / d [N]) while numeric_ldl_lds runs -- nothing in it is live then
+    size_t per_wave = (size_t)ldw + (GENI ? (size_t)(N + (N & 1u)) : 0u);
+    if (GENI && per_wave < (size_t)R.nnzL + N) per_wave = (size_t)R.nnzL + N + (((size_t)R.nnzL + N) & 1u);
     double *w = lds + (size_t)cpgw::wave_in_block() * per_wave;
     double *qs = w + ldw, *us = qs + n;
     const bool shared = GENI || R.shared_mats != 0;      // (a literal in the generated-executor build: its kernel serves shared-matrix handles only)
@@ -468,19 +542,24 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         cpgw::mem_order();
 
         // ---- 4. numeric LDL' through the dot-product schedule, 5. coefficients of the substitution program
-        numeric_ldl(R, B, F0.sigma, lane);
 #ifdef CPG_GENI_HEADER
         double cf[CPG_GENI_NSTEPS];          // (dead, hence free, in the streaming instantiation)
-        if (GENI) {
-            cpgw::mem_order();
-            load_instance_coefficients(R, B, cf, lane);
-            // idle lanes of a step gather the zero slot, idle lanes of a chunk store to the dummy slots behind the
-            // program's own: everything starts finite
-            for (unsigned t = (unsigned)lane; t < (unsigned)ldw; t += 64u) w[t] = 0.0;
+        auto factor_in_lds = [&]() __attribute__((always_inline)) {
+            cpgw::mem_order();                // B.rinv
+            numeric_ldl_lds(R, w, w + R.nnzL, (const double *)B.rinv, lane);
+            load_instance_coefficients(R, w, w + R.nnzL, cf, lane);
             cpgw::lds_order();
-        } else
+            // the slice goes back to its ADMM use: idle lanes of a step gather the zero slot, idle lanes of a chunk
+            // store to the dummy slots behind the program's own (everything starts finite); q and u of the instance
+            for (unsigned t = (unsigned)lane; t < (unsigned)ldw; t += 64u) w[t] = 0.0;
+            for (unsigned i = (unsigned)lane; i < n; i += 64u) qs[i] = cpgw::gld((const double *)B.q, i);
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
+            cpgw::lds_order();
+        };
+        if (GENI) factor_in_lds();
+        else
 #endif
-        substitution_values(R, B, lane);
+        { numeric_ldl(R, B, F0.sigma, lane); substitution_values(R, B, lane); }
 
         // ---- 6. ADMM from cold start with the instance's own factor
         DevFamily F = F0;
@@ -494,15 +573,12 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         for (int s = 0; s < NSX; s++) {
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
             qr[s] = i < n ? cpgw::gld((const double *)B.q, i) : 0.0;
-            if (GENI && i < n) qs[i] = qr[s];
         }
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
             ur[s] = i < m ? cpgw::gld((const double *)B.u, i) : 0.0;
-            if (GENI && i < m) us[i] = ur[s];
         }
-        cpgw::lds_order();
         const CtxT cx{F, R, B, w, lane, qr, ur, qs, us};
         double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
@@ -602,12 +678,11 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                         if (i < m) cpgw::gst(B.rinv, i, ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr));
                     }
                     cpgw::mem_order();
-                    numeric_ldl(R, B, F0.sigma, lane);
 #ifdef CPG_GENI_HEADER
-                    if (GENI) { cpgw::mem_order(); load_instance_coefficients(R, B, cf, lane); }
+                    if (GENI) factor_in_lds();
                     else
 #endif
-                    substitution_values(R, B, lane);
+                    { numeric_ldl(R, B, F0.sigma, lane); substitution_values(R, B, lane); }
                 }
             }
             if (last) {
