@@ -272,7 +272,7 @@ static int launch_refactor_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevS
 // the same body with the generated instance executor: a lane keeps its CPG_GENI_NSTEPS coefficients in registers
 // for the whole ADMM loop, so the budget is the 256 VGPRs of two wavefronts per SIMD
 template <int NSX, int NSZ>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512, 2)
 osqp_instance_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -943,11 +943,28 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if ((rc = upload<double>(h, own, einv.data(), m, &R.Einvs))) return rc;
     }
     R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_lcol = nullptr; R.fac_kc = nullptr; R.fac_krow = nullptr;
-#ifdef CPG_GENI_HEADER
-    std::vector<unsigned short> gcols, grows, glcol;              // alive until the sync below
-    std::vector<unsigned> gsrc;
-    std::vector<double> fkc;
+    std::vector<double> fkc;                                      // alive until the sync below
     std::vector<int> fkrow;
+    if (r->shared_mats) {   // KKT values of the factorisation's destinations: constants of the family, except -1 / rho_vec
+        bool ok = true;
+        const size_t nd = (size_t)r->nnzL + N;
+        fkc.assign(nd, 0.0); fkrow.assign(nd, -1);
+        for (size_t d = 0; ok && d < nd; d++) {
+            const int kind = r->ksrc_kind[d], idx = r->ksrc_idx[d];
+            const bool piv = d >= (size_t)r->nnzL;
+            if (kind == CPG_K_P) { if (idx < 0 || idx >= r->nnzP) ok = false; else fkc[d] = r->Ps[idx] + (piv ? h->F.sigma : 0.0); }
+            else if (kind == CPG_K_A) { if (idx < 0 || idx >= r->nnzA) ok = false; else fkc[d] = r->As[idx]; }
+            else if (kind == CPG_K_SIGMA) fkc[d] = h->F.sigma;
+            else if (kind == CPG_K_RHO) { if (idx < 0 || (size_t)idx >= m) ok = false; else fkrow[d] = idx; }
+            else if (kind != CPG_K_NONE) ok = false;
+        }
+        if (!ok) { set_error("cpg_hip_set_refactor: KKT source table out of range"); return CPG_E_BADARG; }
+        if ((rc = upload<double>(h, own, fkc.data(), fkc.size(), &R.fac_kc))) return rc;
+        if ((rc = upload<int>(h, own, fkrow.data(), fkrow.size(), &R.fac_krow))) return rc;
+    }
+#ifdef CPG_GENI_HEADER
+    std::vector<unsigned short> gcols, grows, glcol;
+    std::vector<unsigned> gsrc;
     if (r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
         unsigned hsh = 0x811C9DC5u;
         auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = (const unsigned char *)p;
@@ -996,22 +1013,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                 }
             }
         }
-        if (ok) {   // KKT values of the factorisation's destinations: constants of the family, except -1 / rho_vec
-            const size_t nd = (size_t)r->nnzL + N;
-            fkc.assign(nd, 0.0); fkrow.assign(nd, -1);
-            for (size_t d = 0; ok && d < nd; d++) {
-                const int kind = r->ksrc_kind[d], idx = r->ksrc_idx[d];
-                const bool piv = d >= (size_t)r->nnzL;
-                if (kind == CPG_K_P) { if (idx < 0 || idx >= r->nnzP) ok = false; else fkc[d] = r->Ps[idx] + (piv ? h->F.sigma : 0.0); }
-                else if (kind == CPG_K_A) { if (idx < 0 || idx >= r->nnzA) ok = false; else fkc[d] = r->As[idx]; }
-                else if (kind == CPG_K_SIGMA) fkc[d] = h->F.sigma;
-                else if (kind == CPG_K_RHO) { if (idx < 0 || (size_t)idx >= m) ok = false; else fkrow[d] = idx; }
-                else if (kind != CPG_K_NONE) ok = false;
-            }
-        }
         if (ok) {
-            if ((rc = upload<double>(h, own, fkc.data(), fkc.size(), &R.fac_kc))) return rc;
-            if ((rc = upload<int>(h, own, fkrow.data(), fkrow.size(), &R.fac_krow))) return rc;
             if ((rc = upload<unsigned short>(h, own, glcol.data(), glcol.size(), &R.gi_lcol))) return rc;
             if ((rc = upload<unsigned short>(h, own, gcols.data(), gcols.size(), &R.gi_cols))) return rc;
             if ((rc = upload<unsigned short>(h, own, grows.data(), grows.size(), &R.gi_rows))) return rc;
@@ -1157,7 +1159,8 @@ static cpg::DevBatch make_batch(int64_t B, const double *d_theta, const double *
 static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, cpg::DevBatch &Bt) {
     const int W = 4;
 #ifdef CPG_GENI_HEADER
-    if (h->R.gi_ok && h->program_in_lds != 0) {       // generated instance executor (cpg_hip_set_program_placement(0): the streaming one)
+    if (h->R.gi_ok && h->program_in_lds != 0) {
+        const int W = 8;                               // one workgroup of eight wavefronts per CU shares the tables       // generated instance executor (cpg_hip_set_program_placement(0): the streaming one)
         const size_t tab = (size_t)(((CPG_GENI_NSTEPS + 3) / 4) * 256 + ((CPG_GENI_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
         const size_t nq = (size_t)(h->F.n + h->F.m);
         size_t per_wave = (size_t)(CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS) + nq + (nq & 1);   // work vector | q | u ...
@@ -1165,9 +1168,7 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
         if (per_wave < fac) per_wave = fac + (fac & 1);
         const size_t lds = tab + (size_t)W * per_wave * sizeof(double);
         if (lds <= h->lds_limit) {
-            int per_cu = 2;                            // 8 wavefronts per CU: the register budget of the kernel
-            if (h->blocks_per_cu > 0 && h->blocks_per_cu < per_cu) per_cu = h->blocks_per_cu;
-            if ((size_t)per_cu * lds > h->lds_limit) per_cu = (int)(h->lds_limit / lds);
+            const int per_cu = 1;                      // 8 wavefronts per CU: the register budget of the kernel
             long long blocks = (Bt.B + W - 1) / W;
             const long long cap = (long long)h->num_cu * per_cu;
             if (blocks > cap) blocks = cap;

@@ -268,30 +268,35 @@ CPG_DEV void numeric_ldl(const DevRefactor &R, const InstBuf &B, double reg, int
         }
     }
 }
-// Coefficients of the substitution program from the factor (1, -L_ij or 1 / d_j per entry).
+// Coefficients of the substitution program from the factor (1, -L_ij or 1 / d_j per entry).  MFORM: B.Lx holds the
+// undivided entries of numeric_ldl_m (l_ij = M_ij / d_j), B.Dginv the reciprocal pivots.
+template <bool MFORM = false>
 CPG_DEV void substitution_values(const DevRefactor &R, const InstBuf &B, int lane) {
     for (unsigned e = (unsigned)lane; e < (unsigned)R.sol_nnz; e += 64u) {
         const int kind = cpgw::gld(R.sol_kind, e);
         const unsigned idx = (unsigned)cpgw::gld(R.sol_idx, e);
         double v = 0.0;
         if (kind == 1) v = 1.0;
-        else if (kind == 2) v = -cpgw::gld((const double *)B.Lx, idx);
+        else if (kind == 2) v = MFORM ? -(cpgw::gld((const double *)B.Lx, idx) * cpgw::gld((const double *)B.Dginv, (unsigned)cpgw::gld(R.Lcol, idx)))
+                                      : -cpgw::gld((const double *)B.Lx, idx);
         else if (kind == 3) v = cpgw::gld((const double *)B.Dginv, idx);
         cpgw::gst(B.sv, e, v);
     }
     cpgw::mem_order();
 }
 
-#ifdef CPG_GENI_HEADER
-// Numeric LDL' of shared-matrix mode with the factor in the wavefront's LDS slice (Ml [nnzL] | Dil [N]): the same
-// dot-product schedule as numeric_ldl, in the form that needs ONE dependent step per level of the elimination tree
-// instead of two -- the entries of a column are kept UNDIVIDED (M_ij = l_ij d_j = K_ij - sum_k M_ik M_jk / d_k), so
-// they do not wait for their column's pivot; what is stored per pivot is 1 / d_j.  Every operand of the dependent
-// chain is an LDS read; the schedule's index tables (shared, L2) and the constant part of the KKT values do not
-// depend on the factor and are requested one batch / one chunk ahead.  The instances of a shared-matrix batch
-// differ in rho only: this is the whole per-instance cost of a rho change (config 2: ~ 9 of the 14 ms the
-// per-instance phase spent outside its iterations were the global-memory round trips of the generic version).
-CPG_DEV void numeric_ldl_lds(const DevRefactor &R, double *Ml, double *Dil, const double *rinv, int lane) {
+// Numeric LDL' of shared-matrix mode: the same dot-product schedule as numeric_ldl, in the form that needs ONE
+// dependent step per level of the elimination tree instead of two -- the entries of a column are kept UNDIVIDED
+// (M_ij = l_ij d_j = K_ij - sum_k M_ik M_jk / d_k), so they do not wait for their column's pivot; what is stored
+// per pivot is 1 / d_j.  The factor (Ml [nnzL], Dil [N]) lives in the wavefront's LDS slice (LDS: the generated
+// instance kernel) or in its global buffer; the schedule's index tables (shared, L2), the chunk headers and the
+// KKT values -- family constants in this mode except the -1 / rho_vec of the (2,2) diagonal -- do not depend on the
+// factor and are requested one batch / one chunk ahead, so a level costs one round trip of its operands.  The
+// instances of a shared-matrix batch differ in rho only: this is the whole per-instance cost of a rho change
+// (config 2: most of the 14 ms the per-instance phase spent outside its iterations were the ~ 5 dependent
+// global-memory round trips per chunk of the generic version).
+template <bool LDS>
+CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const double *rinv, int lane) {
     constexpr int NB = CPG_LDL_BATCH;
     // header of the first chunk; the next one is requested while a chunk runs
     int hL = cpgw::gld(R.fac_ctab, 0u), hlast = cpgw::gld(R.fac_ctab, 1u), hbase = cpgw::gld(R.fac_ctab, 2u), hlg = cpgw::gld(R.fac_ctab, 3u);
@@ -329,7 +334,7 @@ CPG_DEV void numeric_ldl_lds(const DevRefactor &R, double *Ml, double *Dil, cons
         for (int s = 0; s < L; s += NB) {
             double la[NB], lb[NB], dk[NB];
 #pragma unroll
-            for (int t = 0; t < NB; t++) { la[t] = Ml[ia[t]]; lb[t] = Ml[ib[t]]; dk[t] = Dil[ik[t]]; }
+            for (int t = 0; t < NB; t++) { la[t] = cpgw::gld((const double *)Ml, ia[t]); lb[t] = cpgw::gld((const double *)Ml, ib[t]); dk[t] = cpgw::gld((const double *)Dil, ik[t]); }
             unsigned na[NB], nb[NB], nk[NB];
             if (s + NB < L) load_indices(s + NB, na, nb, nk);   // uniform
 #pragma unroll
@@ -341,14 +346,15 @@ CPG_DEV void numeric_ldl_lds(const DevRefactor &R, double *Ml, double *Dil, cons
         acc = cpgw::group_sum_first_dyn(acc, lg);
         if (has) {
             const double v = (kc - kr) - acc;
-            if (task >= (unsigned)R.nnzL) Dil[task - (unsigned)R.nnzL] = 1.0 / v;
-            else Ml[task] = v;
+            if (task >= (unsigned)R.nnzL) cpgw::gst(Dil, task - (unsigned)R.nnzL, 1.0 / v);
+            else cpgw::gst(Ml, task, v);
         }
-        if (last) cpgw::lds_order();     // level complete: the next one reads what this one stored
+        if (last) { if (LDS) cpgw::lds_order(); else cpgw::mem_order(); }     // level complete: the next one reads what this one stored
     }
-    cpgw::lds_order();
+    if (LDS) cpgw::lds_order(); else cpgw::mem_order();
 }
 
+#ifdef CPG_GENI_HEADER
 // the instance's coefficients of the generated executor, from its factor in LDS (one gather per step and lane, once
 // per factorisation: the ADMM loop then reads none): -l_ij = -M_ij / d_j, 1 / d_i, or 1
 CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, const double *Dil, double (&cf)[CPG_GENI_NSTEPS], int lane) {
@@ -542,11 +548,21 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         cpgw::mem_order();
 
         // ---- 4. numeric LDL' through the dot-product schedule, 5. coefficients of the substitution program
+        auto factor_generic = [&]() __attribute__((always_inline)) {
+            if (shared && R.fac_kc) {      // shared-matrix mode: one dependent step per level, KKT values from the family's table
+                cpgw::mem_order();
+                numeric_ldl_m<false>(R, B.Lx, B.Dginv, (const double *)B.rinv, lane);
+                substitution_values<true>(R, B, lane);
+            } else {
+                numeric_ldl(R, B, F0.sigma, lane);
+                substitution_values<false>(R, B, lane);
+            }
+        };
 #ifdef CPG_GENI_HEADER
         double cf[CPG_GENI_NSTEPS];          // (dead, hence free, in the streaming instantiation)
         auto factor_in_lds = [&]() __attribute__((always_inline)) {
             cpgw::mem_order();                // B.rinv
-            numeric_ldl_lds(R, w, w + R.nnzL, (const double *)B.rinv, lane);
+            numeric_ldl_m<true>(R, w, w + R.nnzL, (const double *)B.rinv, lane);
             load_instance_coefficients(R, w, w + R.nnzL, cf, lane);
             cpgw::lds_order();
             // the slice goes back to its ADMM use: idle lanes of a step gather the zero slot, idle lanes of a chunk
@@ -559,7 +575,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         if (GENI) factor_in_lds();
         else
 #endif
-        { numeric_ldl(R, B, F0.sigma, lane); substitution_values(R, B, lane); }
+        factor_generic();
 
         // ---- 6. ADMM from cold start with the instance's own factor
         DevFamily F = F0;
@@ -682,7 +698,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                     if (GENI) factor_in_lds();
                     else
 #endif
-                    { numeric_ldl(R, B, F0.sigma, lane); substitution_values(R, B, lane); }
+                    factor_generic();
                 }
             }
             if (last) {
