@@ -156,6 +156,10 @@ struct InstCtx {
     const double (&qr)[NSX];
     const double (&ur)[NSZ];
     const double *qm, *um;
+    // shared-matrix mode: the termination test's products run through the family's natural-layout row programs
+    // (coalesced, shared by every wavefront: cache hits) instead of per-lane walks over the instance's matrices --
+    // a walk is a chain of dependent round trips per row (pointer -> entry number -> value)
+    bool rowprog;
     CPG_DEV double q(int s, unsigned i) const { return QUMEM ? qm[i] : qr[s]; }
     CPG_DEV double u(int s, unsigned i) const { return QUMEM ? um[i] : ur[s]; }
     template <bool ENT, bool OFFS, int NB = CPG_ROW_WALK_BATCH>
@@ -166,6 +170,7 @@ struct InstCtx {
         return acc;
     }
     CPG_DEV double ax(int s) const {
+        if (rowprog) return natural_chunk(F.A_rows, s, w, lane);
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
 #ifdef CPG_REFACTOR_ROW_COPY
         return i < (unsigned)F.m ? row_dot<false, false, CPG_ROW_COPY_BATCH>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i) : 0.0;
@@ -174,10 +179,12 @@ struct InstCtx {
 #endif
     }
     CPG_DEV double px(int s) const {
+        if (rowprog) return natural_chunk(F.P_rows, s, w, lane);
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
         return j < (unsigned)F.n ? row_dot<true, false>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j) : 0.0;
     }
     CPG_DEV double atx(int s) const {
+        if (rowprog) return natural_chunk(F.At_rows, s, w, lane);
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
         return j < (unsigned)F.n ? row_dot<false, true>(R.Ap, nullptr, R.Ai, (const double *)B.A, j) : 0.0;
     }
@@ -595,7 +602,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
             ur[s] = i < m ? cpgw::gld((const double *)B.u, i) : 0.0;
         }
-        const CtxT cx{F, R, B, w, lane, qr, ur, qs, us};
+        const CtxT cx{F, R, B, w, lane, qr, ur, qs, us, shared && F.A_rows.n_chunks > 0};
         double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
         for (int s = 0; s < NSX; s++) x[s] = 0.0;

@@ -451,12 +451,21 @@ class BatchSolver:
             prim_idx, dual_idx = np.arange(n, dtype=np.int32), np.arange(m, dtype=np.int32)
         keep += [ones_n, ones_m, ctype, fpos, prim_idx, dual_idx]
         empty = _Program(0, 0, None, None, None, None)
+        rows_A = rows_P = rows_At = empty
+        if shared_mats:
+            # products of the termination test through natural-layout row programs of the workspace's matrices
+            # (canonical order): coalesced and shared by every wavefront, against per-lane row walks
+            Pfull = sp.csr_matrix(Ps + sp.triu(Ps, 1).T)
+            Acsr = sp.csr_matrix(As)
+            rows_A = _program_struct(_sp.pack([_sp.spmv_phase(Acsr, 0, 'A')], natural=True), keep)
+            rows_P = _program_struct(_sp.pack([_sp.spmv_phase(Pfull, 0, 'P')], natural=True), keep)
+            rows_At = _program_struct(_sp.pack([_sp.spmv_phase(sp.csr_matrix(Acsr.T), n, 'At')], natural=True), keep)
         fam = _Family(
             n=n, m=m, n_eq=desc.n_eq, is_maximization=int(desc.is_maximization),
             sigma=o.settings['sigma'], alpha=o.settings['alpha'], rho=o.settings['rho'],
             D=_d(ones_n), E=_d(ones_m), c=1.0, ctype=ctype.ctypes.data_as(_i8p),
             n_slots=rplan.sol.n_slots, fpos=fpos.ctypes.data_as(_u16p), n_vary_x=n, n_vary_z=m,
-            kkt=empty, A_rows=empty, P_rows=empty, At_rows=empty,
+            kkt=empty, A_rows=rows_A, P_rows=rows_P, At_rows=rows_At,
             kkt_ragged=_Ragged(0, 0, None, None, None, None),
             n_prim=len(prim_idx), prim_idx=prim_idx.ctypes.data_as(_ip),
             n_dual=len(dual_idx), dual_idx=dual_idx.ctypes.data_as(_ip), ord=None)

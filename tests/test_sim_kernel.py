@@ -203,3 +203,34 @@ def test_refactor_path_parameter_in_P(sim_lib, oracle_lib):
     assert r.prim['delta_u'].shape == (B, 1, 1) and r.dual['d2'].shape == (B, 1, 1)
     bs.close()
 
+
+
+def test_generated_instance_executor_and_both_ldl_forms(oracle_lib, tmp_path):
+    """shared-matrix mode of the per-instance factor kernel (rho adaptation hand-over) in a family library: the
+    generated instance executor (register-resident coefficients, LDL' in LDS) and the streaming executor (LDL' in
+    the wavefront's global buffer) both use the one-step-per-level factorisation and must give the oracle's
+    results -- through several rho adaptations (tight tolerances) and a max_iter cut-off."""
+    import ctypes as C
+    from cvxpygen_amd.runtime import build_family_plan
+    from sim import build_sim
+    d = families.mpc(6, 3, 10)
+    plan = build_family_plan(d)
+    lib = build_sim.build_family(plan, str(tmp_path), 'mpc6')
+    vals = -2 + 4 * np.random.default_rng(4).random((4, 6))
+    for executor in ('generated', 'stream'):
+        bs = BatchSolver(d, lib_path=lib, plan=plan)
+        bs.set_launch(waves_per_block=2)
+        bs.set_updated(['x_init'])
+        assert bs._hybrid
+        if executor == 'stream':
+            bs.lib.check(bs.lib.L.cpg_hip_set_program_placement(bs.h_rs, 0), 'placement')
+        v = C.c_double(-1)
+        bs.lib.check(bs.lib.L.cpg_hip_get_setting(bs.h_rs, b'generated_instance_executor', C.byref(v)), 'get')
+        assert v.value == (1.0 if executor == 'generated' else 0.0)
+        for stg in ({}, dict(eps_abs=1e-7, eps_rel=1e-7), dict(max_iter=60)):
+            r = bs.solve({'x_init': vals}, updated_params=['x_init'], **stg)
+            o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, 'x_init', vals), ['x_init'], **stg)
+            _assert_parity(r, o, prim, dual)
+            if 'eps_abs' in stg:
+                assert o['iter'].max() > 100          # more than one adaptation point was passed
+        bs.close()
