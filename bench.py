@@ -192,6 +192,7 @@ def main():
     ap.add_argument('--all-params', action='store_true', help='every parameter varies per instance (matrix parameters: per-instance refactorisation path)')
     ap.add_argument('--instance-executor', choices=['auto', 'stream', 'generated'], default='auto',
                     help='experiments: executor of the per-instance factor kernel behind the shared-factor one (family libraries)')
+    ap.add_argument('--debug-stage', type=int, default=0, help='experiments: the per-instance factor kernel stops after stage k of its set-up (results are garbage)')
     ap.add_argument('--rccl-lib', default='librccl.so', help='RCCL library of the result gather (CPU tier: the recording stand-in of tests/sim/fake_rccl)')
     args = ap.parse_args()
 
@@ -263,6 +264,8 @@ def main():
         stg['eps_abs'] = stg['eps_rel'] = args.eps
     if args.check_termination:
         stg['check_termination'] = args.check_termination
+    if args.debug_stage:
+        stg['debug_stage'] = args.debug_stage
     solver.apply_settings(**stg)                 # reference defaults unless an experiment overrides them
     dev = DeviceBatch(solver, B)
     dev.upload(theta)
@@ -397,19 +400,24 @@ def main():
             ad = 50
             it1 = np.minimum(it, ad)          # iterations served by the shared-factor kernel (every instance hands over at its first rho change)
             ho = it > ad                       # (instances whose estimate stayed inside the tolerance band continue on the shared factor: counted there)
+            import ctypes as _C
+            gv = _C.c_double(0)
+            solver.lib.L.cpg_hip_get_setting(solver.h_rs, b'generated_instance_executor', _C.byref(gv))
+            inst_kernel = 'osqp_instance_kernel' if gv.value else 'osqp_refactor_kernel'
             phases = {'shared_factor': {'kernel': 'osqp_shared_kernel', 'ms': ms1, 'instances': B,
                                         'iterations': int(it1.sum())},
-                      'per_instance_factor': {'kernel': 'osqp_refactor_kernel', 'ms': ms2, 'instances': n_ho,
+                      'per_instance_factor': {'kernel': inst_kernel, 'ms': ms2, 'instances': n_ho,
                                               'iterations': int((it - it1)[ho].sum()),
                                               'note': 'instances handed over after a rho change: numeric LDL\' for the new rho, then ADMM with their own factor'}}
             if ms2 > ms1:
-                kernel_name, units, k_ms = 'osqp_refactor_kernel', n_ho, ms2
+                kernel_name, units, k_ms = inst_kernel, n_ho, ms2
                 # the hand-over adds the workspace (n + 2m + 1 doubles) written by the kernel in front and read here
                 it2 = float((it - it1)[ho].mean()) if ho.any() else 0.0
-                stream = {'bytes_per_instance': int(it2 * sv), 'what': f'{it2:.1f} iterations x {sv} B of per-instance substitution coefficients',
+                stream = None if gv.value else {'bytes_per_instance': int(it2 * sv), 'what': f'{it2:.1f} iterations x {sv} B of per-instance substitution coefficients',
                           'achieved': it2 * sv * n_ho / (ms2 * 1e-3) / 1e9}
                 rnote = ('dominant kernel of the two-kernel step: per-instance factor phase of the instances whose rho changed; `achieved` prices SURVEY.md 8(d) '
-                         'bytes per instance it serves, `stream` the coefficients it actually streams from HBM per iteration (DESIGN.md section 4.5)')
+                         'bytes per instance it serves' + ('; the generated instance executor keeps the factor in registers: no coefficient stream (DESIGN.md section 4.5)' if gv.value else
+                         ', `stream` the coefficients it actually streams per iteration (DESIGN.md section 4.5)'))
             else:
                 k_ms = ms1
         elif per_instance_kernel:

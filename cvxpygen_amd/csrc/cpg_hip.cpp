@@ -481,7 +481,7 @@ int cpg_hip_set_default_settings(cpg_handle_t h) {
     // defaults of the generated solver, cvxpygen/solvers/osqp.py:102-115
     h->S.max_iter = 4000; h->S.eps_abs = 1e-3; h->S.eps_rel = 1e-3; h->S.eps_prim_inf = 1e-4;
     h->S.eps_dual_inf = 1e-4; h->S.scaled_termination = 0; h->S.check_termination = 25;
-    h->S.warm_starting = 1;
+    h->S.warm_starting = 1; h->S.debug_stage = 0;
     // ... and every other OSQP setting goes back to the linked library's default as well: the generated
     // cpg_set_solver_default_settings IS osqp_set_default_settings(solver.settings) (solvers/osqp.py:101,
     // utils.py:1071-1073).  For OSQP >= 1.0 -- the only API the reference's emitted calls compile against
@@ -509,6 +509,7 @@ int cpg_hip_set_setting(cpg_handle_t h, const char *name, double v) {
     else if (s == "scaled_termination") h->S.scaled_termination = (int)v;
     else if (s == "check_termination") h->S.check_termination = (int)v;
     else if (s == "warm_starting") h->S.warm_starting = (int)v;
+    else if (s == "debug_stage") h->S.debug_stage = (int)v;          // measurements only, see DevSettings
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
 }

@@ -118,6 +118,7 @@ struct DevSettings {
     int adaptive_rho, adaptive_rho_interval;   // rho adaptation every `interval` iterations
     double adaptive_rho_tolerance;
     int warm_starting;            // 1: start from DevBatch::state_in when it is given
+    int debug_stage;              // measurements only (0 = off): the per-instance factor kernel leaves an instance after stage k of its set-up
 };
 struct DevBatch {
     long long B;

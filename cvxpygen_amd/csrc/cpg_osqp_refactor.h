@@ -534,6 +534,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             refresh_row_copy(R, B, lane);            // scaled A in row order: the termination test's A x
 #endif
         }
+        if (__builtin_expect(S.debug_stage == 1, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }     // (timing experiments: canonicalised)
         signed char ct[NSZ];
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
@@ -579,10 +580,12 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
             cpgw::lds_order();
         };
+        if (__builtin_expect(S.debug_stage == 2, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }     // (row classes, rho_vec)
         if (GENI) factor_in_lds();
         else
 #endif
         factor_generic();
+        if (__builtin_expect(S.debug_stage == 3, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }     // (factorised, coefficients loaded)
 
         // ---- 6. ADMM from cold start with the instance's own factor
         DevFamily F = F0;
