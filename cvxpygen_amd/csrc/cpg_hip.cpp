@@ -71,6 +71,7 @@ struct cpg_solver_s {
     // staging for the host-pointer entry point
     DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status, s_state_in, s_state_out;
     struct cpg_pipe_s *pipe = nullptr;  // cpg_hip_solve_batches_pipelined
+    std::vector<int> rows_hdr[3];       // host copies of the chunk tables of A_rows / P_rows / At_rows (literal checks of generated kernels)
     // OSQP library defaults the generated shim has no setter for (cpg_hip_set_build_option); restored, like the
     // others, by cpg_hip_set_default_settings
     int opt_adaptive_rho = 1, opt_adaptive_rho_interval = 50, opt_check_dualgap = 1;
@@ -586,6 +587,8 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
     TRY(upload_program(h, f->A_rows, &F.A_rows));
     TRY(upload_program(h, f->P_rows, &F.P_rows));
     TRY(upload_program(h, f->At_rows, &F.At_rows));
+    { const cpg_program_t *pr[3] = {&f->A_rows, &f->P_rows, &f->At_rows};
+      for (int k = 0; k < 3; k++) h->rows_hdr[k].assign(pr[k]->hdr, pr[k]->hdr + (size_t)pr[k]->n_chunks * 4); }
     F.kkt_ragged.n_chunks = f->kkt_ragged.n_chunks; F.kkt_ragged.nnz = f->kkt_ragged.nnz;
     F.kkt_stream = cpg::StreamProg{nullptr, nullptr, nullptr, 0, 0u};
     if (f->kkt_ragged.n_chunks > 0) {
@@ -943,9 +946,9 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if ((rc = upload<double>(h, own, r->E, m, &R.Es))) return rc;
         if ((rc = upload<double>(h, own, einv.data(), m, &R.Einvs))) return rc;
     }
-    R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_lcol = nullptr; R.fac_kc = nullptr; R.fac_krow = nullptr;
-    std::vector<double> fkc;                                      // alive until the sync below
-    std::vector<int> fkrow;
+    R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_lcol = nullptr; R.fac_kc = nullptr; R.fac_krow = nullptr; R.fac_kc_cl = nullptr; R.fac_krow_cl = nullptr;
+    std::vector<double> fkc, fkc_cl;                              // alive until the sync below
+    std::vector<int> fkrow, fkrow_cl;
     if (r->shared_mats) {   // KKT values of the factorisation's destinations: constants of the family, except -1 / rho_vec
         bool ok = true;
         const size_t nd = (size_t)r->nnzL + N;
@@ -960,8 +963,17 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
             else if (kind != CPG_K_NONE) ok = false;
         }
         if (!ok) { set_error("cpg_hip_set_refactor: KKT source table out of range"); return CPG_E_BADARG; }
+        fkc_cl.assign((size_t)r->fac_chunks * 64, 0.0); fkrow_cl.assign((size_t)r->fac_chunks * 64, -1);
+        for (size_t e = 0; e < fkc_cl.size(); e++) {
+            const unsigned t = r->fac_task[e];
+            if (t == 0xFFFFFFFFu) continue;
+            if (t >= nd) { set_error("cpg_hip_set_refactor: factorisation task out of range"); return CPG_E_BADARG; }
+            fkc_cl[e] = fkc[t]; fkrow_cl[e] = fkrow[t];
+        }
         if ((rc = upload<double>(h, own, fkc.data(), fkc.size(), &R.fac_kc))) return rc;
         if ((rc = upload<int>(h, own, fkrow.data(), fkrow.size(), &R.fac_krow))) return rc;
+        if ((rc = upload<double>(h, own, fkc_cl.data(), fkc_cl.size(), &R.fac_kc_cl))) return rc;
+        if ((rc = upload<int>(h, own, fkrow_cl.data(), fkrow_cl.size(), &R.fac_krow_cl))) return rc;
     }
 #ifdef CPG_GENI_HEADER
     std::vector<unsigned short> gcols, grows, glcol;
@@ -973,6 +985,14 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         mix(r->sol_ctab, (size_t)r->sol_chunks * 16); mix(r->sol_desc, (size_t)r->sol_chunks * 256); mix(r->sol_cols, (size_t)r->sol_nnz * 2);
         static const int steps[][2] = CPG_GENI_STEPS;             // {first entry, active lanes} in execution order
         bool ok = hsh == CPG_GENI_FINGERPRINT;
+        {   // the row programs of the termination test carry their chunk tables as literals
+            const int nn[3] = {CPG_GENI_AROWS_N, CPG_GENI_PROWS_N, CPG_GENI_ATROWS_N};
+            for (int k = 0; ok && k < 3; k++) {
+                if ((int)h->rows_hdr[k].size() != 4 * nn[k]) ok = false;
+                for (int c2 = 0; ok && c2 < nn[k]; c2++)
+                    if (h->rows_hdr[k][4 * c2] != cpg::GeniRows::len(k, c2) || h->rows_hdr[k][4 * c2 + 3] != cpg::GeniRows::off(k, c2)) ok = false;
+            }
+        }
         const unsigned zero_off = (unsigned)(r->sol_slots + CPG_GEN_DUMMY_SLOTS) * 8u;
         if (zero_off > 0xFFFFu || r->sol_slots + CPG_GEN_EXTRA_SLOTS > 0x1FFF) ok = false;
         if (ok) {

@@ -488,7 +488,6 @@ CPG_DEV double natural_chunk(const DevProgram &P, int s, const double *w, int la
     return o[0];
 }
 
-#ifdef CPG_GEN_N
 // The same with the chunk's step count and first step as literals of the generated family (the loops
 // unroll): the coefficient / offset loads of up to CPG_ROWS_BATCH steps are requested together before the
 // first multiply-add consumes one, so a chunk costs about one L2 round trip instead of one per four steps
@@ -515,6 +514,7 @@ CPG_DEV double natural_chunk_lit(const DevProgram &P, const int len, const int o
     }
     return acc;
 }
+#ifdef CPG_GEN_N
 #define CPG_NATURAL_ROWS(P, which, s, w, lane) natural_chunk_lit(P, GenFam::rows_len(which, s), GenFam::rows_off(which, s), w, lane)
 #else
 #define CPG_NATURAL_ROWS(P, which, s, w, lane) natural_chunk(P, s, w, lane)

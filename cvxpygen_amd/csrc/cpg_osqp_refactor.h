@@ -25,6 +25,25 @@
 
 namespace cpg {
 
+#ifdef CPG_GENI_HEADER
+// chunks {steps, first step} of the natural-layout row programs of the shared-matrix handle (canonical order) as
+// literals of the generated family: the termination test's products request the loads of a whole chunk together
+struct GeniRows {
+    static constexpr int len(int which, int s) {
+        constexpr int a[][2] = CPG_GENI_AROWS; constexpr int p[][2] = CPG_GENI_PROWS; constexpr int t[][2] = CPG_GENI_ATROWS;
+        return which == 0 ? (s < CPG_GENI_AROWS_N ? a[s < CPG_GENI_AROWS_N ? s : 0][0] : 0)
+             : which == 1 ? (s < CPG_GENI_PROWS_N ? p[s < CPG_GENI_PROWS_N ? s : 0][0] : 0)
+                          : (s < CPG_GENI_ATROWS_N ? t[s < CPG_GENI_ATROWS_N ? s : 0][0] : 0);
+    }
+    static constexpr int off(int which, int s) {
+        constexpr int a[][2] = CPG_GENI_AROWS; constexpr int p[][2] = CPG_GENI_PROWS; constexpr int t[][2] = CPG_GENI_ATROWS;
+        return which == 0 ? a[s < CPG_GENI_AROWS_N ? s : 0][1] : which == 1 ? p[s < CPG_GENI_PROWS_N ? s : 0][1]
+                                                                            : t[s < CPG_GENI_ATROWS_N ? s : 0][1];
+    }
+};
+#define CPG_GENI_ROWS(P, which, s, w, lane) natural_chunk_lit(P, GeniRows::len(which, s), GeniRows::off(which, s), w, lane)
+#endif
+
 struct DevRefactor {
     int nnzP, nnzA, nnzL, n_eq, np_var, scaling_iters;
     // equilibration views
@@ -67,6 +86,8 @@ struct DevRefactor {
     // included on the pivots) except the -1 / rho_vec of the (2,2) diagonal: fac_krow = its row, -1 elsewhere
     const double *fac_kc;
     const int *fac_krow;
+    const double *fac_kc_cl;            // the same per (chunk, lane) of the factorisation schedule (no detour over the task number)
+    const int *fac_krow_cl;
 };
 
 #define CPG_K_NONE 0
@@ -160,6 +181,14 @@ struct InstCtx {
     // (coalesced, shared by every wavefront: cache hits) instead of per-lane walks over the instance's matrices --
     // a walk is a chain of dependent round trips per row (pointer -> entry number -> value)
     bool rowprog;
+    // (QUMEM = the generated instance kernel: chunk tables of the row programs are literals)
+    CPG_DEV double rows_gen(const DevProgram &P, int which, int s) const {
+#ifdef CPG_GENI_HEADER
+        return CPG_GENI_ROWS(P, which, s, w, lane);
+#else
+        return natural_chunk(P, s, w, lane);
+#endif
+    }
     CPG_DEV double q(int s, unsigned i) const { return QUMEM ? qm[i] : qr[s]; }
     CPG_DEV double u(int s, unsigned i) const { return QUMEM ? um[i] : ur[s]; }
     template <bool ENT, bool OFFS, int NB = CPG_ROW_WALK_BATCH>
@@ -170,7 +199,7 @@ struct InstCtx {
         return acc;
     }
     CPG_DEV double ax(int s) const {
-        if (rowprog) return natural_chunk(F.A_rows, s, w, lane);
+        if (rowprog) return QUMEM ? rows_gen(F.A_rows, 0, s) : natural_chunk(F.A_rows, s, w, lane);
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
 #ifdef CPG_REFACTOR_ROW_COPY
         return i < (unsigned)F.m ? row_dot<false, false, CPG_ROW_COPY_BATCH>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i) : 0.0;
@@ -179,12 +208,12 @@ struct InstCtx {
 #endif
     }
     CPG_DEV double px(int s) const {
-        if (rowprog) return natural_chunk(F.P_rows, s, w, lane);
+        if (rowprog) return QUMEM ? rows_gen(F.P_rows, 1, s) : natural_chunk(F.P_rows, s, w, lane);
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
         return j < (unsigned)F.n ? row_dot<true, false>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j) : 0.0;
     }
     CPG_DEV double atx(int s) const {
-        if (rowprog) return natural_chunk(F.At_rows, s, w, lane);
+        if (rowprog) return QUMEM ? rows_gen(F.At_rows, 2, s) : natural_chunk(F.At_rows, s, w, lane);
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
         return j < (unsigned)F.n ? row_dot<false, true>(R.Ap, nullptr, R.Ai, (const double *)B.A, j) : 0.0;
     }
@@ -305,58 +334,69 @@ CPG_DEV void substitution_values(const DevRefactor &R, const InstBuf &B, int lan
 template <bool LDS>
 CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const double *rinv, int lane) {
     constexpr int NB = CPG_LDL_BATCH;
-    // header of the first chunk; the next one is requested while a chunk runs
-    int hL = cpgw::gld(R.fac_ctab, 0u), hlast = cpgw::gld(R.fac_ctab, 1u), hbase = cpgw::gld(R.fac_ctab, 2u), hlg = cpgw::gld(R.fac_ctab, 3u);
-    unsigned htask = cpgw::gld(R.fac_task, (unsigned)lane), hlw = cpgw::gld(R.fac_len, (unsigned)lane);
-#pragma nounroll
-    for (int c = 0; c < R.fac_chunks; c++) {
-        const int L = cpgw::read_first_lane(hL), last = cpgw::read_first_lane(hlast), lg = cpgw::read_first_lane(hlg);
-        unsigned base = (unsigned)cpgw::read_first_lane(hbase);
-        const unsigned task = htask, lw = hlw;
-        if (c + 1 < R.fac_chunks) {
-            const unsigned c1 = (unsigned)(c + 1);
-            hL = cpgw::gld(R.fac_ctab, 4u * c1); hlast = cpgw::gld(R.fac_ctab, 4u * c1 + 1u);
-            hbase = cpgw::gld(R.fac_ctab, 4u * c1 + 2u); hlg = cpgw::gld(R.fac_ctab, 4u * c1 + 3u);
-            htask = cpgw::gld(R.fac_task, c1 * 64u + (unsigned)lane); hlw = cpgw::gld(R.fac_len, c1 * 64u + (unsigned)lane);
-        }
-        // KKT value of this lane's destination: constant part + the instance's -1 / rho_vec where it enters
-        const bool has = task != 0xFFFFFFFFu;
-        const double kc = has ? cpgw::gld(R.fac_kc, task) : 0.0;
-        const int krow = has ? cpgw::gld(R.fac_krow, task) : -1;
-        const double kr = krow >= 0 ? cpgw::gld(rinv, (unsigned)krow) : 0.0;
-        const int len = (int)(lw & 0xFFFFu), rlen = (int)(lw >> 16);
-        double acc = 0.0;
-        unsigned ia[NB], ib[NB], ik[NB];
-        auto load_indices = [&](int s0, unsigned (&xa)[NB], unsigned (&xb)[NB], unsigned (&xk)[NB]) __attribute__((always_inline)) {
+    // Software pipeline over the chunks: everything a chunk needs that does not depend on the factor -- its header
+    // (scalar loads), the lane's destination, term count and KKT constant (per (chunk, lane) tables), the index
+    // triples of its first batch -- is requested while the chunk(s) in front of it run; a chunk of the (mostly one- or
+    // two-step) schedule then waits for its operands only.
+    struct Hdr { int L, last, lg; unsigned base; };
+    struct LaneTab { unsigned task, lw; double kc; int krow; };
+    struct Idx { unsigned a[NB], b[NB], k[NB]; unsigned base; };
+    const unsigned *ctab = (const unsigned *)R.fac_ctab;
+    const int nch = R.fac_chunks;
+    if (nch <= 0) return;
+    auto hdr = [&](int c) __attribute__((always_inline)) {
+        const unsigned o = 4u * (unsigned)(c < nch ? c : nch - 1);
+        return Hdr{(int)cpgw::sld(ctab, o), (int)cpgw::sld(ctab, o + 1u), (int)cpgw::sld(ctab, o + 3u), cpgw::sld(ctab, o + 2u)};
+    };
+    auto lanetab = [&](int c) __attribute__((always_inline)) {
+        const unsigned e = (unsigned)(c < nch ? c : nch - 1) * 64u + (unsigned)lane;
+        return LaneTab{cpgw::gld(R.fac_task, e), cpgw::gld(R.fac_len, e), cpgw::gld(R.fac_kc_cl, e), cpgw::gld(R.fac_krow_cl, e)};
+    };
+    auto indices = [&](unsigned base, int len, int s0) __attribute__((always_inline)) {
+        Idx x;
 #pragma unroll
-            for (int t = 0; t < NB; t++) {
-                const bool on = s0 + t < len;
-                const unsigned e = on ? base + (unsigned)lane : 0u;
-                base += cpgw::popc64(cpgw::ballot(on));
-                xa[t] = cpgw::gld(R.fac_a, e); xb[t] = cpgw::gld(R.fac_b, e); xk[t] = cpgw::gld(R.fac_k, e);
-            }
-        };
-        load_indices(0, ia, ib, ik);
+        for (int t = 0; t < NB; t++) {
+            const bool on = s0 + t < len;
+            const unsigned e = on ? base + (unsigned)lane : 0u;
+            base += cpgw::popc64(cpgw::ballot(on));
+            x.a[t] = cpgw::gld(R.fac_a, e); x.b[t] = cpgw::gld(R.fac_b, e); x.k[t] = cpgw::gld(R.fac_k, e);
+        }
+        x.base = base;
+        return x;
+    };
+    Hdr h0 = hdr(0), h1 = hdr(1);
+    LaneTab t0 = lanetab(0), t1 = lanetab(1);
+    Idx i0 = indices(h0.base, (int)(t0.lw & 0xFFFFu), 0);
+#pragma nounroll
+    for (int c = 0; c < nch; c++) {
+        const Hdr h2 = hdr(c + 2);
+        const LaneTab t2 = lanetab(c + 2);
+        const Idx i1 = indices(h1.base, (int)(t1.lw & 0xFFFFu), 0);          // first batch of the next chunk
+        const bool has = t0.task != 0xFFFFFFFFu;
+        const double kr = (has && t0.krow >= 0) ? cpgw::gld(rinv, (unsigned)t0.krow) : 0.0;     // the instance's -1 / rho_vec where it enters
+        const int L = cpgw::read_first_lane(h0.L), len = (int)(t0.lw & 0xFFFFu), rlen = (int)(t0.lw >> 16);
+        double acc = 0.0;
+        Idx cur = i0;
 #pragma nounroll
         for (int s = 0; s < L; s += NB) {
             double la[NB], lb[NB], dk[NB];
 #pragma unroll
-            for (int t = 0; t < NB; t++) { la[t] = cpgw::gld((const double *)Ml, ia[t]); lb[t] = cpgw::gld((const double *)Ml, ib[t]); dk[t] = cpgw::gld((const double *)Dil, ik[t]); }
-            unsigned na[NB], nb[NB], nk[NB];
-            if (s + NB < L) load_indices(s + NB, na, nb, nk);   // uniform
+            for (int t = 0; t < NB; t++) { la[t] = cpgw::gld((const double *)Ml, cur.a[t]); lb[t] = cpgw::gld((const double *)Ml, cur.b[t]); dk[t] = cpgw::gld((const double *)Dil, cur.k[t]); }
+            Idx nxt = cur;
+            if (s + NB < L) nxt = indices(cur.base, len, s + NB);   // uniform
 #pragma unroll
             for (int t = 0; t < NB; t++)
                 if (s + t < rlen) acc = fma(la[t] * dk[t], lb[t], acc);
-#pragma unroll
-            for (int t = 0; t < NB; t++) { ia[t] = na[t]; ib[t] = nb[t]; ik[t] = nk[t]; }
+            cur = nxt;
         }
-        acc = cpgw::group_sum_first_dyn(acc, lg);
+        acc = cpgw::group_sum_first_dyn(acc, cpgw::read_first_lane(h0.lg));
         if (has) {
-            const double v = (kc - kr) - acc;
-            if (task >= (unsigned)R.nnzL) cpgw::gst(Dil, task - (unsigned)R.nnzL, 1.0 / v);
-            else cpgw::gst(Ml, task, v);
+            const double v = ((has ? t0.kc : 0.0) - kr) - acc;
+            if (t0.task >= (unsigned)R.nnzL) cpgw::gst(Dil, t0.task - (unsigned)R.nnzL, 1.0 / v);
+            else cpgw::gst(Ml, t0.task, v);
         }
-        if (last) { if (LDS) cpgw::lds_order(); else cpgw::mem_order(); }     // level complete: the next one reads what this one stored
+        if (cpgw::read_first_lane(h0.last)) { if (LDS) cpgw::lds_order(); else cpgw::mem_order(); }     // level complete: the next one reads what this one stored
+        h0 = h1; h1 = h2; t0 = t1; t1 = t2; i0 = i1;
     }
     if (LDS) cpgw::lds_order(); else cpgw::mem_order();
 }

@@ -455,11 +455,8 @@ class BatchSolver:
         if shared_mats:
             # products of the termination test through natural-layout row programs of the workspace's matrices
             # (canonical order): coalesced and shared by every wavefront, against per-lane row walks
-            Pfull = sp.csr_matrix(Ps + sp.triu(Ps, 1).T)
-            Acsr = sp.csr_matrix(As)
-            rows_A = _program_struct(_sp.pack([_sp.spmv_phase(Acsr, 0, 'A')], natural=True), keep)
-            rows_P = _program_struct(_sp.pack([_sp.spmv_phase(Pfull, 0, 'P')], natural=True), keep)
-            rows_At = _program_struct(_sp.pack([_sp.spmv_phase(sp.csr_matrix(Acsr.T), n, 'At')], natural=True), keep)
+            from . import codegen as _cg
+            rows_A, rows_P, rows_At = (_program_struct(pr, keep) for pr in _cg.shared_row_programs(Ps, As))
         fam = _Family(
             n=n, m=m, n_eq=desc.n_eq, is_maximization=int(desc.is_maximization),
             sigma=o.settings['sigma'], alpha=o.settings['alpha'], rho=o.settings['rho'],
