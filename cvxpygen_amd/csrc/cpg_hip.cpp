@@ -946,7 +946,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if ((rc = upload<double>(h, own, r->E, m, &R.Es))) return rc;
         if ((rc = upload<double>(h, own, einv.data(), m, &R.Einvs))) return rc;
     }
-    R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_n = (int)N; R.fac_kc = nullptr; R.fac_krow = nullptr; R.fac_kc_cl = nullptr; R.fac_krow_cl = nullptr;
+    R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_lcol = nullptr; R.fac_kc = nullptr; R.fac_krow = nullptr; R.fac_kc_cl = nullptr; R.fac_krow_cl = nullptr;
     std::vector<double> fkc, fkc_cl;                              // alive until the sync below
     std::vector<int> fkrow, fkrow_cl;
     if (r->shared_mats) {   // KKT values of the factorisation's destinations: constants of the family, except -1 / rho_vec
@@ -976,7 +976,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if ((rc = upload<int>(h, own, fkrow_cl.data(), fkrow_cl.size(), &R.fac_krow_cl))) return rc;
     }
 #ifdef CPG_GENI_HEADER
-    std::vector<unsigned short> gcols, grows;
+    std::vector<unsigned short> gcols, grows, glcol;
     std::vector<unsigned> gsrc;
     if (r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
         unsigned hsh = 0x811C9DC5u;
@@ -998,22 +998,20 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if (ok) {
             const int T4 = (CPG_GENI_NSTEPS + 3) & ~3, C4 = (CPG_GENI_NCHUNKS + 3) & ~3;
             gcols.assign((size_t)T4 * 64, (unsigned short)zero_off);
-            gsrc.assign((size_t)CPG_GENI_NSTEPS * 64, ((unsigned)r->nnzL + (unsigned)N + 1u) * 0x4001u);        // idle lanes: 0.0 * 0.0
+            gsrc.assign((size_t)CPG_GENI_NSTEPS * 64, 0u);
+            glcol.assign((size_t)CPG_GENI_NSTEPS * 64, (unsigned short)0);
             for (int t = 0; ok && t < CPG_GENI_NSTEPS; t++) {
                 const int e = steps[t][0], cnt = steps[t][1];
                 if (e < 0 || cnt < 0 || cnt > 64 || e + cnt > r->sol_nnz) { ok = false; break; }
                 for (int l = 0; l < cnt; l++) {
                     gcols[((size_t)(t / 4) * 64 + l) * 4 + (t % 4)] = r->sol_cols[e + l];
                     const int kind = r->sol_kind[e + l], idx = r->sol_idx[e + l];
-                    // V = [M | 1 / d | 1.0 | 0.0]: coefficient = +- V[i1] * V[i2]
-                    const unsigned oneS = (unsigned)r->nnzL + (unsigned)N, zeroS = oneS + 1u;
-                    unsigned i1 = zeroS, i2 = zeroS, neg = 0u;
-                    if (kind == 1) { i1 = oneS; i2 = oneS; }
-                    else if (kind == 2) { if (idx < 0 || idx >= r->nnzL) { ok = false; break; } i1 = (unsigned)idx; i2 = (unsigned)r->nnzL + (unsigned)r->Lcol[idx]; neg = 1u; }
-                    else if (kind == 3) { if (idx < 0 || (size_t)idx >= N) { ok = false; break; } i1 = oneS; i2 = (unsigned)r->nnzL + (unsigned)idx; }
-                    else if (kind != 0) { ok = false; break; }
-                    if (zeroS >= 0x4000u) { ok = false; break; }
-                    gsrc[(size_t)t * 64 + l] = i1 | (i2 << 14) | (neg << 31);
+                    if (kind < 0 || kind > 3 || idx < 0 || idx >= (1 << 28)) { ok = false; break; }
+                    gsrc[(size_t)t * 64 + l] = ((unsigned)kind << 28) | (unsigned)idx;
+                    if (kind == 2) {
+                        if (idx >= r->nnzL || r->Lcol[idx] < 0 || r->Lcol[idx] > 0xFFFF) { ok = false; break; }
+                        glcol[(size_t)t * 64 + l] = (unsigned short)r->Lcol[idx];
+                    }
                 }
             }
             grows.assign((size_t)C4 * 64, (unsigned short)r->sol_slots);
@@ -1037,6 +1035,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
             }
         }
         if (ok) {
+            if ((rc = upload<unsigned short>(h, own, glcol.data(), glcol.size(), &R.gi_lcol))) return rc;
             if ((rc = upload<unsigned short>(h, own, gcols.data(), gcols.size(), &R.gi_cols))) return rc;
             if ((rc = upload<unsigned short>(h, own, grows.data(), grows.size(), &R.gi_rows))) return rc;
             if ((rc = upload<unsigned>(h, own, gsrc.data(), gsrc.size(), &R.gi_src))) return rc;
@@ -1186,7 +1185,7 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
         const size_t tab = (size_t)(((CPG_GENI_NSTEPS + 3) / 4) * 256 + ((CPG_GENI_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
         const size_t nq = (size_t)(h->F.n + h->F.m);
         size_t per_wave = (size_t)(CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS) + nq + (nq & 1);   // work vector | q | u ...
-        const size_t fac = (size_t)h->R.nnzL + nq + 2;                                        // ... or the factor (+ two constants) while it is computed
+        const size_t fac = (size_t)h->R.nnzL + nq;                                            // ... or the factor while it is computed
         if (per_wave < fac) per_wave = fac + (fac & 1);
         const size_t lds = tab + (size_t)W * per_wave * sizeof(double);
         if (lds <= h->lds_limit) {

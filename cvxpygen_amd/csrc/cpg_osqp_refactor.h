@@ -76,11 +76,12 @@ struct DevRefactor {
     // Generated instance executor (family libraries, shared-matrix mode; cpg_hip_set_refactor checks that the
     // uploaded program is the one the library was generated for): operand byte offsets of all 64 lanes of every
     // step, four steps side by side ([step / 4][lane][4]; idle lanes: the zero slot), output slot | segment mask << 13
-    // of every (chunk, lane), four chunks side by side, and per (step, lane) where the coefficient comes from (gi_src).
+    // of every (chunk, lane), four chunks side by side, and per (step, lane) where the coefficient comes from
+    // (kind << 28 | index; kind 1: 1.0, 2: -L[index], 3: 1 / d[index], 0: none).
     int gi_ok;
     const unsigned short *gi_cols, *gi_rows;
-    const unsigned *gi_src;             // see load_instance_coefficients
-    int gi_n;                           // n + m
+    const unsigned *gi_src;
+    const unsigned short *gi_lcol;      // [step][lane] column of the L entry behind a kind-2 coefficient
     // shared-matrix mode: the KKT value of every destination of the factorisation is a family constant (fac_kc; sigma
     // included on the pivots) except the -1 / rho_vec of the (2,2) diagonal: fac_krow = its row, -1 elsewhere
     const double *fac_kc;
@@ -401,19 +402,19 @@ CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const 
 }
 
 #ifdef CPG_GENI_HEADER
-// the instance's coefficients of the generated executor, from its factor in LDS (once per factorisation: the ADMM
-// loop then reads none).  V = [M (nnzL) | 1 / d (N) | 1.0 | 0.0]: every coefficient is +- V[i1] * V[i2] -- -l_ij =
-// -(M_ij * 1 / d_j), 1 / d_i = 1.0 * (1 / d_i), 1 = 1.0 * 1.0, nothing = 0.0 * 0.0 -- so a step is one table word
-// (i1 | i2 << 14 | negate << 31), two LDS reads and a multiply for every lane alike: no per-lane branches on the kind.
-CPG_DEV void load_instance_coefficients(const DevRefactor &R, double *V, double (&cf)[CPG_GENI_NSTEPS], int lane) {
-    const unsigned one = (unsigned)R.nnzL + (unsigned)(R.gi_n);
-    if (lane == 0) { V[one] = 1.0; V[one + 1u] = 0.0; }
-    cpgw::lds_order();
+// the instance's coefficients of the generated executor, from its factor in LDS (one gather per step and lane, once
+// per factorisation: the ADMM loop then reads none): -l_ij = -M_ij / d_j, 1 / d_i, or 1
+CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, const double *Dil, double (&cf)[CPG_GENI_NSTEPS], int lane) {
 #pragma unroll
     for (int t = 0; t < CPG_GENI_NSTEPS; t++) {
-        const unsigned wd = cpgw::gld(R.gi_src, (unsigned)t * 64u + (unsigned)lane);
-        const double v = V[wd & 0x3FFFu] * V[(wd >> 14) & 0x3FFFu];
-        cf[t] = (wd >> 31) ? -v : v;
+        const unsigned code = cpgw::gld(R.gi_src, (unsigned)t * 64u + (unsigned)lane);
+        const unsigned col = cpgw::gld(R.gi_lcol, (unsigned)t * 64u + (unsigned)lane);
+        const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
+        double v = 0.0;
+        if (kind == 1u) v = 1.0;
+        else if (kind == 2u) v = -(Ml[idx] * Dil[col]);
+        else if (kind == 3u) v = Dil[idx];
+        cf[t] = v;
     }
 }
 #endif
@@ -444,7 +445,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
     // per wavefront: the work vector, and with the generated executor the instance's q and u behind it; the same
     // slice holds the factor (M [nnzL] | 1 / d [N]) while numeric_ldl_lds runs -- nothing in it is live then
     size_t per_wave = (size_t)ldw + (GENI ? (size_t)(N + (N & 1u)) : 0u);
-    if (GENI && per_wave < (size_t)R.nnzL + N + 2u) per_wave = (size_t)R.nnzL + N + 2u + (((size_t)R.nnzL + N) & 1u);      // (+ the 1.0 and 0.0 of load_instance_coefficients)
+    if (GENI && per_wave < (size_t)R.nnzL + N) per_wave = (size_t)R.nnzL + N + (((size_t)R.nnzL + N) & 1u);
     double *w = lds + (size_t)cpgw::wave_in_block() * per_wave;
     double *qs = w + ldw, *us = qs + n;
     const bool shared = GENI || R.shared_mats != 0;      // (a literal in the generated-executor build: its kernel serves shared-matrix handles only)
@@ -610,7 +611,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         auto factor_in_lds = [&]() __attribute__((always_inline)) {
             cpgw::mem_order();                // B.rinv
             numeric_ldl_m<true>(R, w, w + R.nnzL, (const double *)B.rinv, lane);
-            load_instance_coefficients(R, w, cf, lane);
+            load_instance_coefficients(R, w, w + R.nnzL, cf, lane);
             cpgw::lds_order();
             // the slice goes back to its ADMM use: idle lanes of a step gather the zero slot, idle lanes of a chunk
             // store to the dummy slots behind the program's own (everything starts finite); q and u of the instance
