@@ -88,6 +88,7 @@ struct DevRefactor {
     const int *fac_krow;
     const double *fac_kc_cl;            // the same per (chunk, lane) of the factorisation schedule (no detour over the task number)
     const int *fac_krow_cl;
+    const int *fac_kind_cl, *fac_idx_cl;   // per (chunk, lane): KKT source of the destination (per-instance matrices)
 };
 
 #define CPG_K_NONE 0
@@ -331,15 +332,18 @@ CPG_DEV void substitution_values(const DevRefactor &R, const InstBuf &B, int lan
 // instances of a shared-matrix batch differ in rho only: this is the whole per-instance cost of a rho change
 // (config 2: most of the 14 ms the per-instance phase spent outside its iterations were the ~ 5 dependent
 // global-memory round trips per chunk of the generic version).
-template <bool LDS>
-CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const double *rinv, int lane) {
+// KCONST: the KKT values are family constants (shared-matrix mode); otherwise they come from the instance's own
+// P / A (per (chunk, lane) source tables fac_kind_cl / fac_idx_cl) with `reg` on the (1,1) diagonal.
+template <bool LDS, bool KCONST = true>
+CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const double *rinv, int lane,
+                           const double *Pv = nullptr, const double *Av = nullptr, double reg = 0.0) {
     constexpr int NB = CPG_LDL_BATCH;
     // Software pipeline over the chunks: everything a chunk needs that does not depend on the factor -- its header
     // (scalar loads), the lane's destination, term count and KKT constant (per (chunk, lane) tables), the index
     // triples of its first batch -- is requested while the chunk(s) in front of it run; a chunk of the (mostly one- or
     // two-step) schedule then waits for its operands only.
     struct Hdr { int L, last, lg; unsigned base; };
-    struct LaneTab { unsigned task, lw; double kc; int krow; };
+    struct LaneTab { unsigned task, lw; double kc; int krow; int kind; };
     struct Idx { unsigned a[NB], b[NB], k[NB]; unsigned base; };
     const unsigned *ctab = (const unsigned *)R.fac_ctab;
     const int nch = R.fac_chunks;
@@ -350,7 +354,8 @@ CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const 
     };
     auto lanetab = [&](int c) __attribute__((always_inline)) {
         const unsigned e = (unsigned)(c < nch ? c : nch - 1) * 64u + (unsigned)lane;
-        return LaneTab{cpgw::gld(R.fac_task, e), cpgw::gld(R.fac_len, e), cpgw::gld(R.fac_kc_cl, e), cpgw::gld(R.fac_krow_cl, e)};
+        if (KCONST) return LaneTab{cpgw::gld(R.fac_task, e), cpgw::gld(R.fac_len, e), cpgw::gld(R.fac_kc_cl, e), cpgw::gld(R.fac_krow_cl, e), 0};
+        return LaneTab{cpgw::gld(R.fac_task, e), cpgw::gld(R.fac_len, e), 0.0, cpgw::gld(R.fac_idx_cl, e), cpgw::gld(R.fac_kind_cl, e)};
     };
     auto indices = [&](unsigned base, int len, int s0) __attribute__((always_inline)) {
         Idx x;
@@ -373,7 +378,15 @@ CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const 
         const LaneTab t2 = lanetab(c + 2);
         const Idx i1 = indices(h1.base, (int)(t1.lw & 0xFFFFu), 0);          // first batch of the next chunk
         const bool has = t0.task != 0xFFFFFFFFu;
-        const double kr = (has && t0.krow >= 0) ? cpgw::gld(rinv, (unsigned)t0.krow) : 0.0;     // the instance's -1 / rho_vec where it enters
+        double kr = 0.0, kc = t0.kc;     // KKT value of the destination = kc - kr (kr: the instance's 1 / rho_vec where it enters)
+        if (KCONST) { if (has && t0.krow >= 0) kr = cpgw::gld(rinv, (unsigned)t0.krow); }
+        else if (has) {
+            const bool piv = t0.task >= (unsigned)R.nnzL;
+            if (t0.kind == CPG_K_P) kc = cpgw::gld(Pv, (unsigned)t0.krow) + (piv ? reg : 0.0);
+            else if (t0.kind == CPG_K_A) kc = cpgw::gld(Av, (unsigned)t0.krow);
+            else if (t0.kind == CPG_K_SIGMA) kc = reg;
+            else if (t0.kind == CPG_K_RHO) kr = cpgw::gld(rinv, (unsigned)t0.krow);
+        }
         const int L = cpgw::read_first_lane(h0.L), len = (int)(t0.lw & 0xFFFFu), rlen = (int)(t0.lw >> 16);
         double acc = 0.0;
         Idx cur = i0;
@@ -391,7 +404,7 @@ CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const 
         }
         acc = cpgw::group_sum_first_dyn(acc, cpgw::read_first_lane(h0.lg));
         if (has) {
-            const double v = ((has ? t0.kc : 0.0) - kr) - acc;
+            const double v = (kc - kr) - acc;
             if (t0.task >= (unsigned)R.nnzL) cpgw::gst(Dil, t0.task - (unsigned)R.nnzL, 1.0 / v);
             else cpgw::gst(Ml, t0.task, v);
         }
@@ -600,6 +613,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             if (shared && R.fac_kc) {      // shared-matrix mode: one dependent step per level, KKT values from the family's table
                 cpgw::mem_order();
                 numeric_ldl_m<false>(R, B.Lx, B.Dginv, (const double *)B.rinv, lane);
+                substitution_values<true>(R, B, lane);
+            } else if (R.fac_kind_cl) {    // per-instance matrices: same form, KKT values from the instance's scaled P / A
+                cpgw::mem_order();
+                numeric_ldl_m<false, false>(R, B.Lx, B.Dginv, (const double *)B.rinv, lane, (const double *)B.P, (const double *)B.A, F0.sigma);
                 substitution_values<true>(R, B, lane);
             } else {
                 numeric_ldl(R, B, F0.sigma, lane);
