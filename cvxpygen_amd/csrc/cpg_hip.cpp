@@ -948,19 +948,8 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     }
     R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_lcol = nullptr; R.fac_kc = nullptr; R.fac_krow = nullptr; R.fac_kc_cl = nullptr; R.fac_krow_cl = nullptr; R.fac_kind_cl = nullptr; R.fac_idx_cl = nullptr;
     std::vector<double> fkc, fkc_cl;                              // alive until the sync below
-    std::vector<int> fkrow, fkrow_cl, fkind_cl, fidx_cl;
-    {   // KKT source of every (chunk, lane) destination of the factorisation schedule
-        const size_t nd = (size_t)r->nnzL + N;
-        fkind_cl.assign((size_t)r->fac_chunks * 64, CPG_K_NONE); fidx_cl.assign((size_t)r->fac_chunks * 64, 0);
-        for (size_t e = 0; e < fkind_cl.size(); e++) {
-            const unsigned t = r->fac_task[e];
-            if (t == 0xFFFFFFFFu) continue;
-            if (t >= nd) { set_error("cpg_hip_set_refactor: factorisation task out of range"); return CPG_E_BADARG; }
-            fkind_cl[e] = r->ksrc_kind[t]; fidx_cl[e] = r->ksrc_idx[t];
-        }
-        if ((rc = upload<int>(h, own, fkind_cl.data(), fkind_cl.size(), &R.fac_kind_cl))) return rc;
-        if ((rc = upload<int>(h, own, fidx_cl.data(), fidx_cl.size(), &R.fac_idx_cl))) return rc;
-    }
+    std::vector<int> fkrow, fkrow_cl;
+
     if (r->shared_mats) {   // KKT values of the factorisation's destinations: constants of the family, except -1 / rho_vec
         bool ok = true;
         const size_t nd = (size_t)r->nnzL + N;

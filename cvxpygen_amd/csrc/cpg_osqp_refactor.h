@@ -614,11 +614,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 cpgw::mem_order();
                 numeric_ldl_m<false>(R, B.Lx, B.Dginv, (const double *)B.rinv, lane);
                 substitution_values<true>(R, B, lane);
-            } else if (R.fac_kind_cl) {    // per-instance matrices: same form, KKT values from the instance's scaled P / A
-                cpgw::mem_order();
-                numeric_ldl_m<false, false>(R, B.Lx, B.Dginv, (const double *)B.rinv, lane, (const double *)B.P, (const double *)B.A, F0.sigma);
-                substitution_values<true>(R, B, lane);
             } else {
+                // (per-instance matrices keep the two-step form: the one-step form with its KKT values gathered from the
+                // instance's P / A measured SLOWER on this kernel -- config 3 161 -> 147 k/s, all parameters 200 -> 190 k/s,
+                // profiles/r3_s13_*: its extra live values push the ADMM loop's allocation over the edge)
                 numeric_ldl(R, B, F0.sigma, lane);
                 substitution_values<false>(R, B, lane);
             }
