@@ -520,7 +520,7 @@ def main():
             g = gs.gradient({'x_init': x0}, fw.sol_x, fw.sol_y, dv, updated_params=['x_init'])
             tg = min(tg, time.perf_counter() - t0)
             ms = C_float()
-            gs.lib.L.cpg_hip_last_kernel_ms(gs.h_ref, ms)
+            gs.lib.L.cpg_hip_last_kernel_ms(gs.h_grad, ms)
             out['adjoint'] = {'instances': Bg, 'wall_ms_incl_pcie': 1e3 * tg, 'kernel_ms': float(ms.value),
                               'adjoints_per_s_kernel': Bg / (ms.value * 1e-3),
                               'dtheta_shape': list(g['_flat'].shape), 'kernel': 'osqp_gradient_kernel'}

@@ -131,3 +131,58 @@ def test_batched_forward_backward_adapter(sim_lib, oracle_lib, tmp_path):
     # a parameter shared by the whole batch may come without the batch axis
     sol2, _ = mod.forward([dict(A=Ab[0], b=bb)[nm] for nm in order], ctx)
     assert np.abs(sol2[0][0] - sol[0][0]).max() <= 1e-12
+
+
+def test_adjoint_on_the_pruned_factor_pattern(sim_lib, oracle_lib):
+    """config 5 shape: only x_init varies, so the masked KKT matrix of every instance has the workspace's P and A --
+    its factor is built on their numerically non-zero pattern (handle h_rg) while d(P), d(A) still cover every
+    STORED entry (an entry that is zero has a gradient).  Must equal the oracle's adjoint and the stored-pattern path."""
+    d = families.mpc(4, 2, 3)
+    B = 3
+    rng = np.random.default_rng(6)
+    x0 = -2 + 4 * rng.random((B, 4))
+    bs = BatchSolver(d, lib_path=sim_lib, full_output=True)
+    r = bs.solve({'x_init': x0}, updated_params=['x_init'], eps_abs=1e-6, eps_rel=1e-6)
+    dv = {v.name: 0.1 * np.ones((B,) + tuple(v.shape)) for v in d.variables}
+    g = bs.gradient({'x_init': x0}, r.sol_x, r.sol_y, dv, updated_params=['x_init'])
+    assert bs.h_grad is bs.h_rg and bs._rplan_g.nnzL < bs._rplan.nnzL          # the pruned factor was used
+    full = {q.name: np.tile(d.theta0[q.col:q.col + q.size], (B, 1)) for q in d.params}
+    full['x_init'] = x0
+    g2 = bs.gradient(full, r.sol_x, r.sol_y, dv, updated_params=d.param_names)     # matrix parameters listed: stored pattern
+    assert bs.h_grad is bs.h_ref
+    assert np.abs(g['_flat'] - g2['_flat']).max() <= 1e-9 * max(1.0, np.abs(g2['_flat']).max())
+    wts = np.zeros(d.n_var)
+    for v in d.variables:
+        wts[v.indices] = 0.1
+    p = d.param('x_init')
+    for k in range(B):
+        th = d.theta0.copy(); th[p.col:p.col + p.size] = x0[k]
+        go = oracle_lib.qp_adjoint(d, d.canon_at(th), r.sol_x[k], r.sol_y[k], wts)
+        assert np.abs(g['_flat'][k] - go['dtheta']).max() <= 1e-8 * max(1.0, np.abs(go['dtheta']).max())
+        assert np.abs(go['dtheta']).max() > 1e-4
+    # a solve after the adjoint still uses its own tables (the advisor's round-2 finding)
+    r2 = bs.solve({'x_init': x0}, updated_params=['x_init'], eps_abs=1e-6, eps_rel=1e-6)
+    assert r2.iter.tolist() == r.iter.tolist() and np.array_equal(r2.prim_flat, r.prim_flat)
+    bs.close()
+
+
+def test_alternating_solve_subset_and_gradient_all(sim_lib, oracle_lib):
+    """round-2 advisor finding: gradient() over all parameters must not disturb a solve that lists a subset --
+    three rounds of solve(['b']) / gradient(['A', 'b']) give what a fresh solver gives every time"""
+    d = families.nonneg_ls()
+    rng = np.random.default_rng(30)
+    B = 4
+    bs = BatchSolver(d, lib_path=sim_lib, full_output=True)
+    for rnd in range(3):
+        bv = rng.standard_normal((B, 3))
+        r = bs.solve({'b': bv}, updated_params=['b'])
+        th = np.tile(d.theta0, (B, 1)); pb = d.param('b'); th[:, pb.col:pb.col + 3] = bv
+        o = oracle_lib.cpg_solve_batch(d, th, ['b'])
+        assert r.iter.tolist() == o['iter'].tolist()
+        assert np.abs(r.sol_x - o['sol_x']).max() <= 1e-9 * max(1.0, np.abs(o['sol_x']).max()), rnd
+        vals = {'A': np.tile(d.theta0[d.param('A').col:d.param('A').col + 3], (B, 1)), 'b': bv}
+        g = bs.gradient(vals, r.sol_x, r.sol_y, {'x': 0.1 * np.ones((B, 2))}, updated_params=['A', 'b'])
+        wts = np.zeros(d.n_var); wts[d.variables[0].indices] = 0.1
+        go = oracle_lib.qp_adjoint(d, d.canon_at(th[0]), r.sol_x[0], r.sol_y[0], wts)
+        assert np.abs(g['_flat'][0] - go['dtheta']).max() <= 1e-9 * max(1.0, np.abs(go['dtheta']).max())
+    bs.close()
