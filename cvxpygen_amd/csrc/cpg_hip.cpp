@@ -253,16 +253,16 @@ static int launch_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int wav
     return CPG_OK;
 }
 
-template <int NSX, int NSZ>
+template <int NSX, int NSZ, bool SHARED>
 __global__ void __launch_bounds__(256, CPG_REFACTOR_WAVES_PER_SIMD)
 osqp_refactor_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    cpg::osqp_refactor_body<NSX, NSZ>(F, R, S, Bt, cpg_lds, wave_global);
+    cpg::osqp_refactor_body<NSX, NSZ, false, SHARED>(F, R, S, Bt, cpg_lds, wave_global);
 }
 template <int NSX, int NSZ>
 static int launch_refactor_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    auto kern = osqp_refactor_kernel<NSX, NSZ>;
+    auto kern = h->R.shared_mats ? osqp_refactor_kernel<NSX, NSZ, true> : osqp_refactor_kernel<NSX, NSZ, false>;
     if (lds > 48 * 1024)
         RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, stream, h->F, h->R, S, Bt);

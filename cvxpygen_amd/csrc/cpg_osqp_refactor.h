@@ -434,7 +434,10 @@ CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, 
 
 // GENI: the substitution runs through the generated instance executor (register-resident coefficients) instead of
 // the streaming one; the launch code selects it for shared-matrix handles of a family library (R.gi_ok)
-template <int NSX, int NSZ, bool GENI = false>
+// SHARED: shared-matrix mode as a compile-time fact (its own kernel instantiation): the per-instance-matrix kernel
+// then carries none of that mode's code -- this body is inlined into kernels whose register allocation reacts to
+// everything in it (config 3 lost 9 % when the shared-mode paths were merely present, profiles/r3_final1_*).
+template <int NSX, int NSZ, bool GENI = false, bool SHARED = GENI>
 CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const DevSettings &S,
                                 const DevBatch &Bt, double *lds, int wave_global) {
     const int lane = cpgw::lane_id();
@@ -461,7 +464,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
     if (GENI && per_wave < (size_t)R.nnzL + N) per_wave = (size_t)R.nnzL + N + (((size_t)R.nnzL + N) & 1u);
     double *w = lds + (size_t)cpgw::wave_in_block() * per_wave;
     double *qs = w + ldw, *us = qs + n;
-    const bool shared = GENI || R.shared_mats != 0;      // (a literal in the generated-executor build: its kernel serves shared-matrix handles only)
+    constexpr bool shared = SHARED || GENI;
     InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F0, R);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
     const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
@@ -610,7 +613,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 
         // ---- 4. numeric LDL' through the dot-product schedule, 5. coefficients of the substitution program
         auto factor_generic = [&]() __attribute__((always_inline)) {
-            if (shared && R.fac_kc) {      // shared-matrix mode: one dependent step per level, KKT values from the family's table
+            if (shared) {      // shared-matrix mode: one dependent step per level, KKT values from the family's table
                 cpgw::mem_order();
                 numeric_ldl_m<false>(R, B.Lx, B.Dginv, (const double *)B.rinv, lane);
                 substitution_values<true>(R, B, lane);
