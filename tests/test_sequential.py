@@ -166,3 +166,42 @@ def test_drop_in_sequence_on_a_vector_only_family(sim_lib, oracle_lib, tmp_path)
     bs = mod._SOLVER.batch_solver
     assert bs.h.value == bs.h_shared.value
     assert iters[2] <= iters[0]                                       # a nearby problem does not converge slower warm
+
+
+def _three_call_sequence_with_a_rho_change(lib_path, oracle_lib, tmp_path, wrapper):
+    """the reference's static workspace under OSQP >= 1.0 (solvers/osqp.py:100-101): every call resets the SETTINGS
+    (rho back to 0.1), the workspace keeps the rho and factor of its last adapt_rho.  Call 1 adapts rho (MPC: the
+    estimate leaves [rho / 5, 5 rho] at iteration 50), call 2 warm-starts on the adapted factor and compares its
+    estimates with 0.1 again, call 3 cold-starts the iterates but not the workspace's rho."""
+    d = families.mpc(6, 3, 10)
+    prob = LiteProblem.from_descriptor(d)
+    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'seq_rho'), solver='OSQP', wrapper=wrapper)
+    if not wrapper:
+        mod = cpg.load_generated(str(tmp_path / 'seq_rho'), prob)
+        mod._SOLVER.lib_path = lib_path
+    ses = oracle_lib.CpgSession(d)
+    rng = np.random.default_rng(3)
+    rhos = []
+    for k, kw in enumerate(({}, {}, {'warm_start': False})):
+        x0 = -2 + 4 * rng.random(6)
+        prob.param_dict['x_init'].value = x0
+        val = prob.solve(method='CPG', updated_params=['x_init'], **kw)
+        o = ses.solve({'x_init': x0}, warm=bool(kw.get('warm_start', 1)))
+        assert prob._solution.attr['num_iters'] == o['iter'] and prob.status == 'solved', k
+        assert abs(val - o['obj_val']) <= 1e-6 * max(1.0, abs(o['obj_val'])), k
+        for v in d.variables:
+            got = np.ravel(prob.var_dict[v.name].value, order='F')
+            assert np.abs(got - o['x'][v.indices]).max() <= 1e-6 * max(1.0, np.abs(o['x']).max()), (k, v.name)
+        ws = mod._SOLVER._workspace()['state']
+        assert abs(ws[0, -1] - o['rho']) <= 1e-9 * o['rho'], k              # the workspace's rho travels with the state
+        rhos.append(o['rho'])
+    assert rhos[0] != 0.1                                                    # call 1 did adapt
+
+
+def test_three_call_sequence_with_a_rho_change(sim_lib, oracle_lib, tmp_path):
+    _three_call_sequence_with_a_rho_change(sim_lib, oracle_lib, tmp_path, wrapper=False)
+
+
+@pytest.mark.gpu
+def test_three_call_sequence_with_a_rho_change_on_gpu(oracle_lib, tmp_path):
+    _three_call_sequence_with_a_rho_change(None, oracle_lib, tmp_path, wrapper=True)
