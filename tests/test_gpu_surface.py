@@ -270,3 +270,43 @@ def test_portfolio_family_library_vs_oracle(oracle_lib, opts):
     o = oracle_lib.cpg_solve_batch(d, _theta(d, vals), list(vals), **opts)
     _check(r, o, d)
     bs.close()
+
+
+@pytest.mark.parametrize('lib', ['family', 'generic'])
+def test_hybrid_execution_edge_cases(oracle_lib, lib):
+    """the two-kernel execution of the default mode (shared factor until an instance's rho changes, per-instance
+    factor behind it) where its bookkeeping is most exposed: cut-offs at / between the adaptation points, an
+    adaptation interval that is not a multiple of check_termination, two instances per wavefront, and a batch whose
+    instances arrive with different workspace rhos (hand-over at iteration 0) -- all against the oracle."""
+    import os
+    d = families.mpc(6, 3, 10)
+    B = 200
+    x0 = -2 + 4 * np.random.default_rng(23).random((B, 6))
+    th = _theta(d, {'x_init': x0})
+    gen = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'cvxpygen_amd', 'generated', 'mpc6', 'libcpg_mpc6.so')
+    lib_path = gen if (lib == 'family' and os.path.exists(gen)) else None
+    for opts, stg, G in (({}, dict(max_iter=50), 1), ({}, dict(max_iter=63), 1), ({}, dict(max_iter=30), 1),
+                         (dict(adaptive_rho_interval=35), {}, 1), ({}, dict(eps_abs=1e-6, eps_rel=1e-6), 1), ({}, {}, 2)):
+        bs = BatchSolver(d, lib_path=lib_path, build_options=opts)
+        bs.set_launch(0, G, 0)
+        r = bs.solve({'x_init': x0}, updated_params=['x_init'], **stg)
+        o = oracle_lib.cpg_solve_batch(d, th, ['x_init'], **opts, **stg)
+        _check(r, o, d)
+        assert bs._hybrid and (r.status != -3).all() and (r.status != -2).all()
+        bs.close()
+    # workspaces with their own rho (a sequential caller's state): per instance, against CpgSession
+    bs = BatchSolver(d, lib_path=lib_path)
+    r1 = bs.solve({'x_init': x0[:8]}, updated_params=['x_init'], return_state=True)
+    x1 = -2 + 4 * np.random.default_rng(24).random((8, 6))
+    r2 = bs.solve({'x_init': x1}, updated_params=['x_init'], state_in=r1.state, return_state=True)
+    assert len(set(np.round(r1.state[:, -1], 12))) > 1                  # the batch really carries different rhos
+    for k in range(8):
+        ses = oracle_lib.CpgSession(d)
+        ses.solve({'x_init': x0[k]})
+        o = ses.solve({'x_init': x1[k]})
+        assert r2.iter[k] == o['iter'] and r2.status[k] == o['status'], k
+        got = np.concatenate([np.ravel(r2.prim[v.name][k], order='F') for v in d.variables])
+        ref = np.concatenate([o['x'][v.indices] for v in d.variables])
+        assert np.abs(got - ref).max() <= REL_TOL * max(1.0, np.abs(ref).max()), k
+        assert abs(r2.state[k, -1] - o['rho']) <= 1e-9 * o['rho']
+    bs.close()
