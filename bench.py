@@ -262,7 +262,17 @@ def main():
     oracle_mode = dict(adaptive_rho=0, check_dualgap=0) if args.fixed_rho else {}
     if desc.solver == 'CLARABEL':
         from cvxpygen_amd.conic_runtime import ConicBatchSolver
-        solver = ConicBatchSolver(desc, device=local_rank, lib_path=args.lib)
+        cplan = None
+        if lib_path is None and not args.generic:
+            # what generate_code(solver='CLARABEL') builds: substitution-program executor generated for this family
+            # (verified against the plan's fingerprint / rebuilt, as above)
+            from cvxpygen_amd import codegen
+            from cvxpygen_amd.conic_plan import build_conic_plan
+            cplan = build_conic_plan(desc)
+            lib_path = codegen.build_conic_library(cplan, os.path.dirname(gen), args.workload) if rank == 0 else gen
+            if dist is not None:
+                dist.barrier()
+        solver = ConicBatchSolver(desc, device=local_rank, lib_path=lib_path, plan=cplan)
     else:
         solver = BatchSolver(desc, device=local_rank, lib_path=lib_path, build_options=build_options, plan=plan)
     solver.set_launch(args.waves, args.ipw, args.blocks_per_cu)

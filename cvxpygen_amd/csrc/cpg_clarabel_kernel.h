@@ -17,6 +17,11 @@
 // unregularised K; Mehrotra predictor-corrector with sigma = (1 - alpha)^3.
 #pragma once
 #include "cpg_osqp_kernel.h"
+#ifdef CPG_GENC_HEADER
+// generated straight-line executor of this family's substitution program (codegen.emit_instance_program, coef='lds'):
+// cpg::run_program_conic(entries, offsets, slots, w, lane)
+#include CPG_GENC_HEADER
+#endif
 
 namespace cpg {
 
@@ -31,6 +36,9 @@ namespace cpg {
 #define CPG_CL_SOLVED 1
 #define CPG_CL_PRIMAL_INFEASIBLE 2
 #define CPG_CL_DUAL_INFEASIBLE 3
+#define CPG_CL_ALMOST_SOLVED 4
+#define CPG_CL_ALMOST_PRIMAL_INFEASIBLE 5
+#define CPG_CL_ALMOST_DUAL_INFEASIBLE 6
 #define CPG_CL_MAX_ITERATIONS 7
 #define CPG_CL_NUMERICAL_ERROR 9
 #define CPG_CL_INSUFFICIENT_PROGRESS 10
@@ -40,6 +48,9 @@ struct DevConicSettings {
         ir_max_iter;
     double max_step_fraction, tol_gap_abs, tol_gap_rel, tol_feas, tol_infeas_abs, tol_infeas_rel, eq_min, eq_max,
         static_const, static_prop, dyn_eps, dyn_delta, ir_reltol, ir_abstol, ir_stop_ratio, min_terminate_step;
+    // kappa/tau threshold of the infeasibility certificates and the reduced tolerances behind the "almost" statuses
+    // (cvxpygen/solvers/clarabel.py:76-84)
+    double tol_ktratio, red_gap_abs, red_gap_rel, red_feas, red_infeas_abs, red_infeas_rel, red_ktratio;
 };
 
 struct DevConic {
@@ -66,13 +77,18 @@ struct DevConic {
     int lds_doubles;                         // per wavefront
     int fac_triples, n_pfull;                // table lengths needed to stage the tables in LDS
     int tab_doubles;                         // LDS doubles of the block-shared copy of all index tables
+    // generated executor of the substitution program (family library, CPG_GENC_HEADER): operand offsets
+    // [step / 4][lane][4] and output slots [chunk / 4][lane][4]; the entries get `sv_pad` trailing zeros and the work
+    // vector `w_extra` slots (dummy store targets + the zero slot)
+    int gc_ok, sv_pad, w_extra, gc_ncols, gc_nrows;
+    const unsigned short *gc_cols, *gc_rows;
 };
 
 struct ConicBuf {
     double *P, *A, *q, *b, *D, *E, *x, *z, *s, *dx, *dz, *ds, *x2, *z2, *rx, *rz, *tx, *tz, *lam, *wv, *hd, *et,
-        *dsc, *rb, *sol, *er, *cand, *Lx, *Dg, *Dginv, *sv, *w;
+        *dsc, *rb, *sol, *er, *cand, *Lx, *Dg, *Dginv, *sv, *w, *px, *pz, *ps;
 };
-// per-wavefront LDS: nnzP + nnzA + 7n + 14m + 6(n+m) + nnzL + sol_nnz + sol_slots doubles (host: cpg_hip.cpp)
+// per-wavefront LDS: nnzP + nnzA + 8n + 16m + 6(n+m) + nnzL + sol_nnz + sv_pad + sol_slots + w_extra doubles (host: cpg_hip.cpp)
 CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
     ConicBuf o;
     const int n = C.n, m = C.m, N = n + m;
@@ -81,8 +97,9 @@ CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
     o.b = p; p += m; o.E = p; p += m; o.z = p; p += m; o.s = p; p += m; o.dz = p; p += m; o.ds = p; p += m;
     o.z2 = p; p += m; o.rz = p; p += m; o.tz = p; p += m; o.lam = p; p += m; o.wv = p; p += m; o.hd = p; p += m;
     o.et = p; p += m; o.dsc = p; p += m;
+    o.px = p; p += n; o.pz = p; p += m; o.ps = p; p += m;       // previous iterate (insufficient progress falls back to it)
     o.rb = p; p += N; o.sol = p; p += N; o.er = p; p += N; o.cand = p; p += N; o.Dg = p; p += N; o.Dginv = p; p += N;
-    o.Lx = p; p += C.nnzL; o.sv = p; p += C.sol_nnz; o.w = p;
+    o.Lx = p; p += C.nnzL; o.sv = p; p += C.sol_nnz + C.sv_pad; o.w = p;
     return o;
 }
 
@@ -153,6 +170,10 @@ struct ConicCtx {
     CPG_DEV void ldl_apply(const LdsProg &SP, const double *in, double *out, const double *add) const {
         for (unsigned i = (unsigned)lane; i < N; i += 64u) B.w[i] = in[i];
         cpgw::lds_order();
+#ifdef CPG_GENC_HEADER
+        if (C.gc_ok) run_program_conic(B.sv, C.gc_cols, C.gc_rows, B.w, lane);
+        else
+#endif
         run_program_lds<1>(SP, B.w, C.sol_slots, lane);
         for (unsigned i = (unsigned)lane; i < N; i += 64u) {
             const double r = B.w[(unsigned)cpgw::gld(C.sol_fpos, i)];
@@ -435,12 +456,12 @@ struct ConicCtx {
 
 // Solves rb = (rhs_x, dsc - rhs_z) and assembles the step (dx, dz, ds, dtau, dkappa) of the
 // homogeneous embedding; x2 / z2 is the constant part K^{-1}(-q, b), `den` its denominator.
-CPG_DEV void conic_step(const ConicCtx &cx, const LdsProg &SP, double rhs_tau, double rhs_kap, double tau, double kap,
+// (The solve sol = (x1, z1) = K^{-1} rb itself is issued by the caller: the iteration has ONE inlined copy of kkt_solve.)
+CPG_DEV void conic_step(const ConicCtx &cx, double rhs_tau, double rhs_kap, double tau, double kap,
                         double den, double &dtau, double &dkap) {
     const ConicBuf &B = cx.B;
     const unsigned n = cx.n, m = cx.m;
     const int lane = cx.lane;
-    cx.kkt_solve(SP);                          // sol = (x1, z1)
     for (unsigned j = (unsigned)lane; j < n; j += 64u) B.tx[j] = cx.row_P(j, B.sol);
     cpgw::lds_order();
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -470,9 +491,16 @@ CPG_DEV const T *conic_stage(const T *src, unsigned count, double *&cur) {
     return dst;
 }
 
-template <bool TABLES_IN_LDS>
+// SPECIALISED (family library, handle whose family is the one the library was generated for): the family's dimensions
+// are compile-time constants (CPG_GENC_SPECIALISE of the generated header), so every vector of the interior-point state
+// sits at a constant offset from the wave's LDS base, every staged table at a constant offset from the block's, and the
+// loops over n / m / nnz have known trip counts -- instead of ~80 wave-uniform pointers kept in (and spilled from) SGPRs.
+template <bool TABLES_IN_LDS, bool SPECIALISED = false>
 CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const DevBatch &Bt, double *lds, int /*wave_global*/) {
     DevConic C = C0;
+#ifdef CPG_GENC_HEADER
+    if (SPECIALISED) { CPG_GENC_SPECIALISE(C) }
+#endif
     if (TABLES_IN_LDS) {
         double *cur = lds;
         const unsigned n1 = (unsigned)C.n + 1u, m1 = (unsigned)C.m + 1u, NN = (unsigned)(C.n + C.m);
@@ -494,9 +522,17 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
         C.fac_a = conic_stage(C0.fac_a, (unsigned)C.fac_triples, cur);
         C.fac_b = conic_stage(C0.fac_b, (unsigned)C.fac_triples, cur);
         C.fac_k = conic_stage(C0.fac_k, (unsigned)C.fac_triples, cur);
+#ifdef CPG_GENC_HEADER
+        // a family library: the generated executor reads its own two tables instead of the program's three.  (For another
+        // family the program's tables stay in global memory: staging one set or the other under a run-time branch would
+        // turn every table pointer of both executors into a flat one.)
+        C.gc_cols = conic_stage(C0.gc_cols, (unsigned)C.gc_ncols, cur);     // (no entries for another family)
+        C.gc_rows = conic_stage(C0.gc_rows, (unsigned)C.gc_nrows, cur);
+#else
         C.sol_ctab = conic_stage(C0.sol_ctab, (unsigned)C.sol_chunks * 4u, cur);
         C.sol_desc = conic_stage(C0.sol_desc, (unsigned)C.sol_chunks * 64u, cur);
         C.sol_cols = conic_stage(C0.sol_cols, (unsigned)C.sol_nnz, cur);
+#endif
         C.sol_kind = conic_stage(C0.sol_kind, (unsigned)C.sol_nnz, cur);
         C.sol_idx = conic_stage(C0.sol_idx, (unsigned)C.sol_nnz, cur);
         C.sol_fpos = conic_stage(C0.sol_fpos, NN, cur);
@@ -511,6 +547,10 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
     SP.ctab = C.sol_ctab; SP.desc = C.sol_desc; SP.vals = B.sv; SP.cols = C.sol_cols;
     SP.n_chunks = C.sol_chunks; SP.dummy = (unsigned)C.sol_nnz - 1u; SP.rows16 = nullptr;
     const int degree = C.n_nonneg + C.n_soc;
+    // zero padding behind the entries, dummy slots and zero slot behind the work vector (generated executor)
+    for (int t = lane; t < C.sv_pad; t += 64) B.sv[C.sol_nnz + t] = 0.0;
+    for (int t = lane; t < C.w_extra; t += 64) B.w[C.sol_slots + t] = 0.0;
+    cpgw::lds_order();
 
     for (;;) {
         unsigned ig = 0;
@@ -615,23 +655,25 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
         // ---- 3. initial point: identity scaling, one factorisation, shift into the cones
         cx.identity_scaling();
         cx.factor();
-        if (!C.p_is_zero) {
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = -B.q[j];
+        {   // one solve (x, z) = K^{-1}(-q, b), s = -z; for P == 0 two: (x, -s) = K^{-1}(0, b), then (., z) = K^{-1}(-q, 0).  One
+            // inlined copy of kkt_solve here as well.
+            const int nsolve = C.p_is_zero ? 2 : 1;
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = C.p_is_zero ? 0.0 : -B.q[j];
             for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.b[i];
-            cpgw::lds_order();
-            cx.kkt_solve(SP);
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = B.sol[j];
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) { const double zv = B.sol[n + i]; B.z[i] = zv; B.s[i] = -zv; }
-        } else {
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = 0.0;
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.b[i];
-            cpgw::lds_order();
-            cx.kkt_solve(SP);
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) { B.x[j] = B.sol[j]; B.rb[j] = -B.q[j]; }
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.s[i] = -B.sol[n + i]; B.rb[n + i] = 0.0; }
-            cpgw::lds_order();
-            cx.kkt_solve(SP);
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.z[i] = B.sol[n + i];
+#pragma nounroll
+            for (int k = 0; k < nsolve; k++) {
+                cpgw::lds_order();
+                cx.kkt_solve(SP);
+                if (!C.p_is_zero) {
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = B.sol[j];
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) { const double zv = B.sol[n + i]; B.z[i] = zv; B.s[i] = -zv; }
+                } else if (k == 0) {
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) { B.x[j] = B.sol[j]; B.rb[j] = -B.q[j]; }
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.s[i] = -B.sol[n + i]; B.rb[n + i] = 0.0; }
+                } else {
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) B.z[i] = B.sol[n + i];
+                }
+            }
         }
         cpgw::lds_order();
         cx.shift_to_cone(B.s, true);
@@ -639,8 +681,10 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
         double tau = 1.0, kap = 1.0;
 
         // ---- 4. interior-point iterations
-        int status = CPG_CL_UNSOLVED, iter = 0;
+        int status = CPG_CL_UNSOLVED, iter = 0, almost = CPG_CL_UNSOLVED;
         double cost_p = 0.0, res_p = 0.0, res_d = 0.0;
+        double prev_cost_p = CPG_INFTY, prev_res_p = CPG_INFTY, prev_res_d = CPG_INFTY, prev_gap_abs = CPG_INFTY, prev_gap_rel = CPG_INFTY;
+        double prev_tau = 1.0, prev_kap = 1.0;
 #pragma nounroll
         for (;;) {
             // residuals: tx = P x, rx = -P x - A'z - q tau, rz = A x + s - b tau
@@ -682,76 +726,112 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
             const double nx = n_x * tinv, nz = n_z * tinv, ns = n_s * tinv;
             res_p = n_rz * tinv / cpgw::dmax2(1.0, normb + nx + ns);
             res_d = n_rx * tinv * cinv / cpgw::dmax2(1.0, normq + nx + nz);
-            const double gap_abs = fabs(cost_p - cost_d);
-            const double gap_rel = gap_abs / cpgw::dmax2(1.0, cpgw::dmin2(fabs(cost_p), fabs(cost_d)));
+            double gap_abs = fabs(cost_p - cost_d);
+            double gap_rel = gap_abs / cpgw::dmax2(1.0, cpgw::dmin2(fabs(cost_p), fabs(cost_d)));
             const double ktratio = kap / tau;
-            if (ktratio <= 1.0 && (gap_abs < S.tol_gap_abs || gap_rel < S.tol_gap_rel) && res_p < S.tol_feas && res_d < S.tol_feas)
-                status = CPG_CL_SOLVED;
-            else if (ktratio > 1000.0) {
-                const double bz = dbz * cinv, qx = dqx * cinv;
-                if (bz < -S.tol_infeas_abs && res_pinf < -S.tol_infeas_rel * bz) status = CPG_CL_PRIMAL_INFEASIBLE;
-                else if (qx < -S.tol_infeas_abs && res_dinf < -S.tol_infeas_rel * qx) status = CPG_CL_DUAL_INFEASIBLE;
+            const double bz = dbz * cinv, qx = dqx * cinv;
+            // check_convergence: optimality at kappa/tau <= 1, certificates once kappa/tau > 1000 / tol_ktratio
+            auto verdict = [&](double t_gap_abs, double t_gap_rel, double t_feas, double t_inf_abs, double t_inf_rel, double t_kt,
+                               int solved, int pinf, int dinf) -> int {
+                if (ktratio <= 1.0 && (gap_abs < t_gap_abs || gap_rel < t_gap_rel) && res_p < t_feas && res_d < t_feas) return solved;
+                if (ktratio > 1000.0 / t_kt) {
+                    if (bz < -t_inf_abs && res_pinf < -t_inf_rel * bz) return pinf;
+                    if (qx < -t_inf_abs && res_dinf < -t_inf_rel * qx) return dinf;
+                }
+                return CPG_CL_UNSOLVED;
+            };
+            status = verdict(S.tol_gap_abs, S.tol_gap_rel, S.tol_feas, S.tol_infeas_abs, S.tol_infeas_rel, S.tol_ktratio,
+                             CPG_CL_SOLVED, CPG_CL_PRIMAL_INFEASIBLE, CPG_CL_DUAL_INFEASIBLE);
+            // poor progress: the residuals went up at round-off level with the previous gap inside its tolerance, or by a
+            // factor 100 out of the feasibility tolerance -> stop, back on the previous iterate and its figures
+            if (status == CPG_CL_UNSOLVED && iter > 1 && (res_d > prev_res_d || res_p > prev_res_p)) {
+                if (ktratio < 100.0 * 2.220446049250313e-16 && (prev_gap_abs < S.tol_gap_abs || prev_gap_rel < S.tol_gap_rel))
+                    status = CPG_CL_INSUFFICIENT_PROGRESS;
+                if ((res_d > S.tol_feas && res_d > 100.0 * prev_res_d) || (res_p > S.tol_feas && res_p > 100.0 * prev_res_p))
+                    status = CPG_CL_INSUFFICIENT_PROGRESS;
+                if (status == CPG_CL_INSUFFICIENT_PROGRESS) {
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = B.px[j];
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.z[i] = B.pz[i]; B.s[i] = B.ps[i]; }
+                    cpgw::lds_order();
+                    tau = prev_tau; kap = prev_kap;
+                    cost_p = prev_cost_p; res_p = prev_res_p; res_d = prev_res_d; gap_abs = prev_gap_abs; gap_rel = prev_gap_rel;
+                }
             }
             if (status == CPG_CL_UNSOLVED && iter >= S.max_iter) status = CPG_CL_MAX_ITERATIONS;
+            // what these figures are worth at the reduced tolerances: the status of a solve that ends in an error or at
+            // the iteration limit (post_process of the published solver)
+            almost = verdict(S.red_gap_abs, S.red_gap_rel, S.red_feas, S.red_infeas_abs, S.red_infeas_rel, S.red_ktratio,
+                             CPG_CL_ALMOST_SOLVED, CPG_CL_ALMOST_PRIMAL_INFEASIBLE, CPG_CL_ALMOST_DUAL_INFEASIBLE);
             if (status != CPG_CL_UNSOLVED) break;
+            prev_cost_p = cost_p; prev_res_p = res_p; prev_res_d = res_d; prev_gap_abs = gap_abs; prev_gap_rel = gap_rel;
             iter++;
 
             // scaling, factorisation, constant part (x2, z2) = K^{-1}(-q, b)
             if (!cx.update_scaling()) { status = CPG_CL_NUMERICAL_ERROR; break; }
             cx.factor();
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = -B.q[j];
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.b[i];
-            cpgw::lds_order();
-            cx.kkt_solve(SP);
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) { B.x2[j] = B.sol[j]; B.cand[j] = B.x[j] / tau - B.sol[j]; }
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.z2[i] = B.sol[n + i];
-            cpgw::lds_order();
-            double den;
-            {
-                double qx2 = 0.0, bz2 = 0.0, vPv = 0.0, x2Px2 = 0.0;
-                for (unsigned j = (unsigned)lane; j < n; j += 64u) {
-                    qx2 = fma(B.q[j], B.x2[j], qx2);
-                    vPv = fma(B.cand[j], cx.row_P(j, B.cand), vPv);
-                    x2Px2 = fma(B.x2[j], cx.row_P(j, B.x2), x2Px2);
+            // The three solves of an iteration -- constant part (x2, z2) = K^{-1}(-q, b), affine step, combined step -- run
+            // through ONE copy of kkt_solve (substitution sweeps + refinement): inlined three times, the loop body
+            // outgrew the instruction cache two CUs share.  Same operations in the same order as the straight-line form.
+            double den = 0.0, dtau = 0.0, dkap = 0.0, alpha = 1.0, sigma = 0.0, rk = 0.0;
+#pragma nounroll
+            for (int pass = 0; pass < 3; pass++) {
+                if (pass == 0) {
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = -B.q[j];
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.b[i];
+                } else if (pass == 1) {          // affine step: rhs (rx, rz, rtau, tau kappa), ds offset = s
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = B.rx[j];
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.dsc[i] = B.s[i]; B.rb[n + i] = B.s[i] - B.rz[i]; }
+                } else {                         // combined step
+                    cx.combined_ds_offset(sigma * mu);
+                    rk = -sigma * mu + dtau * dkap + tau * kap;
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = (1.0 - sigma) * B.rx[j];
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.dsc[i] - (1.0 - sigma) * B.rz[i];
                 }
-                for (unsigned i = (unsigned)lane; i < m; i += 64u) bz2 = fma(B.b[i], B.z2[i], bz2);
-                qx2 = cpgw::wave_sum(qx2); bz2 = cpgw::wave_sum(bz2); vPv = cpgw::wave_sum(vPv); x2Px2 = cpgw::wave_sum(x2Px2);
-                den = kap / tau - qx2 - bz2 + vPv - x2Px2;
+                cpgw::lds_order();
+                cx.kkt_solve(SP);
+                if (pass == 0) {
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) { B.x2[j] = B.sol[j]; B.cand[j] = B.x[j] / tau - B.sol[j]; }
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) B.z2[i] = B.sol[n + i];
+                    cpgw::lds_order();
+                    double qx2 = 0.0, bz2 = 0.0, vPv = 0.0, x2Px2 = 0.0;
+                    for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                        qx2 = fma(B.q[j], B.x2[j], qx2);
+                        vPv = fma(B.cand[j], cx.row_P(j, B.cand), vPv);
+                        x2Px2 = fma(B.x2[j], cx.row_P(j, B.x2), x2Px2);
+                    }
+                    for (unsigned i = (unsigned)lane; i < m; i += 64u) bz2 = fma(B.b[i], B.z2[i], bz2);
+                    qx2 = cpgw::wave_sum(qx2); bz2 = cpgw::wave_sum(bz2); vPv = cpgw::wave_sum(vPv); x2Px2 = cpgw::wave_sum(x2Px2);
+                    den = kap / tau - qx2 - bz2 + vPv - x2Px2;
+                } else {
+                    const double rhs_tau = pass == 1 ? rtau : (1.0 - sigma) * rtau;
+                    const double rhs_kap = pass == 1 ? tau * kap : rk;
+                    conic_step(cx, rhs_tau, rhs_kap, tau, kap, den, dtau, dkap);
+                    alpha = 1.0;
+                    if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
+                    if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
+                    alpha = cx.step_length(B.z, B.dz, alpha);
+                    alpha = cx.step_length(B.s, B.ds, alpha);
+                    if (pass == 1) sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
+                }
             }
-            // affine step: rhs (rx, rz, rtau, tau kappa), ds offset = s
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = B.rx[j];
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.dsc[i] = B.s[i]; B.rb[n + i] = B.s[i] - B.rz[i]; }
-            cpgw::lds_order();
-            double dtau, dkap;
-            conic_step(cx, SP, rtau, tau * kap, tau, kap, den, dtau, dkap);
-            double alpha = 1.0;
-            if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
-            if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
-            alpha = cx.step_length(B.z, B.dz, alpha);
-            alpha = cx.step_length(B.s, B.ds, alpha);
-            const double sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
-            // combined step
-            cx.combined_ds_offset(sigma * mu);
-            const double rk = -sigma * mu + dtau * dkap + tau * kap;
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = (1.0 - sigma) * B.rx[j];
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.dsc[i] - (1.0 - sigma) * B.rz[i];
-            cpgw::lds_order();
-            conic_step(cx, SP, (1.0 - sigma) * rtau, rk, tau, kap, den, dtau, dkap);
-            alpha = 1.0;
-            if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
-            if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
-            alpha = cx.step_length(B.z, B.dz, alpha);
-            alpha = cx.step_length(B.s, B.ds, alpha);
             alpha *= S.max_step_fraction;
-            if (alpha < S.min_terminate_step) { status = CPG_CL_INSUFFICIENT_PROGRESS; break; }
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] += alpha * B.dx[j];
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.s[i] += alpha * B.ds[i]; B.z[i] += alpha * B.dz[i]; }
+            if (alpha <= cpgw::dmax2(0.0, S.min_terminate_step)) { status = CPG_CL_INSUFFICIENT_PROGRESS; break; }   // undersized step
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) { const double v = B.x[j]; B.px[j] = v; B.x[j] = v + alpha * B.dx[j]; }
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+                const double sv = B.s[i], zv = B.z[i];
+                B.ps[i] = sv; B.pz[i] = zv;
+                B.s[i] = sv + alpha * B.ds[i]; B.z[i] = zv + alpha * B.dz[i];
+            }
+            prev_tau = tau; prev_kap = kap;
             tau += alpha * dtau; kap += alpha * dkap;
             cpgw::lds_order();
         }
 
         // ---- 5. retrieve: cpg_retrieve_prim / _dual / _info (utils.py:1040-1046; clarabel.py:37-46)
-        const bool infeasible = status == CPG_CL_PRIMAL_INFEASIBLE || status == CPG_CL_DUAL_INFEASIBLE;
+        if ((status == CPG_CL_MAX_ITERATIONS || status == CPG_CL_NUMERICAL_ERROR || status == CPG_CL_INSUFFICIENT_PROGRESS) &&
+            almost != CPG_CL_UNSOLVED) status = almost;
+        const bool infeasible = status == CPG_CL_PRIMAL_INFEASIBLE || status == CPG_CL_DUAL_INFEASIBLE ||
+                                status == CPG_CL_ALMOST_PRIMAL_INFEASIBLE || status == CPG_CL_ALMOST_DUAL_INFEASIBLE;
         const double scale = infeasible ? 1.0 : 1.0 / tau;
         for (unsigned k = (unsigned)lane; k < (unsigned)C.n_prim; k += 64u) {
             const unsigned j = (unsigned)cpgw::gld(C.prim_idx, k);

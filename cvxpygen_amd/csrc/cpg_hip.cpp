@@ -62,11 +62,11 @@ struct cpg_solver_s {
     unsigned *d_counter = nullptr;
     int n_vary_x = 0, n_vary_z = 0;
     bool conic = false;                 // interior-point handle (cpg_hip_create_clarabel)
+    bool conic_specialised = false;     // ... of the family its library was generated for (dimensions compiled in)
     cpg::DevConic C{};
     cpg::DevConicSettings CS{};
     double time_limit = 1e10; int verbose = 1, direct_kkt_solver = 1, presolve_enable = 1;   // accepted, unused
-    double reduced[6] = {5e-5, 5e-5, 1e-4, 5e-5, 5e-5, 1e-4}, tol_ktratio = 1e-6, linesearch_backtrack_step = 0.8,
-           min_switch_step_length = 0.1;
+    double linesearch_backtrack_step = 0.8, min_switch_step_length = 0.1;   // asymmetric cones only: accepted, unused
     DevBuf scratch;                     // delta_x / delta_y stash, [waves][G][n + m]
     // staging for the host-pointer entry point
     DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status, s_state_in, s_state_out;
@@ -331,16 +331,16 @@ static int launch_refactor(cpg_handle_t h, rt_stream_t stream, const cpg::DevSet
 #ifndef CPG_CONIC_WAVES_PER_SIMD
 #define CPG_CONIC_WAVES_PER_SIMD 4   // <= 128 VGPRs
 #endif
-template <bool TABLES_IN_LDS>
+template <bool TABLES_IN_LDS, bool SPECIALISED>
 __global__ void __launch_bounds__(512, CPG_CONIC_WAVES_PER_SIMD)
 clarabel_kernel(cpg::DevConic C, cpg::DevConicSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    cpg::clarabel_body<TABLES_IN_LDS>(C, S, Bt, cpg_lds, wave_global);
+    cpg::clarabel_body<TABLES_IN_LDS, SPECIALISED>(C, S, Bt, cpg_lds, wave_global);
 }
-template <bool TABLES_IN_LDS>
+template <bool TABLES_IN_LDS, bool SPECIALISED>
 static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    auto kern = clarabel_kernel<TABLES_IN_LDS>;
+    auto kern = clarabel_kernel<TABLES_IN_LDS, SPECIALISED>;
     if (lds > 48 * 1024)
         RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->C, h->CS, Bt);
@@ -348,7 +348,11 @@ static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, i
     return CPG_OK;
 }
 static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds, bool tables_in_lds) {
-    return tables_in_lds ? launch_conic_t<true>(h, Bt, blocks, waves, lds) : launch_conic_t<false>(h, Bt, blocks, waves, lds);
+#ifdef CPG_GENC_HEADER
+    // the library's own family: dimensions as compile-time constants (clarabel_body<., true>)
+    if (h->conic_specialised && tables_in_lds) return launch_conic_t<true, true>(h, Bt, blocks, waves, lds);
+#endif
+    return tables_in_lds ? launch_conic_t<true, false>(h, Bt, blocks, waves, lds) : launch_conic_t<false, false>(h, Bt, blocks, waves, lds);
 }
 
 
@@ -426,13 +430,13 @@ static double *conic_double_setting(cpg_handle_t h, const std::string &s) {
     if (s == "tol_feas") return &c.tol_feas;
     if (s == "tol_infeas_abs") return &c.tol_infeas_abs;
     if (s == "tol_infeas_rel") return &c.tol_infeas_rel;
-    if (s == "tol_ktratio") return &h->tol_ktratio;
-    if (s == "reduced_tol_gap_abs") return &h->reduced[0];
-    if (s == "reduced_tol_gap_rel") return &h->reduced[1];
-    if (s == "reduced_tol_feas") return &h->reduced[2];
-    if (s == "reduced_tol_infeas_abs") return &h->reduced[3];
-    if (s == "reduced_tol_infeas_rel") return &h->reduced[4];
-    if (s == "reduced_tol_ktratio") return &h->reduced[5];
+    if (s == "tol_ktratio") return &c.tol_ktratio;
+    if (s == "reduced_tol_gap_abs") return &c.red_gap_abs;
+    if (s == "reduced_tol_gap_rel") return &c.red_gap_rel;
+    if (s == "reduced_tol_feas") return &c.red_feas;
+    if (s == "reduced_tol_infeas_abs") return &c.red_infeas_abs;
+    if (s == "reduced_tol_infeas_rel") return &c.red_infeas_rel;
+    if (s == "reduced_tol_ktratio") return &c.red_ktratio;
     if (s == "equilibrate_min_scaling") return &c.eq_min;
     if (s == "equilibrate_max_scaling") return &c.eq_max;
     if (s == "linesearch_backtrack_step") return &h->linesearch_backtrack_step;
@@ -475,8 +479,8 @@ int cpg_hip_set_default_settings(cpg_handle_t h) {
         c.dynamic_reg_enable = 1; c.dyn_eps = 1e-13; c.dyn_delta = 2e-7;
         c.ir_enable = 1; c.ir_reltol = 1e-13; c.ir_abstol = 1e-12; c.ir_max_iter = 10; c.ir_stop_ratio = 5.0;
         h->time_limit = 1e10; h->verbose = 1; h->direct_kkt_solver = 1; h->presolve_enable = 1;
-        h->reduced[0] = 5e-5; h->reduced[1] = 5e-5; h->reduced[2] = 1e-4; h->reduced[3] = 5e-5; h->reduced[4] = 5e-5;
-        h->reduced[5] = 1e-4; h->tol_ktratio = 1e-6; h->linesearch_backtrack_step = 0.8; h->min_switch_step_length = 0.1;
+        c.red_gap_abs = 5e-5; c.red_gap_rel = 5e-5; c.red_feas = 1e-4; c.red_infeas_abs = 5e-5; c.red_infeas_rel = 5e-5;
+        c.red_ktratio = 1e-4; c.tol_ktratio = 1e-6; h->linesearch_backtrack_step = 0.8; h->min_switch_step_length = 0.1;
         return CPG_OK;
     }
     // defaults of the generated solver, cvxpygen/solvers/osqp.py:102-115
@@ -531,6 +535,10 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     if (!h || !name || !v) { set_error("null argument"); return CPG_E_BADARG; }
     std::string s(name);
     if (h->conic) {
+        // (read-only fact about the handle) 1: the substitution program runs on the library's generated executor
+        if (s == "generated_executor") { *v = h->C.gc_ok ? 1.0 : 0.0; return CPG_OK; }
+        // ... 1: the kernel instantiation with this family's dimensions compiled in is the one launched
+        if (s == "specialised_kernel") { *v = h->conic_specialised ? 1.0 : 0.0; return CPG_OK; }
         if (double *d = conic_double_setting(h, s)) { *v = *d; return CPG_OK; }
         if (int *i = conic_int_setting(h, s)) { *v = *i; return CPG_OK; }
         set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG;
@@ -749,6 +757,57 @@ static int open_device(cpg_handle_t h, int device) {
     return CPG_OK;
 }
 
+static bool conic_dims_equal(const cpg::DevConic &a, const cpg::DevConic &b) {
+    return a.n == b.n && a.m == b.m && a.nnzP == b.nnzP && a.nnzA == b.nnzA && a.nnzL == b.nnzL && a.n_zero == b.n_zero &&
+           a.n_nonneg == b.n_nonneg && a.n_soc == b.n_soc && a.is_max == b.is_max && a.p_is_zero == b.p_is_zero &&
+           a.fac_chunks == b.fac_chunks && a.sol_chunks == b.sol_chunks && a.sol_nnz == b.sol_nnz && a.sol_slots == b.sol_slots &&
+           a.fac_triples == b.fac_triples && a.n_pfull == b.n_pfull && a.sv_pad == b.sv_pad && a.w_extra == b.w_extra &&
+           a.gc_ncols == b.gc_ncols && a.gc_nrows == b.gc_nrows;
+}
+// LDS tables of a generated per-instance executor (codegen.emit_instance_program): operand byte offsets
+// [step / 4][lane][4] (lanes without an entry read the zero slot) and output slots [chunk / 4][lane][4] (lanes
+// without a row store to dummy slots chosen per 16-lane store group so that they add no bank conflict; segmented
+// chunks carry their segment mask above bit 13).  `steps`: {first entry, active lanes} in execution order.
+static bool generated_tables(const int *ctab, const unsigned *desc, const unsigned short *cols, int n_chunks, int nnz, int n_slots,
+                             const int (*steps)[2], int T, std::vector<unsigned short> &gcols, std::vector<unsigned short> &grows) {
+    const unsigned zero_off = (unsigned)(n_slots + CPG_GEN_DUMMY_SLOTS) * 8u;
+    if (zero_off > 0xFFFFu || n_slots + CPG_GEN_EXTRA_SLOTS > 0x1FFF) return false;
+    const int T4 = (T + 3) & ~3, C4 = (n_chunks + 3) & ~3;
+    gcols.assign((size_t)T4 * 64, (unsigned short)zero_off);
+    for (int t = 0; t < T; t++) {
+        const int e = steps[t][0], cnt = steps[t][1];
+        if (e < 0 || cnt < 0 || cnt > 64 || e + cnt > nnz) return false;
+        for (int l = 0; l < cnt; l++) gcols[((size_t)(t / 4) * 64 + l) * 4 + (t % 4)] = cols[e + l];
+    }
+    grows.assign((size_t)C4 * 64, (unsigned short)n_slots);
+    for (int c = 0; c < n_chunks; c++) {
+        const bool seg = ctab[4 * c + 3] & 1;
+        for (int g0 = 0; g0 < 64; g0 += 16) {
+            bool used[16] = {false};
+            for (int t = g0; t < g0 + 16; t++) { const unsigned d = desc[(size_t)c * 64 + t]; if ((d & 0xFFFFu) != 0xFFFFu) used[(d & 0xFFFFu) % 16u] = true; }
+            int nxt = 0;
+            for (int t = g0; t < g0 + 16; t++) {
+                const unsigned d = desc[(size_t)c * 64 + t];
+                unsigned slot = d & 0xFFFFu;
+                if (slot == 0xFFFFu) {
+                    while (nxt < CPG_GEN_DUMMY_SLOTS && used[(unsigned)(n_slots + nxt) % 16u]) nxt++;
+                    const int j = nxt < CPG_GEN_DUMMY_SLOTS ? nxt++ : (t & (CPG_GEN_DUMMY_SLOTS - 1));
+                    slot = (unsigned)(n_slots + j);
+                }
+                grows[((size_t)(c >> 2) * 64 + t) * 4 + (c & 3)] = (unsigned short)(slot | ((seg ? (d >> 28) : 0u) << 13));
+            }
+        }
+    }
+    return true;
+}
+static unsigned program_fingerprint(const int *ctab, const unsigned *desc, const unsigned short *cols, int n_chunks, int nnz) {
+    unsigned hsh = 0x811C9DC5u;
+    auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < nbytes; i++) hsh = (hsh ^ b[i]) * 0x01000193u; };
+    mix(ctab, (size_t)n_chunks * 16); mix(desc, (size_t)n_chunks * 256); mix(cols, (size_t)nnz * 2);
+    return hsh;
+}
+
 int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_t *out) {
     if (!f || !out) { set_error("null argument"); return CPG_E_BADARG; }
     if (f->n <= 0 || f->m < 0 || f->n + f->m >= 0xFFFF) { set_error("bad family dimensions"); return CPG_E_BADARG; }
@@ -795,6 +854,30 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     TRY(upload_csr(h, own, f->map_P, &C.map_P)); TRY(upload_csr(h, own, f->map_A, &C.map_A));
     TRY(upload_csr(h, own, f->map_q, &C.map_q)); TRY(upload_csr(h, own, f->map_b, &C.map_b));
     TRY(upload_csr(h, own, f->map_d, &C.map_d));
+    C.gc_ok = 0; C.sv_pad = 0; C.w_extra = 0; C.gc_ncols = 0; C.gc_nrows = 0; C.gc_cols = nullptr; C.gc_rows = nullptr;
+#ifdef CPG_GENC_HEADER
+    // a family library: its generated executor replaces the table-driven one when the substitution program handed in is
+    // the one the executor was generated from
+    if (f->sol_chunks == CPG_GENC_NCHUNKS && f->sol_nnz == CPG_GENC_NNZ && f->sol_slots == CPG_GENC_NSLOTS &&
+        program_fingerprint(f->sol_ctab, f->sol_desc, f->sol_cols, f->sol_chunks, f->sol_nnz) == CPG_GENC_FINGERPRINT &&
+        !(getenv("CPG_CONIC_GENERATED") && atoi(getenv("CPG_CONIC_GENERATED")) == 0)) {
+        static const int steps[][2] = CPG_GENC_STEPS;
+        std::vector<unsigned short> gcols, grows;
+        if (generated_tables(f->sol_ctab, f->sol_desc, f->sol_cols, f->sol_chunks, f->sol_nnz, f->sol_slots, steps, CPG_GENC_NSTEPS, gcols, grows)) {
+            TRY(upload<unsigned short>(h, own, gcols.data(), gcols.size(), &C.gc_cols));
+            TRY(upload<unsigned short>(h, own, grows.data(), grows.size(), &C.gc_rows));
+            C.gc_ncols = (int)gcols.size(); C.gc_nrows = (int)grows.size();
+            C.gc_ok = 1; C.sv_pad = 64; C.w_extra = CPG_GEN_EXTRA_SLOTS;
+            // every dimension the generated header compiled in must be this family's (CPG_GENC_SPECIALISE assigns the
+            // same fields of the kernel's copy of C)
+            cpg::DevConic Cs = C;
+            Cs.n_pfull = f->Prp[n]; Cs.fac_triples = f->fac_triples;
+            cpg::DevConic Ck = Cs;
+            { cpg::DevConic &Cref = Ck; CPG_GENC_SPECIALISE(Cref) }
+            h->conic_specialised = conic_dims_equal(Cs, Ck) && !(getenv("CPG_CONIC_SPECIALISED") && atoi(getenv("CPG_CONIC_SPECIALISED")) == 0);
+        }
+    }
+#endif
     {   // LDS doubles of the block-shared copy of the index tables, same order and rounding as
         // clarabel_body<true> (conic_stage)
         C.fac_triples = f->fac_triples; C.n_pfull = f->Prp[n];
@@ -805,12 +888,16 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
         t += dbl((size_t)n + 1, 4) + dbl((size_t)f->nnzP, 4) + dbl((size_t)n + 1, 4) + 2 * dbl((size_t)C.n_pfull, 4);
         t += dbl((size_t)f->nnzL, 4) + 2 * dbl((size_t)f->nnzL + N, 4);
         t += dbl((size_t)f->fac_chunks * 4, 4) + 2 * dbl((size_t)f->fac_chunks * 64, 4) + 3 * dbl((size_t)f->fac_triples, 4);
+#ifdef CPG_GENC_HEADER
+        t += dbl((size_t)C.gc_ncols, 2) + dbl((size_t)C.gc_nrows, 2);
+#else
         t += dbl((size_t)f->sol_chunks * 4, 4) + dbl((size_t)f->sol_chunks * 64, 4) + dbl((size_t)f->sol_nnz, 2);
+#endif
         t += 2 * dbl((size_t)f->sol_nnz, 4) + dbl((size_t)N, 2);
         C.tab_doubles = (int)t;
     }
     {   // per-wavefront LDS slice, see conic_carve()
-        const long long d = (long long)f->nnzP + f->nnzA + 7LL * n + 14LL * m + 6LL * N + f->nnzL + f->sol_nnz + f->sol_slots;
+        const long long d = (long long)f->nnzP + f->nnzA + 8LL * n + 16LL * m + 6LL * N + f->nnzL + f->sol_nnz + C.sv_pad + f->sol_slots + C.w_extra;
         C.lds_doubles = (int)((d + 1) & ~1LL);
         if ((size_t)C.lds_doubles * 8 > h->lds_limit) {
             set_error("conic family too large: the interior-point state of one instance does not fit the LDS");
@@ -980,10 +1067,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     std::vector<unsigned short> gcols, grows, glcol;
     std::vector<unsigned> gsrc;
     if (r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
-        unsigned hsh = 0x811C9DC5u;
-        auto mix = [&](const void *p, size_t nbytes) { const unsigned char *b = (const unsigned char *)p;
-            for (size_t i = 0; i < nbytes; i++) hsh = (hsh ^ b[i]) * 0x01000193u; };
-        mix(r->sol_ctab, (size_t)r->sol_chunks * 16); mix(r->sol_desc, (size_t)r->sol_chunks * 256); mix(r->sol_cols, (size_t)r->sol_nnz * 2);
+        const unsigned hsh = program_fingerprint(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz);
         static const int steps[][2] = CPG_GENI_STEPS;             // {first entry, active lanes} in execution order
         bool ok = hsh == CPG_GENI_FINGERPRINT;
         {   // the row programs of the termination test carry their chunk tables as literals
@@ -994,43 +1078,19 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                     if (h->rows_hdr[k][4 * c2] != cpg::GeniRows::len(k, c2) || h->rows_hdr[k][4 * c2 + 3] != cpg::GeniRows::off(k, c2)) ok = false;
             }
         }
-        const unsigned zero_off = (unsigned)(r->sol_slots + CPG_GEN_DUMMY_SLOTS) * 8u;
-        if (zero_off > 0xFFFFu || r->sol_slots + CPG_GEN_EXTRA_SLOTS > 0x1FFF) ok = false;
+        if (ok) ok = generated_tables(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz, r->sol_slots, steps, CPG_GENI_NSTEPS, gcols, grows);
         if (ok) {
-            const int T4 = (CPG_GENI_NSTEPS + 3) & ~3, C4 = (CPG_GENI_NCHUNKS + 3) & ~3;
-            gcols.assign((size_t)T4 * 64, (unsigned short)zero_off);
             gsrc.assign((size_t)CPG_GENI_NSTEPS * 64, 0u);
             glcol.assign((size_t)CPG_GENI_NSTEPS * 64, (unsigned short)0);
             for (int t = 0; ok && t < CPG_GENI_NSTEPS; t++) {
                 const int e = steps[t][0], cnt = steps[t][1];
-                if (e < 0 || cnt < 0 || cnt > 64 || e + cnt > r->sol_nnz) { ok = false; break; }
                 for (int l = 0; l < cnt; l++) {
-                    gcols[((size_t)(t / 4) * 64 + l) * 4 + (t % 4)] = r->sol_cols[e + l];
                     const int kind = r->sol_kind[e + l], idx = r->sol_idx[e + l];
                     if (kind < 0 || kind > 3 || idx < 0 || idx >= (1 << 28)) { ok = false; break; }
                     gsrc[(size_t)t * 64 + l] = ((unsigned)kind << 28) | (unsigned)idx;
                     if (kind == 2) {
                         if (idx >= r->nnzL || r->Lcol[idx] < 0 || r->Lcol[idx] > 0xFFFF) { ok = false; break; }
                         glcol[(size_t)t * 64 + l] = (unsigned short)r->Lcol[idx];
-                    }
-                }
-            }
-            grows.assign((size_t)C4 * 64, (unsigned short)r->sol_slots);
-            for (int c = 0; ok && c < r->sol_chunks; c++) {
-                const bool seg = r->sol_ctab[4 * c + 3] & 1;
-                for (int g0 = 0; g0 < 64; g0 += 16) {            // dummy targets per 16-lane store group, as for the shared program
-                    bool used[16] = {false};
-                    for (int t = g0; t < g0 + 16; t++) { const unsigned d = r->sol_desc[(size_t)c * 64 + t]; if ((d & 0xFFFFu) != 0xFFFFu) used[(d & 0xFFFFu) % 16u] = true; }
-                    int nxt = 0;
-                    for (int t = g0; t < g0 + 16; t++) {
-                        const unsigned d = r->sol_desc[(size_t)c * 64 + t];
-                        unsigned slot = d & 0xFFFFu;
-                        if (slot == 0xFFFFu) {
-                            while (nxt < CPG_GEN_DUMMY_SLOTS && used[(unsigned)(r->sol_slots + nxt) % 16u]) nxt++;
-                            const int j = nxt < CPG_GEN_DUMMY_SLOTS ? nxt++ : (t & (CPG_GEN_DUMMY_SLOTS - 1));
-                            slot = (unsigned)(r->sol_slots + j);
-                        }
-                        grows[((size_t)(c >> 2) * 64 + t) * 4 + (c & 3)] = (unsigned short)(slot | ((seg ? (d >> 28) : 0u) << 13));
                     }
                 }
             }

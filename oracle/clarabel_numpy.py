@@ -412,6 +412,8 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
 
     status, it = UNSOLVED, 0
     info = {}
+    prev = dict(res_p=np.inf, res_d=np.inf, gap_abs=np.inf, gap_rel=np.inf, cost_p=np.inf, cost_d=np.inf)
+    prev_iterate = (x, z, s, tau, kap)
     while True:
         # ---- residuals
         Px = Ph @ x
@@ -444,21 +446,40 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
                     dot_bz=dot_bz * cinv, dot_qx=dot_qx * cinv)
 
         def converged(pre):
+            # check_convergence: optimality at kappa/tau <= 1, infeasibility certificates once kappa/tau has passed
+            # 1000 / tol_ktratio (the published solver hard-codes the factor 1000 next to the setting)
             g = lambda k: stg[pre + k]
-            if ktratio <= 1.0 and ((gap_abs < g('tol_gap_abs')) or (gap_rel < g('tol_gap_rel'))) \
-                    and res_p < g('tol_feas') and res_d < g('tol_feas'):
+            if ktratio <= 1.0 and ((info['gap_abs'] < g('tol_gap_abs')) or (info['gap_rel'] < g('tol_gap_rel'))) \
+                    and info['res_p'] < g('tol_feas') and info['res_d'] < g('tol_feas'):
                 return ALMOST_SOLVED if pre else SOLVED
-            if ktratio > 1000.0:
+            if ktratio > 1000.0 / g('tol_ktratio'):
                 if info['dot_bz'] < -g('tol_infeas_abs') and res_pinf < -g('tol_infeas_rel') * info['dot_bz']:
                     return ALMOST_PRIMAL_INFEASIBLE if pre else PRIMAL_INFEASIBLE
                 if info['dot_qx'] < -g('tol_infeas_abs') and res_dinf < -g('tol_infeas_rel') * info['dot_qx']:
                     return ALMOST_DUAL_INFEASIBLE if pre else DUAL_INFEASIBLE
             return UNSOLVED
         status = converged('')
+        # poor progress (check_termination of the published solver): the residuals went up ...
+        if status == UNSOLVED and it > 1 and (res_d > prev['res_d'] or res_p > prev['res_p']):
+            # ... at high accuracy: kappa/tau at round-off level and the previous gap already inside the tolerance
+            if ktratio < 100.0 * np.finfo(float).eps and \
+                    (prev['gap_abs'] < stg['tol_gap_abs'] or prev['gap_rel'] < stg['tol_gap_rel']):
+                status = INSUFFICIENT_PROGRESS
+            # ... or by a factor 100, out of the feasibility tolerance
+            if (res_d > stg['tol_feas'] and res_d > 100.0 * prev['res_d']) or \
+                    (res_p > stg['tol_feas'] and res_p > 100.0 * prev['res_p']):
+                status = INSUFFICIENT_PROGRESS
+            if status == INSUFFICIENT_PROGRESS:
+                # "insufficient progress often involves actual degradation of results": back to the previous iterate
+                # and its cost / residual / gap figures (kappa/tau and the certificate quantities stay)
+                x, z, s, tau, kap = prev_iterate
+                for k_ in ('cost_p', 'cost_d', 'res_p', 'res_d', 'gap_abs', 'gap_rel'):
+                    info[k_] = prev[k_]
         if status == UNSOLVED and it >= int(stg['max_iter']):
             status = MAX_ITERATIONS
         if status != UNSOLVED:
             break
+        prev = dict(info)
         it += 1
         # ---- scaling, factor, constant part of the solution
         if not sc.update(s, z):
@@ -504,9 +525,10 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
         dx, dz, ds, dtau, dkap = kkt_solve((1.0 - sigma) * rx, (1.0 - sigma) * rz, (1.0 - sigma) * rtau, rk,
                                            sc.ds_offset(d_s))
         alpha = step_len(dz, ds, dtau, dkap, True)
-        if alpha < stg['min_terminate_step_length']:
+        if alpha <= max(0.0, stg['min_terminate_step_length']):      # undersized step: stop where we are
             status = INSUFFICIENT_PROGRESS
             break
+        prev_iterate = (x, z, s, tau, kap)
         x = x + alpha * dx
         s = s + alpha * ds
         z = z + alpha * dz
@@ -514,8 +536,11 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
         kap += alpha * dkap
 
     if status in (NUMERICAL_ERROR, INSUFFICIENT_PROGRESS, MAX_ITERATIONS):
-        # the last iterate may still pass the reduced tolerances
-        pass
+        # post_process of the published solver: after an error or the iteration limit the last figures may still pass
+        # the reduced tolerances -> "almost" statuses (cvxpygen/solvers/clarabel.py:79-84 carries their settings)
+        almost = converged('reduced_')
+        if almost != UNSOLVED:
+            status = almost
     if status in (PRIMAL_INFEASIBLE, ALMOST_PRIMAL_INFEASIBLE, DUAL_INFEASIBLE, ALMOST_DUAL_INFEASIBLE):
         scale = 1.0                  # certificates are returned unnormalised by tau
         obj = np.nan

@@ -181,6 +181,46 @@ def test_adp_in_emulator_vs_oracle(sim_lib):
     bs.close()
 
 
+def _fact(bs, name):
+    import ctypes as C
+    v = C.c_double(-1)
+    bs.lib.check(bs.lib.L.cpg_hip_get_setting(bs.h, name.encode(), C.byref(v)), 'get_setting')
+    return v.value
+
+
+def test_generated_conic_executor_in_emulator(tmp_path):
+    """a conic family library (codegen.conic_header: straight-line executor of the substitution program, entries read
+    from the wave's LDS array) gives the table-driven executor's results bit for bit -- same products, same
+    accumulation order --, and hands any OTHER family to the table-driven executor it also carries"""
+    from tests.sim import build_sim
+    d = families.adp()
+    cp = build_conic_plan(d)
+    lib = build_sim.build_conic_family(cp, str(tmp_path), 'adp')
+    hdr = open(os.path.join(str(tmp_path), 'cpg_conic_adp.h')).read()
+    assert 'run_program_conic' in hdr and f'#define CPG_GENC_FINGERPRINT {cp.sol.fingerprint()}u' in hdr
+    pv = _adp_batch(4, 5)
+    bs = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+    r = bs.solve(pv)
+    assert _fact(bs, 'generated_executor') == 1.0 and _fact(bs, 'specialised_kernel') == 1.0
+    o = cl.cpg_solve_batch(d, _theta(d, pv))
+    _assert_parity(r, o, tol=1e-9)
+    os.environ['CPG_CONIC_GENERATED'] = '0'              # same library, table-driven executor
+    try:
+        bt = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+        rt = bt.solve(pv)
+    finally:
+        del os.environ['CPG_CONIC_GENERATED']
+    assert _fact(bt, 'generated_executor') == 0.0 and _fact(bt, 'specialised_kernel') == 0.0
+    assert np.array_equal(r.sol_x, rt.sol_x) and np.array_equal(r.sol_y, rt.sol_y) and r.iter.tolist() == rt.iter.tolist()
+    bs.close(); bt.close()
+    d2 = families.toy_box(solver='CLARABEL')             # another family through the ADP library
+    th = np.tile(d2.theta0, (2, 1)); th[1, :3] = [0.3, 1.0, -1.0]
+    b2 = ConicBatchSolver(d2, lib_path=lib, full_output=True)
+    _assert_parity(b2.solve({'a': th[:, 0], 'lb': th[:, 1], 'ub': th[:, 2]}), cl.cpg_solve_batch(d2, th), tol=1e-9)
+    assert _fact(b2, 'generated_executor') == 0.0
+    b2.close()
+
+
 def test_infeasible_and_lp_instances_in_emulator(sim_lib):
     """status integers of the conic path (Clarabel numbering) and the P == 0 initialisation"""
     d = families.toy_box(solver='CLARABEL')
@@ -201,6 +241,58 @@ def test_infeasible_and_lp_instances_in_emulator(sim_lib):
     assert o['status'].tolist() == [1, 3, 1]            # c < 0: unbounded below
     _assert_parity(r, o, tol=1e-9)
     bs.close()
+
+
+def _almost_cases():
+    """settings under which solves end at the iteration limit or on insufficient progress, where the reduced tolerances
+    (cvxpygen/solvers/clarabel.py:79-84) decide between the "almost" statuses 4 / 5 / 6 and the raw 7 / 10"""
+    d = families.adp()
+    pv = _adp_batch(8, 1)
+    th = _theta(d, pv)
+    cases = [(d, pv, th, dict(max_iters=3)),            # a mix of AlmostSolved (4) and MaxIterations (7)
+             (d, pv, th, dict(max_iters=4)),            # all AlmostSolved
+             (d, pv, th, dict(max_iters=5)),            # Solved where 5 iterations are enough, AlmostSolved elsewhere
+             # feasibility tolerance below round-off: the residuals stop improving -> insufficient progress, back to the
+             # previous iterate, which passes the reduced tolerances
+             # (what trips the test is round-off noise, which depends on the elimination order: the oracle's dense LDL' in
+             # natural order and the kernel's sparse one agree on the status and the point, not on the exact iteration)
+             (d, pv, th, dict(tol_feas=1e-16, tol_gap_abs=1e-3, tol_gap_rel=1e-3, _noise=True))]
+    d3 = families.toy_lp(solver='CLARABEL')
+    th3 = np.tile(d3.theta0, (3, 1)); th3[1, 0] = -1.0; th3[2, 0] = 0.7
+    cases.append((d3, {'c': th3[:, 0]}, th3, dict(max_iters=4)))          # AlmostDualInfeasible (6) for the unbounded instance
+    return cases
+
+
+def _check_almost(lib_for):
+    seen = set()
+    for d, pv, th, stg in _almost_cases():
+        stg = dict(stg)
+        noise = stg.pop('_noise', False)
+        bs = ConicBatchSolver(d, lib_path=lib_for(d), full_output=True)
+        r = bs.solve(pv, **stg)
+        o = cl.cpg_solve_batch(d, th, **{('max_iter' if k == 'max_iters' else k): v for k, v in stg.items()})
+        assert r.status.tolist() == o['status'].tolist(), (stg, r.status, o['status'])
+        if noise:       # the stopping iteration is decided by residuals at round-off level: both sides stop early, on a point
+            assert (r.iter < 20).all() and (o['iter'] < 20).all() and (r.status == 4).all()      # good to the reduced tolerances
+        else:
+            assert r.iter.tolist() == o['iter'].tolist()
+        tol = 1e-4 if noise else 1e-8
+        fin = np.isin(o['status'], (1, 4))
+        assert np.abs(r.sol_x[fin] - o['sol_x'][fin]).max() <= tol * max(1.0, np.abs(o['sol_x'][fin]).max())
+        assert np.abs(r.obj_val[fin] - o['obj_val'][fin]).max() <= tol * max(1.0, np.abs(o['obj_val'][fin]).max())
+        assert np.isnan(r.obj_val[np.isin(o['status'], (2, 3, 5, 6))]).all()
+        seen |= set(o['status'].tolist())
+        bs.close()
+    assert {1, 4, 6, 7} <= seen
+
+
+def test_almost_statuses_in_emulator(sim_lib):
+    _check_almost(lambda d: sim_lib)
+
+
+@pytest.mark.gpu
+def test_almost_statuses_on_gpu():
+    _check_almost(lambda d: None)
 
 
 def test_generate_code_drop_in_for_conic_family(sim_lib, tmp_path):
@@ -251,6 +343,30 @@ def test_adp_on_gpu_vs_oracle():
     th = np.tile(d.theta0, (B, 1)); th[:, 3:9] = pv['f']
     _assert_parity(r2, cl.cpg_solve_batch(d, th))
     bs.close()
+
+
+@pytest.mark.gpu
+def test_generated_conic_executor_on_gpu():
+    """the ADP family library (__graft_entry__.build: generated executor of the substitution program) against the oracle
+    and, bit for bit, against the table-driven executor of the generic library"""
+    from cvxpygen_amd import codegen
+    d = families.adp()
+    cp = build_conic_plan(d)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = codegen.build_conic_library(cp, os.path.join(root, 'cvxpygen_amd', 'generated', 'adp'), 'adp')   # no-op when fresh
+    pv = _adp_batch(300, 11)
+    bs = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+    r = bs.solve(pv)
+    assert _fact(bs, 'generated_executor') == 1.0 and _fact(bs, 'specialised_kernel') == 1.0
+    _assert_parity(r, cl.cpg_solve_batch(d, _theta(d, pv)))
+    pv = _adp_batch(5000, 12)                           # a batch larger than the resident wavefronts, executor against executor
+    r = bs.solve(pv)
+    bg = ConicBatchSolver(d, full_output=True)
+    rg = bg.solve(pv)
+    assert _fact(bg, 'generated_executor') == 0.0
+    assert np.array_equal(r.sol_x, rg.sol_x) and np.array_equal(r.sol_y, rg.sol_y)
+    assert r.iter.tolist() == rg.iter.tolist() and r.status.tolist() == rg.status.tolist()
+    bs.close(); bg.close()
 
 
 @pytest.mark.gpu
