@@ -106,17 +106,18 @@ class GeneratedSolver:
         return self._ws
 
     def _filter_settings(self, kwargs):
-        """settings enabled through `enable_settings` that have no counterpart in the batched kernels:
-        accepted like the reference's `cpg_set_solver_<name>`; polishing itself is not implemented"""
+        """settings the reference only offers through `enable_settings` (`solvers/osqp.py:111-114`): accepted like its
+        `cpg_set_solver_<name>` once enabled and, like there, without effect on the iterates.  The generated solver is
+        EMBEDDED OSQP: `osqp_solve` polishes only outside embedded mode (polish.c allocates a reduced KKT system and
+        is not part of the emitted sources), printing is compiled out, and `delta` / `polish_refine_iter` are read by
+        the polish step alone -- so `polishing=1` changes a field of the settings struct and nothing else."""
         out = dict(kwargs)
         if self.desc.solver == 'OSQP' and not self.two_stage:
             for name in ('verbose', 'polishing', 'polish_refine_iter', 'delta'):
                 if name in out:
                     if name not in self.enabled_settings:
                         raise AttributeError(f'Solver setting "{name}" not available.')
-                    v = out.pop(name)
-                    if name == 'polishing' and int(v):
-                        raise NotImplementedError('solution polishing is not implemented in the HIP backend')
+                    out.pop(name)
         return out
 
     def reset_workspace(self):

@@ -144,6 +144,24 @@ def test_drop_in_keeps_the_reference_workspace_between_calls(sim_lib, oracle_lib
     assert np.abs(prob.var_dict['x'].value - x1).max() > 1e-6
 
 
+def test_enabled_optional_settings_are_fields_without_effect(sim_lib, tmp_path):
+    """`enable_settings=['polishing', ...]` (solvers/osqp.py:111-114): the names become accepted keywords; in the
+    embedded OSQP build the reference emits they change a settings field and not the solve -- same here; a name that
+    was not enabled is refused like any unknown setting"""
+    d = families.toy_box()
+    prob = LiteProblem.from_descriptor(d)
+    cpg.generate_code(prob, code_dir=str(tmp_path / 'opt_code'), solver='OSQP', wrapper=False,
+                      enable_settings=['polishing', 'polish_refine_iter', 'delta'])
+    mod = cpg.load_generated(str(tmp_path / 'opt_code'), prob)
+    mod._SOLVER.lib_path = sim_lib
+    v0 = prob.solve(method='CPG', warm_start=False)
+    it0, x0 = prob._solution.attr['num_iters'], prob.var_dict['x'].value.copy()
+    v1 = prob.solve(method='CPG', warm_start=False, polishing=1, polish_refine_iter=3, delta=1e-7)
+    assert v1 == v0 and prob._solution.attr['num_iters'] == it0 and np.array_equal(prob.var_dict['x'].value, x0)
+    with pytest.raises(AttributeError, match='not available'):
+        prob.solve(method='CPG', verbose=1)                        # not among the enabled names
+
+
 def test_drop_in_sequence_on_a_vector_only_family(sim_lib, oracle_lib, tmp_path):
     """only vector parameters (q, l, u): shared factor in every call, warm start from the previous solution"""
     d = families.toy_box()
