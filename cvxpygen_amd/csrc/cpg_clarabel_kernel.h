@@ -88,7 +88,7 @@ struct ConicBuf {
     double *P, *A, *q, *b, *D, *E, *x, *z, *s, *dx, *dz, *ds, *x2, *z2, *rx, *rz, *tx, *tz, *lam, *wv, *hd, *et,
         *dsc, *rb, *sol, *er, *cand, *Lx, *Dg, *Dginv, *sv, *w, *px, *pz, *ps;
 };
-// per-wavefront LDS: nnzP + nnzA + 8n + 16m + 6(n+m) + nnzL + sol_nnz + sv_pad + sol_slots + w_extra doubles (host: cpg_hip.cpp)
+// per-wavefront LDS: nnzP + nnzA + 7n + 14m + 6(n+m) + nnzL + sol_nnz + sv_pad + sol_slots + w_extra doubles (host: cpg_hip.cpp)
 CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
     ConicBuf o;
     const int n = C.n, m = C.m, N = n + m;
@@ -97,9 +97,11 @@ CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
     o.b = p; p += m; o.E = p; p += m; o.z = p; p += m; o.s = p; p += m; o.dz = p; p += m; o.ds = p; p += m;
     o.z2 = p; p += m; o.rz = p; p += m; o.tz = p; p += m; o.lam = p; p += m; o.wv = p; p += m; o.hd = p; p += m;
     o.et = p; p += m; o.dsc = p; p += m;
-    o.px = p; p += n; o.pz = p; p += m; o.ps = p; p += m;       // previous iterate (insufficient progress falls back to it)
     o.rb = p; p += N; o.sol = p; p += N; o.er = p; p += N; o.cand = p; p += N; o.Dg = p; p += N; o.Dginv = p; p += N;
     o.Lx = p; p += C.nnzL; o.sv = p; p += C.sol_nnz + C.sv_pad; o.w = p;
+    // previous iterate (insufficient progress falls back to it): in the step's place -- a step is dead from the moment it
+    // is applied until the next iteration's solves write a new one, which is after the progress test
+    o.px = o.dx; o.pz = o.dz; o.ps = o.ds;
     return o;
 }
 
@@ -816,11 +818,11 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
             }
             alpha *= S.max_step_fraction;
             if (alpha <= cpgw::dmax2(0.0, S.min_terminate_step)) { status = CPG_CL_INSUFFICIENT_PROGRESS; break; }   // undersized step
-            for (unsigned j = (unsigned)lane; j < n; j += 64u) { const double v = B.x[j]; B.px[j] = v; B.x[j] = v + alpha * B.dx[j]; }
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) { const double v = B.x[j], d = B.dx[j]; B.px[j] = v; B.x[j] = v + alpha * d; }
             for (unsigned i = (unsigned)lane; i < m; i += 64u) {
-                const double sv = B.s[i], zv = B.z[i];
-                B.ps[i] = sv; B.pz[i] = zv;
-                B.s[i] = sv + alpha * B.ds[i]; B.z[i] = zv + alpha * B.dz[i];
+                const double sv = B.s[i], zv = B.z[i], dsv = B.ds[i], dzv = B.dz[i];
+                B.ps[i] = sv; B.pz[i] = zv;                 // (px / pz / ps ARE dx / dz / ds: read the step first)
+                B.s[i] = sv + alpha * dsv; B.z[i] = zv + alpha * dzv;
             }
             prev_tau = tau; prev_kap = kap;
             tau += alpha * dtau; kap += alpha * dkap;

@@ -897,7 +897,7 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
         C.tab_doubles = (int)t;
     }
     {   // per-wavefront LDS slice, see conic_carve()
-        const long long d = (long long)f->nnzP + f->nnzA + 8LL * n + 16LL * m + 6LL * N + f->nnzL + f->sol_nnz + C.sv_pad + f->sol_slots + C.w_extra;
+        const long long d = (long long)f->nnzP + f->nnzA + 7LL * n + 14LL * m + 6LL * N + f->nnzL + f->sol_nnz + C.sv_pad + f->sol_slots + C.w_extra;
         C.lds_doubles = (int)((d + 1) & ~1LL);
         if ((size_t)C.lds_doubles * 8 > h->lds_limit) {
             set_error("conic family too large: the interior-point state of one instance does not fit the LDS");
@@ -1301,6 +1301,19 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
         const bool tables_in_lds = h->program_in_lds != 0 && tab + per_wave <= h->lds_limit;
         const size_t fixed = tables_in_lds ? tab : 0;
         while (W > 1 && fixed + (size_t)W * per_wave > h->lds_limit) W--;
+        if (h->waves_per_block <= 0) {
+            // what counts is the number of resident waves per CU (the kernel is VALU-issue bound from ~12 on): when a
+            // second 8-wave workgroup just misses the LDS, two smaller ones beat one (ADP with the previous-iterate
+            // copy: 8 + 0 waves at 83.8 KB per workgroup, 7 + 7 at 75.1 KB)
+            int best = W, best_res = 0;
+            for (int w2 = W; w2 >= 4; w2--) {
+                int pc = (int)(h->lds_limit / (fixed + (size_t)w2 * per_wave));
+                if (h->blocks_per_cu > 0 && pc > h->blocks_per_cu) pc = h->blocks_per_cu;
+                int res = pc * w2; if (res > 4 * CPG_CONIC_WAVES_PER_SIMD) res = 4 * CPG_CONIC_WAVES_PER_SIMD;
+                if (res > best_res) { best_res = res; best = w2; }
+            }
+            W = best;
+        }
         const size_t lds = fixed + (size_t)W * per_wave;
         long long blocks = (B + W - 1) / W;
         int per_cu = (int)(h->lds_limit / lds); if (per_cu < 1) per_cu = 1;
