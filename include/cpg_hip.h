@@ -231,9 +231,13 @@ typedef struct {
 int cpg_hip_device_count(int *count);
 int cpg_hip_create_osqp(const cpg_osqp_family_t *family, int device, cpg_handle_t *out);
 /* conic interior-point handle; solve with cpg_hip_solve_batch[_device]; `status` then carries
- * Clarabel's SolverStatus integers (1 solved, 2 primal infeasible, 3 dual infeasible, 7 maximum
+ * Clarabel's SolverStatus integers (1 solved, 2 primal infeasible, 3 dual infeasible, 4 / 5 / 6 their
+ * "almost" forms at the reduced tolerances after an error or at the iteration limit, 7 maximum
  * iterations, 9 numerical error, 10 insufficient progress) and the setting names are those of
- * cvxpygen/solvers/clarabel.py:63-119 */
+ * cvxpygen/solvers/clarabel.py:63-119.  In a library compiled for one conic family
+ * (cvxpygen_amd.codegen.build_conic_library) a handle of exactly that family runs the generated executor of
+ * its substitution program with the family's dimensions compiled in; cpg_hip_get_setting reports it as
+ * "generated_executor" / "specialised_kernel" (1.0 / 0.0); any other family runs the table-driven path. */
 int cpg_hip_create_clarabel(const cpg_conic_family_t *family, int device, cpg_handle_t *out);
 int cpg_hip_destroy(cpg_handle_t h);
 const char *cpg_hip_last_error(void);
