@@ -769,32 +769,42 @@ static bool conic_dims_equal(const cpg::DevConic &a, const cpg::DevConic &b) {
 // without a row store to dummy slots chosen per 16-lane store group so that they add no bank conflict; segmented
 // chunks carry their segment mask above bit 13).  `steps`: {first entry, active lanes} in execution order.
 static bool generated_tables(const int *ctab, const unsigned *desc, const unsigned short *cols, int n_chunks, int nnz, int n_slots,
-                             const int (*steps)[2], int T, std::vector<unsigned short> &gcols, std::vector<unsigned short> &grows) {
+                             const int (*steps)[4], int T, std::vector<unsigned short> &gcols, std::vector<unsigned short> &grows,
+                             const int *chunk_shift = nullptr) {
+    // steps carry {first entry, active lanes, coefficient register, lane shift of the chunk}: narrow chunks sit at a
+    // lane offset so that several steps share one coefficient register (codegen.pack_step_registers); `chunk_shift` is the
+    // same shift per chunk, for the output-slot table
     const unsigned zero_off = (unsigned)(n_slots + CPG_GEN_DUMMY_SLOTS) * 8u;
     if (zero_off > 0xFFFFu || n_slots + CPG_GEN_EXTRA_SLOTS > 0x1FFF) return false;
     const int T4 = (T + 3) & ~3, C4 = (n_chunks + 3) & ~3;
     gcols.assign((size_t)T4 * 64, (unsigned short)zero_off);
     for (int t = 0; t < T; t++) {
-        const int e = steps[t][0], cnt = steps[t][1];
-        if (e < 0 || cnt < 0 || cnt > 64 || e + cnt > nnz) return false;
-        for (int l = 0; l < cnt; l++) gcols[((size_t)(t / 4) * 64 + l) * 4 + (t % 4)] = cols[e + l];
+        const int e = steps[t][0], cnt = steps[t][1], sh = steps[t][3];
+        if (e < 0 || cnt < 0 || sh < 0 || sh + cnt > 64 || e + cnt > nnz) return false;
+        for (int l = 0; l < cnt; l++) gcols[((size_t)(t / 4) * 64 + (l + sh)) * 4 + (t % 4)] = cols[e + l];
     }
     grows.assign((size_t)C4 * 64, (unsigned short)n_slots);
     for (int c = 0; c < n_chunks; c++) {
         const bool seg = ctab[4 * c + 3] & 1;
+        const int sh = chunk_shift ? chunk_shift[c] : 0;
+        if (sh < 0 || sh > 48 || (sh & 15)) return false;
+        unsigned dsh[64];                                      // the chunk's lane descriptors at their shifted lanes
+        for (int t = 0; t < 64; t++) dsh[t] = 0xFFFFu;
+        for (int t = 0; t + sh < 64; t++) dsh[t + sh] = desc[(size_t)c * 64 + t];
+        for (int t = 64 - sh; t < 64; t++) if ((desc[(size_t)c * 64 + t] & 0xFFFFu) != 0xFFFFu) return false;    // (a row would fall off)
         for (int g0 = 0; g0 < 64; g0 += 16) {
             bool used[16] = {false};
-            for (int t = g0; t < g0 + 16; t++) { const unsigned d = desc[(size_t)c * 64 + t]; if ((d & 0xFFFFu) != 0xFFFFu) used[(d & 0xFFFFu) % 16u] = true; }
+            for (int t = g0; t < g0 + 16; t++) { const unsigned d = dsh[t]; if ((d & 0xFFFFu) != 0xFFFFu) used[(d & 0xFFFFu) % 16u] = true; }
             int nxt = 0;
             for (int t = g0; t < g0 + 16; t++) {
-                const unsigned d = desc[(size_t)c * 64 + t];
+                const unsigned d = dsh[t];
                 unsigned slot = d & 0xFFFFu;
                 if (slot == 0xFFFFu) {
                     while (nxt < CPG_GEN_DUMMY_SLOTS && used[(unsigned)(n_slots + nxt) % 16u]) nxt++;
                     const int j = nxt < CPG_GEN_DUMMY_SLOTS ? nxt++ : (t & (CPG_GEN_DUMMY_SLOTS - 1));
                     slot = (unsigned)(n_slots + j);
                 }
-                grows[((size_t)(c >> 2) * 64 + t) * 4 + (c & 3)] = (unsigned short)(slot | ((seg ? (d >> 28) : 0u) << 13));
+                grows[((size_t)(c >> 2) * 64 + t) * 4 + (c & 3)] = (unsigned short)(slot | ((seg ? (d >> 28) : 0u) << 13));       // (every lane of a row carries its segment mask)
             }
         }
     }
@@ -861,7 +871,7 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     if (f->sol_chunks == CPG_GENC_NCHUNKS && f->sol_nnz == CPG_GENC_NNZ && f->sol_slots == CPG_GENC_NSLOTS &&
         program_fingerprint(f->sol_ctab, f->sol_desc, f->sol_cols, f->sol_chunks, f->sol_nnz) == CPG_GENC_FINGERPRINT &&
         !(getenv("CPG_CONIC_GENERATED") && atoi(getenv("CPG_CONIC_GENERATED")) == 0)) {
-        static const int steps[][2] = CPG_GENC_STEPS;
+        static const int steps[][4] = CPG_GENC_STEPS;               // {first entry, active lanes, step, 0}
         std::vector<unsigned short> gcols, grows;
         if (generated_tables(f->sol_ctab, f->sol_desc, f->sol_cols, f->sol_chunks, f->sol_nnz, f->sol_slots, steps, CPG_GENC_NSTEPS, gcols, grows)) {
             TRY(upload<unsigned short>(h, own, gcols.data(), gcols.size(), &C.gc_cols));
@@ -1068,7 +1078,8 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     std::vector<unsigned> gsrc;
     if (r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
         const unsigned hsh = program_fingerprint(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz);
-        static const int steps[][2] = CPG_GENI_STEPS;             // {first entry, active lanes} in execution order
+        static const int steps[][4] = CPG_GENI_STEPS;             // {first entry, active lanes, coefficient register, lane shift} in execution order
+        static const int chunk_shift[] = CPG_GENI_CHUNK_SHIFT;
         bool ok = hsh == CPG_GENI_FINGERPRINT;
         {   // the row programs of the termination test carry their chunk tables as literals
             const int nn[3] = {CPG_GENI_AROWS_N, CPG_GENI_PROWS_N, CPG_GENI_ATROWS_N};
@@ -1078,19 +1089,25 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                     if (h->rows_hdr[k][4 * c2] != cpg::GeniRows::len(k, c2) || h->rows_hdr[k][4 * c2 + 3] != cpg::GeniRows::off(k, c2)) ok = false;
             }
         }
-        if (ok) ok = generated_tables(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz, r->sol_slots, steps, CPG_GENI_NSTEPS, gcols, grows);
+        if (ok) ok = generated_tables(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz, r->sol_slots, steps, CPG_GENI_NSTEPS, gcols, grows, chunk_shift);
         if (ok) {
-            gsrc.assign((size_t)CPG_GENI_NSTEPS * 64, 0u);
-            glcol.assign((size_t)CPG_GENI_NSTEPS * 64, (unsigned short)0);
+            // coefficient sources per (register, lane): the steps that share a register occupy disjoint lane ranges
+            gsrc.assign((size_t)CPG_GENI_NREGS * 64, 0u);
+            glcol.assign((size_t)CPG_GENI_NREGS * 64, (unsigned short)0);
+            std::vector<char> taken((size_t)CPG_GENI_NREGS * 64, 0);
             for (int t = 0; ok && t < CPG_GENI_NSTEPS; t++) {
-                const int e = steps[t][0], cnt = steps[t][1];
+                const int e = steps[t][0], cnt = steps[t][1], reg = steps[t][2], sh = steps[t][3];
+                if (reg < 0 || reg >= CPG_GENI_NREGS) { ok = false; break; }
                 for (int l = 0; l < cnt; l++) {
                     const int kind = r->sol_kind[e + l], idx = r->sol_idx[e + l];
                     if (kind < 0 || kind > 3 || idx < 0 || idx >= (1 << 28)) { ok = false; break; }
-                    gsrc[(size_t)t * 64 + l] = ((unsigned)kind << 28) | (unsigned)idx;
+                    const size_t at = (size_t)reg * 64 + (size_t)(l + sh);
+                    if (taken[at]) { ok = false; break; }                // (two steps on one lane of a register)
+                    taken[at] = 1;
+                    gsrc[at] = ((unsigned)kind << 28) | (unsigned)idx;
                     if (kind == 2) {
                         if (idx >= r->nnzL || r->Lcol[idx] < 0 || r->Lcol[idx] > 0xFFFF) { ok = false; break; }
-                        glcol[(size_t)t * 64 + l] = (unsigned short)r->Lcol[idx];
+                        glcol[at] = (unsigned short)r->Lcol[idx];
                     }
                 }
             }

@@ -417,9 +417,10 @@ CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const 
 #ifdef CPG_GENI_HEADER
 // the instance's coefficients of the generated executor, from its factor in LDS (one gather per step and lane, once
 // per factorisation: the ADMM loop then reads none): -l_ij = -M_ij / d_j, 1 / d_i, or 1
-CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, const double *Dil, double (&cf)[CPG_GENI_NSTEPS], int lane) {
+CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, const double *Dil, double (&cf)[CPG_GENI_NREGS], int lane) {
+    // (per coefficient REGISTER: narrow steps share one, each on its own lanes -- codegen.pack_step_registers)
 #pragma unroll
-    for (int t = 0; t < CPG_GENI_NSTEPS; t++) {
+    for (int t = 0; t < CPG_GENI_NREGS; t++) {
         const unsigned code = cpgw::gld(R.gi_src, (unsigned)t * 64u + (unsigned)lane);
         const unsigned col = cpgw::gld(R.gi_lcol, (unsigned)t * 64u + (unsigned)lane);
         const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
@@ -626,7 +627,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             }
         };
 #ifdef CPG_GENI_HEADER
-        double cf[CPG_GENI_NSTEPS];          // (dead, hence free, in the streaming instantiation)
+        double cf[CPG_GENI_NREGS];           // (dead, hence free, in the streaming instantiation)
         auto factor_in_lds = [&]() __attribute__((always_inline)) {
             cpgw::mem_order();                // B.rinv
             numeric_ldl_m<true>(R, w, w + R.nnzL, (const double *)B.rinv, lane);
