@@ -290,3 +290,46 @@ def test_generated_executor_schedule_invariants(opts):
             pp = [c2 for c2 in range(rp.n_chunks) if phase_ids.index(int(rp.chunk_phase[c2])) == pi_ - 2]
             assert pos[('W', t)] > max(pos[('S', c2)] for c2 in pp)
     assert (n_early > 0) == bool(opts.get('early', 4))
+
+
+@pytest.mark.parametrize('make', [lambda: families.mpc(12, 4, 10), lambda: families.mpc(6, 3, 10),
+                                  lambda: families.mpc(8, 3, 7), lambda: families.nonneg_ls(40, 20, sparsity=None, seed=1)])
+def test_coefficient_register_sharing_of_the_instance_executor(make):
+    """codegen.pack_step_registers: narrow chunks of the per-instance substitution program are shifted to lane offsets so
+    that several steps share one coefficient register of the generated instance executor.  Host-side invariants the
+    kernel relies on: no two steps on one lane of a register; every step of a chunk at the chunk's shift; shifts keep
+    reduction groups inside their DPP rows; the emitted header carries the same map the C side rebuilds its tables
+    from; and the executor's arithmetic (simulated here lane by lane on a shifted layout) is the program's."""
+    import re
+    from cvxpygen_amd import codegen, refactor_plan as _rp
+    from cvxpygen_amd.runtime import build_family_plan
+    from cvxpygen_amd.solve_program import execution_steps
+    d = make()
+    plan = build_family_plan(d)
+    o = plan.osqp_shared or plan.osqp
+    Ps, As = o.pruned(d.P, d.A)
+    rp = _rp.build_refactor_plan(Ps, As, o).sol
+    steps = execution_steps(rp)
+    reg, shift, n_regs = codegen.pack_step_registers(rp, steps)
+    assert n_regs <= len(steps) and max(reg) == n_regs - 1
+    taken = {}
+    for t, (_, c, e, cnt) in enumerate(steps):
+        lg, kind = int(rp.ctab[c, 1]), int(rp.ctab[c, 3])
+        gran = 16 if (kind & 1) or lg <= 4 else (32 if lg == 5 else 64)
+        assert shift[c] % gran == 0 and shift[c] + cnt <= 64
+        for l in range(shift[c], shift[c] + cnt):
+            assert (reg[t], l) not in taken, (t, taken.get((reg[t], l)))
+            taken[(reg[t], l)] = t
+    # rows (output lanes) of a shifted chunk stay inside the wavefront
+    for c in range(rp.n_chunks):
+        used = np.nonzero((rp.desc[c] & 0xFFFF) != 0xFFFF)[0]
+        assert used.size == 0 or used.max() + shift[c] < 64
+    if len(steps) > 64:                                   # the headline families do share registers
+        assert n_regs < len(steps)
+    # the header carries exactly this map
+    hdr = codegen.emit_instance_program(rp, 'fam')
+    assert f'#define CPG_GENI_NREGS {n_regs}' in hdr
+    tup = re.search(r'#define CPG_GENI_STEPS \{(.*)\}', hdr).group(1)
+    got = [tuple(int(v) for v in m) for m in re.findall(r'\{(\d+), (\d+), (\d+), (\d+)\}', tup)]
+    assert got == [(e, cnt, reg[t], shift[c]) for t, (_, c, e, cnt) in enumerate(steps)]
+    assert set(re.findall(r'cf\[(\d+)\]', hdr.split('namespace cpg {')[1])) == {str(r) for r in set(reg)}
