@@ -114,3 +114,24 @@ def test_ecos_solver_on_the_gpu(oracle_lib):
     assert r.iter[:64:4].tolist() == o['iter'].tolist()
     assert np.abs(r.sol_x[:64:4] - o['sol_x']).max() <= 1e-6 * max(1.0, np.abs(o['sol_x']).max())
     es.close()
+
+
+@pytest.mark.gpu
+def test_generate_code_ecos_builds_a_family_library_on_the_gpu(tmp_path):
+    """generate_code(solver='ECOS') with its compile step: the library's generated executor belongs to the stacked conic
+    form of THIS family (handle facts), and prob.solve(method='CPG') through it gives the generic library's result"""
+    import ctypes as C
+    e = ecos_from_conic(families.adp_norm())
+    prob = LiteProblem.from_descriptor(e)
+    mod = cpg.generate_code(prob, code_dir=str(tmp_path / 'ecos_lib'), solver='ECOS')
+    val = prob.solve(method='CPG')
+    bs = mod._SOLVER.batch_solver.conic
+    assert 'ecos_lib' in bs.lib.path
+    for fact in (b'generated_executor', b'specialised_kernel'):
+        v = C.c_double(-1)
+        bs.lib.check(bs.lib.L.cpg_hip_get_setting(bs.h, fact, C.byref(v)), 'get_setting')
+        assert v.value == 1.0, fact
+    es = EcosBatchSolver(e)                               # generic library, table-driven executor
+    r = es.solve({}, updated_params=[], B=1)            # every parameter at its code-generation-time value, like `prob`
+    assert abs(val - float(r.obj_val[0])) <= 1e-12 * max(1.0, abs(val))
+    es.close()
