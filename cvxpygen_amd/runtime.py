@@ -934,7 +934,7 @@ class BatchSolver:
                 dd[u.name] = dual[:, k]
             k += sz
         # +-1e30 -> +-inf as the reference shim does (templates/cpg_solver.py.jinja2:98-101)
-        obj = np.where(np.abs(obj) >= 1e30, np.sign(obj) * np.inf, obj)
+        obj = np.where(obj >= 1e30, np.inf, np.where(obj <= -1e30, -np.inf, obj))      # (NaN stays NaN)
         res = BatchResult(prim=pd, dual=dd, obj_val=obj, iter=it, status=st, pri_res=pri,
                           dua_res=dua, solve_time=dt, kernel_ms=ms, prim_flat=prim, dual_flat=dual)
         res.sol_x, res.sol_y = sol_x, sol_y
