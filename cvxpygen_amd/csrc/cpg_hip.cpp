@@ -269,6 +269,26 @@ static int launch_refactor_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevS
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
+#ifdef CPG_REFACTOR_CR_LDS
+// per-instance-matrix kernel with the streaming executor's entry words in LDS (osqp_refactor_body<.., CRLDS>): one
+// workgroup of eight wavefronts per CU shares the copy; compiled for families whose kernel runs two wavefronts per SIMD anyway
+template <int NSX, int NSZ>
+__global__ void __launch_bounds__(512, 2)
+osqp_refactor_crlds_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cpg::osqp_refactor_body<NSX, NSZ, false, false, true>(F, R, S, Bt, cpg_lds, wave_global);
+}
+template <int NSX, int NSZ>
+static int launch_refactor_crlds_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = osqp_refactor_crlds_kernel<NSX, NSZ>;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, stream, h->F, h->R, S, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#endif
 #ifdef CPG_GENI_HEADER
 // the same body with the generated instance executor: a lane keeps its CPG_GENI_NSTEPS coefficients in registers
 // for the whole ADMM loop, so the budget is the 256 VGPRs of two wavefronts per SIMD
@@ -1276,6 +1296,24 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
             Bt.scratch = (double *)h->scratch.p;
             const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
 #define Z(a, b) if (nsx <= a && nsz <= b) return launch_instance_t<a, b>(h, stream, S, Bt, (int)blocks, W, lds);
+            CPG_KERNELS_REFACTOR(Z)
+#undef Z
+        }
+    }
+#endif
+#ifdef CPG_REFACTOR_CR_LDS
+    if (!h->R.shared_mats && h->program_in_lds != 0) {       // (cpg_hip_set_program_placement(0): entry words through L2, as before)
+        const int W8 = 8;
+        const size_t tab = (((size_t)h->R.sol_nnz + 1) / 2) * sizeof(double);
+        const size_t lds8 = tab + (size_t)W8 * h->R.sol_slots * sizeof(double);
+        if (lds8 <= h->lds_limit) {
+            long long blocks = (Bt.B + W8 - 1) / W8;
+            if (blocks > (long long)h->num_cu) blocks = h->num_cu;
+            int rc;
+            if ((rc = ensure(h->scratch, (size_t)blocks * W8 * (size_t)h->R.buf_doubles * sizeof(double)))) return rc;
+            Bt.scratch = (double *)h->scratch.p;
+            const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
+#define Z(a, b) if (nsx <= a && nsz <= b) return launch_refactor_crlds_t<a, b>(h, stream, S, Bt, (int)blocks, W8, lds8);
             CPG_KERNELS_REFACTOR(Z)
 #undef Z
         }

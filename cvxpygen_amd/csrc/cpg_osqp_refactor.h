@@ -438,11 +438,24 @@ CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, 
 // SHARED: shared-matrix mode as a compile-time fact (its own kernel instantiation): the per-instance-matrix kernel
 // then carries none of that mode's code -- this body is inlined into kernels whose register allocation reacts to
 // everything in it (config 3 lost 9 % when the shared-mode paths were merely present, profiles/r3_final1_*).
-template <int NSX, int NSZ, bool GENI = false, bool SHARED = GENI>
+// CRLDS: the entry words of the streaming executor (operand offset | output row | segment mask per entry: shared by all
+// instances, 4 bytes next to every 8-byte coefficient) get a block-shared LDS copy, one workgroup of eight wavefronts
+// per CU.  With the per-instance coefficient streams of the resident wavefronts flowing through it the L2 does not keep
+// that table: config 3 refetched it for every instance and iteration (a third of its FETCH_SIZE).
+template <int NSX, int NSZ, bool GENI = false, bool SHARED = GENI, bool CRLDS = false>
 CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const DevSettings &S,
                                 const DevBatch &Bt, double *lds, int wave_global) {
     const int lane = cpgw::lane_id();
     const unsigned n = (unsigned)F0.n, m = (unsigned)F0.m, N = n + m;
+    const unsigned *cr_tab = R.sol_cr;
+    if (CRLDS) {
+        unsigned *lc = (unsigned *)lds;
+        const unsigned ncr = (unsigned)R.sol_nnz;
+        for (unsigned t = cpgw::thread_in_block(); t < ncr; t += cpgw::block_threads()) lc[t] = cpgw::gld(R.sol_cr, t);
+        cpgw::block_sync();
+        cr_tab = lc;
+        lds += (ncr + 1u) / 2u;
+    }
 #ifdef CPG_GENI_HEADER
     const int ldw = GENI ? CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS : R.sol_slots;
     // block-shared copies of the executor's offset / output-slot tables in front of the work vectors
@@ -651,7 +664,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         DevFamily F = F0;
         F.D = B.D; F.Dinv = B.Dinv; F.E = B.E; F.Einv = B.Einv; F.c = cs; F.cinv = 1.0 / cs;
         StreamProg ST;
-        ST.stab = R.sol_stab; ST.cr = R.sol_cr; ST.vals = B.sv;
+        ST.stab = R.sol_stab; ST.cr = cr_tab; ST.vals = B.sv;
         ST.n_pairs = R.sol_pairs; ST.dummy = (unsigned)R.sol_nnz / 2u - 1u;
         typedef InstCtx<NSX, NSZ, GENI> CtxT;
         double qr[NSX], ur[NSZ];

@@ -234,3 +234,37 @@ def test_generated_instance_executor_and_both_ldl_forms(oracle_lib, tmp_path):
             if 'eps_abs' in stg:
                 assert o['iter'].max() > 100          # more than one adaptation point was passed
         bs.close()
+
+
+def test_entry_words_in_lds_for_the_portfolio_family(oracle_lib, tmp_path):
+    """family library of BASELINE config 3's family (portfolio n=100 m=10: 10 + 13 slots): its per-instance-matrix kernel
+    keeps the streaming executor's entry words in a block-shared LDS copy (CPG_REFACTOR_CR_LDS, eight wavefronts per
+    workgroup); the same solve with the entry words read through L2 (placement 0) must give identical bits, and both
+    the oracle's iterates after 30 iterations"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sim import build_sim
+    from cvxpygen_amd import codegen
+    from cvxpygen_amd.runtime import build_family_plan
+    d = families.portfolio(100, 10)
+    plan = build_family_plan(d)
+    _, defs = codegen.family_library_defs(plan, str(tmp_path), 'portfolio')
+    assert '-DCPG_REFACTOR_CR_LDS=1' in defs
+    lib = build_sim.build_family(plan, str(tmp_path), 'portfolio')
+    rng = np.random.default_rng(5)
+    B, n, m = 2, 100, 10
+    sig = np.zeros((B, m, m)); sig[:, np.arange(m), np.arange(m)] = rng.random((B, m))
+    vals = {'a': rng.standard_normal((B, n)), 'F': np.round(rng.standard_normal((B, n, m))), 'Sig_f_sqrt': sig,
+            'd_sqrt': rng.random((B, n)), 'w_prev': np.zeros((B, n))}
+    th = np.stack([d.theta_from_values({k: v[i] for k, v in vals.items()}) for i in range(B)])
+    upd = ['a', 'F', 'Sig_f_sqrt', 'd_sqrt', 'w_prev']
+    stg = dict(max_iter=30)
+    out = []
+    for placement in (-1, 0):
+        bs = BatchSolver(d, lib_path=lib, plan=plan)
+        bs.set_program_placement(placement)
+        out.append(bs.solve(vals, updated_params=upd, **stg))
+        bs.close()
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, upd, **stg)
+    _assert_parity(out[0], o, prim, dual, tol=1e-8)
+    assert np.array_equal(out[0].prim_flat, out[1].prim_flat) and np.array_equal(out[0].dual_flat, out[1].dual_flat)
