@@ -807,7 +807,7 @@ static bool generated_tables(const int *ctab, const unsigned *desc, const unsign
     for (int c = 0; c < n_chunks; c++) {
         const bool seg = ctab[4 * c + 3] & 1;
         const int sh = chunk_shift ? chunk_shift[c] : 0;
-        if (sh < 0 || sh > 48 || (sh & 15)) return false;
+        if (sh < 0 || sh > 56 || (sh & 7)) return false;          // (multiples of 16; of 8 for chunks of at most 8 lanes)
         unsigned dsh[64];                                      // the chunk's lane descriptors at their shifted lanes
         for (int t = 0; t < 64; t++) dsh[t] = 0xFFFFu;
         for (int t = 0; t + sh < 64; t++) dsh[t + sh] = desc[(size_t)c * 64 + t];

@@ -315,8 +315,10 @@ def test_coefficient_register_sharing_of_the_instance_executor(make):
     taken = {}
     for t, (_, c, e, cnt) in enumerate(steps):
         lg, kind = int(rp.ctab[c, 1]), int(rp.ctab[c, 3])
-        gran = 16 if (kind & 1) or lg <= 4 else (32 if lg == 5 else 64)
+        width = max(s_[3] for s_ in steps if s_[1] == c)
+        gran = 64 if lg >= 6 else 32 if lg == 5 else 8 if (width <= 8 and lg <= 3) else 16      # DPP rows; half rows for tiny chunks
         assert shift[c] % gran == 0 and shift[c] + cnt <= 64
+        assert shift[c] // 16 == (shift[c] + width - 1) // 16 or gran >= 16                     # a half-row chunk stays in its row
         for l in range(shift[c], shift[c] + cnt):
             assert (reg[t], l) not in taken, (t, taken.get((reg[t], l)))
             taken[(reg[t], l)] = t
