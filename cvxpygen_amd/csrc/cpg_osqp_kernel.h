@@ -551,6 +551,7 @@ CPG_DEV double csr_row(const DevCsr &mp, unsigned row, const double *theta, doub
 template <int NSX, int NSZ, int NV>
 struct SharedCtx {
     static constexpr bool kTestsFirst = true;      // check(): verdicts of infeasibility_tests() are passed in
+    static constexpr bool kOpaqueLane = true;
     const DevFamily &F;
     const double *sh, *shu;       // base q / base u (block-shared LDS copy, or the global arrays)
     const Inst<NSX, NSZ, NV> &I;
@@ -755,7 +756,7 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
                        const DevSettings &S, const double (&Ix)[NSX], const double (&Iz)[NSZ],
                        const double (&Iy)[NSZ], const DX &dx, const DY &dy, InfeasVerdict iv,
                        double *w, int lane_in, bool approximate, ScaledNorms *sn = nullptr) {
-    const int lane = Ctx::kTestsFirst ? cpgw::opaque(lane_in) : lane_in;
+    const int lane = (Ctx::kTestsFirst || Ctx::kOpaqueLane) ? cpgw::opaque(lane_in) : lane_in;
     cpgw::assume((unsigned)lane < 64u);
     const bool unsc = !S.scaled_termination;
     const double mult = approximate ? 10.0 : 1.0;

@@ -167,6 +167,10 @@ struct InstCtx {
     // (portfolio family: 0.334 instead of 0.293 ms per iteration of 20 000 instances, 30 instead of 2 scratch
     // instructions per lane and iteration)
     static constexpr bool kTestsFirst = false;
+    // ... but the generated instance kernel (QUMEM) gets a per-call lane id in check(): with the kernel-wide one the
+    // addresses of the per-row scaling reads (instance-invariant) were computed once outside the instance loop, kept
+    // in scratch and reloaded one by one in front of their reads -- 379 "reload address, wait, load" sequences
+    static constexpr bool kOpaqueLane = QUMEM;
     const DevFamily &F;
     const DevRefactor &R;
     const InstBuf &B;
@@ -419,10 +423,16 @@ CPG_DEV void numeric_ldl_m(const DevRefactor &R, double *Ml, double *Dil, const 
 // per factorisation: the ADMM loop then reads none): -l_ij = -M_ij / d_j, 1 / d_i, or 1
 CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, const double *Dil, double (&cf)[CPG_GENI_NREGS], int lane) {
     // (per coefficient REGISTER: narrow steps share one, each on its own lanes -- codegen.pack_step_registers)
+    // (opaque lane: the table addresses below do not depend on the instance, and left alone the compiler computes all
+    // 2 x NREGS of them once, outside the instance loop, keeps them alive through it -- i.e. in scratch -- and reloads
+    // each one right in front of its table read: two dependent memory round trips per read)
+    const unsigned ln = (unsigned)cpgw::opaque(lane);
 #pragma unroll
     for (int t = 0; t < CPG_GENI_NREGS; t++) {
-        const unsigned code = cpgw::gld(R.gi_src, (unsigned)t * 64u + (unsigned)lane);
-        const unsigned col = cpgw::gld(R.gi_lcol, (unsigned)t * 64u + (unsigned)lane);
+        const unsigned code = cpgw::gld(R.gi_src, (unsigned)t * 64u + ln);
+        // (opaque: the column is read here, next to the source word -- left alone the compiler sinks the read into the
+        // L-entry branch below, a second dependent L2 round trip per register)
+        const unsigned col = (unsigned)cpgw::opaque((int)cpgw::gld(R.gi_lcol, (unsigned)t * 64u + ln));
         const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
         double v = 0.0;
         if (kind == 1u) v = 1.0;
@@ -790,7 +800,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 if (o.status == 11) o.status = 7;
             }
         }
-        finalize<NSX, NSZ, false>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);
+        finalize<NSX, NSZ, GENI>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);     // (per-call lane id in the generated instance kernel, see InstCtx)
     }
 }
 
