@@ -186,7 +186,9 @@ struct InstCtx {
     // (coalesced, shared by every wavefront: cache hits) instead of per-lane walks over the instance's matrices --
     // a walk is a chain of dependent round trips per row (pointer -> entry number -> value)
     bool rowprog;
-    // (QUMEM = the generated instance kernel: chunk tables of the row programs are literals)
+    // (QUMEM = the generated instance kernel: chunk tables of the row programs are literals, and the row programs are
+    // what it always runs -- cpg_hip_set_refactor enables it only with them --, so the per-lane walks below are not
+    // even compiled into it: their hoisted per-row addresses were half of its scratch)
     CPG_DEV double rows_gen(const DevProgram &P, int which, int s) const {
 #ifdef CPG_GENI_HEADER
         return CPG_GENI_ROWS(P, which, s, w, lane);
@@ -204,7 +206,7 @@ struct InstCtx {
         return acc;
     }
     CPG_DEV double ax(int s) const {
-        if (rowprog) return QUMEM ? rows_gen(F.A_rows, 0, s) : natural_chunk(F.A_rows, s, w, lane);
+        if (QUMEM || rowprog) return QUMEM ? rows_gen(F.A_rows, 0, s) : natural_chunk(F.A_rows, s, w, lane);
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
 #ifdef CPG_REFACTOR_ROW_COPY
         return i < (unsigned)F.m ? row_dot<false, false, CPG_ROW_COPY_BATCH>(R.Arp, nullptr, R.Acol, (const double *)B.Ar, i) : 0.0;
@@ -213,12 +215,12 @@ struct InstCtx {
 #endif
     }
     CPG_DEV double px(int s) const {
-        if (rowprog) return QUMEM ? rows_gen(F.P_rows, 1, s) : natural_chunk(F.P_rows, s, w, lane);
+        if (QUMEM || rowprog) return QUMEM ? rows_gen(F.P_rows, 1, s) : natural_chunk(F.P_rows, s, w, lane);
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
         return j < (unsigned)F.n ? row_dot<true, false>(R.Prp, R.Pent, R.Pcol, (const double *)B.P, j) : 0.0;
     }
     CPG_DEV double atx(int s) const {
-        if (rowprog) return QUMEM ? rows_gen(F.At_rows, 2, s) : natural_chunk(F.At_rows, s, w, lane);
+        if (QUMEM || rowprog) return QUMEM ? rows_gen(F.At_rows, 2, s) : natural_chunk(F.At_rows, s, w, lane);
         const unsigned j = (unsigned)lane + 64u * (unsigned)s;
         return j < (unsigned)F.n ? row_dot<false, true>(R.Ap, nullptr, R.Ai, (const double *)B.A, j) : 0.0;
     }
@@ -616,9 +618,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         }
         if (__builtin_expect(S.debug_stage == 1, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }     // (timing experiments: canonicalised)
         signed char ct[NSZ];
+        const int lane_rc = GENI ? cpgw::opaque(lane) : lane;      // (generated instance kernel: addresses local to this block, see InstCtx)
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
-            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            const unsigned i = (unsigned)lane_rc + 64u * (unsigned)s;
             ct[s] = 0;
             if (i < m) {
                 double uu = cpgw::gld((const double *)B.u, i);      // shared-matrix mode: already E u
