@@ -91,7 +91,7 @@ def main():
         scratch, occ = g(r'ScratchSize \[bytes/lane\]'), g(r'Occupancy \[waves/SIMD\]')
         print(f'{blk.split(" ")[0][:56]:<56} VGPR {g("VGPRs"):>3} scratch {scratch:>5} B  occupancy {occ}  '
               f'SGPR spills {g("SGPRs Spill")}  VGPR spills {g("VGPRs Spill")}')
-    ok = True
+    ok, seen = True, False
     for name, lines in kernels(open(out).read()):
         hits, sl, n = address_reloads(lines)
         print(f'{name[:56]:<56} {n:>6} instructions, {sl:>5} scratch loads, {hits:>4} address-reload sequences')
@@ -101,6 +101,7 @@ def main():
                    if stats(lines, a, b)['mul'] >= 30 and stats(lines, a, b)['global_load'] == 0 and b - a < 6000]
             for a, b in hot[:1]:
                 st = stats(lines, a, b)
+                seen = True
                 print('    ADMM loop:', st)
                 ok &= st['scratch_load'] == 0 and st['scratch_store'] == 0
         elif 'osqp_refactor' in name:
@@ -113,7 +114,8 @@ def main():
                     st = stats(lines, a, b)
                     print(f'    stream loop: {inner["scratch_load"]} scratch loads; rest of an iteration: '
                           f'{st["scratch_load"] - inner["scratch_load"]} loads, {st["scratch_store"] - inner["scratch_store"]} stores')
-    print('generated instance kernel: ADMM loop free of scratch accesses' if ok else 'SCRATCH ACCESSES IN THE ADMM LOOP')
+    if seen:
+        print('generated instance kernel: ADMM loop free of scratch accesses' if ok else 'SCRATCH ACCESSES IN THE ADMM LOOP')
     sys.exit(0 if ok else 1)
 
 
