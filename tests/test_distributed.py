@@ -131,3 +131,36 @@ def test_bench_gpus_2_starts_two_ranks_and_gathers_over_one_rccl(sim_lib, tmp_pa
     first = sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in sends[:7])
     assert first == [B * rb for rb in row_bytes]
     assert sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in recvs[:7]) == first
+
+
+def test_bench_single_rank_json_line_carries_the_contract(sim_lib):
+    """`python bench.py` at N = 1 (emulator library, tiny batch): ONE JSON line with every field of the driver's contract,
+    the `roofline` and `cpu_baseline` objects of the tier, both kernels of the default-mode step under `phases`, and the
+    fixed-rho fork beside the headline value"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    B, steps = 6, 2
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', str(steps), '--warmup', '1', '--workload', 'mpc6',
+                        '--batch', str(B), '--lib', sim_lib, '--generic', '--cpu-seconds', '1'],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in out, key
+    assert out['n_gpus'] == 1 and out['steps'] == steps and out['warmup'] == 1 and out['higher_is_better'] is True
+    assert out['dtype'] == 'f64' and out['scaling'] == 'weak' and out['vs_baseline'] is None and 'synthetic' in out['data']
+    assert 'workload' in out['config'] and 'model' not in out['config'] and out['config']['solved'] == B
+    assert abs(out['value'] * out['ms_per_step'] / 1e3 - B) < 1e-6 * B            # value = instances / step time
+    r = out['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert 'traffic' in r and r['kernel'] and r['kernel_ms'] <= out['ms_per_step'] + 1e-9
+    c = out['cpu_baseline']
+    assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['unit'] == out['unit'] and c['sample']
+    assert set(out['phases']) == {'shared_factor', 'per_instance_factor'}            # default mode: two kernels per step
+    assert out['phases']['shared_factor']['instances'] == B
+    assert out['fixed_rho']['value'] > 0
