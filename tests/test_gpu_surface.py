@@ -310,3 +310,26 @@ def test_hybrid_execution_edge_cases(oracle_lib, lib):
         assert np.abs(got - ref).max() <= REL_TOL * max(1.0, np.abs(ref).max()), k
         assert abs(r2.state[k, -1] - o['rho']) <= 1e-9 * o['rho']
     bs.close()
+
+
+@pytest.mark.gpu
+def test_family_libraries_run_their_generated_instance_executor():
+    """the per-instance phase of the default mode must run on the generated instance executor of the family library
+    (register-resident coefficients), not fall back silently to the streaming one -- e.g. because its LDS tables no
+    longer fit: the handle says which (`generated_instance_executor`), for the headline family and the notebook one"""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, d in (('mpc12', families.mpc(12, 4, 10)), ('mpc6', families.mpc(6, 3, 10))):
+        gen = os.path.join(root, 'cvxpygen_amd', 'generated', name, f'libcpg_{name}.so')
+        assert os.path.exists(gen), gen                       # __graft_entry__.build() made it
+        bs = BatchSolver(d, lib_path=gen)
+        x0 = -2 + 4 * np.random.default_rng(3).random((64, d.param('x_init').size))
+        r = bs.solve({'x_init': x0}, updated_params=['x_init'])
+        assert bs._hybrid and (r.status == 1).all()
+        v = C.c_double(-1)
+        bs.lib.check(bs.lib.L.cpg_hip_get_setting(bs.h_rs, b'generated_instance_executor', C.byref(v)), 'get_setting')
+        assert v.value == 1.0, name
+        ms = bs.last_phase_ms()
+        assert ms[1] > 0.0 and ms[2] > 0                      # the second kernel ran (instances changed rho)
+        bs.close()
