@@ -259,7 +259,28 @@ def build_schedules(N: int, perm: np.ndarray, Lp: np.ndarray, Li: np.ndarray, sr
     return (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol, sol_kind, sol_idx, stats)
 
 
-def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPlan) -> RefactorPlan:
+# what the planner charges for a reduction stage in the per-instance program of SHARED-MATRIX mode when it runs on the
+# generated instance executor (register-resident coefficients): that executor is a chain of latencies, a reduction stage
+# costs it ~3 dependent DPP steps and a further multiply-add step almost nothing, so rows get one lane each where they
+# are short (MPC 12/4/10: 165 steps / 56 stages instead of 86 / 135; 13.35 instead of 14.03 ms per 96 487 instances)
+INSTANCE_STAGE_SCALE = float(os.environ.get('CPG_INSTANCE_STAGE_SCALE', 0.7))
+
+
+def shared_mode_plan(Ps: sp.csc_matrix, As: sp.csc_matrix, osqp: _setup.OsqpPlan) -> 'RefactorPlan':
+    """The refactorisation plan of shared-matrix mode (rho adaptation hand-over, rows that changed class).  Planned for
+    the generated instance executor (INSTANCE_STAGE_SCALE) when the resulting program fits it -- coefficient registers,
+    LDS tables: codegen.instance_program_fits --, else as every streaming plan.  Used by BOTH the code generator
+    (codegen.instance_header) and the runtime (BatchSolver._ensure_refactor_handle): the library checks the program's
+    fingerprint."""
+    from . import codegen as _cg
+    if INSTANCE_STAGE_SCALE != STREAM_STAGE_SCALE:
+        cand = build_refactor_plan(Ps, As, osqp, stage_scale=INSTANCE_STAGE_SCALE)
+        if _cg.instance_program_fits(cand):
+            return cand
+    return build_refactor_plan(Ps, As, osqp)
+
+
+def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPlan, stage_scale: Optional[float] = None) -> RefactorPlan:
     n, m = P.shape[0], A.shape[0]
     N = n + m
     P, A = sp.csc_matrix(P), sp.csc_matrix(A)
@@ -309,7 +330,8 @@ def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPla
     for i in range(m):
         put(n + i, n + i, K_RHO, i)
     (Lcol, ksrc_kind, ksrc_idx, fac, fac_a, fac_b, fac_k, sol, sol_kind, sol_idx, stats) = \
-        build_schedules(N, perm, Lp, Li, src, forward_in_place='auto', stage_scale=STREAM_STAGE_SCALE)
+        build_schedules(N, perm, Lp, Li, src, forward_in_place='auto',
+                        stage_scale=STREAM_STAGE_SCALE if stage_scale is None else stage_scale)
     return RefactorPlan(n=n, m=m, nnzP=nnzP, nnzA=nnzA, nnzL=nnzL, Ap=A.indptr.astype(np.int32),
                         Ai=A.indices.astype(np.int32), Arp=Arp, Aent=Aent, Acol=Acol, Prp=Prp, Pent=Pent,
                         Pcol=Pcol, Pp=P.indptr.astype(np.int32), Pi=P.indices.astype(np.int32),

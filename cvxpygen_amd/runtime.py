@@ -443,7 +443,7 @@ class BatchSolver:
         if shared_mats:
             o = self.plan.osqp_shared or self.plan.osqp
             Ps, As = o.pruned(desc.P, desc.A)
-            rplan = _rp.build_refactor_plan(Ps, As, o)
+            rplan = _rp.shared_mode_plan(Ps, As, o)      # (the plan codegen.instance_header generated the executor from)
             self._rplan_s = rplan
         elif mode == 'grad':
             o = self.plan.osqp

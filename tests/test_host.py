@@ -308,7 +308,9 @@ def test_coefficient_register_sharing_of_the_instance_executor(make):
     plan = build_family_plan(d)
     o = plan.osqp_shared or plan.osqp
     Ps, As = o.pruned(d.P, d.A)
-    rp = _rp.build_refactor_plan(Ps, As, o).sol
+    rpl = _rp.shared_mode_plan(Ps, As, o)
+    assert codegen.instance_program_fits(rpl)
+    rp = rpl.sol
     steps = execution_steps(rp)
     reg, shift, n_regs = codegen.pack_step_registers(rp, steps)
     assert n_regs <= len(steps) and max(reg) == n_regs - 1
@@ -327,7 +329,7 @@ def test_coefficient_register_sharing_of_the_instance_executor(make):
         used = np.nonzero((rp.desc[c] & 0xFFFF) != 0xFFFF)[0]
         assert used.size == 0 or used.max() + shift[c] < 64
     if len(steps) > 64:                                   # the headline families do share registers
-        assert n_regs < len(steps)
+        assert n_regs < len(steps) and n_regs <= codegen.GENI_MAX_REGS
     # the header carries exactly this map
     hdr = codegen.emit_instance_program(rp, 'fam')
     assert f'#define CPG_GENI_NREGS {n_regs}' in hdr
