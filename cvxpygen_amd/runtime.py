@@ -230,6 +230,13 @@ class FamilyPlan:
 
 def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
                       setup_settings: Optional[Dict[str, float]] = None, bank_layout: bool = True) -> FamilyPlan:
+    from .solve_program import PLAN_LOCK as _lock
+    with _lock:                       # the planner's stage costs are module state: one plan at a time (solve_program.PLAN_LOCK)
+        return _build_family_plan_unlocked(desc, ordering, merge, setup_settings, bank_layout)
+
+
+def _build_family_plan_unlocked(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
+                      setup_settings: Optional[Dict[str, float]] = None, bank_layout: bool = True) -> FamilyPlan:
     t0 = time.time()
     n, m, n_eq = desc.n_var, desc.m, desc.n_eq
     # the shared-factor kernel relies on the two row kinds of the reference's OSQP canonical form

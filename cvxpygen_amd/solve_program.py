@@ -40,6 +40,14 @@ import numpy as np
 import scipy.sparse as sp
 
 import os as _os
+import threading as _threading
+
+# The planner's stage costs are module state that pack_ragged(stage_scale=...) changes for the duration of a call, and
+# __graft_entry__.build() / generate_code plan several families from worker threads: without this lock one family's
+# solve program was planned with another call's scaled costs (a header whose fingerprint no later process reproduces:
+# "this library was generated for a different problem family"), or the costs stayed scaled for good.
+_PLAN_LOCK = _threading.RLock()
+PLAN_LOCK = _PLAN_LOCK          # held by the plan builders around a whole plan (runtime.build_family_plan, refactor_plan, conic_plan)
 
 LANES = 64
 # cost model of the packer, in units of one multiply-add step of a wavefront (environment overrides are
@@ -333,6 +341,12 @@ def assign_slots(phases: List[Phase], N: int, slot_perm: Optional[np.ndarray] = 
 
 def pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None,
          slot_perm: Optional[np.ndarray] = None) -> PackedProgram:
+    with _PLAN_LOCK:               # (reads the stage costs: see pack_ragged)
+        return _pack(phases, natural, N, slot_perm)
+
+
+def _pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None,
+          slot_perm: Optional[np.ndarray] = None) -> PackedProgram:
     """natural=True: chunk c holds rows 64c .. 64c+63, one row per lane (results are consumed in
     registers by the lane that owns the element; nothing is stored to w)."""
     hdr, rows_out, vals_out, cols_out = [], [], [], []
@@ -525,8 +539,16 @@ def _balanced_plan(lens: Sequence[int]):
     return best
 
 
+
+
 def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0,
                 slot_perm: Optional[np.ndarray] = None) -> RaggedProgram:
+    with _PLAN_LOCK:
+        return _pack_ragged(phases, N, balanced, stage_scale, slot_perm)
+
+
+def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0,
+                 slot_perm: Optional[np.ndarray] = None) -> RaggedProgram:
     """balanced=False: rows of a chunk are split over a uniform power-of-two number of lanes;
     balanced=True: variable number of adjacent lanes per row + segmented reduction (fewer steps when
     row lengths are uneven); balanced='auto': per phase whichever of the two the cost model prefers.
@@ -538,7 +560,7 @@ def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float 
         saved = (STAGE_COST, GROUP_STAGE_COST)
         STAGE_COST, GROUP_STAGE_COST = saved[0] * stage_scale, saved[1] * stage_scale
         try:
-            return pack_ragged(phases, N, balanced, slot_perm=slot_perm)
+            return _pack_ragged(phases, N, balanced, slot_perm=slot_perm)
         finally:
             STAGE_COST, GROUP_STAGE_COST = saved
     outs, ins, n_slots, final_pos = assign_slots(phases, N, slot_perm)

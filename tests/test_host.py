@@ -337,3 +337,34 @@ def test_coefficient_register_sharing_of_the_instance_executor(make):
     got = [tuple(int(v) for v in m) for m in re.findall(r'\{(\d+), (\d+), (\d+), (\d+)\}', tup)]
     assert got == [(e, cnt, reg[t], shift[c]) for t, (_, c, e, cnt) in enumerate(steps)]
     assert set(re.findall(r'cf\[(\d+)\]', hdr.split('namespace cpg {')[1])) == {str(r) for r in set(reg)}
+
+
+def test_plans_built_from_worker_threads_equal_the_sequential_ones():
+    """__graft_entry__.build() and generate_code plan families from worker threads while pack_ragged(stage_scale=...)
+    changes the planner's module-level stage costs for the duration of a call: every plan builder holds one lock
+    (solve_program.PLAN_LOCK).  Without it a family's solve program came out planned with another call's costs -- a
+    header whose fingerprint no later process reproduces ("generated for a different problem family")."""
+    from concurrent.futures import ThreadPoolExecutor
+    from cvxpygen_amd import refactor_plan as _rp, solve_program as _spm
+    from cvxpygen_amd.conic_plan import build_conic_plan
+    from cvxpygen_amd.runtime import build_family_plan
+    makes = [lambda: families.mpc(6, 3, 10), lambda: families.mpc(8, 3, 7), lambda: families.nonneg_ls(40, 20, sparsity=None, seed=1)]
+
+    def prints(make):
+        d = make()
+        plan = build_family_plan(d)
+        o = plan.osqp_shared or plan.osqp
+        Ps, As = o.pruned(d.P, d.A)
+        return (plan.kkt_ragged.fingerprint(), _rp.shared_mode_plan(Ps, As, o).sol.fingerprint(),
+                _rp.build_refactor_plan(d.P, d.A, plan.osqp).sol.fingerprint())
+    seq = [prints(mk) for mk in makes]
+    conic = build_conic_plan(families.adp()).sol.fingerprint()
+    costs = (_spm.STAGE_COST, _spm.GROUP_STAGE_COST)
+    for _ in range(2):
+        with ThreadPoolExecutor(max_workers=7) as ex:
+            futs = [ex.submit(prints, mk) for mk in makes + makes]
+            fc = ex.submit(lambda: build_conic_plan(families.adp()).sol.fingerprint())
+            got = [f.result() for f in futs]
+            assert fc.result() == conic
+        assert got == seq + seq
+        assert (_spm.STAGE_COST, _spm.GROUP_STAGE_COST) == costs           # nothing left scaled
