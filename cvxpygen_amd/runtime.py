@@ -228,6 +228,21 @@ class FamilyPlan:
     osqp_shared: Optional[_setup.OsqpPlan] = None
 
 
+def _instance_fingerprints(lib_path: str):
+    """CPG_GENI_FINGERPRINT of the generated instance headers next to a library (what it was compiled from)"""
+    import glob
+    import re
+    out = set()
+    for h in glob.glob(os.path.join(os.path.dirname(os.path.abspath(lib_path)), 'cpg_instance_*.h')):
+        try:
+            m = re.search(r'#define CPG_GENI_FINGERPRINT (\d+)u', open(h).read(4096))
+        except OSError:
+            m = None
+        if m:
+            out.add(int(m.group(1)))
+    return out
+
+
 def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
                       setup_settings: Optional[Dict[str, float]] = None, bank_layout: bool = True) -> FamilyPlan:
     from .solve_program import PLAN_LOCK as _lock
@@ -450,7 +465,17 @@ class BatchSolver:
         if shared_mats:
             o = self.plan.osqp_shared or self.plan.osqp
             Ps, As = o.pruned(desc.P, desc.A)
-            rplan = _rp.shared_mode_plan(Ps, As, o)      # (the plan codegen.instance_header generated the executor from)
+            # The plan codegen.instance_header generated the library's instance executor from (planned for register-
+            # resident coefficients: more, narrower steps) -- when this library has one for this family: its
+            # cpg_instance_<name>.h sits next to it.  Any other library streams the program, and gets the streaming plan.
+            rplan = None
+            fps = _instance_fingerprints(self.lib.path)
+            if fps:
+                cand = _rp.shared_mode_plan(Ps, As, o)
+                if cand.sol.fingerprint() in fps:
+                    rplan = cand
+            if rplan is None:
+                rplan = _rp.build_refactor_plan(Ps, As, o)
             self._rplan_s = rplan
         elif mode == 'grad':
             o = self.plan.osqp

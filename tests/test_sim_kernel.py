@@ -268,3 +268,26 @@ def test_entry_words_in_lds_for_the_portfolio_family(oracle_lib, tmp_path):
     o, prim, dual = _oracle_flat(oracle_lib, d, th, upd, **stg)
     _assert_parity(out[0], o, prim, dual, tol=1e-8)
     assert np.array_equal(out[0].prim_flat, out[1].prim_flat) and np.array_equal(out[0].dual_flat, out[1].dual_flat)
+
+
+def test_shared_mode_plan_follows_the_library(sim_lib, tmp_path):
+    """the refactorisation plan of shared-matrix mode is the one planned for the generated instance executor only when the
+    library carries that executor for this family (its cpg_instance_<name>.h next to it); the generic library streams
+    the program and must get the streaming plan (fewer, wider steps)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sim import build_sim
+    from cvxpygen_amd import refactor_plan as _rp
+    from cvxpygen_amd.runtime import build_family_plan
+    d = families.mpc(6, 3, 10)
+    plan = build_family_plan(d)
+    o = plan.osqp_shared or plan.osqp
+    Ps, As = o.pruned(d.P, d.A)
+    inst, stream = _rp.shared_mode_plan(Ps, As, o).sol.fingerprint(), _rp.build_refactor_plan(Ps, As, o).sol.fingerprint()
+    assert inst != stream
+    x0 = -2 + 4 * np.random.default_rng(2).random((2, 6))
+    for lib, want in ((sim_lib, stream), (build_sim.build_family(plan, str(tmp_path), 'mpc6'), inst)):
+        bs = BatchSolver(d, lib_path=lib, plan=plan)
+        bs.solve({'x_init': x0}, updated_params=['x_init'])
+        assert bs._hybrid and bs._rplan_s.sol.fingerprint() == want
+        bs.close()
