@@ -13,6 +13,7 @@
 
 #include "cpg_osqp_kernel.h"
 #include "cpg_osqp_refactor.h"
+#include "cpg_osqp_resident.h"
 #include "cpg_clarabel_kernel.h"
 
 // ------------------------------------------------------------------------------------ runtime layer
@@ -50,6 +51,8 @@ struct cpg_solver_s {
     cpg::DevRefactor R{};
     bool refactor_mode = false;
     std::vector<void *> refactor_owned;
+    cpg::DevResident Rs{};               // resident per-instance factor kernel (cpg_hip_set_resident); Rs.ok: in use
+    std::vector<void *> resident_owned;
     cpg::DevGradient Gd{};
     bool have_gradient = false;
     std::vector<void *> gradient_owned;
@@ -305,6 +308,26 @@ static int launch_instance_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevS
     if (lds > 48 * 1024)
         RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, stream, h->F, h->R, S, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#endif
+#ifdef CPG_GENR_HEADER
+// resident per-instance factor kernel (cpg_osqp_resident.h): at most four wavefronts per workgroup and ONE workgroup per
+// CU -- one wavefront per SIMD, which owns the SIMD's whole unified register file (256 VGPRs + 256 AGPRs)
+template <int NSX, int NSZ>
+__global__ void __launch_bounds__(256)
+osqp_resident_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevResident Rs, cpg::DevSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cpg::osqp_resident_body<NSX, NSZ>(F, R, Rs, S, Bt, cpg_lds, wave_global);
+}
+template <int NSX, int NSZ>
+static int launch_resident_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
+    auto kern = osqp_resident_kernel<NSX, NSZ>;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, stream, h->F, h->R, h->Rs, S, Bt);
     RT_CHECK(hipGetLastError());
     return CPG_OK;
 }
@@ -576,6 +599,7 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     else if (s == "adaptive_rho_tolerance") *v = h->S.adaptive_rho_tolerance;
     else if (s == "check_dualgap") *v = h->S.check_dualgap;
     // (read-only facts about the handle) 1: per-instance solves of this handle run the generated instance executor
+    else if (s == "resident_executor") *v = (h->refactor_mode && h->Rs.ok && h->program_in_lds != 0) ? 1.0 : 0.0;
     else if (s == "generated_instance_executor") *v = (h->refactor_mode && h->R.gi_ok && h->program_in_lds != 0) ? 1.0 : 0.0;
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
@@ -952,7 +976,7 @@ int cpg_hip_destroy(cpg_handle_t h) {
     if (!h) return CPG_OK;
     rt_set_device(h->device);
     rt_sync(h);
-    free_list(h->owned); free_list(h->update_owned); free_list(h->refactor_owned); free_list(h->gradient_owned);
+    free_list(h->owned); free_list(h->update_owned); free_list(h->refactor_owned); free_list(h->resident_owned); free_list(h->gradient_owned);
     free_buf(h->g_theta); free_buf(h->g_x); free_buf(h->g_y); free_buf(h->g_dprim); free_buf(h->g_dtheta);
     if (h->d_counter) rt_free(h->d_counter);
     free_buf(h->scratch);
@@ -1003,6 +1027,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     if (rc) return rc;
     if ((rc = rt_sync(h))) return rc;
     free_list(h->refactor_owned);
+    free_list(h->resident_owned); h->Rs = cpg::DevResident{};      // (cpg_hip_set_resident installs its tables behind this call)
     std::vector<void *> &own = h->refactor_owned;
     cpg::DevRefactor &R = h->R;
     const size_t n = h->F.n, m = h->F.m, N = n + m;
@@ -1147,6 +1172,186 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     return CPG_OK;
 }
 
+// Tables of the resident per-instance factor kernel (cpg_osqp_resident.h); see include/cpg_hip.h.
+int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg_osqp_resident_t *rs) {
+    int rc = cpg_hip_set_refactor(h, r);
+    if (rc) return rc;
+    free_list(h->resident_owned);
+    h->Rs = cpg::DevResident{};
+    if (!rs) { set_error("null argument"); return CPG_E_BADARG; }
+#ifdef CPG_GENR_HEADER
+    if (r->shared_mats) return CPG_OK;
+    std::vector<void *> &own = h->resident_owned;
+    cpg::DevResident &Rs = h->Rs;
+    const int n = h->F.n, m = h->F.m, N = n + m, nnzL = r->nnzL;
+    if (rs->sol_chunks != CPG_GENR_NCHUNKS || rs->sol_nnz != CPG_GENR_NNZ || rs->sol_slots != CPG_GENR_NSLOTS ||
+        program_fingerprint(rs->sol_ctab, rs->sol_desc, rs->sol_cols, rs->sol_chunks, rs->sol_nnz) != CPG_GENR_FINGERPRINT)
+        return CPG_OK;                                    // another family's library: the streaming kernel serves this handle
+    static const int steps[][4] = CPG_GENR_STEPS;         // {first entry, active lanes, coefficient register, lane shift}
+    static const int chunk_shift[] = CPG_GENR_CHUNK_SHIFT;
+    std::vector<unsigned short> gcols, grows, glcol;
+    std::vector<unsigned> gsrc;
+    if (!generated_tables(rs->sol_ctab, rs->sol_desc, rs->sol_cols, rs->sol_chunks, rs->sol_nnz, rs->sol_slots, steps, CPG_GENR_NSTEPS, gcols, grows, chunk_shift)) {
+        set_error("cpg_hip_set_resident: the merged program does not fit the generated executor's tables"); return CPG_E_BADARG; }
+    gsrc.assign((size_t)CPG_GENR_NREGS * 64, 0u); glcol.assign((size_t)CPG_GENR_NREGS * 64, (unsigned short)0);
+    {
+        std::vector<char> taken((size_t)CPG_GENR_NREGS * 64, 0);
+        for (int t = 0; t < CPG_GENR_NSTEPS; t++) {
+            const int e = steps[t][0], cnt = steps[t][1], reg = steps[t][2], sh = steps[t][3];
+            if (reg < 0 || reg >= CPG_GENR_NREGS) { set_error("cpg_hip_set_resident: coefficient register out of range"); return CPG_E_BADARG; }
+            for (int l = 0; l < cnt; l++) {
+                const int kind = rs->sol_kind[e + l], idx = rs->sol_idx[e + l], lc = rs->sol_lcol[e + l];
+                const size_t at = (size_t)reg * 64 + (size_t)(l + sh);
+                const bool ok = kind >= 0 && kind <= 4 && idx >= 0 && idx < (1 << 28) && !taken[at] &&
+                                (kind != 2 || (idx < nnzL && lc >= 0 && lc < N)) && (kind != 3 || idx < N) && (kind != 4 || idx < rs->nnzX);
+                if (!ok) { set_error("cpg_hip_set_resident: bad coefficient source"); return CPG_E_BADARG; }
+                taken[at] = 1;
+                gsrc[at] = ((unsigned)kind << 28) | (unsigned)idx;
+                glcol[at] = (unsigned short)(kind == 2 ? lc : 0);
+            }
+        }
+    }
+    // ---- flat factorisation + inverse stream
+    const int X0 = nnzL + N, ONE = X0 + rs->nnzX, ZERO = ONE + 1;
+    Rs.nnzX = rs->nnzX; Rs.fac_len = ZERO + 1;
+    std::vector<unsigned> ksrc((size_t)nnzL + N, 0u), ctl;
+    std::vector<cpg::ResEntry> ent;
+    for (int d = 0; d < nnzL + N; d++) {
+        const int kind = r->ksrc_kind[d];
+        const int idx = (kind == CPG_K_P || kind == CPG_K_A || kind == CPG_K_RHO) ? r->ksrc_idx[d] : 0;      // (sigma / none: no operand)
+        const int lim = kind == CPG_K_P ? r->nnzP : kind == CPG_K_A ? r->nnzA : kind == CPG_K_RHO ? m : 1;
+        if (kind < 0 || kind > 4 || idx < 0 || idx >= (lim > 0 ? lim : 1)) { set_error("cpg_hip_set_resident: KKT source table out of range"); return CPG_E_BADARG; }
+        ksrc[d] = ((unsigned)kind << 28) | (unsigned)idx;
+    }
+    {
+        constexpr int DP = CPG_RES_FAC_DEPTH;
+        std::vector<char> has_dot((size_t)Rs.fac_len, 0);
+        size_t level_first = 0;
+        for (int c = 0; c < rs->fac_chunks; c++) {
+            const int L = rs->f_ctab[4 * c], last = rs->f_ctab[4 * c + 1], lg = rs->f_ctab[4 * c + 3];
+            unsigned base = (unsigned)rs->f_ctab[4 * c + 2];
+            if (L < 0 || lg < 0 || lg > 6) { set_error("cpg_hip_set_resident: bad factorisation chunk"); return CPG_E_BADARG; }
+            for (int s = 0; s < L; s++) {
+                unsigned cnt = 0;
+                const unsigned ebase = (unsigned)ent.size();
+                for (int l = 0; l < 64; l++) {
+                    const unsigned lw = rs->f_len[(size_t)c * 64 + l];
+                    const int al = (int)(lw & 0xFFFFu), rl = (int)(lw >> 16);
+                    if (al <= s) continue;
+                    if ((unsigned)l != cnt) { set_error("cpg_hip_set_resident: active lanes are not a prefix"); return CPG_E_BADARG; }
+                    cpg::ResEntry e{(unsigned)ZERO, (unsigned)ZERO, (unsigned)ZERO, 0xFFFFFFFFu};
+                    const unsigned src = base + cnt;
+                    if (s < rl) {
+                        if (src >= (unsigned)rs->fac_triples) { set_error("cpg_hip_set_resident: triple out of range"); return CPG_E_BADARG; }
+                        e.x = rs->f_a[src]; e.y = rs->f_k[src]; e.z = rs->f_b[src];
+                        if (e.x >= (unsigned)Rs.fac_len || e.y >= (unsigned)Rs.fac_len || e.z >= (unsigned)Rs.fac_len) { set_error("cpg_hip_set_resident: factor position out of range"); return CPG_E_BADARG; }
+                    }
+                    if (s == 0) {
+                        const unsigned t = rs->f_task[(size_t)c * 64 + l];
+                        if (t != 0xFFFFFFFFu) {
+                            if ((t & 0x7FFFFFFFu) >= (unsigned)ONE) { set_error("cpg_hip_set_resident: destination out of range"); return CPG_E_BADARG; }
+                            e.w = t; has_dot[t & 0x7FFFFFFFu] = 1;
+                        }
+                    }
+                    ent.push_back(e);
+                    cnt++;
+                }
+                base += cnt;
+                ctl.push_back(ebase | (cnt << 24));
+                ctl.push_back((s == 0 ? 1u : 0u) | (s == L - 1 ? 2u : 0u) | ((unsigned)lg << 4));
+            }
+            // tasks without a single term: their destination already holds its final value (a pivot: its reciprocal)
+            for (int l = 0; l < 64; l++) {
+                const unsigned t = rs->f_task[(size_t)c * 64 + l];
+                if (t == 0xFFFFFFFFu || (rs->f_len[(size_t)c * 64 + l] & 0xFFFFu)) continue;
+                if ((t & 0x7FFFFFFFu) >= (unsigned)(nnzL + N)) { set_error("cpg_hip_set_resident: empty inverse task"); return CPG_E_BADARG; }
+                if (t & 0x80000000u) ksrc[t & 0x7FFFFFFFu] |= 0x80000000u;
+            }
+            if (last) {
+                if (ctl.size() > level_first) ctl[ctl.size() - 1] |= 4u;       // level complete behind the last step emitted in it
+                level_first = ctl.size();
+            }
+        }
+        if (ent.size() >= (1u << 24)) { set_error("cpg_hip_set_resident: schedule too long"); return CPG_E_BADARG; }
+        Rs.f_dummy = (unsigned)ent.size();
+        ent.push_back(cpg::ResEntry{(unsigned)ZERO, (unsigned)ZERO, (unsigned)ZERO, 0xFFFFFFFFu});
+        while ((ctl.size() / 2) % DP) { ctl.push_back(Rs.f_dummy); ctl.push_back(0u); }
+        Rs.fac_steps = (int)(ctl.size() / 2);
+        for (int t = 0; t < 2 * DP; t++) { ctl.push_back(Rs.f_dummy); ctl.push_back(0u); }
+    }
+    // ---- coalesced canonicalisation maps, entry tables
+    struct EllHost { std::vector<int> idx; std::vector<double> coef; int J = 0, rows = 0; };
+    auto make_ell = [&](const cpg_csr_t &M, int rows, EllHost &E) {
+        E.rows = rows > 0 ? rows : 1; E.J = 0;
+        if (M.nnz > 0) for (int i = 0; i < rows; i++) E.J = std::max(E.J, M.ptr[i + 1] - M.ptr[i]);
+        E.idx.assign((size_t)std::max(E.J, 1) * E.rows, 0); E.coef.assign((size_t)std::max(E.J, 1) * E.rows, 0.0);
+        if (M.nnz > 0) for (int i = 0; i < rows; i++)
+            for (int k = M.ptr[i]; k < M.ptr[i + 1]; k++) { E.idx[(size_t)(k - M.ptr[i]) * E.rows + i] = M.idx[k]; E.coef[(size_t)(k - M.ptr[i]) * E.rows + i] = M.val[k]; }
+    };
+    EllHost eP, eA, eq, eu;
+    make_ell(r->map_P, r->nnzP, eP); make_ell(r->map_A, r->nnzA, eA); make_ell(r->map_q, n, eq); make_ell(r->map_u, m, eu);
+    auto up_ell = [&](const EllHost &E, cpg::DevEll &D) {
+        D.J = E.J; D.rows = E.rows;
+        int rc2;
+        if ((rc2 = upload<int>(h, own, E.idx.data(), E.idx.size(), &D.idx))) return rc2;
+        return upload<double>(h, own, E.coef.data(), E.coef.size(), &D.coef);
+    };
+    if ((rc = up_ell(eP, Rs.eP)) || (rc = up_ell(eA, Rs.eA)) || (rc = up_ell(eq, Rs.eq)) || (rc = up_ell(eu, Rs.eu))) return rc;
+    std::vector<unsigned> entA((size_t)std::max(r->nnzA, 1)), entP((size_t)std::max(r->nnzP, 1));
+    if (n > 0xFFFF || m > 0xFFFF) { set_error("cpg_hip_set_resident: family too large"); return CPG_E_UNSUPPORTED; }
+    for (int j = 0; j < n; j++) {
+        for (int k = r->Ap[j]; k < r->Ap[j + 1]; k++) entA[k] = (unsigned)r->Ai[k] | ((unsigned)j << 16);
+        for (int k = r->Pp[j]; k < r->Pp[j + 1]; k++) entP[k] = (unsigned)r->Pi[k] | ((unsigned)j << 16);
+    }
+    // ---- products of the termination test in the streaming executor's layout
+    StreamTables st3[3];
+    std::vector<int> src3[3];
+    const cpg_rows_program_t *rows3[3] = {&rs->rows_A, &rs->rows_P, &rs->rows_At};
+    cpg::DevStreamTab *dst3[3] = {&Rs.pA, &Rs.pP, &Rs.pAt};
+    const int w_slots = rs->out_aty + n;
+    for (int k = 0; k < 3; k++) {
+        const cpg_rows_program_t &p = *rows3[k];
+        for (int c = 0; c < p.n_chunks; c++) if (p.ctab[4 * c + 3] & ~1) { set_error("cpg_hip_set_resident: row program with an unsupported chunk kind"); return CPG_E_BADARG; }
+        if ((rc = build_stream_tables(p.ctab, p.desc, p.cols, p.n_chunks, w_slots, st3[k]))) return rc;
+        src3[k].resize(st3[k].src.size());
+        const int lim = k == 1 ? r->nnzP : r->nnzA;
+        for (size_t e = 0; e < src3[k].size(); e++) {
+            const int from = st3[k].src[e];
+            int v = -1;
+            if (from >= 0) { if (from >= p.nnz) { set_error("cpg_hip_set_resident: row program entry out of range"); return CPG_E_BADARG; } v = p.ent[from]; }
+            if (v >= lim) { set_error("cpg_hip_set_resident: matrix entry out of range"); return CPG_E_BADARG; }
+            src3[k][e] = v;
+        }
+        cpg::DevStreamTab &D = *dst3[k];
+        D.n_pairs = st3[k].n_pairs; D.n_entries = (int)st3[k].cr.size(); D.dummy = (unsigned)st3[k].cr.size() / 2u - 1u;
+        if ((rc = upload<unsigned>(h, own, st3[k].st.data(), st3[k].st.size(), &D.stab))) return rc;
+        if ((rc = upload<unsigned>(h, own, st3[k].cr.data(), st3[k].cr.size(), &D.cr))) return rc;
+        if ((rc = upload<int>(h, own, src3[k].data(), src3[k].size(), &D.src))) return rc;
+    }
+    Rs.out_ax = rs->out_ax; Rs.out_px = rs->out_px; Rs.out_aty = rs->out_aty;
+    const int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
+    if (rs->out_ax < ldw + N || rs->out_px < rs->out_ax + m || rs->out_aty < rs->out_px + n) { set_error("cpg_hip_set_resident: result slots overlap the work vector"); return CPG_E_BADARG; }
+    long long slice = std::max<long long>(Rs.fac_len, w_slots);
+    slice = std::max<long long>(slice, (long long)r->nnzA + r->nnzP + std::max<long long>(r->np_var, (long long)N + std::max(n, m)));
+    slice += slice & 1;
+    if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }
+    Rs.slice_doubles = (int)slice;
+    Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64;
+    if ((rc = upload<unsigned>(h, own, ctl.data(), ctl.size(), &Rs.f_ctl))) return rc;
+    if ((rc = upload<cpg::ResEntry>(h, own, ent.data(), ent.size(), &Rs.f_ent))) return rc;
+    if ((rc = upload<unsigned>(h, own, ksrc.data(), ksrc.size(), &Rs.k_src))) return rc;
+    if ((rc = upload<unsigned>(h, own, gsrc.data(), gsrc.size(), &Rs.g_src))) return rc;
+    if ((rc = upload<unsigned short>(h, own, glcol.data(), glcol.size(), &Rs.g_lcol))) return rc;
+    if ((rc = upload<unsigned short>(h, own, gcols.data(), gcols.size(), &Rs.g_cols))) return rc;
+    if ((rc = upload<unsigned short>(h, own, grows.data(), grows.size(), &Rs.g_rows))) return rc;
+    if ((rc = upload<unsigned>(h, own, entA.data(), entA.size(), &Rs.entA))) return rc;
+    if ((rc = upload<unsigned>(h, own, entP.data(), entP.size(), &Rs.entP))) return rc;
+    if ((rc = rt_sync(h))) return rc;
+    Rs.ok = 1;
+#endif
+    return CPG_OK;
+}
+
 int cpg_hip_set_handover(cpg_handle_t h, cpg_handle_t per_instance) {
     if (!h || h->conic || (per_instance && per_instance->conic)) { set_error("cpg_hip_set_handover: OSQP handles only"); return CPG_E_BADARG; }
     if (per_instance && (per_instance->device != h->device || per_instance->F.n != h->F.n || per_instance->F.m != h->F.m ||
@@ -1277,6 +1482,27 @@ static cpg::DevBatch make_batch(int64_t B, const double *d_theta, const double *
 // per-instance factor kernel of handle `h` (its tables, its scratch) on `stream` with settings `S`
 static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, cpg::DevBatch &Bt) {
     const int W = 4;
+#ifdef CPG_GENR_HEADER
+    if (h->Rs.ok && !h->R.shared_mats && h->program_in_lds != 0) {
+        // resident kernel: one workgroup per CU, as many wavefronts (<= 4: one per SIMD) as slices fit the LDS
+        const size_t tab = (size_t)(((CPG_GENR_NSTEPS + 3) / 4) * 256 + ((CPG_GENR_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
+        const size_t slice = (size_t)h->Rs.slice_doubles * sizeof(double);
+        int NW = h->waves_per_block > 0 ? h->waves_per_block : 4;
+        if (NW > 4) NW = 4;
+        while (NW > 1 && tab + (size_t)NW * slice > h->lds_limit) NW--;
+        if (tab + (size_t)NW * slice <= h->lds_limit) {
+            long long blocks = (Bt.B + NW - 1) / NW;
+            if (blocks > (long long)h->num_cu) blocks = h->num_cu;
+            int rc;
+            if ((rc = ensure(h->scratch, (size_t)blocks * NW * (size_t)h->Rs.buf_doubles * sizeof(double)))) return rc;
+            Bt.scratch = (double *)h->scratch.p;
+            const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
+#define Z(a, b) if (nsx <= a && nsz <= b) return launch_resident_t<a, b>(h, stream, S, Bt, (int)blocks, NW, tab + (size_t)NW * slice);
+            CPG_KERNELS_REFACTOR(Z)
+#undef Z
+        }
+    }
+#endif
 #ifdef CPG_GENI_HEADER
     if (h->R.gi_ok && h->program_in_lds != 0) {
         const int W = 8;                               // one workgroup of eight wavefronts per CU shares the tables       // generated instance executor (cpg_hip_set_program_placement(0): the streaming one)

@@ -563,6 +563,7 @@ struct SharedCtx {
     CPG_DEV double u(int s, unsigned i) const {
         return s < Inst<NSX, NSZ, NV>::NVZ ? I.uv[s < Inst<NSX, NSZ, NV>::NVZ ? s : 0] : shu[i];
     }
+    CPG_DEV void products(int) const {}             // (contexts that compute ALL rows of a product at once do it here)
     CPG_DEV double ax(int s) const { return CPG_NATURAL_ROWS(F.A_rows, 0, s, w, lane); }     // (A v)_i, v = w[0..n)
     CPG_DEV double px(int s) const { return CPG_NATURAL_ROWS(F.P_rows, 1, s, w, lane); }     // (P v)_j
     CPG_DEV double atx(int s) const { return CPG_NATURAL_ROWS(F.At_rows, 2, s, w, lane); }   // (A' v)_j, v = w[n..)
@@ -646,6 +647,7 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
 #pragma unroll
     for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = dyp[s]; }
     cpgw::lds_order();
+    cx.products(4);
     double r = 0.0;
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
@@ -681,6 +683,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
 #pragma unroll
     for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.n) w[i] = dx(s, i); }
     cpgw::lds_order();
+    cx.products(2);
     double r = 0.0;
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
@@ -692,6 +695,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
     r = cpgw::wave_max_nonneg(r);
     bool res = false;
     if (r < cs * eps * nrm) {
+        cx.products(1);
         bool viol = false;
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
@@ -767,6 +771,7 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
 #pragma unroll
     for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = Iy[s]; }
     cpgw::lds_order();
+    cx.products(7);
     double rp = 0.0, nz = 0.0, na = 0.0, sup = 0.0;
     double s_rp = 0.0, s_nz = 0.0, s_na = 0.0;
 #pragma unroll

@@ -196,6 +196,7 @@ struct InstCtx {
         return natural_chunk(P, s, w, lane);
 #endif
     }
+    CPG_DEV void products(int) const {}
     CPG_DEV double q(int s, unsigned i) const { return QUMEM ? qm[i] : qr[s]; }
     CPG_DEV double u(int s, unsigned i) const { return QUMEM ? um[i] : ur[s]; }
     template <bool ENT, bool OFFS, int NB = CPG_ROW_WALK_BATCH>

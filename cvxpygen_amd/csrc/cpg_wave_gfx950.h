@@ -74,6 +74,9 @@ CPG_DEV unsigned mbcnt(unsigned long long mask) {
 CPG_DEV unsigned popc64(unsigned long long m) { return (unsigned)__popcll(m); }
 
 CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
+// max of non-negative doubles in LDS (they order like their bit patterns): ds_max_u64, no return value
+CPG_DEV void lds_max_u64(unsigned long long *p, double v) { atomicMax(p, (unsigned long long)__double_as_longlong(v)); }
+CPG_DEV double u64_as_double(unsigned long long v) { return __longlong_as_double((long long)v); }
 // keeps the instruction scheduler from interleaving unrolled loop bodies (register pressure)
 CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and

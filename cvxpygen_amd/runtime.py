@@ -98,6 +98,22 @@ class _Refactor(C.Structure):
                 ('shared_mats', C.c_int32), ('Ps', _dp), ('As', _dp), ('D', _dp), ('E', _dp), ('c', C.c_double)]
 
 
+class _RowsProgram(C.Structure):
+    _fields_ = [('n_chunks', C.c_int32), ('nnz', C.c_int32), ('ctab', _ip), ('desc', C.POINTER(C.c_uint32)), ('cols', _u16p),
+                ('ent', _ip)]
+
+
+class _Resident(C.Structure):
+    _fields_ = [('nnzX', C.c_int32), ('fac_chunks', C.c_int32), ('fac_triples', C.c_int32), ('f_ctab', _ip),
+                ('f_task', C.POINTER(C.c_uint32)), ('f_len', C.POINTER(C.c_uint32)),
+                ('f_a', C.POINTER(C.c_uint32)), ('f_b', C.POINTER(C.c_uint32)), ('f_k', C.POINTER(C.c_uint32)),
+                ('sol_chunks', C.c_int32), ('sol_nnz', C.c_int32), ('sol_slots', C.c_int32),
+                ('sol_ctab', _ip), ('sol_desc', C.POINTER(C.c_uint32)), ('sol_cols', _u16p),
+                ('sol_kind', _ip), ('sol_idx', _ip), ('sol_lcol', _ip),
+                ('rows_A', _RowsProgram), ('rows_P', _RowsProgram), ('rows_At', _RowsProgram),
+                ('out_ax', C.c_int32), ('out_px', C.c_int32), ('out_aty', C.c_int32)]
+
+
 class _Gradient(C.Structure):
     _fields_ = [('NP', C.c_int32), ('Pcolidx', _ip), ('Acolidx', _ip), ('tptr', _ip), ('tkind', _ip),
                 ('tidx', _ip), ('tcoef', _dp)]
@@ -117,7 +133,7 @@ class CpgLibrary:
 
     SYMBOLS = ['cpg_hip_device_count', 'cpg_hip_create_osqp', 'cpg_hip_create_clarabel', 'cpg_hip_destroy', 'cpg_hip_last_error',
                'cpg_hip_status_string', 'cpg_hip_set_default_settings', 'cpg_hip_set_setting',
-               'cpg_hip_get_setting', 'cpg_hip_set_build_option', 'cpg_hip_set_handover', 'cpg_hip_last_phase_ms', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
+               'cpg_hip_get_setting', 'cpg_hip_set_build_option', 'cpg_hip_set_handover', 'cpg_hip_last_phase_ms', 'cpg_hip_set_update', 'cpg_hip_set_refactor', 'cpg_hip_set_resident', 'cpg_hip_set_gradient', 'cpg_hip_gradient_batch',
                'cpg_hip_solve_batch',
                'cpg_hip_solve_batch_device', 'cpg_hip_solve_batch_state', 'cpg_hip_solve_batch_device_state', 'cpg_hip_solve_batches_pipelined', 'cpg_hip_host_malloc',
                'cpg_hip_host_free', 'cpg_hip_synchronize', 'cpg_hip_get_stream', 'cpg_hip_last_kernel_ms',
@@ -147,6 +163,7 @@ class CpgLibrary:
         L.cpg_hip_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.cpg_hip_set_update.argtypes = [C.c_void_p, C.POINTER(_Update)]
         L.cpg_hip_set_refactor.argtypes = [C.c_void_p, C.POINTER(_Refactor)]
+        L.cpg_hip_set_resident.argtypes = [C.c_void_p, C.POINTER(_Refactor), C.POINTER(_Resident)]
         L.cpg_hip_set_gradient.argtypes = [C.c_void_p, C.POINTER(_Gradient)]
         L.cpg_hip_gradient_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp]
         L.cpg_hip_solve_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _ip, _ip, _dp, _dp]
@@ -228,14 +245,15 @@ class FamilyPlan:
     osqp_shared: Optional[_setup.OsqpPlan] = None
 
 
-def _instance_fingerprints(lib_path: str):
-    """CPG_GENI_FINGERPRINT of the generated instance headers next to a library (what it was compiled from)"""
+def _instance_fingerprints(lib_path: str, stem: str = 'cpg_instance', prefix: str = 'GENI'):
+    """CPG_GENI_FINGERPRINT of the generated instance headers next to a library (what it was compiled from); with
+    stem 'cpg_resident' / prefix 'GENR' the same for the resident executors (codegen.resident_header)"""
     import glob
     import re
     out = set()
-    for h in glob.glob(os.path.join(os.path.dirname(os.path.abspath(lib_path)), 'cpg_instance_*.h')):
+    for h in glob.glob(os.path.join(os.path.dirname(os.path.abspath(lib_path)), stem + '_*.h')):
         try:
-            m = re.search(r'#define CPG_GENI_FINGERPRINT (\d+)u', open(h).read(4096))
+            m = re.search(r'#define CPG_' + prefix + r'_FINGERPRINT (\d+)u', open(h).read(4096))
         except OSError:
             m = None
         if m:
@@ -427,6 +445,7 @@ class BatchSolver:
         self.h_shared = self.h
         self.h_ref = C.c_void_p()          # canonical-order handle of the refactorisation path (structural pattern)
         self._rplan = None
+        self._rplan_res = None             # resident_plan.ResidentPlan when the library carries this family's resident executor
         self.h_rs = C.c_void_p()           # ... and of shared-matrix mode (numerically non-zero pattern, plan.osqp_shared)
         self._rplan_s = None
         self._rs_key = None
@@ -496,7 +515,20 @@ class BatchSolver:
             self._rplan_g = rplan
         else:
             o = self.plan.osqp
-            rplan = self._rplan or _rp.build_refactor_plan(desc.P, desc.A, o)
+            rplan = self._rplan
+            if rplan is None:
+                # the plan codegen.resident_header generated this library's resident executor from (merged levels,
+                # register-resident coefficients) -- when the library has one for this family; its `base` is the plan
+                # every other library streams
+                self._rplan_res = None
+                if _instance_fingerprints(self.lib.path, 'cpg_resident', 'GENR'):
+                    from . import resident_plan as _rs
+                    cand = _rs.build_resident_plan(desc.P, desc.A, o)
+                    if cand.sol.fingerprint() in _instance_fingerprints(self.lib.path, 'cpg_resident', 'GENR'):
+                        self._rplan_res = cand
+                        rplan = cand.base
+                if rplan is None:
+                    rplan = _rp.build_refactor_plan(desc.P, desc.A, o)
             self._rplan = rplan
         keep = self._keep
         n, m = desc.n_var, desc.m
@@ -620,7 +652,20 @@ class BatchSolver:
             np_var=len(cols), P_base=_d(Pb), A_base=_d(Ab), q_base=_d(qb), u_base=_d(ub), d_base=d_base,
             map_P=MP, map_A=MA, map_q=Mq, map_u=Mu, map_d=Md, q_setup=_d(q_setup),
             shared_mats=int(bool(shared_mats)), Ps=_d(Ps), As=_d(As), D=_d(Dv), E=_d(Ev), c=float(o.scaling.c))
-        self.lib.check(self.lib.L.cpg_hip_set_refactor(hh, C.byref(rf)), 'cpg_hip_set_refactor')
+        res = getattr(self, '_rplan_res', None) if mode == 'struct' else None
+        if res is not None:
+            def rows(prog, ent):
+                return _RowsProgram(n_chunks=prog.n_chunks, nnz=prog.nnz, ctab=i32(prog.ctab), desc=u32(prog.desc), cols=u16(prog.cols), ent=i32(ent))
+            rs = _Resident(
+                nnzX=res.nnzX, fac_chunks=int(res.f_ctab.shape[0]), fac_triples=len(res.f_a), f_ctab=i32(res.f_ctab),
+                f_task=u32(res.f_task), f_len=u32(res.f_len), f_a=u32(res.f_a), f_b=u32(res.f_b), f_k=u32(res.f_k),
+                sol_chunks=res.sol.n_chunks, sol_nnz=res.sol.nnz, sol_slots=res.sol.n_slots, sol_ctab=i32(res.sol.ctab),
+                sol_desc=u32(res.sol.desc), sol_cols=u16(res.sol.cols), sol_kind=i32(res.sol_kind), sol_idx=i32(res.sol_idx),
+                sol_lcol=i32(res.sol_lcol), rows_A=rows(res.rows_A, res.rows_A_ent), rows_P=rows(res.rows_P, res.rows_P_ent),
+                rows_At=rows(res.rows_At, res.rows_At_ent), out_ax=res.out_ax, out_px=res.out_px, out_aty=res.out_aty)
+            self.lib.check(self.lib.L.cpg_hip_set_resident(hh, C.byref(rf), C.byref(rs)), 'cpg_hip_set_resident')
+        else:
+            self.lib.check(self.lib.L.cpg_hip_set_refactor(hh, C.byref(rf)), 'cpg_hip_set_refactor')
         if shared_mats:
             self._rs_keep, self._rs_key = keep, key
         elif mode == 'grad':

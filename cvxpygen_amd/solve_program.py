@@ -67,6 +67,10 @@ class Phase:
     intra: bool = False      # some row reads another row of the same phase -> deferred stores
     name: str = ''
     accumulate: bool = False  # w[row] += sum instead of w[row] = sum (ragged packing only; in-place rows)
+    # rows read other rows' slots of the SAME phase (accumulate form of a merged group's diagonal-block inverse,
+    # resident_plan.py): every gather of the phase must come before its first store.  The generated executors issue a
+    # phase's gathers first anyway; chunk-by-chunk executors (run_program_stream) refuse such a program (chunk kind bit 2)
+    deferred: bool = False
 
     @property
     def nnz(self) -> int:
@@ -612,7 +616,7 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
                     vals.append(np.array([lane_v[t][s] for t in range(cnt)]))
                     cols.append(np.array([8 * lane_c[t][s] for t in range(cnt)], dtype=np.uint16))
                     n_ent += cnt
-                ctab.append([L, S, first, 1 | (2 if ph.accumulate else 0)])
+                ctab.append([L, S, first, 1 | (2 if ph.accumulate else 0) | (4 if ph.deferred else 0)])
                 desc.append(D)
                 first += n_ent
             continue
@@ -646,7 +650,7 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
                 vals.append(np.array([lane_v[t][s] for t in range(cnt)]))
                 cols.append(np.array([8 * lane_c[t][s] for t in range(cnt)], dtype=np.uint16))
                 n_ent += cnt
-            ctab.append([L, int(np.log2(g)), first, 2 if ph.accumulate else 0])
+            ctab.append([L, int(np.log2(g)), first, (2 if ph.accumulate else 0) | (4 if ph.deferred else 0)])
             desc.append(D)
             first += n_ent
     vals.append(np.zeros(1))
@@ -660,15 +664,24 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
 
 
 def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
-    """Host emulation of `run_program_lds` (tests)."""
+    """Host emulation of `run_program_lds` (tests).  Chunks of a `deferred` phase (kind bit 2) store when their
+    phase is complete: all of its gathers see the values from before the phase."""
     lane = np.arange(LANES)
     dummy = prog.nnz - 1
+    pending = []                        # (slots, values, accumulate) of the open deferred phase
+
+    def flush():
+        for R_, v_, acc_ in pending:
+            w[R_] = (w[R_] + v_) if acc_ else v_
+        pending.clear()
     for c in range(prog.n_chunks):
-        L, lg, first, _ = prog.ctab[c]
+        L, lg, first, kind = (int(v) for v in prog.ctab[c])
+        if pending and (not (kind & 4) or prog.chunk_phase is None or prog.chunk_phase[c] != prog.chunk_phase[c - 1]):
+            flush()
         d = prog.desc[c]
         row, ln = d & 0xFFFF, d >> 16
-        accumulate = bool(prog.ctab[c, 3] & 2)
-        if prog.ctab[c, 3] & 1:
+        accumulate = bool(kind & 2)
+        if kind & 1:
             ln = ln & 0xFFF            # balanced chunk: segmented shift-add reduction
             acc = np.zeros(LANES)
             base = first
@@ -684,7 +697,10 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
                 sh[okl] = acc[src[okl]]
                 acc = acc + np.where(((d >> 28) >> st) & 1, sh, 0.0)
             ok = row != NO_ROW
-            w[row[ok]] = (w[row[ok]] + acc[ok]) if accumulate else acc[ok]
+            if kind & 4:
+                pending.append((row[ok].copy(), acc[ok].copy(), accumulate))
+            else:
+                w[row[ok]] = (w[row[ok]] + acc[ok]) if accumulate else acc[ok]
             continue
         g = 1 << lg
         acc = np.zeros(LANES)
@@ -697,7 +713,11 @@ def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
         red = acc.reshape(LANES // g, g).sum(axis=1)
         R = row[::g]
         ok = R != NO_ROW
-        w[R[ok]] = (w[R[ok]] + red[ok]) if accumulate else red[ok]
+        if kind & 4:
+            pending.append((R[ok].copy(), red[ok].copy(), accumulate))
+        else:
+            w[R[ok]] = (w[R[ok]] + red[ok]) if accumulate else red[ok]
+    flush()
     return w
 
 

@@ -178,6 +178,32 @@ typedef struct {
     double c;
 } cpg_osqp_refactor_t;
 
+/* RESIDENT per-instance factor kernel (cvxpygen_amd/csrc/cpg_osqp_resident.h, cvxpygen_amd/resident_plan.py): the same
+ * path as cpg_osqp_refactor_t -- osqp_update_data_mat + osqp_solve per instance (cvxpygen/solvers/osqp.py:20-62) -- with the
+ * instance's factor kept on the CU.  Tables next to those of cpg_osqp_refactor_t:
+ *   f_*     the numeric LDL' schedule of the refactor tables FOLLOWED BY the schedule that inverts the diagonal blocks of
+ *           merged level groups; all positions are absolute in  fac = [M (nnzL) | 1/d (n + m) | X (nnzX) | 1.0 | 0.0];
+ *           f_task: destination, bit 31 = pivot (store the reciprocal)
+ *   sol_*   the MERGED substitution program; sol_kind 0 zero, 1 one, 2 -L[idx] (column sol_lcol), 3 1/d[idx], 4 X[idx]
+ *   rows_*  ragged row programs of the termination test's products on the work vector; `ent`: entry of A (of upper-
+ *           triangular P) behind every coefficient, -1 padding */
+typedef struct {
+    int32_t n_chunks, nnz;
+    const int32_t *ctab; const uint32_t *desc; const uint16_t *cols;
+    const int32_t *ent;
+} cpg_rows_program_t;
+typedef struct {
+    int32_t nnzX, fac_chunks, fac_triples;
+    const int32_t *f_ctab;                  /* [fac_chunks][4]: steps, level complete, first triple, log2 lanes per task */
+    const uint32_t *f_task, *f_len;         /* [fac_chunks][64] */
+    const uint32_t *f_a, *f_b, *f_k;        /* [fac_triples] */
+    int32_t sol_chunks, sol_nnz, sol_slots;
+    const int32_t *sol_ctab; const uint32_t *sol_desc; const uint16_t *sol_cols;
+    const int32_t *sol_kind, *sol_idx, *sol_lcol;
+    cpg_rows_program_t rows_A, rows_P, rows_At;
+    int32_t out_ax, out_px, out_aty;        /* first work-vector slot of A x, P x, A' y */
+} cpg_osqp_resident_t;
+
 /* QP adjoint (gradient=True in the reference): transposed canonical maps over ALL user parameters.
  * For parameter column c, entries tptr[c] .. tptr[c+1]: kind 0 q[idx], 1 l[idx], 2 u[idx],
  * 3 P entry idx, 4 A entry idx, with coefficient tcoef (rows of the reference's canon_<p>_map,
@@ -271,6 +297,12 @@ int cpg_hip_set_update(cpg_handle_t h, const cpg_osqp_update_t *upd);
 /* per-instance refactorisation path; after this call solves go through it until cpg_hip_set_update
  * is called again */
 int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *rf);
+
+/* cpg_hip_set_refactor(h, rf), and -- when this library carries the generated resident executor of exactly this
+ * family (cvxpygen_amd.codegen.resident_header; the merged program's fingerprint decides) -- the resident kernel's
+ * tables: solves then run cpg_osqp_resident.h instead of the streaming kernel.  cpg_hip_get_setting(h,
+ * "resident_executor") reports which (1.0 / 0.0); any other library keeps the streaming kernel and returns CPG_OK. */
+int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *rf, const cpg_osqp_resident_t *rs);
 
 /* adjoint tables; requires cpg_hip_set_refactor on the same handle (canonical ordering) */
 int cpg_hip_set_gradient(cpg_handle_t h, const cpg_osqp_gradient_t *g);

@@ -123,6 +123,11 @@ inline bool wave_any(bool p) {
 inline unsigned atomic_next(unsigned *ctr) {
     return __atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED);
 }
+inline void lds_max_u64(unsigned long long *p, double v) {       // (fibers switch at the primitives only: a plain update is atomic)
+    unsigned long long b; std::memcpy(&b, &v, 8);
+    if (b > *p) *p = b;
+}
+inline double u64_as_double(unsigned long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 inline void mem_order() { wave_sync(); }
 inline unsigned long long ballot(bool p) {
     SimWave *w = cur->wv;
