@@ -1184,7 +1184,9 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     std::vector<void *> &own = h->resident_owned;
     cpg::DevResident &Rs = h->Rs;
     const int n = h->F.n, m = h->F.m, N = n + m, nnzL = r->nnzL;
-    if (rs->sol_chunks != CPG_GENR_NCHUNKS || rs->sol_nnz != CPG_GENR_NNZ || rs->sol_slots != CPG_GENR_NSLOTS ||
+    if (n != CPG_GENR_N || m != CPG_GENR_M || h->F.n_eq != CPG_GENR_NEQ || r->nnzA != CPG_GENR_NNZA || r->nnzP != CPG_GENR_NNZP ||
+        nnzL != CPG_GENR_NNZL || rs->nnzX != CPG_GENR_NNZX ||
+        rs->sol_chunks != CPG_GENR_NCHUNKS || rs->sol_nnz != CPG_GENR_NNZ || rs->sol_slots != CPG_GENR_NSLOTS ||
         program_fingerprint(rs->sol_ctab, rs->sol_desc, rs->sol_cols, rs->sol_chunks, rs->sol_nnz) != CPG_GENR_FINGERPRINT)
         return CPG_OK;                                    // another family's library: the streaming kernel serves this handle
     static const int steps[][4] = CPG_GENR_STEPS;         // {first entry, active lanes, coefficient register, lane shift}
@@ -1308,7 +1310,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     std::vector<int> src3[3];
     const cpg_rows_program_t *rows3[3] = {&rs->rows_A, &rs->rows_P, &rs->rows_At};
     cpg::DevStreamTab *dst3[3] = {&Rs.pA, &Rs.pP, &Rs.pAt};
-    const int w_slots = rs->out_aty + n;
+    const int w_slots = std::max(rs->out_ax + m, rs->out_aty + n);
     for (int k = 0; k < 3; k++) {
         const cpg_rows_program_t &p = *rows3[k];
         for (int c = 0; c < p.n_chunks; c++) if (p.ctab[4 * c + 3] & ~1) { set_error("cpg_hip_set_resident: row program with an unsupported chunk kind"); return CPG_E_BADARG; }
@@ -1330,8 +1332,10 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     }
     Rs.out_ax = rs->out_ax; Rs.out_px = rs->out_px; Rs.out_aty = rs->out_aty;
     const int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
-    if (rs->out_ax < ldw + N || rs->out_px < rs->out_ax + m || rs->out_aty < rs->out_px + n) { set_error("cpg_hip_set_resident: result slots overlap the work vector"); return CPG_E_BADARG; }
-    long long slice = std::max<long long>(Rs.fac_len, w_slots);
+    if (rs->out_ax < ldw + N || rs->out_px < ldw + N || rs->out_aty < rs->out_px + n) { set_error("cpg_hip_set_resident: result slots overlap the work vector"); return CPG_E_BADARG; }
+    Rs.out_cf = w_slots;
+    constexpr int n_lds_regs = CPG_GENR_NREGS > CPG_GENR_NACC ? CPG_GENR_NREGS - CPG_GENR_NACC : 0;
+    long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots + 64LL * n_lds_regs);
     slice = std::max<long long>(slice, (long long)r->nnzA + r->nnzP + std::max<long long>(r->np_var, (long long)N + std::max(n, m)));
     slice += slice & 1;
     if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }

@@ -218,6 +218,7 @@ CPG_DEV void run_program(const DevProgram &P, double *w, int ldw, int lane) {
 struct StreamPairD { double a, b; };
 struct StreamPairU { unsigned a, b; };
 struct alignas(8) OffsetQuad { unsigned a, b; };     // operand offsets of four steps (generated executor)
+CPG_DEV OffsetQuad quad_from(unsigned long long v) { OffsetQuad q; q.a = (unsigned)v; q.b = (unsigned)(v >> 32); return q; }
 CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double *w) {
     const int stages = (int)(f & 7u);
     // segmented chunks: all three stages, branch-free (the mask of an unused stage is zero)
@@ -771,7 +772,7 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
 #pragma unroll
     for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < (unsigned)F.m) w[(unsigned)F.n + i] = Iy[s]; }
     cpgw::lds_order();
-    cx.products(7);
+    cx.products(1);          // (contexts whose products share result slots: A x is consumed before P x and A' y are formed)
     double rp = 0.0, nz = 0.0, na = 0.0, sup = 0.0;
     double s_rp = 0.0, s_nz = 0.0, s_na = 0.0;
 #pragma unroll
@@ -792,6 +793,7 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
         }
         cpgw::sched_fence();
     }
+    cx.products(6);
     double rd = 0.0, nq = 0.0, nat = 0.0, npx = 0.0, quad = 0.0, lin = 0.0;
     double s_rd = 0.0, s_nq = 0.0, s_nat = 0.0, s_npx = 0.0;
 #pragma unroll

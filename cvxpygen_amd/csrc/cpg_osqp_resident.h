@@ -60,7 +60,8 @@ struct DevResident {
     DevEll eP, eA, eq, eu;
     const unsigned *entA, *entP;           // row | column << 16 of every stored entry
     DevStreamTab pA, pP, pAt;              // A x, P x, A' y on the work vector [x | y | .. | A x | P x | A' y]
-    int out_ax, out_px, out_aty;           // first slot of the products' results
+    int out_ax, out_px, out_aty;           // first slot of the products' results (A x shares the slots of P x | A' y)
+    int out_cf;                            // ... and of the coefficient registers that are not AGPRs, [register][lane]
     int slice_doubles;                     // LDS doubles per wavefront
     long long buf_doubles;                 // per-wavefront buffer in global memory
 };
@@ -75,14 +76,6 @@ CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, co
     o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
     o.cA = b; b += Rs.pA.n_entries; o.cP = b; b += Rs.pP.n_entries; o.cAt = b; b += Rs.pAt.n_entries;
     return o;
-}
-
-CPG_DEV double ell_row(const DevEll &E, unsigned k, const double *th, double v) {
-    for (int j = 0; j < E.J; j++) {
-        const unsigned e = (unsigned)j * (unsigned)E.rows + k;
-        v = fma(cpgw::gld(E.coef, e), th[(unsigned)cpgw::gld(E.idx, e)], v);
-    }
-    return v;
 }
 
 // Numeric LDL' of the instance's KKT matrix in the M-form of numeric_ldl_m (undivided column entries, reciprocal
@@ -135,8 +128,11 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
     cpgw::lds_order();
 }
 
-// the instance's coefficients of the generated executor from `fac`: -l_ij = -M_ij / d_j, 1 / d_i, X_ij or 1
-CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const double *fac, double (&cf)[CPG_GENR_NREGS], int lane) {
+// the instance's coefficients of the generated executor from `fac`: -l_ij = -M_ij / d_j, 1 / d_i, X_ij or 1; the first
+// CPG_GENR_NACC registers are named AGPR pairs (run_program_res_put of the generated header); the others are returned in
+// cfv and go to the LDS slice once the factor in it is dead
+constexpr int kResLds = CPG_GENR_NREGS - CPG_GENR_NACC > 0 ? CPG_GENR_NREGS - CPG_GENR_NACC : 0;     // coefficient registers held in LDS
+CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const double *fac, double (&cfv)[kResLds > 0 ? kResLds : 1], int lane) {
     const unsigned ln = (unsigned)cpgw::opaque(lane);            // (see load_instance_coefficients: addresses local to this block)
     const unsigned nnzL = (unsigned)R.nnzL, X0 = (unsigned)(Rs.fac_len - 2 - Rs.nnzX);
 #pragma unroll
@@ -149,7 +145,8 @@ CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, 
         else if (kind == 2u) v = -(fac[idx] * fac[nnzL + col]);
         else if (kind == 3u) v = fac[nnzL + idx];
         else if (kind == 4u) v = fac[X0 + idx];
-        cf[t] = v;
+        if (t < CPG_GENR_NACC) run_program_res_put(t, v, (CPG_LDS double *)nullptr, lane);
+        else cfv[t >= CPG_GENR_NACC ? t - CPG_GENR_NACC : 0] = v;
     }
 }
 
@@ -173,9 +170,17 @@ struct ResidentCtx {
         run_program_stream(ST, w, lane);
     }
     CPG_DEV void products(int which) const {        // 1: A w[0..n)   2: P w[0..n)   4: A' w[n..n+m)
-        if (which & 1) run(Rs.pA, B.cA);
-        if (which & 2) run(Rs.pP, B.cP);
-        if (which & 4) run(Rs.pAt, B.cAt);
+        // rows without an entry are never written by their program, and A x shares the slots of P x | A' y: clear first
+        // (behind every lane's last read of the previous product)
+        cpgw::lds_order();
+        if (which & 1) for (unsigned i = (unsigned)lane; i < (unsigned)F.m; i += 64u) w[(unsigned)Rs.out_ax + i] = 0.0;
+        if (which & 2) for (unsigned i = (unsigned)lane; i < (unsigned)F.n; i += 64u) w[(unsigned)Rs.out_px + i] = 0.0;
+        if (which & 4) for (unsigned i = (unsigned)lane; i < (unsigned)F.n; i += 64u) w[(unsigned)Rs.out_aty + i] = 0.0;
+        cpgw::lds_order();
+        // (one copy of the executor per call site: the tables are picked at run time)
+#pragma nounroll
+        for (int k = 0; k < 3; k++)
+            if ((which >> k) & 1) run(k == 0 ? Rs.pA : (k == 1 ? Rs.pP : Rs.pAt), k == 0 ? B.cA : (k == 1 ? B.cP : B.cAt));
         cpgw::lds_order();
     }
     CPG_DEV double ax(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.m ? w[(unsigned)Rs.out_ax + i] : 0.0; }
@@ -183,67 +188,92 @@ struct ResidentCtx {
     CPG_DEV double atx(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.n ? w[(unsigned)Rs.out_aty + i] : 0.0; }
 };
 
+// The pieces of an instance's life that are NOT its ADMM iterations are real function calls (noinline), each with a
+// register allocation of its own: inlined into one body, the set-up (~230 live registers of matrix entries), the
+// termination test (four copies of the streaming executor) and the factorisation decided where the allocator put the
+// ADMM loop's coefficients -- in scratch memory, ~100 reloads per iteration (profiles/r4_s2_isa_*).  The AMDGPU calling
+// convention keeps a32 - a255 and half of the VGPRs across a call: the coefficients stay where they are.
+
+template <int NSZ>
+struct ResSetupOut {
+    double cs, dconst;
+    unsigned free_rows;           // bit s: row lane + 64 s is free (infinite bound)
+    signed char ct[NSZ];          // row classes for check(): 1 equality, 0 inequality, -1 free
+};
+
+// steps 1 - 3 of an instance: canonicalise, equilibrate, scaled data (the wavefront's buffer B, program-order copies)
 template <int NSX, int NSZ>
-CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const DevResident &Rs, const DevSettings &S,
-                                const DevBatch &Bt, double *lds, int wave_global) {
-    const int lane = cpgw::lane_id();
-    const unsigned n = (unsigned)F0.n, m = (unsigned)F0.m, N = n + m;
-    constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
-    // block-shared copies of the executor's offset / output-slot tables in front of the wavefronts' slices
-    constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u, t_nrows = ((CPG_GENR_NCHUNKS + 3u) / 4u) * 256u;
-    unsigned short *lc = (unsigned short *)lds, *lr = lc + t_ncols;
-    for (unsigned t = cpgw::thread_in_block(); t < t_ncols; t += cpgw::block_threads()) lc[t] = cpgw::gld(Rs.g_cols, t);
-    for (unsigned t = cpgw::thread_in_block(); t < t_nrows; t += cpgw::block_threads()) lr[t] = cpgw::gld(Rs.g_rows, t);
-    cpgw::block_sync();
-    lds += (t_ncols + t_nrows) / 4u;
-    // The wavefront's slice, three lives:
-    //   set-up    A (nnzA) | P (nnzP) | D (n) | E (m) | norms (max(n, m))      theta is staged where D starts
-    //   factor    fac = M (nnzL) | 1/d (N) | X | 1.0 | 0.0
-    //   ADMM      w (ldw) | q (n) | u (m) | A x (m) | P x (n) | A' y (n)
-    double *sl = lds + (size_t)cpgw::wave_in_block() * (size_t)Rs.slice_doubles;
-    double *w = sl, *qs = w + ldw, *us = qs + n;
-    double *Al = sl, *Pl = Al + R.nnzA, *Dl = Pl + R.nnzP, *El = Dl + n;
+CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, const double *theta,
+                                     double ri_eq, double ri_in, double ri_fr, int lane, ResSetupOut<NSZ> &out) {
+    constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m, n_eq = CPG_GENR_NEQ;
+    double *sl = cpgw::lds_window() + sl_off;
+    double *Al = sl, *Pl = Al + CPG_GENR_NNZA, *Dl = Pl + CPG_GENR_NNZP, *El = Dl + n;
     unsigned long long *nrm = (unsigned long long *)(El + m);
-    const ResBuf B = res_carve(Bt.scratch + (size_t)wave_global * (size_t)Rs.buf_doubles, F0, R, Rs);
-    const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
-    const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
-    const unsigned n_work = Bt.list_count ? cpgw::sld(Bt.list_count, 0u) : 0u;
-    typedef ResidentCtx<NSX, NSZ> CtxT;
-
-    for (;;) {
-        unsigned ig = 0;
-        if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
-        ig = (unsigned)cpgw::read_first_lane((int)ig);
-        long long b = (long long)ig;
-        if (Bt.list) {
-            if (ig >= n_work) break;
-            b = (long long)cpgw::read_first_lane(cpgw::gld(Bt.list, ig));
-        } else if (b >= Bt.B) break;
-        const double *theta = Bt.theta + (size_t)b * R.np_var;
-        // rho of the workspace / of the settings: see osqp_refactor_body
-        const double *state_in = (Bt.state_in && (S.warm_starting || Bt.resume)) ? Bt.state_in + (size_t)b * state_len : nullptr;
-        double rho = Bt.state_in ? cpgw::gld(Bt.state_in + (size_t)b * state_len, n + 2u * m) : F0.rho;
-        rho = cpgw::dmin2(cpgw::dmax2(rho, CPG_RHO_MIN), CPG_RHO_MAX);
-        double rho_stg = F0.rho;
-        double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
-
-        // ---- 1. theta -> LDS; canonicalise P, A (LDS), q, u (registers), d
-        {
-            double *th = Dl;
-            for (unsigned t = (unsigned)lane; t < (unsigned)R.np_var; t += 64u) th[t] = cpgw::gld(theta, t);
-            cpgw::lds_order();
-            for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) Al[k] = ell_row(Rs.eA, k, th, cpgw::gld(R.A_base, k));
-            for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) Pl[k] = ell_row(Rs.eP, k, th, cpgw::gld(R.P_base, k));
-        }
+    {
+        // ---- 1. theta -> LDS; canonicalise P, A, q, u (registers: entry k = lane + 64 t of a matrix, entry i = lane + 64 s
+        //         of a vector), d.  The family's dimensions are compile-time constants: every table read below is an
+        //         independent, unrolled load -- with one wavefront per SIMD a loop that waits for one global load per
+        //         trip is a chain of memory latencies.
+        constexpr int KA = (CPG_GENR_NNZA + 63) / 64 > 0 ? (CPG_GENR_NNZA + 63) / 64 : 1, KP = (CPG_GENR_NNZP + 63) / 64 > 0 ? (CPG_GENR_NNZP + 63) / 64 : 1;
+        constexpr unsigned nnzA = CPG_GENR_NNZA, nnzP = CPG_GENR_NNZP;
+        unsigned ea[KA], ep[KP];           // row | column << 16
+        double av[KA], pv[KP];
         double qr[NSX], ur[NSZ];
         {
-            const double *th = Dl;
+            double *th = Dl;
+            for (unsigned t0 = 0; t0 < (unsigned)R.np_var; t0 += 512u) {
+                double tv[8];
 #pragma unroll
-            for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qr[s] = i < n ? ell_row(Rs.eq, i, th, cpgw::gld(R.q_base, i)) : 0.0; }
+                for (int u = 0; u < 8; u++) { const unsigned t = t0 + 64u * (unsigned)u + (unsigned)lane; tv[u] = t < (unsigned)R.np_var ? cpgw::gld(theta, t) : 0.0; }
 #pragma unroll
-            for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; ur[s] = i < m ? ell_row(Rs.eu, i, th, cpgw::gld(R.u_base, i)) : 0.0; }
+                for (int u = 0; u < 8; u++) { const unsigned t = t0 + 64u * (unsigned)u + (unsigned)lane; if (t < (unsigned)R.np_var) th[t] = tv[u]; }
+            }
+            cpgw::lds_order();
+#pragma unroll
+            for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)lane + 64u * (unsigned)t; ea[t] = k < nnzA ? cpgw::gld(Rs.entA, k) : 0u; av[t] = k < nnzA ? cpgw::gld(R.A_base, k) : 0.0; }
+#pragma unroll
+            for (int t = 0; t < KP; t++) { const unsigned k = (unsigned)lane + 64u * (unsigned)t; ep[t] = k < nnzP ? cpgw::gld(Rs.entP, k) : 0u; pv[t] = k < nnzP ? cpgw::gld(R.P_base, k) : 0.0; }
+#pragma unroll
+            for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qr[s] = i < n ? cpgw::gld(R.q_base, i) : 0.0; }
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; ur[s] = i < m ? cpgw::gld(R.u_base, i) : 0.0; }
+#pragma nounroll
+            for (int j = 0; j < Rs.eA.J; j++) {
+#pragma unroll
+                for (int t = 0; t < KA; t++) {
+                    const unsigned k = (unsigned)lane + 64u * (unsigned)t, e = (unsigned)j * (unsigned)Rs.eA.rows + (k < nnzA ? k : 0u);
+                    av[t] = fma(cpgw::gld(Rs.eA.coef, e), th[(unsigned)cpgw::gld(Rs.eA.idx, e)], av[t]);
+                }
+            }
+#pragma nounroll
+            for (int j = 0; j < Rs.eP.J; j++) {
+#pragma unroll
+                for (int t = 0; t < KP; t++) {
+                    const unsigned k = (unsigned)lane + 64u * (unsigned)t, e = (unsigned)j * (unsigned)Rs.eP.rows + (k < nnzP ? k : 0u);
+                    pv[t] = fma(cpgw::gld(Rs.eP.coef, e), th[(unsigned)cpgw::gld(Rs.eP.idx, e)], pv[t]);
+                }
+            }
+#pragma nounroll
+            for (int j = 0; j < Rs.eq.J; j++) {
+#pragma unroll
+                for (int s = 0; s < NSX; s++) {
+                    const unsigned i = (unsigned)lane + 64u * (unsigned)s, e = (unsigned)j * (unsigned)Rs.eq.rows + (i < n ? i : 0u);
+                    qr[s] = fma(cpgw::gld(Rs.eq.coef, e), th[(unsigned)cpgw::gld(Rs.eq.idx, e)], qr[s]);
+                }
+            }
+#pragma nounroll
+            for (int j = 0; j < Rs.eu.J; j++) {
+#pragma unroll
+                for (int s = 0; s < NSZ; s++) {
+                    const unsigned i = (unsigned)lane + 64u * (unsigned)s, e = (unsigned)j * (unsigned)Rs.eu.rows + (i < m ? i : 0u);
+                    ur[s] = fma(cpgw::gld(Rs.eu.coef, e), th[(unsigned)cpgw::gld(Rs.eu.idx, e)], ur[s]);
+                }
+            }
         }
         const double dconst = csr_row(R.map_d, 0, theta, R.d_base);
+        double qsu[NSX];                       // q of the code-generation-time workspace (cost scaling)
+#pragma unroll
+        for (int s = 0; s < NSX; s++) { const unsigned j = (unsigned)lane + 64u * (unsigned)s; qsu[s] = j < n ? cpgw::gld(R.q_setup, j) : 0.0; }
         cpgw::lds_order();
 
         // ---- 2. Ruiz equilibration from scratch, cumulative form (D, E in LDS); entry-parallel sweeps: an entry's
@@ -253,11 +283,14 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         double cs = 1.0;
         cpgw::lds_order();
         auto p_norms = [&]() __attribute__((always_inline)) {       // column norms of c D P D (both triangles)
-            for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) {
-                const unsigned rc = cpgw::gld(Rs.entP, k), i = rc & 0xFFFFu, j = rc >> 16;
-                const double p = Pl[k], di = Dl[i], dj = Dl[j];
-                cpgw::lds_max_u64(nrm + j, fabs(cs * dj * p * di));
-                if (i != j) cpgw::lds_max_u64(nrm + i, fabs(cs * di * p * dj));
+#pragma unroll
+            for (int t = 0; t < KP; t++) {
+                const unsigned k = (unsigned)lane + 64u * (unsigned)t, i = ep[t] & 0xFFFFu, j = ep[t] >> 16;
+                if (k < nnzP) {
+                    const double p = pv[t], di = Dl[i], dj = Dl[j];
+                    cpgw::lds_max_u64(nrm + j, fabs(cs * dj * p * di));
+                    if (i != j) cpgw::lds_max_u64(nrm + i, fabs(cs * di * p * dj));
+                }
             }
         };
 #pragma nounroll
@@ -266,20 +299,19 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
             for (unsigned i = (unsigned)lane; i < n; i += 64u) nrm[i] = 0ull;
             cpgw::lds_order();
             p_norms();
-            for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) {
-                const unsigned rc = cpgw::gld(Rs.entA, k), r = rc & 0xFFFFu, c = rc >> 16;
-                cpgw::lds_max_u64(nrm + c, fabs(El[r] * Al[k] * Dl[c]));
-            }
+            double mag[KA];
+#pragma unroll
+            for (int t = 0; t < KA; t++) { const unsigned r = ea[t] & 0xFFFFu, c = ea[t] >> 16; mag[t] = fabs(El[r] * av[t] * Dl[c]); }
+#pragma unroll
+            for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)lane + 64u * (unsigned)t; if (k < nnzA) cpgw::lds_max_u64(nrm + (ea[t] >> 16), mag[t]); }
             cpgw::lds_order();
 #pragma unroll
             for (int s = 0; s < NSX; s++) { const unsigned j = (unsigned)lane + 64u * (unsigned)s; dn[s] = j < n ? cpgw::u64_as_double(nrm[j]) : 0.0; }
             cpgw::lds_order();
             for (unsigned i = (unsigned)lane; i < m; i += 64u) nrm[i] = 0ull;
             cpgw::lds_order();
-            for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) {
-                const unsigned rc = cpgw::gld(Rs.entA, k), r = rc & 0xFFFFu, c = rc >> 16;
-                cpgw::lds_max_u64(nrm + r, fabs(El[r] * Al[k] * Dl[c]));
-            }
+#pragma unroll
+            for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)lane + 64u * (unsigned)t; if (k < nnzA) cpgw::lds_max_u64(nrm + (ea[t] & 0xFFFFu), mag[t]); }
             cpgw::lds_order();
 #pragma unroll
             for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; en[s] = i < m ? cpgw::u64_as_double(nrm[i]) : 0.0; }
@@ -300,7 +332,7 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
                 const unsigned j = (unsigned)lane + 64u * (unsigned)s;
                 if (j < n) {
                     psum += cpgw::u64_as_double(nrm[j]);
-                    qn = cpgw::dmax2(qn, fabs(cs * Dl[j] * cpgw::gld(R.q_setup, j)));
+                    qn = cpgw::dmax2(qn, fabs(cs * Dl[j] * qsu[s]));
                 }
             }
             psum = cpgw::wave_sum(psum);
@@ -309,19 +341,14 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
             cs = cs * (1.0 / lim_scaling(cpgw::dmax2(cm, qn)));
             cpgw::lds_order();
         }
-        // ---- 3. scaled data: matrices (LDS, then the wavefront's buffer: the factorisations read their KKT values
-        //         there, the termination tests their program-order copies), scaling vectors, q, u, row classes
-        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) {
-            const unsigned rc = cpgw::gld(Rs.entA, k), r = rc & 0xFFFFu, c = rc >> 16;
-            const double v = El[r] * Al[k] * Dl[c];
-            Al[k] = v; cpgw::gst(B.A, k, v);
-        }
-        for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzP; k += 64u) {
-            const unsigned rc = cpgw::gld(Rs.entP, k), i = rc & 0xFFFFu, j = rc >> 16;
-            const double v = cs * Dl[i] * Pl[k] * Dl[j];
-            Pl[k] = v; cpgw::gst(B.P, k, v);
-        }
-        signed char ct[NSZ];
+        // ---- 3. scaled data: matrices (LDS for the copies below; the wavefront's buffer: the factorisations read their
+        //         KKT values there, the termination tests their program-order copies), scaling vectors, q, u, row classes
+#pragma unroll
+        for (int t = 0; t < KA; t++) { const unsigned r = ea[t] & 0xFFFFu, c = ea[t] >> 16; av[t] = El[r] * av[t] * Dl[c]; }
+#pragma unroll
+        for (int t = 0; t < KP; t++) { const unsigned i = ep[t] & 0xFFFFu, j = ep[t] >> 16; pv[t] = cs * Dl[i] * pv[t] * Dl[j]; }
+        signed char (&ct)[NSZ] = out.ct;
+        unsigned free_rows = 0u;
 #pragma unroll
         for (int s = 0; s < NSX; s++) {
             const unsigned j = (unsigned)lane + 64u * (unsigned)s;
@@ -339,15 +366,28 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
             if (i < m) {
                 const double ei = El[i], uu = ei * ur[s];
                 cpgw::gst(B.E, i, ei); cpgw::gst(B.Einv, i, 1.0 / ei); cpgw::gst(B.u, i, uu);
-                ct[s] = i < (unsigned)R.n_eq ? 1 : (uu > CPG_INFTY * CPG_MIN_SCALING ? -1 : 0);
+                ct[s] = i < n_eq ? 1 : (uu > CPG_INFTY * CPG_MIN_SCALING ? -1 : 0);
+                if (ct[s] == -1) free_rows |= 1u << s;
                 cpgw::gst(B.rinv, i, ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr));
             }
         }
+        cpgw::lds_order();                 // (D, E are dead: the scaled matrices take the front of the slice)
+#pragma unroll
+        for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)lane + 64u * (unsigned)t; if (k < nnzA) { Al[k] = av[t]; cpgw::gst(B.A, k, av[t]); } }
+#pragma unroll
+        for (int t = 0; t < KP; t++) { const unsigned k = (unsigned)lane + 64u * (unsigned)t; if (k < nnzP) { Pl[k] = pv[t]; cpgw::gst(B.P, k, pv[t]); } }
         cpgw::lds_order();
         auto copy_values = [&](const DevStreamTab &T, double *dst, const double *src) __attribute__((always_inline)) {
-            for (unsigned e = (unsigned)lane; e < (unsigned)T.n_entries; e += 64u) {
-                const int k = cpgw::gld(T.src, e);
-                cpgw::gst(dst, e, k >= 0 ? src[(unsigned)k] : 0.0);
+#pragma nounroll
+            for (unsigned e0 = 0; e0 < (unsigned)T.n_entries; e0 += 512u) {
+                int kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const unsigned e = e0 + 64u * (unsigned)u + (unsigned)lane; kk[u] = e < (unsigned)T.n_entries ? cpgw::gld(T.src, e) : -1; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const unsigned e = e0 + 64u * (unsigned)u + (unsigned)lane;
+                    if (e < (unsigned)T.n_entries) cpgw::gst(dst, e, kk[u] >= 0 ? src[(unsigned)kk[u]] : 0.0);
+                }
             }
         };
         copy_values(Rs.pA, B.cA, Al);
@@ -356,141 +396,265 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         cpgw::lds_order();
         cpgw::mem_order();
 
-        // ---- 4. numeric LDL' + inverses of the merged diagonal blocks in the slice, 5. coefficients -> registers
-        double cf[CPG_GENR_NREGS];
-        auto factorise = [&]() __attribute__((always_inline)) {
-            const unsigned nd = (unsigned)R.nnzL + N;
-            for (unsigned d = (unsigned)lane; d < nd; d += 64u) {
-                const unsigned code = cpgw::gld(Rs.k_src, d), kind = (code >> 28) & 7u, idx = code & 0x0FFFFFFFu;
-                double v = 0.0;
-                if (kind == CPG_K_P) v = cpgw::gld((const double *)B.P, idx) + (d >= (unsigned)R.nnzL ? F0.sigma : 0.0);
-                else if (kind == CPG_K_A) v = cpgw::gld((const double *)B.A, idx);
-                else if (kind == CPG_K_SIGMA) v = F0.sigma;
-                else if (kind == CPG_K_RHO) v = -cpgw::gld((const double *)B.rinv, idx);
-                sl[d] = (code >> 31) ? 1.0 / v : v;
+        out.cs = cs; out.dconst = dconst; out.free_rows = free_rows;
+    }
+}
+
+// step 4: KKT values into the slice, numeric LDL' + inverses of the merged diagonal blocks
+CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, double sigma, int lane) {
+    double *sl = cpgw::lds_window() + sl_off;
+    {
+            constexpr unsigned nd = CPG_GENR_NNZL + CPG_GENR_N + CPG_GENR_M;
+            constexpr int KD = (int)((nd + 63u) / 64u);
+            const unsigned lk = (unsigned)cpgw::opaque(lane);
+#pragma unroll
+            for (int t0 = 0; t0 < KD; t0 += 16) {            // KKT values of the destinations: 16 independent sources at a time
+                unsigned code[16];
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const unsigned d = lk + 64u * (unsigned)(t0 + u); code[u] = (t0 + u < KD && d < nd) ? cpgw::gld(Rs.k_src, d) : 0u; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const unsigned kind = (code[u] >> 28) & 7u, idx = code[u] & 0x0FFFFFFFu;
+                    v[u] = 0.0;
+                    if (kind == CPG_K_P) v[u] = cpgw::gld((const double *)B.P, idx);
+                    else if (kind == CPG_K_A) v[u] = cpgw::gld((const double *)B.A, idx);
+                    else if (kind == CPG_K_RHO) v[u] = -cpgw::gld((const double *)B.rinv, idx);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const unsigned d = lk + 64u * (unsigned)(t0 + u), kind = (code[u] >> 28) & 7u;
+                    double vv = v[u];
+                    if (kind == CPG_K_P) vv = vv + (d >= (unsigned)CPG_GENR_NNZL ? sigma : 0.0);
+                    else if (kind == CPG_K_SIGMA) vv = sigma;
+                    if (t0 + u < KD && d < nd) sl[d] = (code[u] >> 31) ? 1.0 / vv : vv;
+                }
             }
             for (unsigned d = nd + (unsigned)lane; d < (unsigned)Rs.fac_len; d += 64u) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
             cpgw::lds_order();
             resident_factor(Rs, sl, lane);
-            resident_coefficients(R, Rs, sl, cf, lane);
-            cpgw::lds_order();
-            // the slice goes back to its ADMM use (idle lanes of a step gather the zero slot, idle lanes of a chunk store
-            // to the dummy slots: everything starts finite); q and u of the instance
-            // (... and the results of the termination test's products: rows without an entry are never written)
-            for (unsigned t = (unsigned)lane; t < (unsigned)ldw; t += 64u) w[t] = 0.0;
-            for (unsigned t = (unsigned)ldw + N + (unsigned)lane; t < (unsigned)Rs.slice_doubles; t += 64u) w[t] = 0.0;
-            for (unsigned i = (unsigned)lane; i < n; i += 64u) qs[i] = cpgw::gld((const double *)B.q, i);
-            for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
-            cpgw::lds_order();
-        };
-        factorise();
+    }
+    // step 5: the coefficients into their registers (AGPRs by name; the ones that do not fit the 128 pairs behind the
+    // products' results in the slice), and the slice back to its ADMM use: idle lanes of a step gather the zero slot, idle
+    // lanes of a chunk store to the dummy slots (everything starts finite); the results of the termination test's products
+    // (rows without an entry are never written); q and u of the instance
+    {
+        constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m;
+        constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
+        double cfv[kResLds > 0 ? kResLds : 1];
+#pragma unroll
+        for (int t = 0; t < (kResLds > 0 ? kResLds : 1); t++) cfv[t] = 0.0;
+        resident_coefficients(R, Rs, sl, cfv, lane);
+        cpgw::lds_order();
+        double *w = sl, *qs = w + ldw, *us = qs + n;
+        for (unsigned t = (unsigned)ldw + N + (unsigned)lane; t < (unsigned)Rs.slice_doubles; t += 64u) w[t] = 0.0;
+        cpgw::lds_order();
+#pragma unroll
+        for (int t = 0; t < kResLds; t++) w[(unsigned)Rs.out_cf + 64u * (unsigned)t + (unsigned)lane] = cfv[t];
+        for (unsigned t = (unsigned)lane; t < (unsigned)ldw; t += 64u) w[t] = 0.0;
+        for (unsigned i = (unsigned)lane; i < n; i += 64u) qs[i] = cpgw::gld((const double *)B.q, i);
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
+        cpgw::lds_order();
+    }
+}
 
-        // ---- 6. ADMM with the instance's own factor
+
+// The iterates of an instance between two calls (in memory: what a call takes by reference lives there), the steps of
+// the last checked iteration.
+template <int NSX, int NSZ>
+struct ResState { double x[NSX], z[NSZ], y[NSZ], dx[NSX], dy[NSZ]; };
+struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
+
+// `count` ADMM iterations, the last one keeping its steps delta x / delta y for the termination test.  The only function
+// that runs the generated executor: x, z, y and the VGPR coefficients are loaded once, nothing in here is a call, and the
+// loop holds no scratch access (scripts/isa_resident.py checks it).
+template <int NSX, int NSZ>
+CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, unsigned free_rows, unsigned sl_off, unsigned cf_off, int count, int lane) {
+    constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
+    constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
+    constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u;
+    const CPG_LDS unsigned short *lc = (const CPG_LDS unsigned short *)cpgw::lds_window3(), *lr = lc + t_ncols;
+    CPG_LDS double *w = cpgw::lds_window3() + sl_off;
+    const CPG_LDS double *qs = w + ldw, *us = qs + n, *cfl = w + cf_off;
+    const double rho_eq = rr.rho_eq, rho_in = rr.rho_in, rho_fr = rr.rho_fr, ri_eq = rr.ri_eq, ri_in = rr.ri_in, ri_fr = rr.ri_fr;
+    const double sigma_ = rr.sigma, alpha_ = rr.alpha;
+    double x[NSX], z[NSZ], y[NSZ], dxr[NSX], dyr[NSZ];
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { x[s] = st.x[s]; dxr[s] = 0.0; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { z[s] = st.z[s]; y[s] = st.y[s]; dyr[s] = 0.0; }
+    auto admm_iteration = [&](const bool chk) __attribute__((always_inline)) {
+        double qt[NSX];
+#pragma unroll
+        for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qt[s] = i < n ? qs[i] : 0.0; }
+#pragma unroll
+        for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < n) w[i] = sigma_ * x[s] - qt[s]; }
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            const double ri = i < n_eq ? ri_eq : (((free_rows >> s) & 1u) ? ri_fr : ri_in);
+            if (i < m) w[n + i] = z[s] - ri * y[s];
+        }
+        cpgw::lds_order();
+        run_program_res(cfl, lc, lr, w, lane);
+#pragma unroll
+        for (int s = 0; s < NSX; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            const double xn = i < n ? alpha_ * w[i] + (1.0 - alpha_) * x[s] : 0.0;
+            if (chk) dxr[s] = xn - x[s];          // (unconditional: the steps are dead across the iterations between two checks)
+            x[s] = xn;
+        }
+#pragma unroll
+        for (int s = 0; s < NSZ; s++) {
+            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+            const bool eq = i < n_eq, fr = (free_rows >> s) & 1u;
+            const double rv = eq ? rho_eq : (fr ? rho_fr : rho_in);
+            const double ri = eq ? ri_eq : (fr ? ri_fr : ri_in);
+            const double zp = z[s], yp = y[s];
+            const double zt = (zp - ri * yp) + ri * (i < m ? w[n + i] : 0.0);
+            const double zr = alpha_ * zt + (1.0 - alpha_) * zp;
+            const double uu = i < m ? us[i] : 0.0;
+            const double zn = eq ? uu : cpgw::dmin2(zr + ri * yp, uu);
+            const double dyv = rv * (zr - zn);
+            z[s] = i < m ? zn : 0.0; y[s] = i < m ? yp + dyv : 0.0;
+            if (chk) dyr[s] = i < m ? dyv : 0.0;
+        }
+        cpgw::lds_order();
+    };
+#pragma nounroll
+    for (int k = 0; k < count - 1; k++) admm_iteration(false);
+    if (count > 0) admm_iteration(true);
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { st.x[s] = x[s]; if (count > 0) st.dx[s] = dxr[s]; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { st.z[s] = z[s]; st.y[s] = y[s]; if (count > 0) st.dy[s] = dyr[s]; }
+}
+
+template <int NSX, int NSZ>
+CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F, const DevResident &Rs, const ResBuf &B, const signed char (&ct)[NSZ],
+                                                const DevSettings &S, const double (&x)[NSX], const double (&z)[NSZ], const double (&y)[NSZ],
+                                                const double (&dxr)[NSX], const double (&dyr)[NSZ], unsigned sl_off, int lane,
+                                                bool approximate, ScaledNorms *sn) {
+    typedef ResidentCtx<NSX, NSZ> CtxT;
+    double *w = cpgw::lds_window() + sl_off;
+    const double *qs = w + (CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + CPG_GENR_N;
+    const CtxT cx{F, Rs, B, w, qs, us, lane};
+    return check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr},
+                                                               InfeasVerdict{false, false}, w, lane, approximate, sn);
+}
+template <int NSX, int NSZ>
+CPG_DEV_NOINLINE void resident_finalize(const DevFamily &F, const DevBatch &Bt, const double (&x)[NSX], const double (&z)[NSZ],
+                                               const double (&y)[NSZ], double dconst, long long b, unsigned sl_off, int lane, int iter,
+                                               const CheckOut &o, double rho) {
+    double *w = cpgw::lds_window() + sl_off;
+    finalize<NSX, NSZ, true>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);
+}
+
+template <int NSX, int NSZ>
+CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const DevResident &Rs, const DevSettings &S,
+                                const DevBatch &Bt, double *lds, int wave_global) {
+    const int lane = cpgw::lane_id();
+    // the family's dimensions are compile-time constants of its library (cpg_hip_set_resident checks them): bounds tests
+    // of full 64-entry slots fold away -- as run-time values they cost the ADMM loop ~130 branches and ~290 exec-mask
+    // reloads (v_readlane of spilled SGPR pairs) per iteration
+    constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m, n_eq = CPG_GENR_NEQ;
+    constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
+    // block-shared copies of the executor's offset / output-slot tables in front of the wavefronts' slices
+    constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u, t_nrows = ((CPG_GENR_NCHUNKS + 3u) / 4u) * 256u;
+    unsigned short *lc = (unsigned short *)lds, *lr = lc + t_ncols;
+    for (unsigned t = cpgw::thread_in_block(); t < t_ncols; t += cpgw::block_threads()) lc[t] = cpgw::gld(Rs.g_cols, t);
+    for (unsigned t = cpgw::thread_in_block(); t < t_nrows; t += cpgw::block_threads()) lr[t] = cpgw::gld(Rs.g_rows, t);
+    cpgw::block_sync();
+    lds += (t_ncols + t_nrows) / 4u;
+    // The wavefront's slice, three lives:
+    //   set-up    A (nnzA) | P (nnzP) | D (n) | E (m) | norms (max(n, m))      theta is staged where D starts
+    //   factor    fac = M (nnzL) | 1/d (N) | X | 1.0 | 0.0
+    //   ADMM      w (ldw) | q (n) | u (m) | A x (m)  or  P x (n) | A' y (n) | coefficients beyond the 128 AGPR pairs
+    const unsigned sl_off = (t_ncols + t_nrows) / 4u + (unsigned)cpgw::wave_in_block() * (unsigned)Rs.slice_doubles;
+    const ResBuf B = res_carve(Bt.scratch + (size_t)wave_global * (size_t)Rs.buf_doubles, F0, R, Rs);
+    const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
+    const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
+    const unsigned n_work = Bt.list_count ? cpgw::sld(Bt.list_count, 0u) : 0u;
+
+    for (;;) {
+        unsigned ig = 0;
+        if (lane == 0) ig = cpgw::atomic_next(Bt.counter);
+        ig = (unsigned)cpgw::read_first_lane((int)ig);
+        long long b = (long long)ig;
+        if (Bt.list) {
+            if (ig >= n_work) break;
+            b = (long long)cpgw::read_first_lane(cpgw::gld(Bt.list, ig));
+        } else if (b >= Bt.B) break;
+        const double *theta = Bt.theta + (size_t)b * R.np_var;
+        // rho of the workspace / of the settings: see osqp_refactor_body
+        const double *state_in = (Bt.state_in && (S.warm_starting || Bt.resume)) ? Bt.state_in + (size_t)b * state_len : nullptr;
+        double rho = Bt.state_in ? cpgw::gld(Bt.state_in + (size_t)b * state_len, n + 2u * m) : F0.rho;
+        rho = cpgw::dmin2(cpgw::dmax2(rho, CPG_RHO_MIN), CPG_RHO_MAX);
+        double rho_stg = F0.rho;
+        double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
+
+        ResSetupOut<NSZ> su;
+        resident_setup<NSX, NSZ>(R, Rs, B, sl_off, theta, ri_eq, ri_in, ri_fr, lane, su);
+        const double cs = su.cs, dconst = su.dconst;
+
+        // ---- 4. - 6.  factorise (call), iterate to the next event (call), test / adapt (call), in osqp_solve's order.  The
+        //      instance's state between the calls lives in memory (st); the AGPR-held coefficients survive them by name.
         DevFamily F = F0;
         F.D = B.D; F.Dinv = B.Dinv; F.E = B.E; F.Einv = B.Einv; F.c = cs; F.cinv = 1.0 / cs;
-        const CtxT cx{F, Rs, B, w, qs, us, lane};
-        double x[NSX], z[NSZ], y[NSZ];
+        ResState<NSX, NSZ> st;
 #pragma unroll
-        for (int s = 0; s < NSX; s++) x[s] = 0.0;
+        for (int s = 0; s < NSX; s++) { st.x[s] = 0.0; st.dx[s] = 0.0; }
 #pragma unroll
-        for (int s = 0; s < NSZ; s++) { z[s] = 0.0; y[s] = 0.0; }
-        if (state_in) load_state<NSX, NSZ>(F, state_in, x, z, y, lane);
+        for (int s = 0; s < NSZ; s++) { st.z[s] = 0.0; st.y[s] = 0.0; st.dy[s] = 0.0; }
+        if (state_in) load_state<NSX, NSZ>(F, state_in, st.x, st.z, st.y, lane);
         CheckOut o;
         o.prim_res = 0; o.dual_res = 0; o.obj = 0; o.status = 11;
         int iter = Bt.resume ? cpgw::read_first_lane(cpgw::gld((const int *)Bt.iter, (unsigned)b)) : 0;
         if (iter > 0) rho_stg = rho;
-        double dxr[NSX], dyr[NSZ];
-#pragma unroll
-        for (int s = 0; s < NSX; s++) dxr[s] = 0.0;
-#pragma unroll
-        for (int s = 0; s < NSZ; s++) dyr[s] = 0.0;
-        auto admm_iteration = [&](const bool chk) __attribute__((always_inline)) {
-            double qt[NSX];
-#pragma unroll
-            for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qt[s] = i < n ? qs[i] : 0.0; }
-#pragma unroll
-            for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < n) w[i] = F.sigma * x[s] - qt[s]; }
-#pragma unroll
-            for (int s = 0; s < NSZ; s++) {
-                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
-                if (i < m) w[n + i] = z[s] - ri * y[s];
-            }
-            cpgw::lds_order();
-            run_program_res(cf, lc, lr, w, lane);
-            double wt[NSZ], ut[NSZ];
-#pragma unroll
-            for (int s = 0; s < NSZ; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; wt[s] = i < m ? w[n + i] : 0.0; ut[s] = i < m ? us[i] : 0.0; }
-#pragma unroll
-            for (int s = 0; s < NSX; s++) {
-                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                if (i < n) {
-                    const double xn = F.alpha * w[i] + (1.0 - F.alpha) * x[s];
-                    if (chk) dxr[s] = xn - x[s];
-                    x[s] = xn;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < NSZ; s++) {
-                const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                if (i < m) {
-                    const double rv = ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr);
-                    const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
-                    const double zp = z[s], yp = y[s];
-                    const double zt = (zp - ri * yp) + ri * wt[s];
-                    const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
-                    const double uu = ut[s];
-                    const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
-                    const double dyv = rv * (zr - zn);
-                    z[s] = zn; y[s] = yp + dyv;
-                    if (chk) dyr[s] = dyv;
-                }
-            }
-            cpgw::lds_order();
-        };
+        bool need_factor = true;
         const int chk_int = S.check_termination, ad_int = S.adaptive_rho ? S.adaptive_rho_interval : 0;
 #pragma nounroll
         while (o.status == 11) {
+            if (need_factor) { resident_factorise(R, Rs, B, sl_off, F0.sigma, lane); need_factor = false; }
             if (iter < S.max_iter) {
                 int next_ev = S.max_iter;
                 if (chk_int > 0) { const int c = (iter / chk_int + 1) * chk_int; if (c < next_ev) next_ev = c; }
                 if (ad_int > 0) { const int c = (iter / ad_int + 1) * ad_int; if (c < next_ev) next_ev = c; }
-#pragma nounroll
-                for (; iter < next_ev - 1; iter++) admm_iteration(false);
-                iter++;
-                admm_iteration(true);
+                const ResRho rr{rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, F0.sigma, F0.alpha};
+                resident_iterate<NSX, NSZ>(st, rr, su.free_rows, sl_off, (unsigned)Rs.out_cf, next_ev - iter, lane);
+                iter = next_ev;
             }
             const bool can_check = chk_int > 0 && iter > 0 && iter % chk_int == 0;
             const bool adapt = ad_int > 0 && iter > 0 && iter % ad_int == 0;
             const bool last = iter >= S.max_iter;
             ScaledNorms sn;
-            bool have_info = false;
-            if (can_check) {
-                o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
-                have_info = true;
-                if (o.status != 11) break;
-            }
-            if (adapt) {
-                if (!have_info) (void)check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
-                const double rn = rho_estimate(sn, rho_stg);
-                if (rn > rho_stg * S.adaptive_rho_tolerance || rn < rho_stg / S.adaptive_rho_tolerance) {
-                    rho = rn; rho_stg = rn; rho_eq = 1e3 * rho; rho_in = rho; ri_eq = 1.0 / rho_eq; ri_in = 1.0 / rho_in;
+            bool approx = false;
+            for (;;) {
+                const CheckOut oc = resident_check<NSX, NSZ>(F, Rs, B, su.ct, S, st.x, st.z, st.y, st.dx, st.dy, sl_off, lane, approx, &sn);
+                if (approx) { o = oc; break; }
+                if (can_check) { o = oc; if (o.status != 11) break; }
+                if (adapt) {
+                    const double rn = rho_estimate(sn, rho_stg);
+                    if (rn > rho_stg * S.adaptive_rho_tolerance || rn < rho_stg / S.adaptive_rho_tolerance) {
+                        rho = rn; rho_stg = rn; rho_eq = 1e3 * rho; rho_in = rho; ri_eq = 1.0 / rho_eq; ri_in = 1.0 / rho_in;
 #pragma unroll
-                    for (int s = 0; s < NSZ; s++) {
-                        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                        if (i < m) cpgw::gst(B.rinv, i, ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr));
+                        for (int s = 0; s < NSZ; s++) {
+                            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                            if (i < m) cpgw::gst(B.rinv, i, su.ct[s] == 1 ? ri_eq : (su.ct[s] == 0 ? ri_in : ri_fr));
+                        }
+                        cpgw::mem_order();
+                        need_factor = true;
                     }
-                    cpgw::mem_order();
-                    factorise();
                 }
+                if (last) {
+                    if (!can_check) o = oc;
+                    if (o.status == 11) { approx = true; continue; }
+                }
+                break;
             }
-            if (last) {
-                if (!can_check) o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false);
-                if (o.status == 11) o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, true);
-                if (o.status == 11) o.status = 7;
-            }
+            if (last && o.status == 11) o.status = 7;
         }
-        finalize<NSX, NSZ, true>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);
+        resident_finalize<NSX, NSZ>(F, Bt, st.x, st.z, st.y, dconst, b, sl_off, lane, iter, o, rho);
     }
 }
 #endif  // CPG_GENR_HEADER

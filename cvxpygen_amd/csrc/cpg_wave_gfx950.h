@@ -9,10 +9,22 @@
 #include <hip/hip_runtime.h>
 
 #define CPG_DEV __device__ __forceinline__
+#define CPG_DEV_NOINLINE __device__ __attribute__((noinline))      // a real call: a register allocation of its own
 #define CPG_LANES 64
 
 namespace cpgw {
 
+// the workgroup's dynamic LDS window, for functions that are real calls (CPG_DEV_NOINLINE): a pointer handed through a
+// call is a generic pointer (flat_load / flat_store), an offset into this array keeps the accesses LDS instructions
+// (pointers of functions that are real calls carry their address space in the TYPE: the compiler does not infer it
+// through the dynamic-LDS table a non-kernel function reads its window from, and a generic pointer costs a 64-bit address
+// register per access and flat_load instead of ds_read)
+#define CPG_LDS __attribute__((address_space(3)))
+CPG_DEV double *lds_window() {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    return cpg_lds;
+}
+CPG_DEV CPG_LDS double *lds_window3() { return (CPG_LDS double *)lds_window(); }
 CPG_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 CPG_DEV int wave_in_block() { return (int)(threadIdx.x >> 6); }
 CPG_DEV unsigned thread_in_block() { return threadIdx.x; }
@@ -77,6 +89,20 @@ CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
 // max of non-negative doubles in LDS (they order like their bit patterns): ds_max_u64, no return value
 CPG_DEV void lds_max_u64(unsigned long long *p, double v) { atomicMax(p, (unsigned long long)__double_as_longlong(v)); }
 CPG_DEV double u64_as_double(unsigned long long v) { return __longlong_as_double((long long)v); }
+// A double kept in two NAMED accumulation registers (AGPRs a<A>, a<B>).  gfx950's unified register file gives a wavefront
+// that owns its SIMD 256 AGPRs next to the 256 VGPRs; vector ALU instructions cannot name them, v_accvgpr_read / _write
+// move a dword.  The resident kernel keeps its substitution coefficients there, by NAME: handed to the register allocator
+// (as "a"-constrained values, or as plain doubles) they ended up in scratch memory, 100 - 270 reloads per ADMM iteration
+// (profiles/r4_isa_*).  Libraries that use these macros are compiled with -mllvm -amdgpu-spill-vgpr-to-agpr=0
+// (codegen.family_library_defs): the compiler itself then never touches an AGPR, the write's clobber makes it count the
+// register in the kernel's allocation, and no call saves or restores anything.
+#define CPG_ACC_WRITE2(v, A, B)                                                                                   \
+    do { const double v__ = (v); const int lo__ = __double2loint(v__), hi__ = __double2hiint(v__);                 \
+         asm volatile("v_accvgpr_write_b32 a" #A ", %0\n\tv_accvgpr_write_b32 a" #B ", %1" : : "v"(lo__), "v"(hi__) : "a" #A, "a" #B); } while (0)
+#define CPG_ACC_READ2(var, A, B)                                                                                  \
+    do { int lo__, hi__;                                                                                          \
+         asm volatile("v_accvgpr_read_b32 %0, a" #A "\n\tv_accvgpr_read_b32 %1, a" #B : "=v"(lo__), "=v"(hi__));     \
+         var = __hiloint2double(hi__, lo__); } while (0)
 // keeps the instruction scheduler from interleaving unrolled loop bodies (register pressure)
 CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and

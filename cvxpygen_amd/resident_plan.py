@@ -292,13 +292,14 @@ def _build(P, A, osqp, stage_scale, groups) -> ResidentPlan:
     sol_kind = (codes >> 32).astype(np.int32); sol_idx = (codes & 0xFFFFFFFF).astype(np.int32)
     sol_lcol = np.where(sol_kind == SRC_NEG_L, Lcol[np.where(sol_kind == SRC_NEG_L, sol_idx, 0)], 0).astype(np.int32)
 
-    # ---- products of the termination test on w = [x (n) | y (m) | A x (m) | P x (n) | A' y (n)]
+    # ---- products of the termination test on w = [x (n) | y (m) | .. | A x (m)  or  P x (n) | A' y (n)]
     Acsr = sp.csr_matrix((np.arange(base.nnzA) + 1.0, (base.Ai, np.repeat(np.arange(n), np.diff(base.Ap)))), shape=(m, n))
     Acsr.sort_indices()
-    # (the results sit behind the executor's work vector and the instance's q / u in the wavefront's LDS slice)
+    # (the results sit behind the executor's work vector and the instance's q / u in the wavefront's LDS slice; A x is
+    # consumed before P x and A' y are formed -- update_info's primal residual, then its dual residual -- and shares their slots)
     out_ax = sol.n_slots + _sp.GEN_EXTRA_SLOTS + N
-    out_px, out_aty = out_ax + m, out_ax + m + n
-    w_slots = out_aty + n
+    out_px, out_aty = out_ax, out_ax + n
+    w_slots = out_ax + max(m, 2 * n)
 
     def product(M: sp.csr_matrix, col_off: int, out_off: int, name: str):
         M = sp.csr_matrix(M); M.sort_indices()

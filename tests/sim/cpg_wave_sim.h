@@ -17,10 +17,16 @@
 #include <cstring>
 
 #define CPG_DEV inline
+#define CPG_DEV_NOINLINE inline
 #define CPG_LANES 64
+
+extern __thread double cpg_lds[];     // the running workgroup's LDS window (fake_hip/hip/hip_runtime.h)
 
 namespace cpgw {
 
+#define CPG_LDS
+inline double *lds_window() { return ::cpg_lds; }
+inline double *lds_window3() { return ::cpg_lds; }
 struct SimBarrier { int count = 0, gen = 0, n = 0; };
 struct SimWave {                 // shared by the 64 fibers of one emulated wavefront
     SimBarrier bar;
@@ -36,6 +42,7 @@ struct SimThread {               // one fiber = one GPU thread
     SimBarrier *block_bar;
     bool done;
     SimThread *next;             // ring of the workgroup's fibers
+    double acc[128];             // the lane's accumulation registers, as pairs (CPG_ACC_WRITE2 / _READ2)
 };
 inline thread_local SimThread *cur;
 
@@ -142,6 +149,8 @@ inline unsigned mbcnt(unsigned long long mask) {
     return (unsigned)__builtin_popcountll(mask & ((1ULL << cur->lane) - 1ULL));
 }
 inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
+#define CPG_ACC_WRITE2(v, A, B) do { cpgw::cur->acc[(A) / 2] = (v); } while (0)      // the lane's AGPR pair a<A>, a<B>
+#define CPG_ACC_READ2(var, A, B) do { var = cpgw::cur->acc[(A) / 2]; } while (0)
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
 inline void assume(bool) {}
