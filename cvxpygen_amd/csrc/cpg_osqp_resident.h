@@ -204,7 +204,8 @@ struct ResSetupOut {
 // steps 1 - 3 of an instance: canonicalise, equilibrate, scaled data (the wavefront's buffer B, program-order copies)
 template <int NSX, int NSZ>
 CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, const double *theta,
-                                     double ri_eq, double ri_in, double ri_fr, int lane, ResSetupOut<NSZ> &out) {
+                                     double ri_eq, double ri_in, double ri_fr, int, ResSetupOut<NSZ> &out) {
+    const int lane = cpgw::lane_id();      // (not the argument: the compiler knows this one's range, and folds the bounds tests of full slots)
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m, n_eq = CPG_GENR_NEQ;
     double *sl = cpgw::lds_window() + sl_off;
     double *Al = sl, *Pl = Al + CPG_GENR_NNZA, *Dl = Pl + CPG_GENR_NNZP, *El = Dl + n;
@@ -401,7 +402,8 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R, const DevResident &Rs
 }
 
 // step 4: KKT values into the slice, numeric LDL' + inverses of the merged diagonal blocks
-CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, double sigma, int lane) {
+CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, double sigma, int) {
+    const int lane = cpgw::lane_id();
     double *sl = cpgw::lds_window() + sl_off;
     {
             constexpr unsigned nd = CPG_GENR_NNZL + CPG_GENR_N + CPG_GENR_M;
@@ -469,7 +471,8 @@ struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha
 // that runs the generated executor: x, z, y and the VGPR coefficients are loaded once, nothing in here is a call, and the
 // loop holds no scratch access (scripts/isa_resident.py checks it).
 template <int NSX, int NSZ>
-CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, unsigned free_rows, unsigned sl_off, unsigned cf_off, int count, int lane) {
+CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, unsigned free_rows, unsigned sl_off, unsigned cf_off, int count, int) {
+    const int lane = cpgw::lane_id();      // (range known: bounds tests of full slots fold away)
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
     constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u;
@@ -478,12 +481,14 @@ CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr,
     const CPG_LDS double *qs = w + ldw, *us = qs + n, *cfl = w + cf_off;
     const double rho_eq = rr.rho_eq, rho_in = rr.rho_in, rho_fr = rr.rho_fr, ri_eq = rr.ri_eq, ri_in = rr.ri_in, ri_fr = rr.ri_fr;
     const double sigma_ = rr.sigma, alpha_ = rr.alpha;
-    double x[NSX], z[NSZ], y[NSZ], dxr[NSX], dyr[NSZ];
+    double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
-    for (int s = 0; s < NSX; s++) { x[s] = st.x[s]; dxr[s] = 0.0; }
+    for (int s = 0; s < NSX; s++) x[s] = st.x[s];
 #pragma unroll
-    for (int s = 0; s < NSZ; s++) { z[s] = st.z[s]; y[s] = st.y[s]; dyr[s] = 0.0; }
-    auto admm_iteration = [&](const bool chk) __attribute__((always_inline)) {
+    for (int s = 0; s < NSZ; s++) { z[s] = st.z[s]; y[s] = st.y[s]; }
+#pragma nounroll
+    for (int k = 0; k < count; k++) {
+        const bool chk = k == count - 1;       // (wave-uniform: the checked iteration leaves its steps in st)
         double qt[NSX];
 #pragma unroll
         for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qt[s] = i < n ? qs[i] : 0.0; }
@@ -501,7 +506,7 @@ CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr,
         for (int s = 0; s < NSX; s++) {
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
             const double xn = i < n ? alpha_ * w[i] + (1.0 - alpha_) * x[s] : 0.0;
-            if (chk) dxr[s] = xn - x[s];          // (unconditional: the steps are dead across the iterations between two checks)
+            if (chk) st.dx[s] = xn - x[s];
             x[s] = xn;
         }
 #pragma unroll
@@ -517,25 +522,23 @@ CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr,
             const double zn = eq ? uu : cpgw::dmin2(zr + ri * yp, uu);
             const double dyv = rv * (zr - zn);
             z[s] = i < m ? zn : 0.0; y[s] = i < m ? yp + dyv : 0.0;
-            if (chk) dyr[s] = i < m ? dyv : 0.0;
+            if (chk) st.dy[s] = i < m ? dyv : 0.0;
         }
         cpgw::lds_order();
-    };
-#pragma nounroll
-    for (int k = 0; k < count - 1; k++) admm_iteration(false);
-    if (count > 0) admm_iteration(true);
+    }
 #pragma unroll
-    for (int s = 0; s < NSX; s++) { st.x[s] = x[s]; if (count > 0) st.dx[s] = dxr[s]; }
+    for (int s = 0; s < NSX; s++) st.x[s] = x[s];
 #pragma unroll
-    for (int s = 0; s < NSZ; s++) { st.z[s] = z[s]; st.y[s] = y[s]; if (count > 0) st.dy[s] = dyr[s]; }
+    for (int s = 0; s < NSZ; s++) { st.z[s] = z[s]; st.y[s] = y[s]; }
 }
 
 template <int NSX, int NSZ>
 CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F, const DevResident &Rs, const ResBuf &B, const signed char (&ct)[NSZ],
                                                 const DevSettings &S, const double (&x)[NSX], const double (&z)[NSZ], const double (&y)[NSZ],
-                                                const double (&dxr)[NSX], const double (&dyr)[NSZ], unsigned sl_off, int lane,
+                                                const double (&dxr)[NSX], const double (&dyr)[NSZ], unsigned sl_off, int,
                                                 bool approximate, ScaledNorms *sn) {
     typedef ResidentCtx<NSX, NSZ> CtxT;
+    const int lane = cpgw::lane_id();
     double *w = cpgw::lds_window() + sl_off;
     const double *qs = w + (CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + CPG_GENR_N;
     const CtxT cx{F, Rs, B, w, qs, us, lane};
@@ -544,8 +547,9 @@ CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F, const DevResident &
 }
 template <int NSX, int NSZ>
 CPG_DEV_NOINLINE void resident_finalize(const DevFamily &F, const DevBatch &Bt, const double (&x)[NSX], const double (&z)[NSZ],
-                                               const double (&y)[NSZ], double dconst, long long b, unsigned sl_off, int lane, int iter,
+                                               const double (&y)[NSZ], double dconst, long long b, unsigned sl_off, int, int iter,
                                                const CheckOut &o, double rho) {
+    const int lane = cpgw::lane_id();
     double *w = cpgw::lds_window() + sl_off;
     finalize<NSX, NSZ, true>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);
 }
