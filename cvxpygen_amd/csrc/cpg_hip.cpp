@@ -1340,7 +1340,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     slice += slice & 1;
     if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }
     Rs.slice_doubles = (int)slice;
-    Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64;
+    Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64 * 16 + 64;
     if ((rc = upload<unsigned>(h, own, ctl.data(), ctl.size(), &Rs.f_ctl))) return rc;
     if ((rc = upload<cpg::ResEntry>(h, own, ent.data(), ent.size(), &Rs.f_ent))) return rc;
     if ((rc = upload<unsigned>(h, own, ksrc.data(), ksrc.size(), &Rs.k_src))) return rc;

@@ -67,7 +67,8 @@ struct DevResident {
 };
 
 #ifdef CPG_GENR_HEADER
-struct ResBuf { double *A, *P, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *cA, *cP, *cAt; };
+struct ResBuf { double *A, *P, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *cA, *cP, *cAt, *clow; };
+constexpr int kResLow = CPG_GENR_NACC < 16 ? CPG_GENR_NACC : 16;      // coefficient registers in the caller-saved a0 - a31
 CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, const DevResident &Rs) {
     ResBuf o;
     const size_t n = (size_t)F.n, m = (size_t)F.m;
@@ -75,6 +76,7 @@ CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, co
     o.D = b; b += n; o.Dinv = b; b += n; o.E = b; b += m; o.Einv = b; b += m;
     o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
     o.cA = b; b += Rs.pA.n_entries; o.cP = b; b += Rs.pP.n_entries; o.cAt = b; b += Rs.pAt.n_entries;
+    o.clow = b; b += 64 * 16;
     return o;
 }
 
@@ -132,7 +134,7 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
 // CPG_GENR_NACC registers are named AGPR pairs (run_program_res_put of the generated header); the others are returned in
 // cfv and go to the LDS slice once the factor in it is dead
 constexpr int kResLds = CPG_GENR_NREGS - CPG_GENR_NACC > 0 ? CPG_GENR_NREGS - CPG_GENR_NACC : 0;     // coefficient registers held in LDS
-CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const double *fac, double (&cfv)[kResLds > 0 ? kResLds : 1], int lane) {
+CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, const double *fac, double (&cfv)[kResLds > 0 ? kResLds : 1], int lane) {
     const unsigned ln = (unsigned)cpgw::opaque(lane);            // (see load_instance_coefficients: addresses local to this block)
     const unsigned nnzL = (unsigned)R.nnzL, X0 = (unsigned)(Rs.fac_len - 2 - Rs.nnzX);
 #pragma unroll
@@ -147,6 +149,7 @@ CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, 
         else if (kind == 4u) v = fac[X0 + idx];
         if (t < CPG_GENR_NACC) run_program_res_put(t, v, (CPG_LDS double *)nullptr, lane);
         else cfv[t >= CPG_GENR_NACC ? t - CPG_GENR_NACC : 0] = v;
+        if (t < kResLow) cpgw::gst(B.clow, 64u * (unsigned)t + ln, v);
     }
 }
 
@@ -193,6 +196,8 @@ struct ResidentCtx {
 // termination test (four copies of the streaming executor) and the factorisation decided where the allocator put the
 // ADMM loop's coefficients -- in scratch memory, ~100 reloads per iteration (profiles/r4_s2_isa_*).  The AMDGPU calling
 // convention keeps a32 - a255 and half of the VGPRs across a call: the coefficients stay where they are.
+
+CPG_DEV_NOINLINE void resident_reserve_agprs() { CPG_ACC_RESERVE_BODY(); }
 
 template <int NSZ>
 struct ResSetupOut {
@@ -436,17 +441,23 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident
             cpgw::lds_order();
             resident_factor(Rs, sl, lane);
     }
-    // step 5: the coefficients into their registers (AGPRs by name; the ones that do not fit the 128 pairs behind the
-    // products' results in the slice), and the slice back to its ADMM use: idle lanes of a step gather the zero slot, idle
-    // lanes of a chunk store to the dummy slots (everything starts finite); the results of the termination test's products
-    // (rows without an entry are never written); q and u of the instance
+}
+
+// step 5, a leaf of its own (see cpg_wave_gfx950.h: no compiler-allocated AGPR in here): the coefficients into their
+// registers -- AGPRs by name, a copy of the caller-saved ones (a0 - a31) in the wavefront's buffer, the ones beyond the
+// 128 pairs behind the products' results in the slice -- and the slice back to its ADMM use: idle lanes of a step gather
+// the zero slot, idle lanes of a chunk store to the dummy slots (everything starts finite); the results of the
+// termination test's products; q and u of the instance
+CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, int) {
+    const int lane = cpgw::lane_id();
+    double *sl = cpgw::lds_window() + sl_off;
     {
         constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m;
         constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
         double cfv[kResLds > 0 ? kResLds : 1];
 #pragma unroll
         for (int t = 0; t < (kResLds > 0 ? kResLds : 1); t++) cfv[t] = 0.0;
-        resident_coefficients(R, Rs, sl, cfv, lane);
+        resident_coefficients(R, Rs, B, sl, cfv, lane);
         cpgw::lds_order();
         double *w = sl, *qs = w + ldw, *us = qs + n;
         for (unsigned t = (unsigned)ldw + N + (unsigned)lane; t < (unsigned)Rs.slice_doubles; t += 64u) w[t] = 0.0;
@@ -457,10 +468,9 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident
         for (unsigned i = (unsigned)lane; i < n; i += 64u) qs[i] = cpgw::gld((const double *)B.q, i);
         for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
         cpgw::lds_order();
+        cpgw::mem_order();
     }
 }
-
-
 // The iterates of an instance between two calls (in memory: what a call takes by reference lives there), the steps of
 // the last checked iteration.
 template <int NSX, int NSZ>
@@ -471,8 +481,12 @@ struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha
 // that runs the generated executor: x, z, y and the VGPR coefficients are loaded once, nothing in here is a call, and the
 // loop holds no scratch access (scripts/isa_resident.py checks it).
 template <int NSX, int NSZ>
-CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, unsigned free_rows, unsigned sl_off, unsigned cf_off, int count, int) {
+CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, const double *clow, unsigned free_rows, unsigned sl_off_v, unsigned cf_off_v,
+                                       int count_v, int) {
     const int lane = cpgw::lane_id();      // (range known: bounds tests of full slots fold away)
+    // (arguments arrive in VGPRs: tell the compiler which of them are wave-uniform)
+    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v), cf_off = (unsigned)cpgw::read_first_lane((int)cf_off_v);
+    const int count = cpgw::read_first_lane(count_v);
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
     constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u;
@@ -481,6 +495,14 @@ CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr,
     const CPG_LDS double *qs = w + ldw, *us = qs + n, *cfl = w + cf_off;
     const double rho_eq = rr.rho_eq, rho_in = rr.rho_in, rho_fr = rr.rho_fr, ri_eq = rr.ri_eq, ri_in = rr.ri_in, ri_fr = rr.ri_fr;
     const double sigma_ = rr.sigma, alpha_ = rr.alpha;
+    {   // a0 - a31 are caller-saved: whatever ran since the last iterations may have used them (the kernel's own code parks
+        // a VGPR there around its calls); their coefficients come back from the wavefront's buffer
+        double v[kResLow > 0 ? kResLow : 1];
+#pragma unroll
+        for (int t = 0; t < kResLow; t++) v[t] = cpgw::gld(clow, 64u * (unsigned)t + (unsigned)lane);
+#pragma unroll
+        for (int t = 0; t < kResLow; t++) run_program_res_put(t, v[t], (CPG_LDS double *)nullptr, lane);
+    }
     double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
     for (int s = 0; s < NSX; s++) x[s] = st.x[s];
@@ -558,6 +580,7 @@ template <int NSX, int NSZ>
 CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const DevResident &Rs, const DevSettings &S,
                                 const DevBatch &Bt, double *lds, int wave_global) {
     const int lane = cpgw::lane_id();
+    resident_reserve_agprs();
     // the family's dimensions are compile-time constants of its library (cpg_hip_set_resident checks them): bounds tests
     // of full 64-entry slots fold away -- as run-time values they cost the ADMM loop ~130 branches and ~290 exec-mask
     // reloads (v_readlane of spilled SGPR pairs) per iteration
@@ -619,13 +642,16 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         const int chk_int = S.check_termination, ad_int = S.adaptive_rho ? S.adaptive_rho_interval : 0;
 #pragma nounroll
         while (o.status == 11) {
-            if (need_factor) { resident_factorise(R, Rs, B, sl_off, F0.sigma, lane); need_factor = false; }
+            if (need_factor) { resident_factorise(R, Rs, B, sl_off, F0.sigma, lane); resident_store_coefficients(R, Rs, B, sl_off, lane); need_factor = false; }
             if (iter < S.max_iter) {
                 int next_ev = S.max_iter;
                 if (chk_int > 0) { const int c = (iter / chk_int + 1) * chk_int; if (c < next_ev) next_ev = c; }
                 if (ad_int > 0) { const int c = (iter / ad_int + 1) * ad_int; if (c < next_ev) next_ev = c; }
                 const ResRho rr{rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, F0.sigma, F0.alpha};
-                resident_iterate<NSX, NSZ>(st, rr, su.free_rows, sl_off, (unsigned)Rs.out_cf, next_ev - iter, lane);
+                if (__builtin_expect(S.debug_stage == 7, 0)) {        // (experiments: one call per iteration)
+                    for (int k = iter; k < next_ev; k++) resident_iterate<NSX, NSZ>(st, rr, B.clow, su.free_rows, sl_off, (unsigned)Rs.out_cf, 1, lane);
+                } else
+                resident_iterate<NSX, NSZ>(st, rr, B.clow, su.free_rows, sl_off, (unsigned)Rs.out_cf, next_ev - iter, lane);
                 iter = next_ev;
             }
             const bool can_check = chk_int > 0 && iter > 0 && iter % chk_int == 0;

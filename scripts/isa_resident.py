@@ -43,3 +43,31 @@ for l in rows:
         continue
     seen.add(key)
     print(l)
+
+# compiler-allocated AGPRs (outside the kernel's inline asm) per function: must be 0 in the functions that hold named
+# coefficients live without a call boundary in between (cpg_wave_gfx950.h)
+import re
+asm = open(out).read().split('\n')
+func, inasm, cnt, low = '', False, {}, {}
+for l in asm:
+    m = re.match(r'^(_Z\w+):', l)
+    if m:
+        func = m.group(1)
+    if '#ASMSTART' in l:
+        inasm = True
+    elif '#ASMEND' in l:
+        inasm = False
+    elif not inasm and 'resident' in func and not l.strip().startswith(';') and re.search(r'[ ,]a\[?\d+', l):
+        hi = max(int(x) for x in re.findall(r'[ ,]a\[?(\d+)', l))
+        if 'osqp_resident_kernel' in func and hi < 32:
+            low[func] = low.get(func, 0) + 1          # (caller-saved a0 - a31: the iterations restore them)
+            continue
+        cnt[func] = cnt.get(func, 0) + 1
+print('compiler-allocated AGPR operands outside inline asm:')
+bad = False
+for f in sorted(set(x for x in [re.match(r'^(_Z\w+):', l).group(1) for l in asm if re.match(r'^(_Z\w+):', l)] if 'resident' in x)):
+    c = cnt.get(f, 0)
+    must = any(k in f for k in ('resident_iterate', 'resident_store_coefficients', 'osqp_resident_kernel'))
+    print(f'    {f[:70]:70s} {c}' + (f' (+ {low[f]} on a0 - a31)' if f in low else '') + ('   <-- MUST BE 0' if must and c else ''))
+    bad |= bool(must and c)
+sys.exit(1 if bad else 0)

@@ -151,6 +151,7 @@ inline unsigned mbcnt(unsigned long long mask) {
 inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
 #define CPG_ACC_WRITE2(v, A, B) do { cpgw::cur->acc[(A) / 2] = (v); } while (0)      // the lane's AGPR pair a<A>, a<B>
 #define CPG_ACC_READ2(var, A, B) do { var = cpgw::cur->acc[(A) / 2]; } while (0)
+#define CPG_ACC_RESERVE_BODY() do { } while (0)
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
 inline void assume(bool) {}
