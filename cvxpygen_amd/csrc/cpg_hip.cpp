@@ -1333,14 +1333,12 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     Rs.out_ax = rs->out_ax; Rs.out_px = rs->out_px; Rs.out_aty = rs->out_aty;
     const int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     if (rs->out_ax < ldw + N || rs->out_px < ldw + N || rs->out_aty < rs->out_px + n) { set_error("cpg_hip_set_resident: result slots overlap the work vector"); return CPG_E_BADARG; }
-    Rs.out_cf = w_slots;
-    constexpr int n_lds_regs = CPG_GENR_NREGS > CPG_GENR_NACC ? CPG_GENR_NREGS - CPG_GENR_NACC : 0;
-    long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots + 64LL * n_lds_regs);
+    long long slice = std::max<long long>(Rs.fac_len, w_slots);
     slice = std::max<long long>(slice, (long long)r->nnzA + r->nnzP + std::max<long long>(r->np_var, (long long)N + std::max(n, m)));
     slice += slice & 1;
     if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }
     Rs.slice_doubles = (int)slice;
-    Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64 * 16 + 64;
+    Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64LL * CPG_GENR_NREGS + 64;
     if ((rc = upload<unsigned>(h, own, ctl.data(), ctl.size(), &Rs.f_ctl))) return rc;
     if ((rc = upload<cpg::ResEntry>(h, own, ent.data(), ent.size(), &Rs.f_ent))) return rc;
     if ((rc = upload<unsigned>(h, own, ksrc.data(), ksrc.size(), &Rs.k_src))) return rc;

@@ -61,14 +61,12 @@ struct DevResident {
     const unsigned *entA, *entP;           // row | column << 16 of every stored entry
     DevStreamTab pA, pP, pAt;              // A x, P x, A' y on the work vector [x | y | .. | A x | P x | A' y]
     int out_ax, out_px, out_aty;           // first slot of the products' results (A x shares the slots of P x | A' y)
-    int out_cf;                            // ... and of the coefficient registers that are not AGPRs, [register][lane]
     int slice_doubles;                     // LDS doubles per wavefront
     long long buf_doubles;                 // per-wavefront buffer in global memory
 };
 
 #ifdef CPG_GENR_HEADER
-struct ResBuf { double *A, *P, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *cA, *cP, *cAt, *clow; };
-constexpr int kResLow = CPG_GENR_NACC < 16 ? CPG_GENR_NACC : 16;      // coefficient registers in the caller-saved a0 - a31
+struct ResBuf { double *A, *P, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *cA, *cP, *cAt, *cf; };
 CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, const DevResident &Rs) {
     ResBuf o;
     const size_t n = (size_t)F.n, m = (size_t)F.m;
@@ -76,7 +74,7 @@ CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, co
     o.D = b; b += n; o.Dinv = b; b += n; o.E = b; b += m; o.Einv = b; b += m;
     o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
     o.cA = b; b += Rs.pA.n_entries; o.cP = b; b += Rs.pP.n_entries; o.cAt = b; b += Rs.pAt.n_entries;
-    o.clow = b; b += 64 * 16;
+    o.cf = b; b += 64 * CPG_GENR_NREGS;
     return o;
 }
 
@@ -130,26 +128,22 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
     cpgw::lds_order();
 }
 
-// the instance's coefficients of the generated executor from `fac`: -l_ij = -M_ij / d_j, 1 / d_i, X_ij or 1; the first
-// CPG_GENR_NACC registers are named AGPR pairs (run_program_res_put of the generated header); the others are returned in
-// cfv and go to the LDS slice once the factor in it is dead
-constexpr int kResLds = CPG_GENR_NREGS - CPG_GENR_NACC > 0 ? CPG_GENR_NREGS - CPG_GENR_NACC : 0;     // coefficient registers held in LDS
-CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, const double *fac, double (&cfv)[kResLds > 0 ? kResLds : 1], int lane) {
+// the instance's coefficients of the generated executor from `fac`: -l_ij = -M_ij / d_j, 1 / d_i, X_ij or 1 per (coefficient
+// register, lane), to the wavefront's buffer in the layout the iteration function loads them in ([register][lane])
+CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, const double *fac, int lane) {
     const unsigned ln = (unsigned)cpgw::opaque(lane);            // (see load_instance_coefficients: addresses local to this block)
     const unsigned nnzL = (unsigned)R.nnzL, X0 = (unsigned)(Rs.fac_len - 2 - Rs.nnzX);
-#pragma unroll
+#pragma unroll 8
     for (int t = 0; t < CPG_GENR_NREGS; t++) {
         const unsigned code = cpgw::gld(Rs.g_src, (unsigned)t * 64u + ln);
-        const unsigned col = (unsigned)cpgw::opaque((int)cpgw::gld(Rs.g_lcol, (unsigned)t * 64u + ln));
+        const unsigned col = (unsigned)cpgw::gld(Rs.g_lcol, (unsigned)t * 64u + ln);
         const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
         double v = 0.0;
         if (kind == 1u) v = 1.0;
         else if (kind == 2u) v = -(fac[idx] * fac[nnzL + col]);
         else if (kind == 3u) v = fac[nnzL + idx];
         else if (kind == 4u) v = fac[X0 + idx];
-        if (t < CPG_GENR_NACC) run_program_res_put(t, v, (CPG_LDS double *)nullptr, lane);
-        else cfv[t >= CPG_GENR_NACC ? t - CPG_GENR_NACC : 0] = v;
-        if (t < kResLow) cpgw::gst(B.clow, 64u * (unsigned)t + ln, v);
+        cpgw::gst(B.cf, (unsigned)t * 64u + ln, v);
     }
 }
 
@@ -196,8 +190,6 @@ struct ResidentCtx {
 // termination test (four copies of the streaming executor) and the factorisation decided where the allocator put the
 // ADMM loop's coefficients -- in scratch memory, ~100 reloads per iteration (profiles/r4_s2_isa_*).  The AMDGPU calling
 // convention keeps a32 - a255 and half of the VGPRs across a call: the coefficients stay where they are.
-
-CPG_DEV_NOINLINE void resident_reserve_agprs() { CPG_ACC_RESERVE_BODY(); }
 
 template <int NSZ>
 struct ResSetupOut {
@@ -443,34 +435,25 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident
     }
 }
 
-// step 5, a leaf of its own (see cpg_wave_gfx950.h: no compiler-allocated AGPR in here): the coefficients into their
-// registers -- AGPRs by name, a copy of the caller-saved ones (a0 - a31) in the wavefront's buffer, the ones beyond the
-// 128 pairs behind the products' results in the slice -- and the slice back to its ADMM use: idle lanes of a step gather
-// the zero slot, idle lanes of a chunk store to the dummy slots (everything starts finite); the results of the
-// termination test's products; q and u of the instance
+// step 5: the coefficients of the generated executor to the wavefront's buffer, and the slice back to its ADMM use: idle
+// lanes of a step gather the zero slot, idle lanes of a chunk store to the dummy slots (everything starts finite); the
+// results of the termination test's products; q and u of the instance
 CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, int) {
     const int lane = cpgw::lane_id();
     double *sl = cpgw::lds_window() + sl_off;
-    {
-        constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m;
-        constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
-        double cfv[kResLds > 0 ? kResLds : 1];
-#pragma unroll
-        for (int t = 0; t < (kResLds > 0 ? kResLds : 1); t++) cfv[t] = 0.0;
-        resident_coefficients(R, Rs, B, sl, cfv, lane);
-        cpgw::lds_order();
-        double *w = sl, *qs = w + ldw, *us = qs + n;
-        for (unsigned t = (unsigned)ldw + N + (unsigned)lane; t < (unsigned)Rs.slice_doubles; t += 64u) w[t] = 0.0;
-        cpgw::lds_order();
-#pragma unroll
-        for (int t = 0; t < kResLds; t++) w[(unsigned)Rs.out_cf + 64u * (unsigned)t + (unsigned)lane] = cfv[t];
-        for (unsigned t = (unsigned)lane; t < (unsigned)ldw; t += 64u) w[t] = 0.0;
-        for (unsigned i = (unsigned)lane; i < n; i += 64u) qs[i] = cpgw::gld((const double *)B.q, i);
-        for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
-        cpgw::lds_order();
-        cpgw::mem_order();
-    }
+    constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M;
+    constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
+    resident_coefficients(R, Rs, B, sl, lane);
+    cpgw::lds_order();
+    double *w = sl, *qs = w + ldw, *us = qs + n;
+    for (unsigned t = (unsigned)lane; t < (unsigned)Rs.slice_doubles; t += 64u) w[t] = 0.0;
+    cpgw::lds_order();
+    for (unsigned i = (unsigned)lane; i < n; i += 64u) qs[i] = cpgw::gld((const double *)B.q, i);
+    for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
+    cpgw::lds_order();
+    cpgw::mem_order();
 }
+
 // The iterates of an instance between two calls (in memory: what a call takes by reference lives there), the steps of
 // the last checked iteration.
 template <int NSX, int NSZ>
@@ -481,28 +464,27 @@ struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha
 // that runs the generated executor: x, z, y and the VGPR coefficients are loaded once, nothing in here is a call, and the
 // loop holds no scratch access (scripts/isa_resident.py checks it).
 template <int NSX, int NSZ>
-CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, const double *clow, unsigned free_rows, unsigned sl_off_v, unsigned cf_off_v,
+CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, const double *cfg, unsigned free_rows, unsigned sl_off_v,
                                        int count_v, int) {
     const int lane = cpgw::lane_id();      // (range known: bounds tests of full slots fold away)
     // (arguments arrive in VGPRs: tell the compiler which of them are wave-uniform)
-    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v), cf_off = (unsigned)cpgw::read_first_lane((int)cf_off_v);
+    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
     const int count = cpgw::read_first_lane(count_v);
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
     constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u;
     const CPG_LDS unsigned short *lc = (const CPG_LDS unsigned short *)cpgw::lds_window3(), *lr = lc + t_ncols;
     CPG_LDS double *w = cpgw::lds_window3() + sl_off;
-    const CPG_LDS double *qs = w + ldw, *us = qs + n, *cfl = w + cf_off;
+    const CPG_LDS double *qs = w + ldw, *us = qs + n;
     const double rho_eq = rr.rho_eq, rho_in = rr.rho_in, rho_fr = rr.rho_fr, ri_eq = rr.ri_eq, ri_in = rr.ri_in, ri_fr = rr.ri_fr;
     const double sigma_ = rr.sigma, alpha_ = rr.alpha;
-    {   // a0 - a31 are caller-saved: whatever ran since the last iterations may have used them (the kernel's own code parks
-        // a VGPR there around its calls); their coefficients come back from the wavefront's buffer
-        double v[kResLow > 0 ? kResLow : 1];
+    // The coefficients: ~2 registers per step and lane, loaded once per call (one call = the iterations between two
+    // termination tests; 74 KB per call on the portfolio family) and held in the wavefront's 512 registers -- which of them
+    // are VGPRs and which AGPR copies read through v_accvgpr_read at their use is the compiler's business, in a function
+    // that contains nothing but this loop (hand-named AGPRs were tried and dropped: DESIGN.md 4.6)
+    double cf[CPG_GENR_NREGS];
 #pragma unroll
-        for (int t = 0; t < kResLow; t++) v[t] = cpgw::gld(clow, 64u * (unsigned)t + (unsigned)lane);
-#pragma unroll
-        for (int t = 0; t < kResLow; t++) run_program_res_put(t, v[t], (CPG_LDS double *)nullptr, lane);
-    }
+    for (int t = 0; t < CPG_GENR_NREGS; t++) cf[t] = cpgw::gld(cfg, (unsigned)t * 64u + (unsigned)lane);
     double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
     for (int s = 0; s < NSX; s++) x[s] = st.x[s];
@@ -523,7 +505,7 @@ CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr,
             if (i < m) w[n + i] = z[s] - ri * y[s];
         }
         cpgw::lds_order();
-        run_program_res(cfl, lc, lr, w, lane);
+        run_program_res(cf, lc, lr, w, lane);
 #pragma unroll
         for (int s = 0; s < NSX; s++) {
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
@@ -580,7 +562,6 @@ template <int NSX, int NSZ>
 CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const DevResident &Rs, const DevSettings &S,
                                 const DevBatch &Bt, double *lds, int wave_global) {
     const int lane = cpgw::lane_id();
-    resident_reserve_agprs();
     // the family's dimensions are compile-time constants of its library (cpg_hip_set_resident checks them): bounds tests
     // of full 64-entry slots fold away -- as run-time values they cost the ADMM loop ~130 branches and ~290 exec-mask
     // reloads (v_readlane of spilled SGPR pairs) per iteration
@@ -596,7 +577,7 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
     // The wavefront's slice, three lives:
     //   set-up    A (nnzA) | P (nnzP) | D (n) | E (m) | norms (max(n, m))      theta is staged where D starts
     //   factor    fac = M (nnzL) | 1/d (N) | X | 1.0 | 0.0
-    //   ADMM      w (ldw) | q (n) | u (m) | A x (m)  or  P x (n) | A' y (n) | coefficients beyond the 128 AGPR pairs
+    //   ADMM      w (ldw) | q (n) | u (m) | A x (m)  or  P x (n) | A' y (n)
     const unsigned sl_off = (t_ncols + t_nrows) / 4u + (unsigned)cpgw::wave_in_block() * (unsigned)Rs.slice_doubles;
     const ResBuf B = res_carve(Bt.scratch + (size_t)wave_global * (size_t)Rs.buf_doubles, F0, R, Rs);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
@@ -623,6 +604,9 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         ResSetupOut<NSZ> su;
         resident_setup<NSX, NSZ>(R, Rs, B, sl_off, theta, ri_eq, ri_in, ri_fr, lane, su);
         const double cs = su.cs, dconst = su.dconst;
+        // (experiments: leave the instance after stage k of its life: 1 set-up, 2 factorisation, 3 coefficients, 4 first iterations)
+#define CPG_RES_STOP_AFTER(k) if (__builtin_expect(S.debug_stage == (k), 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }
+        CPG_RES_STOP_AFTER(1)
 
         // ---- 4. - 6.  factorise (call), iterate to the next event (call), test / adapt (call), in osqp_solve's order.  The
         //      instance's state between the calls lives in memory (st); the AGPR-held coefficients survive them by name.
@@ -642,23 +626,31 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         const int chk_int = S.check_termination, ad_int = S.adaptive_rho ? S.adaptive_rho_interval : 0;
 #pragma nounroll
         while (o.status == 11) {
-            if (need_factor) { resident_factorise(R, Rs, B, sl_off, F0.sigma, lane); resident_store_coefficients(R, Rs, B, sl_off, lane); need_factor = false; }
+            if (need_factor) {
+                resident_factorise(R, Rs, B, sl_off, F0.sigma, lane);
+                if (__builtin_expect(S.debug_stage == 2, 0)) break;
+                resident_store_coefficients(R, Rs, B, sl_off, lane);
+                if (__builtin_expect(S.debug_stage == 3, 0)) break;
+                need_factor = false;
+            }
             if (iter < S.max_iter) {
                 int next_ev = S.max_iter;
                 if (chk_int > 0) { const int c = (iter / chk_int + 1) * chk_int; if (c < next_ev) next_ev = c; }
                 if (ad_int > 0) { const int c = (iter / ad_int + 1) * ad_int; if (c < next_ev) next_ev = c; }
                 const ResRho rr{rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, F0.sigma, F0.alpha};
                 if (__builtin_expect(S.debug_stage == 7, 0)) {        // (experiments: one call per iteration)
-                    for (int k = iter; k < next_ev; k++) resident_iterate<NSX, NSZ>(st, rr, B.clow, su.free_rows, sl_off, (unsigned)Rs.out_cf, 1, lane);
+                    for (int k = iter; k < next_ev; k++) resident_iterate<NSX, NSZ>(st, rr, B.cf, su.free_rows, sl_off, 1, lane);
                 } else
-                resident_iterate<NSX, NSZ>(st, rr, B.clow, su.free_rows, sl_off, (unsigned)Rs.out_cf, next_ev - iter, lane);
+                resident_iterate<NSX, NSZ>(st, rr, B.cf, su.free_rows, sl_off, next_ev - iter, lane);
                 iter = next_ev;
+                if (__builtin_expect(S.debug_stage == 4, 0)) break;
             }
             const bool can_check = chk_int > 0 && iter > 0 && iter % chk_int == 0;
             const bool adapt = ad_int > 0 && iter > 0 && iter % ad_int == 0;
             const bool last = iter >= S.max_iter;
             ScaledNorms sn;
             bool approx = false;
+            if (__builtin_expect(S.debug_stage == 9 && !last, 0)) continue;      // (experiments: no test before max_iter)
             for (;;) {
                 const CheckOut oc = resident_check<NSX, NSZ>(F, Rs, B, su.ct, S, st.x, st.z, st.y, st.dx, st.dy, sl_off, lane, approx, &sn);
                 if (approx) { o = oc; break; }
@@ -683,7 +675,9 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
                 break;
             }
             if (last && o.status == 11) o.status = 7;
+            if (__builtin_expect(S.debug_stage == 5, 0)) break;
         }
+        if (__builtin_expect(S.debug_stage >= 2 && S.debug_stage <= 5, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = iter; } continue; }
         resident_finalize<NSX, NSZ>(F, Bt, st.x, st.z, st.y, dconst, b, sl_off, lane, iter, o, rho);
     }
 }

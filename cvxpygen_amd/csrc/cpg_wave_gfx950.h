@@ -89,29 +89,6 @@ CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
 // max of non-negative doubles in LDS (they order like their bit patterns): ds_max_u64, no return value
 CPG_DEV void lds_max_u64(unsigned long long *p, double v) { atomicMax(p, (unsigned long long)__double_as_longlong(v)); }
 CPG_DEV double u64_as_double(unsigned long long v) { return __longlong_as_double((long long)v); }
-// A double kept in two NAMED accumulation registers (AGPRs a<A>, a<B>).  gfx950's unified register file gives a wavefront
-// that owns its SIMD 256 AGPRs next to the 256 VGPRs; vector ALU instructions cannot name them, v_accvgpr_read / _write
-// move a dword.  The resident kernel keeps its substitution coefficients there, by NAME: handed to the register allocator
-// (as "a"-constrained values, or as plain doubles) they ended up in scratch memory, 100 - 270 reloads per ADMM iteration
-// (profiles/r4_isa_*).  The compiler does not know about these values.  What keeps them alive:
-//   * a32 - a255 are callee-saved in the AMDGPU calling convention: a called function that uses one restores it;
-//   * the macros declare NO clobber (a function that clobbered a callee-saved register would restore the OLD value in
-//     its epilogue), and the functions that write / read them are small leaves in which the compiler allocates no AGPR
-//     of its own -- scripts/isa_resident.py checks exactly that on the compiled library;
-//   * a0 - a31 are caller-saved (and the kernel's own code parks a VGPR there around its calls): the function that runs
-//     the iterations re-writes them from memory when it starts;
-//   * libraries using this are compiled with -mllvm -amdgpu-spill-vgpr-to-agpr=0 (codegen.resident_compiler_flags), and
-//     the kernel calls one leaf function whose only content is a clobber of a0 and a255 (CPG_ACC_RESERVE_BODY), which
-//     makes its allocation count all 256 AGPRs.
-#define CPG_ACC_WRITE2(v, A, B)                                                                                   \
-    do { const double v__ = (v); const int lo__ = __double2loint(v__), hi__ = __double2hiint(v__);                 \
-         asm volatile("v_accvgpr_write_b32 a" #A ", %0\n\tv_accvgpr_write_b32 a" #B ", %1" : : "v"(lo__), "v"(hi__)); } while (0)
-// (a leaf function whose only content is this clobber: the kernel that calls it is allocated all 256 AGPRs)
-#define CPG_ACC_RESERVE_BODY() asm volatile("; the wavefront's 256 AGPRs are named by hand (CPG_ACC_WRITE2)" : : : "a0", "a255")
-#define CPG_ACC_READ2(var, A, B)                                                                                  \
-    do { int lo__, hi__;                                                                                          \
-         asm volatile("v_accvgpr_read_b32 %0, a" #A "\n\tv_accvgpr_read_b32 %1, a" #B : "=v"(lo__), "=v"(hi__));     \
-         var = __hiloint2double(hi__, lo__); } while (0)
 // keeps the instruction scheduler from interleaving unrolled loop bodies (register pressure)
 CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and

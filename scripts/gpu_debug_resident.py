@@ -20,8 +20,11 @@ vals = {'a': rng.standard_normal((B, n)), 'F': np.round(rng.standard_normal((B, 
 th = np.stack([d.theta_from_values({k: v[i] for k, v in vals.items()}) for i in range(B)])
 upd = ['a', 'F', 'Sig_f_sqrt', 'd_sqrt', 'w_prev']
 bs = BatchSolver(d, lib_path=lib, plan=plan)
-for stg in (dict(max_iter=1), dict(max_iter=2), dict(max_iter=2, debug_stage=7), dict(max_iter=3), dict(max_iter=25), dict(max_iter=25, debug_stage=7), dict(max_iter=60), dict()):
-    for placement in (-1, 0):
+import json
+STGS = json.loads(sys.argv[2]) if len(sys.argv) > 2 else [dict(max_iter=1), dict(max_iter=2), dict(max_iter=3), dict(max_iter=25), dict(max_iter=60), dict()]
+for stg in STGS:
+    print('>>', stg, flush=True)
+    for placement in ((-1,) if 'debug_stage' in stg else (-1, 0)):
         bs.set_program_placement(placement)
         r = bs.solve(vals, updated_params=upd, **stg)
         v = C.c_double(-1)

@@ -44,8 +44,8 @@ for l in rows:
     seen.add(key)
     print(l)
 
-# compiler-allocated AGPRs (outside the kernel's inline asm) per function: must be 0 in the functions that hold named
-# coefficients live without a call boundary in between (cpg_wave_gfx950.h)
+# compiler-allocated AGPRs (outside the kernel's inline asm) per function: only a0 - a31 may appear in the functions that
+# hold named coefficients (a32 - a255) live without a call boundary in between (cpg_wave_gfx950.h)
 import re
 asm = open(out).read().split('\n')
 func, inasm, cnt, low = '', False, {}, {}
@@ -58,9 +58,9 @@ for l in asm:
     elif '#ASMEND' in l:
         inasm = False
     elif not inasm and 'resident' in func and not l.strip().startswith(';') and re.search(r'[ ,]a\[?\d+', l):
-        hi = max(int(x) for x in re.findall(r'[ ,]a\[?(\d+)', l))
-        if 'osqp_resident_kernel' in func and hi < 32:
-            low[func] = low.get(func, 0) + 1          # (caller-saved a0 - a31: the iterations restore them)
+        hi = max(int(x) for x in re.findall(r'[ ,:]a?\[?(\d+)\]?', ' ' + ' '.join(re.findall(r'a\[\d+:\d+\]|a\d+', l))) or [0])
+        if hi < 32:
+            low[func] = low.get(func, 0) + 1          # (caller-saved a0 - a31: no coefficient lives there)
             continue
         cnt[func] = cnt.get(func, 0) + 1
 print('compiler-allocated AGPR operands outside inline asm:')

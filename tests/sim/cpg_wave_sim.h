@@ -42,7 +42,6 @@ struct SimThread {               // one fiber = one GPU thread
     SimBarrier *block_bar;
     bool done;
     SimThread *next;             // ring of the workgroup's fibers
-    double acc[128];             // the lane's accumulation registers, as pairs (CPG_ACC_WRITE2 / _READ2)
 };
 inline thread_local SimThread *cur;
 
@@ -149,9 +148,6 @@ inline unsigned mbcnt(unsigned long long mask) {
     return (unsigned)__builtin_popcountll(mask & ((1ULL << cur->lane) - 1ULL));
 }
 inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
-#define CPG_ACC_WRITE2(v, A, B) do { cpgw::cur->acc[(A) / 2] = (v); } while (0)      // the lane's AGPR pair a<A>, a<B>
-#define CPG_ACC_READ2(var, A, B) do { var = cpgw::cur->acc[(A) / 2]; } while (0)
-#define CPG_ACC_RESERVE_BODY() do { } while (0)
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
 inline void assume(bool) {}
