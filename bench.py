@@ -564,11 +564,17 @@ def main():
             gs.close()
         if args.check:
             from oracle import binding as ob
-            nchk = 256
-            p = desc.param('x_init')
+            nchk = min(B, 64 if args.workload == 'portfolio' else 256)
             th = np.tile(desc.theta0, (nchk, 1))
-            th[:, p.col:p.col + p.size] = theta[:nchk]
-            o = ob.cpg_solve_batch(desc, th, ['x_init'], **oracle_mode)
+            if args.workload == 'portfolio':
+                upd = list(pv.keys())
+                th[:, solver._var_cols] = theta[:nchk]            # theta_var columns of the varying parameters
+            else:
+                upd = ['x_init']
+                p = desc.param('x_init')
+                th[:, p.col:p.col + p.size] = theta[:nchk]
+            stg_o = {k_: v_ for k_, v_ in stg.items() if k_ != 'debug_stage'}
+            o = ob.cpg_solve_batch(desc, th, upd, **oracle_mode, **stg_o)
             po = np.concatenate([o['sol_x'][:, v.indices] for v in desc.variables], axis=1)
             do = np.concatenate([o['sol_y'][:, d.indices] for d in desc.duals], axis=1)
             out['check'] = {

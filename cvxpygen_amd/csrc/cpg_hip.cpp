@@ -158,8 +158,7 @@ struct StreamTables {
     int n_pairs = 0;
 };
 static int build_stream_tables(const int *ctab, const unsigned *desc, const unsigned short *cols, int n_chunks,
-                               int n_slots, StreamTables &T) {
-    constexpr int DP = CPG_STREAM_DEPTH / 2;
+                               int n_slots, StreamTables &T, const int DP = CPG_STREAM_DEPTH / 2) {
     if (n_slots >= 0x1FFF) { set_error("substitution program: work vector too large for the packed entry table"); return CPG_E_BADARG; }
     struct Step { unsigned base, cnt, flags; int chunk; };
     std::vector<Step> steps;
@@ -1314,7 +1313,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     for (int k = 0; k < 3; k++) {
         const cpg_rows_program_t &p = *rows3[k];
         for (int c = 0; c < p.n_chunks; c++) if (p.ctab[4 * c + 3] & ~1) { set_error("cpg_hip_set_resident: row program with an unsupported chunk kind"); return CPG_E_BADARG; }
-        if ((rc = build_stream_tables(p.ctab, p.desc, p.cols, p.n_chunks, w_slots, st3[k]))) return rc;
+        if ((rc = build_stream_tables(p.ctab, p.desc, p.cols, p.n_chunks, w_slots, st3[k], CPG_RES_PRODUCT_DEPTH / 2))) return rc;
         src3[k].resize(st3[k].src.size());
         const int lim = k == 1 ? r->nnzP : r->nnzA;
         for (size_t e = 0; e < src3[k].size(); e++) {
@@ -1333,7 +1332,8 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     Rs.out_ax = rs->out_ax; Rs.out_px = rs->out_px; Rs.out_aty = rs->out_aty;
     const int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     if (rs->out_ax < ldw + N || rs->out_px < ldw + N || rs->out_aty < rs->out_px + n) { set_error("cpg_hip_set_resident: result slots overlap the work vector"); return CPG_E_BADARG; }
-    long long slice = std::max<long long>(Rs.fac_len, w_slots);
+    Rs.out_sc = w_slots;                                  // 1 / D | 1 / E of the instance behind the products' results
+    long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots + N);
     slice = std::max<long long>(slice, (long long)r->nnzA + r->nnzP + std::max<long long>(r->np_var, (long long)N + std::max(n, m)));
     slice += slice & 1;
     if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }

@@ -228,8 +228,9 @@ CPG_DEV void stream_chunk_end(unsigned f, unsigned rowmask, double &acc, double 
     cpgw::lds_order();
     acc = 0.0;
 }
+template <int DEPTH = CPG_STREAM_DEPTH>          // (tables built for a depth serve every smaller power of two)
 CPG_DEV void run_program_stream(const StreamProg &P, double *w, int lane) {
-    constexpr int DP = CPG_STREAM_DEPTH / 2;
+    constexpr int DP = DEPTH / 2;
     const char *wb = (const char *)w;
     // The ring starts with DP empty pairs (zero coefficients) and the loop runs DP pairs past the end
     // of the stream: see above (one fixed order of loads).
@@ -565,6 +566,12 @@ struct SharedCtx {
         return s < Inst<NSX, NSZ, NV>::NVZ ? I.uv[s < Inst<NSX, NSZ, NV>::NVZ ? s : 0] : shu[i];
     }
     CPG_DEV void products(int) const {}             // (contexts that compute ALL rows of a product at once do it here)
+    // entries of the scaling vectors as the termination test reads them (a context may keep them closer than global memory)
+    CPG_DEV void stage(int) const {}
+    CPG_DEV double sE(unsigned i) const { return cpgw::gld(F.E, i); }
+    CPG_DEV double sEinv(unsigned i) const { return cpgw::gld(F.Einv, i); }
+    CPG_DEV double sD(unsigned i) const { return cpgw::gld(F.D, i); }
+    CPG_DEV double sDinv(unsigned i) const { return cpgw::gld(F.Dinv, i); }
     CPG_DEV double ax(int s) const { return CPG_NATURAL_ROWS(F.A_rows, 0, s, w, lane); }     // (A v)_i, v = w[0..n)
     CPG_DEV double px(int s) const { return CPG_NATURAL_ROWS(F.P_rows, 1, s, w, lane); }     // (P v)_j
     CPG_DEV double atx(int s) const { return CPG_NATURAL_ROWS(F.At_rows, 2, s, w, lane); }   // (A' v)_j, v = w[n..)
@@ -622,6 +629,7 @@ struct NoDelta {      // check() of a kernel that ran the infeasibility tests it
 template <int NSX, int NSZ, typename Ctx, typename DY>
 CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
                                bool unsc, double eps, double *w, const DY &dy, int lane) {
+    cx.stage(1);               // (contexts that keep E closer than global memory for this test)
     double nrm = 0.0, lhs = 0.0;
     double dyp[NSZ];                                   // delta_y projected on the polar of the recession cone of [l, u]
 #pragma unroll
@@ -636,7 +644,7 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
             double d = dy(s, i);
             if (iu && il) d = 0.0; else if (iu) d = cpgw::dmin2(d, 0.0); else if (il) d = cpgw::dmax2(d, 0.0);
             dyp[s] = d;
-            nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.E, i) * d : d));
+            nrm = cpgw::dmax2(nrm, fabs(unsc ? cx.sE(i) * d : d));
             lhs += uu * cpgw::dmax2(d, 0.0) + ll * cpgw::dmin2(d, 0.0);
         }
         cpgw::sched_fence();
@@ -654,7 +662,7 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         const double t = cx.atx(s);
-        if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cpgw::gld(F.Dinv, i) * t : t));
+        if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cx.sDinv(i) * t : t));
         cpgw::sched_fence();
     }
     r = cpgw::wave_max_nonneg(r);
@@ -666,13 +674,14 @@ CPG_DEV bool primal_infeasible(const DevFamily &F, const Ctx &cx, const signed c
 template <int NSX, int NSZ, typename Ctx, typename DX>
 CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed char (&ct)[NSZ],
                              bool unsc, double eps, double *w, const DX &dx, int lane) {
+    cx.stage(2);               // (... D)
     double nrm = 0.0, qdx = 0.0;
 #pragma unroll
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         if (i < (unsigned)F.n) {
             const double d = dx(s, i);
-            nrm = cpgw::dmax2(nrm, fabs(unsc ? cpgw::gld(F.D, i) * d : d));
+            nrm = cpgw::dmax2(nrm, fabs(unsc ? cx.sD(i) * d : d));
             qdx += cx.q(s, i) * d;
         }
     }
@@ -690,7 +699,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
     for (int s = 0; s < NSX; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         const double t = cx.px(s);
-        if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cpgw::gld(F.Dinv, i) * t : t));
+        if (i < (unsigned)F.n) r = cpgw::dmax2(r, fabs(unsc ? cx.sDinv(i) * t : t));
         cpgw::sched_fence();
     }
     r = cpgw::wave_max_nonneg(r);
@@ -703,7 +712,7 @@ CPG_DEV bool dual_infeasible(const DevFamily &F, const Ctx &cx, const signed cha
             const unsigned i = (unsigned)lane + 64u * (unsigned)s;
             const double a = cx.ax(s);
             if (i < (unsigned)F.m) {
-                const double av = unsc ? cpgw::gld(F.Einv, i) * a : a;
+                const double av = unsc ? cx.sEinv(i) * a : a;
                 if ((cx.u(s, i) < CPG_INFTY * CPG_MIN_SCALING && av > eps * nrm) ||
                     (ct[s] == 1 && av < -eps * nrm)) viol = true;
             }
@@ -780,7 +789,7 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         const double ax = cx.ax(s);
         if (i < (unsigned)F.m) {
-            const double ei = unsc ? cpgw::gld(F.Einv, i) : 1.0;
+            const double ei = unsc ? cx.sEinv(i) : 1.0;
             rp = cpgw::dmax2(rp, fabs(ei * (ax - Iz[s])));
             nz = cpgw::dmax2(nz, fabs(ei * Iz[s]));
             na = cpgw::dmax2(na, fabs(ei * ax));
@@ -802,7 +811,7 @@ CPG_DEV CheckOut check(const DevFamily &F, const Ctx &cx, const signed char (&ct
         const double px = cx.px(s);
         const double aty = cx.atx(s);
         if (i < (unsigned)F.n) {
-            const double di = unsc ? cpgw::gld(F.Dinv, i) : 1.0;
+            const double di = unsc ? cx.sDinv(i) : 1.0;
             const double qq = cx.q(s, i);
             rd = cpgw::dmax2(rd, fabs(di * (qq + px + aty)));
             nq = cpgw::dmax2(nq, fabs(di * qq));

@@ -197,6 +197,11 @@ struct InstCtx {
 #endif
     }
     CPG_DEV void products(int) const {}
+    CPG_DEV void stage(int) const {}
+    CPG_DEV double sE(unsigned i) const { return cpgw::gld(F.E, i); }
+    CPG_DEV double sEinv(unsigned i) const { return cpgw::gld(F.Einv, i); }
+    CPG_DEV double sD(unsigned i) const { return cpgw::gld(F.D, i); }
+    CPG_DEV double sDinv(unsigned i) const { return cpgw::gld(F.Dinv, i); }
     CPG_DEV double q(int s, unsigned i) const { return QUMEM ? qm[i] : qr[s]; }
     CPG_DEV double u(int s, unsigned i) const { return QUMEM ? um[i] : ur[s]; }
     template <bool ENT, bool OFFS, int NB = CPG_ROW_WALK_BATCH>

@@ -43,7 +43,8 @@ struct DevEll {                   // out[k] = base[k] + sum_j coef[j * rows + k]
     const int *idx;
     const double *coef;
 };
-#define CPG_RES_FAC_DEPTH 8       // steps of the factorisation stream in flight
+#define CPG_RES_FAC_DEPTH 8       // steps of the factorisation stream in flight (each is a copy of the step's code)
+#define CPG_RES_PRODUCT_DEPTH 16  // steps of a product of the termination test in flight (run_program_stream)
 struct DevResident {
     int ok;
     int nnzX, fac_len, fac_steps;          // fac = [M (nnzL) | 1/d (N) | X (nnzX) | 1.0 | 0.0]; fac_steps: multiple of the depth
@@ -61,11 +62,26 @@ struct DevResident {
     const unsigned *entA, *entP;           // row | column << 16 of every stored entry
     DevStreamTab pA, pP, pAt;              // A x, P x, A' y on the work vector [x | y | .. | A x | P x | A' y]
     int out_ax, out_px, out_aty;           // first slot of the products' results (A x shares the slots of P x | A' y)
+    int out_sc;                            // ... and of 1 / D (n) | 1 / E (m): the residuals of every termination test unscale with them
     int slice_doubles;                     // LDS doubles per wavefront
     long long buf_doubles;                 // per-wavefront buffer in global memory
 };
 
 #ifdef CPG_GENR_HEADER
+// A wave-uniform struct that arrives by reference (the caller's stack): one batch of loads, and every word through
+// v_readfirstlane -- the compiler then knows the pointers in it are uniform (scalar base addresses, s_load for the tables)
+// instead of reloading a field from the stack, as a per-lane value, in front of each use.
+template <class T>
+CPG_DEV T uniform_copy(const T &src) {
+    static_assert(sizeof(T) % 4 == 0, "word-sized structs only");
+    T dst;
+    int words[sizeof(T) / 4];
+    __builtin_memcpy(words, &src, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) words[i] = cpgw::read_first_lane(words[i]);
+    __builtin_memcpy(&dst, words, sizeof(T));
+    return dst;
+}
 struct ResBuf { double *A, *P, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *cA, *cP, *cAt, *cf; };
 CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, const DevResident &Rs) {
     ResBuf o;
@@ -113,7 +129,7 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
             const double la = fac[en.x], dk = fac[en.y], lb = fac[en.z];
             acc = fma(la * dk, lb, acc);
             if (fl & 2u) {
-                const double r = cpgw::group_sum_first_dyn(acc, (int)(fl >> 4));
+                const double r = cpgw::group_sum_first_flat(acc, (int)(fl >> 4));
                 if (dest != 0xFFFFFFFFu) {
                     const unsigned d = dest & 0x7FFFFFFFu;
                     const double v = fac[d] - r;
@@ -133,7 +149,7 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
 CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, const double *fac, int lane) {
     const unsigned ln = (unsigned)cpgw::opaque(lane);            // (see load_instance_coefficients: addresses local to this block)
     const unsigned nnzL = (unsigned)R.nnzL, X0 = (unsigned)(Rs.fac_len - 2 - Rs.nnzX);
-#pragma unroll 8
+#pragma unroll 16
     for (int t = 0; t < CPG_GENR_NREGS; t++) {
         const unsigned code = cpgw::gld(Rs.g_src, (unsigned)t * 64u + ln);
         const unsigned col = (unsigned)cpgw::gld(Rs.g_lcol, (unsigned)t * 64u + ln);
@@ -147,6 +163,35 @@ CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, 
     }
 }
 
+// The products of the termination test, a real call (one wavefront per SIMD runs straight-line code at the speed of its
+// instruction fetch, and the test reaches this executor from four places: inlined, resident_check was 104 KB of code
+// against a 64 KB instruction cache shared by two CUs).  1: A w[0..n)   2: P w[0..n)   4: A' w[n..n+m); rows without an
+// entry are never written by their program and A x shares the slots of P x | A' y, so the result slots are cleared first.
+CPG_DEV_NOINLINE void resident_products(const DevResident &Rs_, const double *cA, const double *cP, const double *cAt, unsigned w_off_v, int which_v) {
+    const int lane = cpgw::lane_id();
+    const DevResident Rs = uniform_copy(Rs_);
+    const int which = cpgw::read_first_lane(which_v);
+    double *w = cpgw::lds_window() + (unsigned)cpgw::read_first_lane((int)w_off_v);
+    constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M;
+    cpgw::lds_order();              // (behind every lane's last read of the previous product)
+    if (which & 1) for (unsigned i = (unsigned)lane; i < m; i += 64u) w[(unsigned)Rs.out_ax + i] = 0.0;
+    if (which & 2) for (unsigned i = (unsigned)lane; i < n; i += 64u) w[(unsigned)Rs.out_px + i] = 0.0;
+    if (which & 4) for (unsigned i = (unsigned)lane; i < n; i += 64u) w[(unsigned)Rs.out_aty + i] = 0.0;
+    cpgw::lds_order();
+#pragma nounroll
+    for (int k = 0; k < 3; k++) {
+        if (!((which >> k) & 1)) continue;
+        const DevStreamTab &T = k == 0 ? Rs.pA : (k == 1 ? Rs.pP : Rs.pAt);
+        const double *vals = k == 0 ? cA : (k == 1 ? cP : cAt);
+        StreamProg ST;
+        ST.stab = T.stab; ST.cr = T.cr; ST.n_pairs = T.n_pairs; ST.dummy = T.dummy;
+        ST.vals = (const double *)(((unsigned long long)(unsigned)cpgw::read_first_lane((int)((unsigned long long)vals >> 32)) << 32) |
+                                   (unsigned)cpgw::read_first_lane((int)(unsigned long long)vals));
+        run_program_stream<CPG_RES_PRODUCT_DEPTH>(ST, w, lane);
+    }
+    cpgw::lds_order();
+}
+
 // q / u of the instance in the wavefront's LDS slice; the three products of the termination test through their row
 // programs on per-instance copies of the scaled matrices in program order
 template <int NSX, int NSZ>
@@ -157,29 +202,33 @@ struct ResidentCtx {
     const DevResident &Rs;
     const ResBuf &B;
     double *w;
+    unsigned w_off;               // ... as an offset into the workgroup's LDS window (for the calls)
     const double *qm, *um;
     int lane;
     CPG_DEV double q(int, unsigned i) const { return qm[i]; }
     CPG_DEV double u(int, unsigned i) const { return um[i]; }
-    CPG_DEV void run(const DevStreamTab &T, const double *vals) const {
-        StreamProg ST;
-        ST.stab = T.stab; ST.cr = T.cr; ST.vals = vals; ST.n_pairs = T.n_pairs; ST.dummy = T.dummy;
-        run_program_stream(ST, w, lane);
+    // Scaling vectors: with one wavefront per SIMD a global load per 64-entry slot inside the test's loops is a memory
+    // round trip each (~60 of them per test, most of its 96 us: profiles/r4_s3_*).  1 / D and 1 / E sit in the slice; D / E,
+    // which only the infeasibility tests read, are staged into the products' result slots when such a test starts (one
+    // batch of loads) and consumed before the test's first product overwrites them.
+    CPG_DEV double sDinv(unsigned i) const { return w[(unsigned)Rs.out_sc + i]; }
+    CPG_DEV double sEinv(unsigned i) const { return w[(unsigned)Rs.out_sc + (unsigned)F.n + i]; }
+    CPG_DEV double sE(unsigned i) const { return w[(unsigned)Rs.out_ax + i]; }
+    CPG_DEV double sD(unsigned i) const { return w[(unsigned)Rs.out_ax + i]; }
+    CPG_DEV void stage(int which) const {
+        const double *src = which == 1 ? (const double *)B.E : (const double *)B.D;
+        const unsigned cnt = which == 1 ? (unsigned)F.m : (unsigned)F.n;
+        cpgw::lds_order();
+        for (unsigned i0 = 0; i0 < cnt; i0 += 512u) {
+            double v[8];
+#pragma unroll
+            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; v[u_] = i < cnt ? cpgw::gld(src, i) : 0.0; }
+#pragma unroll
+            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; if (i < cnt) w[(unsigned)Rs.out_ax + i] = v[u_]; }
+        }
+        cpgw::lds_order();
     }
-    CPG_DEV void products(int which) const {        // 1: A w[0..n)   2: P w[0..n)   4: A' w[n..n+m)
-        // rows without an entry are never written by their program, and A x shares the slots of P x | A' y: clear first
-        // (behind every lane's last read of the previous product)
-        cpgw::lds_order();
-        if (which & 1) for (unsigned i = (unsigned)lane; i < (unsigned)F.m; i += 64u) w[(unsigned)Rs.out_ax + i] = 0.0;
-        if (which & 2) for (unsigned i = (unsigned)lane; i < (unsigned)F.n; i += 64u) w[(unsigned)Rs.out_px + i] = 0.0;
-        if (which & 4) for (unsigned i = (unsigned)lane; i < (unsigned)F.n; i += 64u) w[(unsigned)Rs.out_aty + i] = 0.0;
-        cpgw::lds_order();
-        // (one copy of the executor per call site: the tables are picked at run time)
-#pragma nounroll
-        for (int k = 0; k < 3; k++)
-            if ((which >> k) & 1) run(k == 0 ? Rs.pA : (k == 1 ? Rs.pP : Rs.pAt), k == 0 ? B.cA : (k == 1 ? B.cP : B.cAt));
-        cpgw::lds_order();
-    }
+    CPG_DEV void products(int which) const { resident_products(Rs, B.cA, B.cP, B.cAt, w_off, which); }
     CPG_DEV double ax(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.m ? w[(unsigned)Rs.out_ax + i] : 0.0; }
     CPG_DEV double px(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.n ? w[(unsigned)Rs.out_px + i] : 0.0; }
     CPG_DEV double atx(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.n ? w[(unsigned)Rs.out_aty + i] : 0.0; }
@@ -200,9 +249,13 @@ struct ResSetupOut {
 
 // steps 1 - 3 of an instance: canonicalise, equilibrate, scaled data (the wavefront's buffer B, program-order copies)
 template <int NSX, int NSZ>
-CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, const double *theta,
+CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, unsigned sl_off_v, const double *theta_v,
                                      double ri_eq, double ri_in, double ri_fr, int, ResSetupOut<NSZ> &out) {
     const int lane = cpgw::lane_id();      // (not the argument: the compiler knows this one's range, and folds the bounds tests of full slots)
+    const DevRefactor R = uniform_copy(R_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_);
+    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
+    const double *theta = (const double *)(((unsigned long long)(unsigned)cpgw::read_first_lane((int)((unsigned long long)theta_v >> 32)) << 32) |
+                                           (unsigned)cpgw::read_first_lane((int)(unsigned long long)theta_v));
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m, n_eq = CPG_GENR_NEQ;
     double *sl = cpgw::lds_window() + sl_off;
     double *Al = sl, *Pl = Al + CPG_GENR_NNZA, *Dl = Pl + CPG_GENR_NNZP, *El = Dl + n;
@@ -399,8 +452,10 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R, const DevResident &Rs
 }
 
 // step 4: KKT values into the slice, numeric LDL' + inverses of the merged diagonal blocks
-CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, double sigma, int) {
+CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, unsigned sl_off_v, double sigma, int) {
     const int lane = cpgw::lane_id();
+    const DevRefactor R = uniform_copy(R_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_);
+    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
     double *sl = cpgw::lds_window() + sl_off;
     {
             constexpr unsigned nd = CPG_GENR_NNZL + CPG_GENR_N + CPG_GENR_M;
@@ -438,8 +493,10 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R, const DevResident
 // step 5: the coefficients of the generated executor to the wavefront's buffer, and the slice back to its ADMM use: idle
 // lanes of a step gather the zero slot, idle lanes of a chunk store to the dummy slots (everything starts finite); the
 // results of the termination test's products; q and u of the instance
-CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, unsigned sl_off, int) {
+CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, unsigned sl_off_v, int) {
     const int lane = cpgw::lane_id();
+    const DevRefactor R = uniform_copy(R_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_);
+    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
     double *sl = cpgw::lds_window() + sl_off;
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M;
     constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
@@ -448,8 +505,18 @@ CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R, const De
     double *w = sl, *qs = w + ldw, *us = qs + n;
     for (unsigned t = (unsigned)lane; t < (unsigned)Rs.slice_doubles; t += 64u) w[t] = 0.0;
     cpgw::lds_order();
-    for (unsigned i = (unsigned)lane; i < n; i += 64u) qs[i] = cpgw::gld((const double *)B.q, i);
-    for (unsigned i = (unsigned)lane; i < m; i += 64u) us[i] = cpgw::gld((const double *)B.u, i);
+    // q | u and 1 / D | 1 / E of the instance, eight loads in flight
+    auto fill = [&](double *dst, const double *a, unsigned na, const double *b2, unsigned nb) __attribute__((always_inline)) {
+        for (unsigned i0 = 0; i0 < na + nb; i0 += 512u) {
+            double v[8];
+#pragma unroll
+            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; v[u_] = i < na ? cpgw::gld(a, i) : (i < na + nb ? cpgw::gld(b2, i - na) : 0.0); }
+#pragma unroll
+            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; if (i < na + nb) dst[i] = v[u_]; }
+        }
+    };
+    fill(qs, (const double *)B.q, n, (const double *)B.u, m);
+    fill(w + (unsigned)Rs.out_sc, (const double *)B.Dinv, n, (const double *)B.Einv, m);
     cpgw::lds_order();
     cpgw::mem_order();
 }
@@ -460,11 +527,16 @@ template <int NSX, int NSZ>
 struct ResState { double x[NSX], z[NSZ], y[NSZ], dx[NSX], dy[NSZ]; };
 struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
 
+// (a real call, ~7 us each -- one per termination test: inlined into the kernel the same loop carried 29 scratch loads and
+// 23 stores per iteration and the default mode ran 95 instead of 65 ms per 20 000 instances, profiles/r4_s5_*)
+#ifndef CPG_RES_ITERATE_LINKAGE
+#define CPG_RES_ITERATE_LINKAGE CPG_DEV_NOINLINE
+#endif
 // `count` ADMM iterations, the last one keeping its steps delta x / delta y for the termination test.  The only function
 // that runs the generated executor: x, z, y and the VGPR coefficients are loaded once, nothing in here is a call, and the
 // loop holds no scratch access (scripts/isa_resident.py checks it).
 template <int NSX, int NSZ>
-CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr, const double *cfg, unsigned free_rows, unsigned sl_off_v,
+CPG_RES_ITERATE_LINKAGE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr_, const double *cfg, unsigned free_rows, unsigned sl_off_v,
                                        int count_v, int) {
     const int lane = cpgw::lane_id();      // (range known: bounds tests of full slots fold away)
     // (arguments arrive in VGPRs: tell the compiler which of them are wave-uniform)
@@ -476,6 +548,7 @@ CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr,
     const CPG_LDS unsigned short *lc = (const CPG_LDS unsigned short *)cpgw::lds_window3(), *lr = lc + t_ncols;
     CPG_LDS double *w = cpgw::lds_window3() + sl_off;
     const CPG_LDS double *qs = w + ldw, *us = qs + n;
+    const ResRho rr = uniform_copy(rr_);
     const double rho_eq = rr.rho_eq, rho_in = rr.rho_in, rho_fr = rr.rho_fr, ri_eq = rr.ri_eq, ri_in = rr.ri_in, ri_fr = rr.ri_fr;
     const double sigma_ = rr.sigma, alpha_ = rr.alpha;
     // The coefficients: ~2 registers per step and lane, loaded once per call (one call = the iterations between two
@@ -537,23 +610,47 @@ CPG_DEV_NOINLINE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr,
 }
 
 template <int NSX, int NSZ>
-CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F, const DevResident &Rs, const ResBuf &B, const signed char (&ct)[NSZ],
-                                                const DevSettings &S, const double (&x)[NSX], const double (&z)[NSZ], const double (&y)[NSZ],
-                                                const double (&dxr)[NSX], const double (&dyr)[NSZ], unsigned sl_off, int,
-                                                bool approximate, ScaledNorms *sn) {
+CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F_, const DevResident &Rs_, const ResBuf &B_, const signed char (&ct_)[NSZ],
+                                                const DevSettings &S_, const double (&x_)[NSX], const double (&z_)[NSZ], const double (&y_)[NSZ],
+                                                const double (&dxr_)[NSX], const double (&dyr_)[NSZ], unsigned sl_off_v, int,
+                                                bool approximate_v, ScaledNorms *sn_) {
     typedef ResidentCtx<NSX, NSZ> CtxT;
     const int lane = cpgw::lane_id();
+    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
+    const bool approximate = cpgw::read_first_lane(approximate_v ? 1 : 0) != 0;
+    // Everything that arrives by reference is copied into locals once, with all loads in flight together: read where it is
+    // used, every entry was a flat load from the caller's stack in front of its use -- ~100 memory round trips per test
+    // with nobody to hide them (one wavefront per SIMD): 96 us per test (profiles/r4_s3_*).
+    const DevFamily F = uniform_copy(F_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_); const DevSettings S = uniform_copy(S_);
+    double x[NSX], z[NSZ], y[NSZ], dxr[NSX], dyr[NSZ];
+    signed char ct[NSZ];
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { x[s] = x_[s]; dxr[s] = dxr_[s]; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { z[s] = z_[s]; y[s] = y_[s]; dyr[s] = dyr_[s]; ct[s] = ct_[s]; }
+    ScaledNorms sn_local;
+    ScaledNorms *sn = &sn_local;
     double *w = cpgw::lds_window() + sl_off;
     const double *qs = w + (CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + CPG_GENR_N;
-    const CtxT cx{F, Rs, B, w, qs, us, lane};
-    return check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr},
-                                                               InfeasVerdict{false, false}, w, lane, approximate, sn);
+    const CtxT cx{F, Rs, B, w, sl_off, qs, us, lane};
+    const CheckOut o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr},
+                                                                           InfeasVerdict{false, false}, w, lane, approximate, sn);
+    if (sn_) *sn_ = sn_local;
+    return o;
 }
 template <int NSX, int NSZ>
-CPG_DEV_NOINLINE void resident_finalize(const DevFamily &F, const DevBatch &Bt, const double (&x)[NSX], const double (&z)[NSZ],
-                                               const double (&y)[NSZ], double dconst, long long b, unsigned sl_off, int, int iter,
-                                               const CheckOut &o, double rho) {
+CPG_DEV_NOINLINE void resident_finalize(const DevFamily &F_, const DevBatch &Bt_, const double (&x_)[NSX], const double (&z_)[NSZ],
+                                               const double (&y_)[NSZ], double dconst, long long b_v, unsigned sl_off_v, int, int iter,
+                                               const CheckOut &o_, double rho) {
     const int lane = cpgw::lane_id();
+    const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
+    const long long b = ((long long)cpgw::read_first_lane((int)(b_v >> 32)) << 32) | (unsigned)cpgw::read_first_lane((int)b_v);
+    const DevFamily F = uniform_copy(F_); const DevBatch Bt = uniform_copy(Bt_); const CheckOut o = o_;      // (see resident_check)
+    double x[NSX], z[NSZ], y[NSZ];
+#pragma unroll
+    for (int s = 0; s < NSX; s++) x[s] = x_[s];
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) { z[s] = z_[s]; y[s] = y_[s]; }
     double *w = cpgw::lds_window() + sl_off;
     finalize<NSX, NSZ, true>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);
 }
@@ -577,7 +674,7 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
     // The wavefront's slice, three lives:
     //   set-up    A (nnzA) | P (nnzP) | D (n) | E (m) | norms (max(n, m))      theta is staged where D starts
     //   factor    fac = M (nnzL) | 1/d (N) | X | 1.0 | 0.0
-    //   ADMM      w (ldw) | q (n) | u (m) | A x (m)  or  P x (n) | A' y (n)
+    //   ADMM      w (ldw) | q (n) | u (m) | A x (m)  or  P x (n) | A' y (n) | 1 / D (n) | 1 / E (m)
     const unsigned sl_off = (t_ncols + t_nrows) / 4u + (unsigned)cpgw::wave_in_block() * (unsigned)Rs.slice_doubles;
     const ResBuf B = res_carve(Bt.scratch + (size_t)wave_global * (size_t)Rs.buf_doubles, F0, R, Rs);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;

@@ -45,6 +45,19 @@ CPG_DEV double group_sum_first_dyn(double v, int lg) {   // lg wave-uniform
         default: return group_sum_first<6>(v);
     }
 }
+// The same without a branch per depth (lg wave-uniform, 0 .. 6): all six stages, a stage beyond lg adds zero.  For cold
+// code whose size matters more than six moves (the resident kernel's factorisation stream: the unrolled steps of its
+// prefetch ring each carry a copy, and one wavefront per SIMD executes straight-line code at the speed of its
+// instruction fetch).
+CPG_DEV double group_sum_first_flat(double v, int lg) {
+    { const double t = row_shl<1>(v); v += lg >= 1 ? t : 0.0; }
+    { const double t = row_shl<2>(v); v += lg >= 2 ? t : 0.0; }
+    { const double t = row_shl<4>(v); v += lg >= 3 ? t : 0.0; }
+    { const double t = row_shl<8>(v); v += lg >= 4 ? t : 0.0; }
+    { const double t = up16(v); v += lg >= 5 ? t : 0.0; }
+    { const double t = up32(v); v += lg >= 6 ? t : 0.0; }
+    return v;
+}
 // Segmented sum for rows that occupy a variable number (<= 8) of ADJACENT lanes inside one 16-lane
 // DPP row: in stage j lane t adds lane t + 2^j iff bit j of its mask is set (the source lane belongs
 // to the same row); after S stages the first lane of every row holds the row sum.
