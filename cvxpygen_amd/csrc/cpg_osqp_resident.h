@@ -163,35 +163,6 @@ CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, 
     }
 }
 
-// The products of the termination test, a real call (one wavefront per SIMD runs straight-line code at the speed of its
-// instruction fetch, and the test reaches this executor from four places: inlined, resident_check was 104 KB of code
-// against a 64 KB instruction cache shared by two CUs).  1: A w[0..n)   2: P w[0..n)   4: A' w[n..n+m); rows without an
-// entry are never written by their program and A x shares the slots of P x | A' y, so the result slots are cleared first.
-CPG_DEV_NOINLINE void resident_products(const DevResident &Rs_, const double *cA, const double *cP, const double *cAt, unsigned w_off_v, int which_v) {
-    const int lane = cpgw::lane_id();
-    const DevResident Rs = uniform_copy(Rs_);
-    const int which = cpgw::read_first_lane(which_v);
-    double *w = cpgw::lds_window() + (unsigned)cpgw::read_first_lane((int)w_off_v);
-    constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M;
-    cpgw::lds_order();              // (behind every lane's last read of the previous product)
-    if (which & 1) for (unsigned i = (unsigned)lane; i < m; i += 64u) w[(unsigned)Rs.out_ax + i] = 0.0;
-    if (which & 2) for (unsigned i = (unsigned)lane; i < n; i += 64u) w[(unsigned)Rs.out_px + i] = 0.0;
-    if (which & 4) for (unsigned i = (unsigned)lane; i < n; i += 64u) w[(unsigned)Rs.out_aty + i] = 0.0;
-    cpgw::lds_order();
-#pragma nounroll
-    for (int k = 0; k < 3; k++) {
-        if (!((which >> k) & 1)) continue;
-        const DevStreamTab &T = k == 0 ? Rs.pA : (k == 1 ? Rs.pP : Rs.pAt);
-        const double *vals = k == 0 ? cA : (k == 1 ? cP : cAt);
-        StreamProg ST;
-        ST.stab = T.stab; ST.cr = T.cr; ST.n_pairs = T.n_pairs; ST.dummy = T.dummy;
-        ST.vals = (const double *)(((unsigned long long)(unsigned)cpgw::read_first_lane((int)((unsigned long long)vals >> 32)) << 32) |
-                                   (unsigned)cpgw::read_first_lane((int)(unsigned long long)vals));
-        run_program_stream<CPG_RES_PRODUCT_DEPTH>(ST, w, lane);
-    }
-    cpgw::lds_order();
-}
-
 // q / u of the instance in the wavefront's LDS slice; the three products of the termination test through their row
 // programs on per-instance copies of the scaled matrices in program order
 template <int NSX, int NSZ>
@@ -228,7 +199,25 @@ struct ResidentCtx {
         }
         cpgw::lds_order();
     }
-    CPG_DEV void products(int which) const { resident_products(Rs, B.cA, B.cP, B.cAt, w_off, which); }
+    CPG_DEV void run(const DevStreamTab &T, const double *vals) const {
+        StreamProg ST;
+        ST.stab = T.stab; ST.cr = T.cr; ST.vals = vals; ST.n_pairs = T.n_pairs; ST.dummy = T.dummy;
+        run_program_stream<CPG_RES_PRODUCT_DEPTH>(ST, w, lane);
+    }
+    CPG_DEV void products(int which) const {        // 1: A w[0..n)   2: P w[0..n)   4: A' w[n..n+m)
+        // rows without an entry are never written by their program, and A x shares the slots of P x | A' y: clear first
+        // (behind every lane's last read of the previous product).  (As a real call -- one copy of the executor instead of
+        // one per call site -- a test took 2.27 instead of 1.69 ms per 20 000 instances: profiles/r4_s4c_*.)
+        cpgw::lds_order();
+        if (which & 1) for (unsigned i = (unsigned)lane; i < (unsigned)F.m; i += 64u) w[(unsigned)Rs.out_ax + i] = 0.0;
+        if (which & 2) for (unsigned i = (unsigned)lane; i < (unsigned)F.n; i += 64u) w[(unsigned)Rs.out_px + i] = 0.0;
+        if (which & 4) for (unsigned i = (unsigned)lane; i < (unsigned)F.n; i += 64u) w[(unsigned)Rs.out_aty + i] = 0.0;
+        cpgw::lds_order();
+#pragma nounroll
+        for (int k = 0; k < 3; k++)
+            if ((which >> k) & 1) run(k == 0 ? Rs.pA : (k == 1 ? Rs.pP : Rs.pAt), k == 0 ? B.cA : (k == 1 ? B.cP : B.cAt));
+        cpgw::lds_order();
+    }
     CPG_DEV double ax(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.m ? w[(unsigned)Rs.out_ax + i] : 0.0; }
     CPG_DEV double px(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.n ? w[(unsigned)Rs.out_px + i] : 0.0; }
     CPG_DEV double atx(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.n ? w[(unsigned)Rs.out_aty + i] : 0.0; }
@@ -698,12 +687,19 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         double rho_stg = F0.rho;
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
+        // (experiments, debug_stage 20: the 100 MHz time stamps of the instance's stages replace its primal results)
+        const bool probe = __builtin_expect(S.debug_stage == 20, 0);
+        unsigned long long ts[8];
+        int n_ts = 0;
+#define CPG_RES_PROBE() do { if (probe && n_ts < 8) ts[n_ts++] = cpgw::clock100(); } while (0)
+        CPG_RES_PROBE();
         ResSetupOut<NSZ> su;
         resident_setup<NSX, NSZ>(R, Rs, B, sl_off, theta, ri_eq, ri_in, ri_fr, lane, su);
         const double cs = su.cs, dconst = su.dconst;
         // (experiments: leave the instance after stage k of its life: 1 set-up, 2 factorisation, 3 coefficients, 4 first iterations)
 #define CPG_RES_STOP_AFTER(k) if (__builtin_expect(S.debug_stage == (k), 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }
         CPG_RES_STOP_AFTER(1)
+        CPG_RES_PROBE();
 
         // ---- 4. - 6.  factorise (call), iterate to the next event (call), test / adapt (call), in osqp_solve's order.  The
         //      instance's state between the calls lives in memory (st); the AGPR-held coefficients survive them by name.
@@ -725,8 +721,10 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         while (o.status == 11) {
             if (need_factor) {
                 resident_factorise(R, Rs, B, sl_off, F0.sigma, lane);
+                CPG_RES_PROBE();
                 if (__builtin_expect(S.debug_stage == 2, 0)) break;
                 resident_store_coefficients(R, Rs, B, sl_off, lane);
+                CPG_RES_PROBE();
                 if (__builtin_expect(S.debug_stage == 3, 0)) break;
                 need_factor = false;
             }
@@ -740,6 +738,7 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
                 } else
                 resident_iterate<NSX, NSZ>(st, rr, B.cf, su.free_rows, sl_off, next_ev - iter, lane);
                 iter = next_ev;
+                CPG_RES_PROBE();
                 if (__builtin_expect(S.debug_stage == 4, 0)) break;
             }
             const bool can_check = chk_int > 0 && iter > 0 && iter % chk_int == 0;
@@ -750,6 +749,7 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
             if (__builtin_expect(S.debug_stage == 9 && !last, 0)) continue;      // (experiments: no test before max_iter)
             for (;;) {
                 const CheckOut oc = resident_check<NSX, NSZ>(F, Rs, B, su.ct, S, st.x, st.z, st.y, st.dx, st.dy, sl_off, lane, approx, &sn);
+                CPG_RES_PROBE();
                 if (approx) { o = oc; break; }
                 if (can_check) { o = oc; if (o.status != 11) break; }
                 if (adapt) {
@@ -776,6 +776,10 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         }
         if (__builtin_expect(S.debug_stage >= 2 && S.debug_stage <= 5, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = iter; } continue; }
         resident_finalize<NSX, NSZ>(F, Bt, st.x, st.z, st.y, dconst, b, sl_off, lane, iter, o, rho);
+        if (probe) {
+            CPG_RES_PROBE();
+            if (lane == 0) for (int k = 0; k < n_ts && k < F0.n_prim; k++) Bt.prim[(size_t)b * F0.n_prim + k] = (double)(ts[k] - ts[0]);
+        }
     }
 }
 #endif  // CPG_GENR_HEADER

@@ -86,6 +86,7 @@ CPG_DEV unsigned mbcnt(unsigned long long mask) {
 CPG_DEV unsigned popc64(unsigned long long m) { return (unsigned)__popcll(m); }
 
 CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
+CPG_DEV unsigned long long clock100() { return __builtin_amdgcn_s_memrealtime(); }      // 100 MHz (timing experiments)
 // max of non-negative doubles in LDS (they order like their bit patterns): ds_max_u64, no return value
 CPG_DEV void lds_max_u64(unsigned long long *p, double v) { atomicMax(p, (unsigned long long)__double_as_longlong(v)); }
 CPG_DEV double u64_as_double(unsigned long long v) { return __longlong_as_double((long long)v); }

@@ -134,6 +134,7 @@ inline void lds_max_u64(unsigned long long *p, double v) {       // (fibers swit
     if (b > *p) *p = b;
 }
 inline double u64_as_double(unsigned long long v) { double d; std::memcpy(&d, &v, 8); return d; }
+inline unsigned long long clock100() { return 0ull; }
 inline void mem_order() { wave_sync(); }
 inline unsigned long long ballot(bool p) {
     SimWave *w = cur->wv;
