@@ -83,6 +83,28 @@ CPG_DEV T uniform_copy(const T &src) {
     return dst;
 }
 struct ResBuf { double *A, *P, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *cA, *cP, *cAt, *cf; };
+// every pointer of a struct that arrived through a call, marked as global memory (cpgw::as_global)
+#define CPG_G(x) x = cpgw::as_global(x)
+CPG_DEV void globalise(ResBuf &B) { CPG_G(B.A); CPG_G(B.P); CPG_G(B.D); CPG_G(B.Dinv); CPG_G(B.E); CPG_G(B.Einv); CPG_G(B.q); CPG_G(B.u); CPG_G(B.rinv); CPG_G(B.cA); CPG_G(B.cP); CPG_G(B.cAt); CPG_G(B.cf); }
+CPG_DEV void globalise(DevStreamTab &T) { CPG_G(T.stab); CPG_G(T.cr); CPG_G(T.src); }
+CPG_DEV void globalise(DevEll &E) { CPG_G(E.idx); CPG_G(E.coef); }
+CPG_DEV void globalise(DevResident &Rs) {
+    CPG_G(Rs.f_ctl); CPG_G(Rs.f_ent); CPG_G(Rs.k_src); CPG_G(Rs.g_src); CPG_G(Rs.g_lcol); CPG_G(Rs.g_cols); CPG_G(Rs.g_rows);
+    globalise(Rs.eP); globalise(Rs.eA); globalise(Rs.eq); globalise(Rs.eu); CPG_G(Rs.entA); CPG_G(Rs.entP);
+    globalise(Rs.pA); globalise(Rs.pP); globalise(Rs.pAt);
+}
+CPG_DEV void globalise(DevRefactor &R) {     // (the members the resident path reads)
+    CPG_G(R.P_base); CPG_G(R.A_base); CPG_G(R.q_base); CPG_G(R.u_base); CPG_G(R.q_setup);
+    CPG_G(R.map_d.ptr); CPG_G(R.map_d.idx); CPG_G(R.map_d.val);
+}
+CPG_DEV void globalise(DevFamily &F) { CPG_G(F.D); CPG_G(F.Dinv); CPG_G(F.E); CPG_G(F.Einv); CPG_G(F.prim_idx); CPG_G(F.dual_idx); CPG_G(F.ord); CPG_G(F.ctype); }
+CPG_DEV void globalise(DevBatch &Bt) {
+    CPG_G(Bt.theta); CPG_G(Bt.prim); CPG_G(Bt.dual); CPG_G(Bt.obj); CPG_G(Bt.pri_res); CPG_G(Bt.dua_res); CPG_G(Bt.iter); CPG_G(Bt.status);
+    CPG_G(Bt.state_in); CPG_G(Bt.state_out);
+}
+#undef CPG_G
+template <class T>
+CPG_DEV T uniform_global_copy(const T &src) { T d = uniform_copy(src); globalise(d); return d; }
 CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, const DevResident &Rs) {
     ResBuf o;
     const size_t n = (size_t)F.n, m = (size_t)F.m;
@@ -241,10 +263,12 @@ template <int NSX, int NSZ>
 CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, unsigned sl_off_v, const double *theta_v,
                                      double ri_eq, double ri_in, double ri_fr, int, ResSetupOut<NSZ> &out) {
     const int lane = cpgw::lane_id();      // (not the argument: the compiler knows this one's range, and folds the bounds tests of full slots)
-    const DevRefactor R = uniform_copy(R_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_);
+    const DevRefactor R = uniform_global_copy(R_); const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
-    const double *theta = (const double *)(((unsigned long long)(unsigned)cpgw::read_first_lane((int)((unsigned long long)theta_v >> 32)) << 32) |
+    const double *theta = nullptr;
+    theta = (const double *)(((unsigned long long)(unsigned)cpgw::read_first_lane((int)((unsigned long long)theta_v >> 32)) << 32) |
                                            (unsigned)cpgw::read_first_lane((int)(unsigned long long)theta_v));
+    theta = cpgw::as_global(theta);
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m, n_eq = CPG_GENR_NEQ;
     double *sl = cpgw::lds_window() + sl_off;
     double *Al = sl, *Pl = Al + CPG_GENR_NNZA, *Dl = Pl + CPG_GENR_NNZP, *El = Dl + n;
@@ -443,7 +467,7 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &R
 // step 4: KKT values into the slice, numeric LDL' + inverses of the merged diagonal blocks
 CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, unsigned sl_off_v, double sigma, int) {
     const int lane = cpgw::lane_id();
-    const DevRefactor R = uniform_copy(R_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_);
+    const DevRefactor R = uniform_global_copy(R_); const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
     double *sl = cpgw::lds_window() + sl_off;
     {
@@ -484,7 +508,7 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R_, const DevResiden
 // results of the termination test's products; q and u of the instance
 CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, unsigned sl_off_v, int) {
     const int lane = cpgw::lane_id();
-    const DevRefactor R = uniform_copy(R_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_);
+    const DevRefactor R = uniform_global_copy(R_); const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
     double *sl = cpgw::lds_window() + sl_off;
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M;
@@ -516,6 +540,48 @@ template <int NSX, int NSZ>
 struct ResState { double x[NSX], z[NSZ], y[NSZ], dx[NSX], dy[NSZ]; };
 struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
 
+// One ADMM iteration on the instance's registers.
+template <int NSX, int NSZ>
+CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ], const double (&cf)[CPG_GENR_NREGS],
+                           const CPG_LDS unsigned short *lc, const CPG_LDS unsigned short *lr, CPG_LDS double *w, const CPG_LDS double *qs,
+                           const CPG_LDS double *us, const ResRho &rr, unsigned free_rows, int lane) {
+    constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
+    double qt[NSX];
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qt[s] = i < n ? qs[i] : 0.0; }
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < n) w[i] = rr.sigma * x[s] - qt[s]; }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const double ri = i < n_eq ? rr.ri_eq : (((free_rows >> s) & 1u) ? rr.ri_fr : rr.ri_in);
+        if (i < m) w[n + i] = z[s] - ri * y[s];
+    }
+    cpgw::lds_order();
+    run_program_res(cf, lc, lr, w, lane);
+#pragma unroll
+    for (int s = 0; s < NSX; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const double xn = i < n ? rr.alpha * w[i] + (1.0 - rr.alpha) * x[s] : 0.0;
+        x[s] = xn;
+    }
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const bool eq = i < n_eq, fr = (free_rows >> s) & 1u;
+        const double rv = eq ? rr.rho_eq : (fr ? rr.rho_fr : rr.rho_in);
+        const double ri = eq ? rr.ri_eq : (fr ? rr.ri_fr : rr.ri_in);
+        const double zp = z[s], yp = y[s];
+        const double zt = (zp - ri * yp) + ri * (i < m ? w[n + i] : 0.0);
+        const double zr = rr.alpha * zt + (1.0 - rr.alpha) * zp;
+        const double uu = i < m ? us[i] : 0.0;
+        const double zn = eq ? uu : cpgw::dmin2(zr + ri * yp, uu);
+        const double dyv = rv * (zr - zn);
+        z[s] = i < m ? zn : 0.0; y[s] = i < m ? yp + dyv : 0.0;
+    }
+    cpgw::lds_order();
+}
+
 // (a real call, ~7 us each -- one per termination test: inlined into the kernel the same loop carried 29 scratch loads and
 // 23 stores per iteration and the default mode ran 95 instead of 65 ms per 20 000 instances, profiles/r4_s5_*)
 #ifndef CPG_RES_ITERATE_LINKAGE
@@ -538,59 +604,38 @@ CPG_RES_ITERATE_LINKAGE void resident_iterate(ResState<NSX, NSZ> &st, const ResR
     CPG_LDS double *w = cpgw::lds_window3() + sl_off;
     const CPG_LDS double *qs = w + ldw, *us = qs + n;
     const ResRho rr = uniform_copy(rr_);
-    const double rho_eq = rr.rho_eq, rho_in = rr.rho_in, rho_fr = rr.rho_fr, ri_eq = rr.ri_eq, ri_in = rr.ri_in, ri_fr = rr.ri_fr;
-    const double sigma_ = rr.sigma, alpha_ = rr.alpha;
     // The coefficients: ~2 registers per step and lane, loaded once per call (one call = the iterations between two
     // termination tests; 74 KB per call on the portfolio family) and held in the wavefront's 512 registers -- which of them
     // are VGPRs and which AGPR copies read through v_accvgpr_read at their use is the compiler's business, in a function
     // that contains nothing but this loop (hand-named AGPRs were tried and dropped: DESIGN.md 4.6)
     double cf[CPG_GENR_NREGS];
 #pragma unroll
-    for (int t = 0; t < CPG_GENR_NREGS; t++) cf[t] = cpgw::gld(cfg, (unsigned)t * 64u + (unsigned)lane);
+    for (int t = 0; t < CPG_GENR_NREGS; t++) cf[t] = cpgw::gld(cpgw::as_global(cfg), (unsigned)t * 64u + (unsigned)lane);
     double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
     for (int s = 0; s < NSX; s++) x[s] = st.x[s];
 #pragma unroll
     for (int s = 0; s < NSZ; s++) { z[s] = st.z[s]; y[s] = st.y[s]; }
+    // count - 1 iterations, then the checked one: ONE copy of the iteration's code (a second copy, or store blocks inside
+    // the loop, cost the loop's register allocation: 22 scratch reloads per iteration); the steps of the checked iteration
+    // are delta x = x(k+1) - x(k), delta y = y(k+1) - y(k), from the iterates saved in front of it
 #pragma nounroll
-    for (int k = 0; k < count; k++) {
-        const bool chk = k == count - 1;       // (wave-uniform: the checked iteration leaves its steps in st)
-        double qt[NSX];
+    for (int pass = 0; pass < 2; pass++) {
+        const int nk = pass == 0 ? count - 1 : (count > 0 ? 1 : 0);
+#pragma nounroll
+        for (int k = 0; k < nk; k++) resident_step<NSX, NSZ>(x, z, y, cf, lc, lr, w, qs, us, rr, free_rows, lane);
+        if (pass == 0) {
 #pragma unroll
-        for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; qt[s] = i < n ? qs[i] : 0.0; }
+            for (int s = 0; s < NSX; s++) st.dx[s] = x[s];
 #pragma unroll
-        for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; if (i < n) w[i] = sigma_ * x[s] - qt[s]; }
-#pragma unroll
-        for (int s = 0; s < NSZ; s++) {
-            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-            const double ri = i < n_eq ? ri_eq : (((free_rows >> s) & 1u) ? ri_fr : ri_in);
-            if (i < m) w[n + i] = z[s] - ri * y[s];
+            for (int s = 0; s < NSZ; s++) st.dy[s] = y[s];
         }
-        cpgw::lds_order();
-        run_program_res(cf, lc, lr, w, lane);
+    }
+    if (count > 0) {
 #pragma unroll
-        for (int s = 0; s < NSX; s++) {
-            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-            const double xn = i < n ? alpha_ * w[i] + (1.0 - alpha_) * x[s] : 0.0;
-            if (chk) st.dx[s] = xn - x[s];
-            x[s] = xn;
-        }
+        for (int s = 0; s < NSX; s++) st.dx[s] = x[s] - st.dx[s];
 #pragma unroll
-        for (int s = 0; s < NSZ; s++) {
-            const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-            const bool eq = i < n_eq, fr = (free_rows >> s) & 1u;
-            const double rv = eq ? rho_eq : (fr ? rho_fr : rho_in);
-            const double ri = eq ? ri_eq : (fr ? ri_fr : ri_in);
-            const double zp = z[s], yp = y[s];
-            const double zt = (zp - ri * yp) + ri * (i < m ? w[n + i] : 0.0);
-            const double zr = alpha_ * zt + (1.0 - alpha_) * zp;
-            const double uu = i < m ? us[i] : 0.0;
-            const double zn = eq ? uu : cpgw::dmin2(zr + ri * yp, uu);
-            const double dyv = rv * (zr - zn);
-            z[s] = i < m ? zn : 0.0; y[s] = i < m ? yp + dyv : 0.0;
-            if (chk) st.dy[s] = i < m ? dyv : 0.0;
-        }
-        cpgw::lds_order();
+        for (int s = 0; s < NSZ; s++) st.dy[s] = y[s] - st.dy[s];
     }
 #pragma unroll
     for (int s = 0; s < NSX; s++) st.x[s] = x[s];
@@ -610,7 +655,7 @@ CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F_, const DevResident 
     // Everything that arrives by reference is copied into locals once, with all loads in flight together: read where it is
     // used, every entry was a flat load from the caller's stack in front of its use -- ~100 memory round trips per test
     // with nobody to hide them (one wavefront per SIMD): 96 us per test (profiles/r4_s3_*).
-    const DevFamily F = uniform_copy(F_); const DevResident Rs = uniform_copy(Rs_); const ResBuf B = uniform_copy(B_); const DevSettings S = uniform_copy(S_);
+    const DevFamily F = uniform_global_copy(F_); const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_); const DevSettings S = uniform_copy(S_);
     double x[NSX], z[NSZ], y[NSZ], dxr[NSX], dyr[NSZ];
     signed char ct[NSZ];
 #pragma unroll
@@ -634,7 +679,7 @@ CPG_DEV_NOINLINE void resident_finalize(const DevFamily &F_, const DevBatch &Bt_
     const int lane = cpgw::lane_id();
     const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
     const long long b = ((long long)cpgw::read_first_lane((int)(b_v >> 32)) << 32) | (unsigned)cpgw::read_first_lane((int)b_v);
-    const DevFamily F = uniform_copy(F_); const DevBatch Bt = uniform_copy(Bt_); const CheckOut o = o_;      // (see resident_check)
+    const DevFamily F = uniform_global_copy(F_); const DevBatch Bt = uniform_global_copy(Bt_); const CheckOut o = o_;      // (see resident_check)
     double x[NSX], z[NSZ], y[NSZ];
 #pragma unroll
     for (int s = 0; s < NSX; s++) x[s] = x_[s];

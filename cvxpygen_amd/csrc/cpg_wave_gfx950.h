@@ -24,6 +24,14 @@ CPG_DEV double *lds_window() {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     return cpg_lds;
 }
+// A pointer that is known to point to global memory, said so in a way the optimiser keeps: the address-space inference
+// rewrites the accesses through a generic pointer that was cast from a global one to global_load / global_store.  Pointers that reach a called function
+// inside a struct are generic to the compiler: their accesses become flat_load, which counts on the LDS counter too --
+// every wait for an LDS read then also waits for the table prefetches in flight.
+template <class T>
+CPG_DEV T *as_global(T *p) {      // (through an integer: a flat address of global memory IS its global address)
+    return (T *)(__attribute__((address_space(1))) T *)(unsigned long long)p;
+}
 CPG_DEV CPG_LDS double *lds_window3() { return (CPG_LDS double *)lds_window(); }
 CPG_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 CPG_DEV int wave_in_block() { return (int)(threadIdx.x >> 6); }

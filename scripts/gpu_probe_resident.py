@@ -12,7 +12,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 stg = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
 d = families.portfolio(100, 10)
 plan = build_family_plan(d)
-lib = os.path.join(ROOT, 'cvxpygen_amd', 'generated', 'portfolio', 'libcpg_portfolio.so')
+lib = os.path.join(ROOT, 'cvxpygen_amd', 'generated', 'portfolio', os.environ.get('CPG_PROBE_LIB', 'libcpg_portfolio.so'))
 pv = bench.portfolio_params(d, B, 1000)
 bs = BatchSolver(d, lib_path=lib, plan=plan)
 r = bs.solve(pv, updated_params=list(pv.keys()), debug_stage=20, **stg)

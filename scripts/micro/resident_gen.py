@@ -20,7 +20,8 @@ if merged:
 else:
     rp = rpl.build_refactor_plan(d.P, d.A, plan.osqp, stage_scale=ss)
     sol = rp.sol
-txt = codegen.emit_instance_program(sol, fam, prefetch_next=os.environ.get('MICRO_PREFETCH', '1') != '0')
+txt = codegen.emit_instance_program(sol, fam, prefetch_next=os.environ.get('MICRO_PREFETCH', '1') != '0',
+                                    gather_batch=int(os.environ.get('MICRO_GATHER_BATCH', 0)), lookahead=int(os.environ.get('MICRO_LOOKAHEAD', 12)))
 open(os.path.join(out, 'cpg_instance_micro.h'), 'w').write(txt)
 steps = execution_steps(sol)
 reg_of, shift_of, nregs = codegen.pack_step_registers(sol, steps)

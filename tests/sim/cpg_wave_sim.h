@@ -27,6 +27,7 @@ namespace cpgw {
 #define CPG_LDS
 inline double *lds_window() { return ::cpg_lds; }
 inline double *lds_window3() { return ::cpg_lds; }
+template <class T> inline T *as_global(T *p) { return p; }
 struct SimBarrier { int count = 0, gen = 0, n = 0; };
 struct SimWave {                 // shared by the 64 fibers of one emulated wavefront
     SimBarrier bar;
