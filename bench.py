@@ -85,6 +85,17 @@ def adp_params(B: int, seed: int):
     return {'f': f, 'G': G}
 
 
+def resident_kernel_in_use(solver) -> bool:
+    """does the per-instance factor handle of this solver run the resident kernel (family library with this family's resident executor)?"""
+    import ctypes as _C
+    h = getattr(solver, 'h_ref', None)
+    if h is None or not h.value:
+        return False
+    v = _C.c_double(0)
+    solver.lib.L.cpg_hip_get_setting(h, b'resident_executor', _C.byref(v))
+    return v.value == 1.0
+
+
 def portfolio_params(desc, B: int, seed: int):
     """per-instance values of examples/portfolio.ipynb cell 7"""
     rng = np.random.default_rng(seed)
@@ -409,7 +420,7 @@ def main():
         try:
             # records are stamped with the fingerprint of the kernel sources and name their kernel: a record taken on
             # other kernels is refused instead of silently replayed (scripts/record_traffic.py writes them)
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r3_hbm_traffic.json')))
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
             key = args.workload + ('_all_params' if args.all_params else '') + ('_fixed_rho' if args.fixed_rho else '')
             rec = tj.get(key)
             if rec and rec['instances'] == B:
@@ -418,7 +429,7 @@ def main():
                     binding = rec.get('binding_resource')
                     traffic_src = f"{rec.get('source')}; kernel {rec.get('kernel')}"
                 else:
-                    traffic_stale = f"record {key} of profiles/r3_hbm_traffic.json was taken on other kernel sources ({rec.get('source_fingerprint')}): refused"
+                    traffic_stale = f"record {key} of profiles/hbm_traffic.json was taken on other kernel sources ({rec.get('source_fingerprint')}): refused"
         except (OSError, ValueError, KeyError):
             pass
         rnote = ('compulsory traffic only (theta in, solution out); the iteration state never leaves '
@@ -428,6 +439,7 @@ def main():
         kernel_name = ('clarabel_kernel' if args.workload == 'adp' else 'osqp_refactor_kernel' if per_instance_kernel else 'osqp_shared_kernel')
         units = B
         stream = None
+        out_plan_extra = {}
         sv = 8 * int(rpl.stats['sol_stream_entries']) if rpl is not None else 0
         phases = None
         if hybrid:
@@ -457,6 +469,20 @@ def main():
                          ', `stream` the coefficients it actually streams per iteration (DESIGN.md section 4.5)'))
             else:
                 k_ms = ms1
+        elif per_instance_kernel and resident_kernel_in_use(solver):
+            # resident per-instance factor kernel (cpg_osqp_resident.h): factor in LDS, substitution coefficients in registers --
+            # no coefficient stream; what it reads from memory per instance beyond SURVEY.md 8(d)'s bytes is in DESIGN.md 4.6
+            kernel_name = 'osqp_resident_kernel'
+            rpl_res = getattr(solver, '_rplan_res', None)
+            stream = None
+            rnote = ('resident per-instance factor kernel: numeric LDL\' + block inverses in LDS, merged substitution program with its '
+                     'coefficients in registers (one wavefront per SIMD, 512 registers); `achieved` prices SURVEY.md 8(d) bytes per instance. '
+                     'Per instance it moves ~100 KB of set-up state once, 74 KB of coefficients per termination test (reloaded into registers) and '
+                     '~60 KB of program-order matrix copies per product of the test -- not the 73 KB PER ITERATION of the streaming kernel '
+                     '(DESIGN.md section 4.6); the kernel is latency bound, not HBM bound')
+            if rpl_res is not None:
+                out_plan_extra = {'resident_phases': int(rpl_res.sol.n_phases), 'resident_steps': int(rpl_res.stats.get('sol_steps', 0)),
+                                  'merged_groups': int(rpl_res.stats.get('merged', 0))}
         elif per_instance_kernel:
             # per-instance factor: every ADMM iteration streams the substitution coefficients of the
             # instance (8 bytes per entry of the streaming layout) from its buffer in HBM
@@ -491,12 +517,12 @@ def main():
                                     'max_iter=4000, check_termination=25, rho=0.1 fixed, cold start'),
                        'parallelism': f'shard{world}', **stats,
                        'library': os.path.relpath(solver.lib.path, ROOT),
-                       'plan': {k: (round(v, 3) if isinstance(v, float) else v)
-                                for k, v in solver.plan.stats.items()}},
+                       'plan': {**{k: (round(v, 3) if isinstance(v, float) else v)
+                                   for k, v in solver.plan.stats.items()}, **out_plan_extra}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': (f'REPLAYED, not measured in this run: bytes per step (all kernels of the step) from the rocprofv3 PMC '
-                                          f'passes recorded in profiles/r3_hbm_traffic.json ({traffic_src})') if traffic else traffic_stale,
+                                          f'passes recorded in profiles/hbm_traffic.json ({traffic_src})') if traffic else traffic_stale,
                          'binding_resource': binding,
                          'kernel': kernel_name, 'kernel_ms': k_ms, 'units_per_launch': int(units),
                          'algorithmic_bytes_per_instance': bytes_per_inst, 'stream': stream,

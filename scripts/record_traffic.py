@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turns the per-kernel FETCH_SIZE / WRITE_SIZE totals of two rocprofv3 --pmc passes (scripts/rocpd_pmc.py output,
-one line per kernel and counter) into a record of profiles/r3_hbm_traffic.json that bench.py replays next to its
+one line per kernel and counter) into a record of profiles/hbm_traffic.json that bench.py replays next to its
 live timing: HBM-side bytes per STEP (all solve kernels of one step), stamped with the fingerprint of the kernel
 sources the measurement was taken on (bench.source_fingerprint) -- bench.py refuses a record whose stamp differs.
 
@@ -27,7 +27,7 @@ def main(key, instances, pmc_file, source=''):
         raise SystemExit(f'no FETCH_SIZE / WRITE_SIZE lines in {pmc_file}')
     fetch = sum(2.0 * 1024.0 * v.get('FETCH_SIZE', 0.0) for v in per_kernel.values())
     write = sum(1024.0 * v.get('WRITE_SIZE', 0.0) for v in per_kernel.values())
-    path = os.path.join(ROOT, 'profiles', 'r3_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     rec = json.load(open(path)) if os.path.exists(path) else {
         '_what': 'HBM-side bytes per bench step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB per dispatch, '
                  'FETCH_SIZE x 2 on gfx950 per MI355X_MICROARCH.md); Infinity-Cache hits are counted; replayed by bench.py only when '
