@@ -85,6 +85,23 @@ def adp_params(B: int, seed: int):
     return {'f': f, 'G': G}
 
 
+BINDING = {
+    # (workload, all parameters per instance, fixed-rho fork)
+    ('mpc12', False, False): 'latency: the dominant kernel (per-instance factor phase, osqp_instance_kernel) keeps no unit busy -- VALU 55 %, LDS 31 %, '
+                             '49 % of the wave cycles waiting, two wavefronts per SIMD at 256 VGPRs; the shared-factor kernel in front of it: LDS pipe '
+                             '81 % busy, 26 % of it bank conflicts (profiles/r3_final7_pmc_config2.txt)',
+    ('mpc12', False, True): 'LDS throughput: SQ_LDS_IDX_ACTIVE 84 % of the CU cycles, 24 % of it bank conflicts; VALU 50 % (profiles/r2_final6_pmc_config2.txt)',
+    ('mpc6', False, False): 'latency (as mpc12: per-instance factor phase behind an LDS-bound shared-factor kernel)',
+    ('portfolio', False, False): 'latency: resident per-instance factor kernel at one wavefront per SIMD (three per CU), a chain of LDS / register '
+                                 'dependencies per ADMM iteration and of memory round trips in its set-up / termination tests; HBM-side traffic 1.3 TB/s = '
+                                 '16 % of the peak (profiles/r4_pmc_config3.txt, r4_probe_stages_config3.txt)',
+    ('portfolio', False, True): 'latency (as the default mode; fewer termination tests and no refactorisations)',
+    ('mpc12', True, False): 'HBM stream + dependent chunk ends: per-instance substitution coefficients read in every iteration on a 242-level chain '
+                            '(profiles/r3_final7_bench_allparams.json)',
+    ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 83 % of the SIMD cycles (profiles/r3_conic_pmc_config4.txt)',
+}
+
+
 def resident_kernel_in_use(solver) -> bool:
     """does the per-instance factor handle of this solver run the resident kernel (family library with this family's resident executor)?"""
     import ctypes as _C
@@ -112,37 +129,74 @@ def make_theta(desc, B: int, seed: int) -> np.ndarray:
     return -2.0 + 4.0 * rng.random((B, p.size))
 
 
+def effective_cpus():
+    """CPUs this process may really use: the scheduler affinity mask and the cgroup CPU quota (a lease on a 256-thread host
+    is often worth a dozen cores: omp_get_max_threads() says 256, the quota decides).  Returns (count, how it was found)."""
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:                                   # cgroup v2
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                               # cgroup v1
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = n_aff if quota is None else max(1, min(n_aff, int(np.ceil(quota))))
+    return n, f'sched_getaffinity {n_aff}' + ('' if quota is None else f', cgroup cpu quota {quota:.1f}')
+
+
+def _cpu_sweep(run, unit_per_probe: int, target_seconds: float, cap: int, unit: str, what: str):
+    """The oracle timed on the box's host cores: single thread first, then a sweep over thread counts (1, 8, 32, the effective
+    CPU count, everything omp sees) on a sample sized for ~target_seconds of the best setting; reports the best rate with
+    the thread count that produced it, the single-thread rate, and the whole sweep -- `cores` is the count that was USED."""
+    from oracle import binding as ob
+    omp_max = int(ob.lib().oracle_num_threads())
+    eff, how = effective_cpus()
+    t1 = run(unit_per_probe, 1, 1)                              # one thread
+    rate1 = unit_per_probe / t1
+    counts = sorted({c for c in (8, 32, eff, omp_max) if 1 < c <= omp_max})
+    budget = max(2.0, 0.6 * target_seconds / max(1, len(counts)))
+    sweep = {1: rate1}
+    for c in counts:
+        Bc = int(max(2 * c, min(cap, budget * rate1 * min(c, eff))))
+        sweep[c] = Bc / run(Bc, 2, c)
+    best = max(sweep, key=sweep.get)
+    Bf = int(max(2 * best, min(cap, 0.4 * target_seconds * sweep[best])))
+    tf = run(Bf, 3, best)
+    return {'value': Bf / tf, 'unit': unit, 'cores': int(best), 'kind': 'port',
+            'single_thread': rate1, 'effective_cpus': int(eff), 'effective_cpus_from': how, 'omp_max_threads': omp_max,
+            'thread_sweep': {str(k): round(v, 1) for k, v in sorted(sweep.items())},
+            'sample': f'{Bf} instances of the same workload ({what}), OpenMP static over instances on {best} threads, {tf:.1f} s wall; '
+                      f'thread sweep on smaller samples beside it'}
+
+
 def cpu_baseline(desc, target_seconds: float = 12.0, **mode):
-    """Oracle (scalar-C restatement of the generated solver, oracle/osqp_oracle.c) on all host cores;
+    """Oracle (scalar-C restatement of the generated solver, oracle/osqp_oracle.c) on the host cores;
     bounded sample of the same workload, same mode (mode: oracle settings, e.g. adaptive_rho=0)."""
     from oracle import binding as ob
     ob.build()
-    cores = ob.lib().oracle_num_threads()
     p = desc.param('x_init')
 
-    def run(B, seed):
+    def run(B, seed, threads):
         th = np.tile(desc.theta0, (B, 1))
         th[:, p.col:p.col + p.size] = make_theta(desc, B, seed)
         t0 = time.time()
-        ob.cpg_solve_batch(desc, th, ['x_init'], nthreads=cores, **mode)
+        ob.cpg_solve_batch(desc, th, ['x_init'], nthreads=threads, **mode)
         return time.time() - t0
-
-    t_probe = run(8 * cores, 1)
-    per_inst = t_probe / (8 * cores)
-    B = int(max(8 * cores, min(200000, target_seconds / max(per_inst, 1e-9))))
-    t = run(B, 2)
-    return {'value': B / t, 'unit': 'QP instances/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'{B} instances of the same workload (same settings, cold start), '
-                      f'OpenMP static over instances, {t:.1f} s wall'}
+    return _cpu_sweep(run, 64, target_seconds, 200000, 'QP instances/s', 'same settings, cold start')
 
 
 def cpu_baseline_portfolio(desc, target_seconds: float = 12.0, **mode):
-    """config 3 on the host: the C oracle with per-instance osqp_update_data_mat, all host cores"""
+    """config 3 on the host: the C oracle with per-instance osqp_update_data_mat"""
     from oracle import binding as ob
     ob.build()
-    cores = ob.lib().oracle_num_threads()
 
-    def run(B, seed):
+    def run(B, seed, threads):
         pv = portfolio_params(desc, B, seed)
         th = np.tile(desc.theta0, (B, 1))
         for nm, v in pv.items():
@@ -150,14 +204,9 @@ def cpu_baseline_portfolio(desc, target_seconds: float = 12.0, **mode):
             for k in range(B):
                 th[k, p.col:p.col + p.size] = desc.flatten_param(nm, v[k])
         t0 = time.time()
-        ob.cpg_solve_batch(desc, th, list(pv.keys()), nthreads=cores, **mode)
+        ob.cpg_solve_batch(desc, th, list(pv.keys()), nthreads=threads, **mode)
         return time.time() - t0
-
-    t_probe = run(2 * cores, 1)
-    B = int(max(2 * cores, min(20000, target_seconds / max(t_probe / (2 * cores), 1e-9))))
-    t = run(B, 2)
-    return {'value': B / t, 'unit': 'QP instances/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'{B} instances of the same workload, OpenMP static over instances, {t:.1f} s wall'}
+    return _cpu_sweep(run, 8, target_seconds, 20000, 'QP instances/s', 'per-instance osqp_update_data_mat')
 
 
 def _adp_chunk(args):
@@ -414,7 +463,9 @@ def main():
             bytes_per_inst = 8 * (27 + 6 + 2) + 32                      # config 4: theta 27, u 6, dual 2, info
         k_ms = float(np.mean(kernel_ms))
         traffic = None          # recorded PMC measurement of the same command (profiles/), not re-measured live
-        binding = None
+        # what binds the dominant kernel, from the PMC passes under profiles/ (a property of the kernel design, reported next to
+        # the contractual HBM figure; the traffic record below is replayed only on matching sources, this is not tied to it)
+        binding = BINDING.get((args.workload, bool(args.all_params), bool(args.fixed_rho)))
         traffic_src = None
         traffic_stale = None
         try:
@@ -426,7 +477,7 @@ def main():
             if rec and rec['instances'] == B:
                 if rec.get('source_fingerprint') == source_fingerprint():
                     traffic = rec['fetch_bytes'] + rec['write_bytes']
-                    binding = rec.get('binding_resource')
+                    binding = rec.get('binding_resource') or binding
                     traffic_src = f"{rec.get('source')}; kernel {rec.get('kernel')}"
                 else:
                     traffic_stale = f"record {key} of profiles/hbm_traffic.json was taken on other kernel sources ({rec.get('source_fingerprint')}): refused"
@@ -446,17 +497,21 @@ def main():
             # two kernels per step; the roofline object describes the one that takes longer
             ms1, ms2, n_ho = phase
             it = res.iter.astype(np.int64)
-            ad = 50
-            it1 = np.minimum(it, ad)          # iterations served by the shared-factor kernel (every instance hands over at its first rho change)
-            ho = it > ad                       # (instances whose estimate stayed inside the tolerance band continue on the shared factor: counted there)
+            from cvxpygen_amd.runtime import BUILD_OPTION_DEFAULTS
+            ad = int({**BUILD_OPTION_DEFAULTS, **build_options}['adaptive_rho_interval'])
+            # ESTIMATE of the iteration split (the kernels record only totals): an instance that runs past the first adaptation point is
+            # counted as handed over there.  Instances whose estimate stays inside the tolerance band hand over later or never -- the
+            # measured number of hand-overs (n_ho) and the two kernel times are what is exact.
+            it1 = np.minimum(it, ad)
+            ho = it > ad
             import ctypes as _C
             gv = _C.c_double(0)
             solver.lib.L.cpg_hip_get_setting(solver.h_rs, b'generated_instance_executor', _C.byref(gv))
             inst_kernel = 'osqp_instance_kernel' if gv.value else 'osqp_refactor_kernel'
             phases = {'shared_factor': {'kernel': 'osqp_shared_kernel', 'ms': ms1, 'instances': B,
-                                        'iterations': int(it1.sum())},
+                                        'iterations_estimate': int(it1.sum())},
                       'per_instance_factor': {'kernel': inst_kernel, 'ms': ms2, 'instances': n_ho,
-                                              'iterations': int((it - it1)[ho].sum()),
+                                              'iterations_estimate': int((it - it1)[ho].sum()), 'handed_over_by_iteration_count': int(ho.sum()),
                                               'note': 'instances handed over after a rho change: numeric LDL\' for the new rho, then ADMM with their own factor'}}
             if ms2 > ms1:
                 kernel_name, units, k_ms = inst_kernel, n_ho, ms2

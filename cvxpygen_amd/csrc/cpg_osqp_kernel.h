@@ -759,7 +759,7 @@ struct ScaledNorms {
 // `sn` (optional) receives the scaled norms of the same products.
 //
 // Two forms, chosen by the context type, because this code is inlined into kernels whose register allocation
-// around their hot loops reacts to it (both measured):
+// around their hot loops reacts to it (both measured, HISTORY.md 4.1c / 4.2):
 //   Ctx::kTestsFirst  (shared-factor kernel)  the caller has run infeasibility_tests() right after the iteration
 //                     and passes the verdicts `iv`; the lane id is re-derived per call (cpgw::opaque) so that the
 //                     dozens of per-lane addresses of the test are computed here and die here;

@@ -165,7 +165,7 @@ struct InstCtx {
     // check() runs the infeasibility tests itself, in OSQP's order, with the caller's lane id: on this kernel the
     // form that keeps the shared-factor kernel spill-free costs the ADMM loop its register allocation
     // (portfolio family: 0.334 instead of 0.293 ms per iteration of 20 000 instances, 30 instead of 2 scratch
-    // instructions per lane and iteration)
+    // instructions per lane and iteration; HISTORY.md 4.2)
     static constexpr bool kTestsFirst = false;
     // ... but the generated instance kernel (QUMEM) gets a per-call lane id in check(): with the kernel-wide one the
     // addresses of the per-row scaling reads (instance-invariant) were computed once outside the instance loop, kept

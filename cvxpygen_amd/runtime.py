@@ -719,7 +719,7 @@ class BatchSolver:
         kernel in shared-matrix mode ("hybrid": two kernels per solve, cpg_hip_set_handover);
         'shared' / 'refactor' force one kernel (a caller that forces 'shared' guarantees that P and A at these
         values are the family's; 'refactor' = every instance equilibrates and factors from iteration 0); q_setup: the unscaled q the workspace held when its matrices were last
-        updated (the cost scaling of OSQP's re-equilibration sees that one)."""
+        updated (the cost scaling of OSQP's re-equilibration sees that one, HISTORY.md 4.3)."""
         desc, p, o = self.desc, self.plan, self.plan.osqp
         if updated_params is None:
             updated_params = desc.param_names

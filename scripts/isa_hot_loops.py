@@ -7,7 +7,7 @@ gfx950 to assembly with the family's definitions and reports, per kernel,
     fit the L2, every reload there is a memory-latency stall in a loop that is a chain of latencies already) and, for
     the streaming kernels, inside the stream loop and in the rest of an iteration,
   * "address-reload sequences": a 64-bit address reloaded from scratch right in front of the global access that uses it
-    -- the signature of instance-invariant addresses computed outside the persistent instance loop.
+    -- the signature of instance-invariant addresses computed outside the persistent instance loop (HISTORY.md 4.5).
 
 This is how round 3's register-sharing, coefficient-load and termination-test changes were judged before they went to
 the GPU (each costs ~2.5 min of hipcc here instead of a GPU session).

@@ -44,30 +44,19 @@ for l in rows:
     seen.add(key)
     print(l)
 
-# compiler-allocated AGPRs (outside the kernel's inline asm) per function: only a0 - a31 may appear in the functions that
-# hold named coefficients (a32 - a255) live without a call boundary in between (cpg_wave_gfx950.h)
+# the function that runs the ADMM iterations: its loop must hold (next to) no scratch access
 import re
-asm = open(out).read().split('\n')
-func, inasm, cnt, low = '', False, {}, {}
-for l in asm:
-    m = re.match(r'^(_Z\w+):', l)
-    if m:
-        func = m.group(1)
-    if '#ASMSTART' in l:
-        inasm = True
-    elif '#ASMEND' in l:
-        inasm = False
-    elif not inasm and 'resident' in func and not l.strip().startswith(';') and re.search(r'[ ,]a\[?\d+', l):
-        hi = max(int(x) for x in re.findall(r'[ ,:]a?\[?(\d+)\]?', ' ' + ' '.join(re.findall(r'a\[\d+:\d+\]|a\d+', l))) or [0])
-        if hi < 32:
-            low[func] = low.get(func, 0) + 1          # (caller-saved a0 - a31: no coefficient lives there)
-            continue
-        cnt[func] = cnt.get(func, 0) + 1
-print('compiler-allocated AGPR operands outside inline asm:')
-bad = False
-for f in sorted(set(x for x in [re.match(r'^(_Z\w+):', l).group(1) for l in asm if re.match(r'^(_Z\w+):', l)] if 'resident' in x)):
-    c = cnt.get(f, 0)
-    must = any(k in f for k in ('resident_iterate', 'resident_store_coefficients', 'osqp_resident_kernel'))
-    print(f'    {f[:70]:70s} {c}' + (f' (+ {low[f]} on a0 - a31)' if f in low else '') + ('   <-- MUST BE 0' if must and c else ''))
-    bad |= bool(must and c)
-sys.exit(1 if bad else 0)
+lines = open(out).read().split('\n')
+a = next(i for i, l in enumerate(lines) if re.match(r'^_Z\w*resident_iterate\w*:', l))
+b = next(i for i in range(a, len(lines)) if lines[i].startswith('.Lfunc_end'))
+labels = {m.group(1): i for i in range(a, b) for m in [re.match(r'^(\.LBB\d+_\d+):', lines[i])] if m}
+best = None
+for i in range(a, b):
+    m = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', lines[i])
+    if m and m.group(1) in labels and labels[m.group(1)] < i:
+        body = [x.strip().split()[0] for x in lines[labels[m.group(1)]:i + 1] if x.startswith('\t') and not x.strip().startswith(('.', ';'))]
+        f64 = sum(1 for x in body if x.startswith(('v_fma_f64', 'v_fmac_f64', 'v_mul_f64', 'v_add_f64')))
+        if f64 >= 100 and (best is None or len(body) < best[0]):
+            best = (len(body), sum(1 for x in body if x.startswith('scratch_load')), sum(1 for x in body if x.startswith('scratch_store')),
+                    sum(1 for x in body if x == 'v_accvgpr_read_b32'), sum(1 for x in body if x.startswith('ds_')))
+print('ADMM loop of resident_iterate: %d instructions, scratch loads / stores %d / %d, AGPR reads %d, LDS operations %d' % best)
