@@ -271,6 +271,7 @@ def main():
     ap.add_argument('--instance-executor', choices=['auto', 'stream', 'generated'], default='auto',
                     help='experiments: executor of the per-instance factor kernel behind the shared-factor one (family libraries)')
     ap.add_argument('--debug-stage', type=int, default=0, help='experiments: the per-instance factor kernel stops after stage k of its set-up (results are garbage)')
+    ap.add_argument('--rccl-timeout', type=float, default=60.0, help='seconds ncclCommInitRank may take before the gather falls back to the host transport')
     ap.add_argument('--rccl-lib', default='librccl.so', help='RCCL library of the result gather (CPU tier: the recording stand-in of tests/sim/fake_rccl)')
     args = ap.parse_args()
 
@@ -372,13 +373,23 @@ def main():
     gather, gather_kind, gather_ms = None, None, 0.0
     Btot = world * B
     if world > 1:
-        from cvxpygen_amd.sharding import RcclGather, result_spec
+        from cvxpygen_amd.sharding import job_key, make_gather, result_spec
         def bcast_uid(raw):        # the RCCL unique id rides on the launcher's process group: no rendezvous file to go stale
             box = [raw]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        gather = RcclGather(solver, rank, world, key=os.environ.get('MASTER_PORT', '0'), lib=args.rccl_lib, uid_exchange=bcast_uid)
-        gather_kind = 'rccl ncclSend/ncclRecv to rank 0 (device memory), on the solve stream'
+        def all_ranks(ok):         # every rank has its communicator, or every rank takes the host transport
+            import torch
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        gather, kind, note = make_gather(solver, rank, world, key=job_key(), lib=args.rccl_lib, uid_exchange=bcast_uid,
+                                         agree=all_ranks, init_timeout=args.rccl_timeout)
+        if kind == 'rccl':
+            gather_kind = 'rccl ncclSend/ncclRecv to rank 0 (device memory), on the solve stream'
+        else:
+            gather_kind = f'host (rccl init failed: {note}): D2H per rank + shared-memory slices read by rank 0'
+            print(f'[bench rank {rank}] RCCL gather not available ({note}); results travel through host shared memory', file=sys.stderr)
         spec = result_spec(dev)
         arrays = [(k, dev._ptrs[k], B, rb) for k, (rb, dt, tail, nm) in spec.items()]
 
@@ -545,6 +556,9 @@ def main():
                       'achieved': stats['mean_iter'] * sv * B / (k_ms * 1e-3) / 1e9}
             rnote = ('`achieved` prices SURVEY.md 8(d) bytes per instance; `stream` the per-instance substitution coefficients read from HBM in every ADMM '
                      'iteration (DESIGN.md section 4.2); the shared index tables stay in L2')
+            if args.workload == 'portfolio' and traffic_src is None:
+                binding = ('HBM stream + latency: streaming per-instance factor kernel (this library carries no resident executor for the family): '
+                           'substitution coefficients re-read from HBM in every ADMM iteration (profiles/r3_final7_pmc_config3.txt)')
         achieved = bytes_per_inst * units / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = world * B * args.steps / elapsed
         out = {

@@ -56,12 +56,28 @@ def _wait_for(path: str, timeout: float = 120.0) -> None:
 # --------------------------------------------------------------------------------------------------
 class HostGather:
     """Gather of row blocks through one shared-memory array per call: rank r writes rows
-    [lo_r, hi_r) (shard_bounds), raises its flag; the root returns the full array."""
+    [lo_r, hi_r) (shard_bounds), raises its flag; the root returns the full array.
 
-    def __init__(self, rank: int, world: int, key: str, root: int = 0):
+    A segment (and its ready file) that a killed run left under the same key must not receive a shard of THIS
+    job: every segment carries a fresh nonce (also the content of its ready file), a rank delivers a random
+    token with its shard and returns only after the root echoed that token into the SAME mapping -- a stale
+    mapping never echoes a fresh token, and the rank re-attaches when the ready file's nonce changes under it."""
+
+    SLOT = 64                                   # header bytes per rank: [0] flag, [8:16] token of the rank, [16:24] echo of the root
+
+    def __init__(self, rank: int, world: int, key: str, root: int = 0, timeout: float = 600.0):
         self.rank, self.world, self.root, self.key = rank, world, root, str(key)
         self._seq = 0
         self.name = 'host_shm'
+        self.timeout = timeout
+
+    @staticmethod
+    def _read(path: str) -> Optional[bytes]:
+        try:
+            with open(path, 'rb') as f:
+                return f.read()
+        except OSError:
+            return None
 
     def gather_rows(self, local: np.ndarray, B: int) -> Optional[np.ndarray]:
         local = np.ascontiguousarray(local)
@@ -70,49 +86,108 @@ class HostGather:
             raise ValueError(f'rank {self.rank} owns {hi - lo} rows, got {local.shape[0]}')
         tail = local.shape[1:]
         row_bytes = int(np.prod(tail, dtype=np.int64)) * local.dtype.itemsize if tail else local.dtype.itemsize
-        hdr = 64 * self.world
+        S = self.SLOT
+        hdr = S * self.world + S                # (+ one slot for the segment's nonce)
+        size = hdr + max(1, B * row_bytes)
         name = f'cpg_{self.key}_{self._seq}'
         self._seq += 1
         ready = f'/dev/shm/{name}.ready'
+        t0 = time.time()
         if self.rank == self.root:
+            nonce = os.urandom(16)
+            if os.path.exists(ready):           # left by a killed run: take it away BEFORE the segment is replaced
+                os.remove(ready)
             try:
-                shm = shared_memory.SharedMemory(name=name, create=True, size=hdr + max(1, B * row_bytes))
+                shm = shared_memory.SharedMemory(name=name, create=True, size=size)
             except FileExistsError:
-                # a segment a killed run left under the same key: nobody of THIS job can be attached yet (the
-                # ready file is written after the segment exists), so it is safe to replace
-                if os.path.exists(ready):
-                    os.remove(ready)
                 stale = shared_memory.SharedMemory(name=name)
                 stale.close(); stale.unlink()
-                shm = shared_memory.SharedMemory(name=name, create=True, size=hdr + max(1, B * row_bytes))
-            shm.buf[:hdr] = bytes(hdr)
-            open(ready, 'w').close()
-        else:
-            _wait_for(ready)
-            shm = shared_memory.SharedMemory(name=name)
-        try:
-            full = np.ndarray((B,) + tail, dtype=local.dtype, buffer=shm.buf, offset=hdr)
-            full[lo:hi] = local
-            shm.buf[64 * self.rank] = 1
-            if self.rank != self.root:
+                shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+            try:
+                shm.buf[:hdr] = bytes(hdr)
+                shm.buf[S * self.world:S * self.world + 16] = nonce
+                with open(ready + '.tmp', 'wb') as f:
+                    f.write(nonce)
+                os.replace(ready + '.tmp', ready)
+                full = np.ndarray((B,) + tail, dtype=local.dtype, buffer=shm.buf, offset=hdr)
+                full[lo:hi] = local
+                others = [r for r in range(self.world) if r != self.root]
+                while not all(shm.buf[S * r] == 1 for r in others):
+                    if time.time() - t0 > self.timeout:
+                        raise TimeoutError('HostGather: a rank did not deliver its shard')
+                    time.sleep(0.0005)
+                out = np.array(full)
                 del full
-                return None
-            t0 = time.time()
-            while not all(shm.buf[64 * r] == 1 for r in range(self.world)):
-                if time.time() - t0 > 600:
-                    raise TimeoutError('HostGather: a rank did not deliver its shard')
-                time.sleep(0.0005)
-            out = np.array(full)
-            del full
-            return out
-        finally:
-            shm.close()
-            if self.rank == self.root:
+                for r in others:                # the echo: "this mapping is the one the root read"
+                    shm.buf[S * r + 16:S * r + 24] = bytes(shm.buf[S * r + 8:S * r + 16])
+                return out
+            finally:
+                shm.close()
                 shm.unlink()
-                os.remove(ready)
+                if os.path.exists(ready):
+                    os.remove(ready)
+        token = os.urandom(8)
+        while True:
+            if time.time() - t0 > self.timeout:
+                raise TimeoutError('HostGather: the root did not take this rank\'s shard')
+            nonce = self._read(ready)
+            if not nonce or len(nonce) != 16:
+                time.sleep(0.001)
+                continue
+            try:
+                shm = shared_memory.SharedMemory(name=name)
+            except FileNotFoundError:
+                time.sleep(0.001)
+                continue
+            try:
+                if shm.size < size or bytes(shm.buf[S * self.world:S * self.world + 16]) != nonce:
+                    time.sleep(0.001)           # segment and ready file of different generations
+                    continue
+                full = np.ndarray((B,) + tail, dtype=local.dtype, buffer=shm.buf, offset=hdr)
+                full[lo:hi] = local
+                del full
+                o = S * self.rank
+                shm.buf[o + 8:o + 16] = token
+                shm.buf[o] = 1
+                while True:
+                    if bytes(shm.buf[o + 16:o + 24]) == token:
+                        return None
+                    if self._read(ready) != nonce and bytes(shm.buf[o + 16:o + 24]) != token:
+                        break                   # the root replaced (or never owned) this segment: deliver again
+                    if time.time() - t0 > self.timeout:
+                        raise TimeoutError('HostGather: the root did not take this rank\'s shard')
+                    time.sleep(0.0005)
+            finally:
+                shm.close()
 
     def close(self) -> None:
         pass
+
+
+class HostDeviceGather(HostGather):
+    """HostGather behind the interface of RcclGather (enqueue / fetch on device result arrays): every rank copies
+    its result rows D2H after its solve and delivers them through the shared-memory slices.  The transport
+    `make_gather` falls back to when the RCCL communicator cannot be created."""
+
+    def __init__(self, solver, rank: int, world: int, key: str, root: int = 0):
+        super().__init__(rank, world, key, root)
+        self.s = solver
+        self._full: Dict[str, Optional[np.ndarray]] = {}
+
+    def enqueue(self, arrays, B: int) -> None:
+        """same arguments as RcclGather.enqueue; synchronous (waits for the solve, copies, gathers)"""
+        s = self.s
+        s.synchronize()
+        for name, d_ptr, rows, row_bytes in arrays:
+            blk = np.empty((rows, row_bytes), dtype=np.uint8)
+            if rows:
+                s.lib.check(s.lib.L.cpg_hip_memcpy_d2h(s.h, blk.ctypes.data_as(C.c_void_p), d_ptr, blk.nbytes), 'd2h')
+            self._full[name] = blk if self.world == 1 else self.gather_rows(blk, B)
+
+    def fetch(self, name: str, d_ptr, row_bytes: int, B: int, dtype, tail=()) -> Optional[np.ndarray]:
+        if self.rank != self.root:
+            return None
+        return np.ascontiguousarray(self._full[name]).reshape(-1).view(dtype).reshape((B,) + tuple(tail))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -127,9 +202,11 @@ class RcclGather:
     NCCL_UINT8 = 1
 
     def __init__(self, solver, rank: int, world: int, key: str, root: int = 0, lib: str = 'librccl.so',
-                 uid_exchange=None):
+                 uid_exchange=None, init_timeout: float = 120.0):
         """uid_exchange(raw: bytes | None) -> bytes: delivers the root's 128-byte RCCL unique id to every rank (the
-        root passes it, the others pass None); default: a /dev/shm file keyed by `key` (see job_key)."""
+        root passes it, the others pass None); default: a /dev/shm file keyed by `key` (see job_key).
+        init_timeout: seconds ncclCommInitRank may take (it is a collective: a peer that never arrives, or a
+        fabric RCCL cannot bring up, would otherwise hang the job) -- TimeoutError after that."""
         self.rank, self.world, self.root, self.key = rank, world, root, str(key)
         self.s = solver
         self.name = 'rccl'
@@ -163,8 +240,23 @@ class RcclGather:
             raw = open(path, 'rb').read()
             C.memmove(C.byref(uid), raw, min(128, len(raw)))
         self.comm = C.c_void_p()
-        self._ck(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), 'ncclCommInitRank')
         self._gbufs: Dict[str, list] = {}      # root: one device gather buffer per named array [ptr, bytes]
+        import threading
+        box: Dict[str, object] = {}
+
+        def init():                            # (a foreign call releases the GIL: the wait below can time out)
+            try:
+                box['rc'] = L.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
+            except BaseException as e:         # noqa: BLE001 -- handed to the caller's thread
+                box['exc'] = e
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(init_timeout)
+        if th.is_alive():
+            raise TimeoutError(f'ncclCommInitRank did not return within {init_timeout:.0f} s')
+        if 'exc' in box:
+            raise box['exc']
+        self._ck(int(box['rc']), 'ncclCommInitRank')
 
     def _ck(self, rc: int, what: str) -> None:
         if rc != 0:
@@ -240,6 +332,39 @@ class RcclGather:
 
 
 # --------------------------------------------------------------------------------------------------
+def make_gather(solver, rank: int, world: int, key: str, root: int = 0, lib: str = 'librccl.so', uid_exchange=None,
+                agree=None, init_timeout: float = 120.0):
+    """The gather of a multi-GPU job: RcclGather when EVERY rank could create its communicator, else
+    HostDeviceGather (D2H + shared-memory slices).  `agree(ok: bool) -> bool` must return the AND over all ranks
+    (e.g. an all-reduce over the launcher's process group); without it each rank decides alone, which is only
+    safe when the failure is the same everywhere (library missing).  Returns (gather, kind, note): kind 'rccl' or
+    'host', note = the reason of the fallback ('' when none)."""
+    g, err = None, ''
+    called = []
+
+    def exchange(raw):
+        called.append(1)
+        return uid_exchange(raw)
+    try:
+        g = RcclGather(solver, rank, world, key=key, root=root, lib=lib, uid_exchange=exchange if uid_exchange is not None else None,
+                       init_timeout=init_timeout)
+    except (OSError, RuntimeError, TimeoutError, AttributeError) as e:
+        err = f'{type(e).__name__}: {e}'
+        if uid_exchange is not None and not called:     # the exchange is a collective of the launcher: take part in it
+            uid_exchange(bytes(128) if rank == root else None)
+    ok = g is not None
+    all_ok = agree(ok) if agree is not None else ok
+    if all_ok:
+        return g, 'rccl', ''
+    if g is not None:                          # another rank failed: this rank's communicator is of no use
+        try:
+            g.close()
+        except Exception:                      # noqa: BLE001
+            pass
+    return HostDeviceGather(solver, rank, world, key=key, root=root), 'host', (err or 'another rank could not create its communicator')
+
+
+# --------------------------------------------------------------------------------------------------
 def result_spec(dev) -> Dict[str, tuple]:
     """device result arrays of a DeviceBatch: key -> (row bytes, dtype, trailing shape, name in the result dict)"""
     return dict(prim=(dev.n_prim * 8, np.float64, (dev.n_prim,), 'prim'), dual=(dev.n_dual * 8, np.float64, (dev.n_dual,), 'dual'),
@@ -256,7 +381,7 @@ def solve_sharded(solver, theta_var: np.ndarray, rank: int, world: int, gather, 
     lo, hi = shard_bounds(B, rank, world)
     local = np.ascontiguousarray(theta_var[lo:hi])
     out: Dict[str, np.ndarray] = {}
-    if isinstance(gather, RcclGather):
+    if isinstance(gather, (RcclGather, HostDeviceGather)):
         solver.apply_settings(**kwargs)
         dev = DeviceBatch(solver, hi - lo)
         dev.upload(local)

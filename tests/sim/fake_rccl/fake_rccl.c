@@ -29,6 +29,7 @@ int ncclGetUniqueId(ncclUniqueId *id) {
     logf_("getuid pid=%d\n", (int)getpid()); return 0; }
 int ncclCommInitRank(void **comm, int world, ncclUniqueId id, int rank) {
     if (id.internal[127] != 7) return 1;                      /* the id must arrive whole */
+    { const char *fr = getenv("CPG_FAKE_RCCL_FAIL_RANK"); if (fr && atoi(fr) == rank) return 2; }   /* test hook: this rank cannot create its communicator */
     fake_comm *c = (fake_comm *)calloc(1, sizeof(fake_comm)); c->rank = rank; c->world = world;
     snprintf(c->tag, sizeof(c->tag), "%s", id.internal + 1); *comm = c;
     logf_("init rank=%d world=%d\n", rank, world); return 0; }

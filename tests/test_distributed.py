@@ -99,19 +99,15 @@ def _fake_rccl():
     return so
 
 
-def test_bench_gpus_2_starts_two_ranks_and_gathers_over_one_rccl(sim_lib, tmp_path):
-    """`python bench.py --gpus 2` (no launcher around it, as the driver calls --gpus 1) must start two ranks by
-    itself, report n_gpus 2, and move every rank's results to the root through ONE communicator: checked on the
-    emulator library with the recording RCCL stand-in (send / receive schedule of RcclGather.enqueue)."""
+def _bench_two_ranks(sim_lib, workload, B, steps, rccl_lib, log=None, extra=()):
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    log = tmp_path / 'rccl.log'
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
-    env['CPG_FAKE_RCCL_LOG'] = str(log)
-    B, steps = 6, 2
+    if log is not None:
+        env['CPG_FAKE_RCCL_LOG'] = str(log)
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', str(steps), '--warmup', '1',
-                        '--workload', 'mpc6', '--batch', str(B), '--lib', sim_lib, '--rccl-lib', _fake_rccl(), '--generic'],
+                        '--workload', workload, '--batch', str(B), '--lib', sim_lib, '--rccl-lib', rccl_lib, '--generic', *extra],
                        capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
@@ -120,10 +116,23 @@ def test_bench_gpus_2_starts_two_ranks_and_gathers_over_one_rccl(sim_lib, tmp_pa
     assert out['n_gpus'] == 2 and out['config']['instances_per_gpu'] == B and out['scaling'] == 'weak'
     assert out['config']['solved'] == 2 * B                  # the root saw both shards' statuses through the gather
     assert out['value'] > 0 and abs(out['ms_per_step'] * steps * out['value'] / 1e3 - 2 * B * steps) < 1e-6 * B
+    return out, p.stderr
+
+
+@pytest.mark.parametrize('workload,B,n_user', [('mpc6', 6, (96, 96)), ('portfolio', 2, (210, 112))])
+def test_bench_gpus_2_starts_two_ranks_and_gathers_over_one_rccl(sim_lib, tmp_path, workload, B, n_user):
+    """`python bench.py --gpus 2` (no launcher around it, as the driver calls --gpus 1) must start two ranks by
+    itself, report n_gpus 2, and move every rank's results to the root through ONE communicator: checked on the
+    emulator library with the recording RCCL stand-in (send / receive schedule of RcclGather.enqueue) -- for the
+    headline workload's family and for config 3's (per-instance factor kernel in front of the gather)."""
+    log = tmp_path / 'rccl.log'
+    steps = 2 if workload == 'mpc6' else 1
+    out, _ = _bench_two_ranks(sim_lib, workload, B, steps, _fake_rccl(), log)
+    assert out['config']['gather'].startswith('rccl')
     txt = log.read_text().splitlines()
     assert sum(ln.startswith('getuid') for ln in txt) == 1 and sum(ln.startswith('init') for ln in txt) == 2   # one id, one communicator per rank
     # per step one group per rank: rank 1 sends its 7 result arrays to rank 0, rank 0 posts the 7 matching receives
-    row_bytes = sorted([8 * 96, 8 * 96, 8, 4, 4, 8, 8])      # prim, dual (MPC 6/3/10: 96 user entries each), obj, iter, status, pri, dua
+    row_bytes = sorted([8 * n_user[0], 8 * n_user[1], 8, 4, 4, 8, 8])      # prim, dual (user entries), obj, iter, status, pri, dua
     sends = [ln for ln in txt if ln.startswith('send')]
     recvs = [ln for ln in txt if ln.startswith('recv')]
     assert len(sends) == len(recvs) == 7 * (steps + 1)
@@ -131,6 +140,52 @@ def test_bench_gpus_2_starts_two_ranks_and_gathers_over_one_rccl(sim_lib, tmp_pa
     first = sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in sends[:7])
     assert first == [B * rb for rb in row_bytes]
     assert sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in recvs[:7]) == first
+
+
+def test_bench_gpus_2_falls_back_to_the_host_gather_when_rccl_cannot_start(sim_lib, tmp_path):
+    """no usable RCCL (library missing; communicator creation failing on one rank only): every rank takes the
+    shared-memory transport, the JSON line says so under config.gather, the results still reach the root"""
+    out, err = _bench_two_ranks(sim_lib, 'mpc6', 4, 1, str(tmp_path / 'no_such_librccl.so'))
+    assert out['config']['gather'].startswith('host (rccl init failed: OSError')
+    assert 'RCCL gather not available' in err
+    # one rank's ncclCommInitRank fails (stand-in: CPG_FAKE_RCCL_FAIL_RANK), the other's succeeds: both must agree on the host transport
+    os.environ['CPG_FAKE_RCCL_FAIL_RANK'] = '1'
+    try:
+        out, err = _bench_two_ranks(sim_lib, 'mpc6', 4, 1, _fake_rccl(), tmp_path / 'r.log')
+    finally:
+        del os.environ['CPG_FAKE_RCCL_FAIL_RANK']
+    assert out['config']['gather'].startswith('host (rccl init failed')
+
+
+def test_host_gather_ignores_the_segment_of_a_killed_run():
+    """a segment AND its ready file left under the same key by a killed run: a rank that attaches to them before the
+    root replaced them must deliver again into the root's segment (token echo), not into the orphan"""
+    import threading
+    from multiprocessing import shared_memory
+    from cvxpygen_amd.sharding import HostGather
+    key = f'stale{os.getpid()}'
+    name = f'cpg_{key}_0'
+    S = HostGather.SLOT
+    hdr = S * 2 + S
+    stale = shared_memory.SharedMemory(name=name, create=True, size=hdr + 6 * 8)
+    stale.buf[:hdr] = bytes(hdr)
+    stale.buf[2 * S:2 * S + 16] = b'0123456789abcdef'
+    with open(f'/dev/shm/{name}.ready', 'wb') as f:
+        f.write(b'0123456789abcdef')
+    stale.close()
+    got = {}
+
+    def rank1():
+        got[1] = HostGather(1, 2, key, timeout=30).gather_rows(np.array([4.0, 5.0, 6.0]), 6)
+    th = threading.Thread(target=rank1)
+    th.start()
+    import time
+    time.sleep(0.3)                                          # rank 1 sits in the orphan by now
+    got[0] = HostGather(0, 2, key, timeout=30).gather_rows(np.array([1.0, 2.0, 3.0]), 6)
+    th.join(30)
+    assert not th.is_alive() and got[1] is None
+    assert got[0].tolist() == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+    assert not os.path.exists(f'/dev/shm/{name}.ready') and not os.path.exists(f'/dev/shm/{name}')
 
 
 def test_bench_single_rank_json_line_carries_the_contract(sim_lib):
