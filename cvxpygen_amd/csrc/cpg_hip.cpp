@@ -82,6 +82,7 @@ struct cpg_solver_s {
     // hybrid execution of rho adaptation (cpg_hip_set_handover): instances of this shared-factor handle whose
     // rho changes continue on `linked`'s per-instance factor kernel, launched behind on this handle's stream
     cpg_solver_s *linked = nullptr;
+    bool flag_rho_changes = false;    // build option: a solve WITHOUT a linked handle may flag rho changes as status -2 instead of refusing
     DevBuf ho_state, ho_list;
     rt_event_t ev_mid{};
     bool two_phase_last = false;
@@ -569,6 +570,7 @@ int cpg_hip_set_build_option(cpg_handle_t h, const char *name, double v) {
     else if (s == "adaptive_rho_interval") h->S.adaptive_rho_interval = h->opt_adaptive_rho_interval = (int)v;
     else if (s == "adaptive_rho_tolerance") h->S.adaptive_rho_tolerance = h->opt_adaptive_rho_tolerance = v;
     else if (s == "check_dualgap") h->S.check_dualgap = h->opt_check_dualgap = (int)v;
+    else if (s == "flag_rho_changes") h->flag_rho_changes = v != 0.0;
     else { set_error("Build option \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
 }
@@ -1629,6 +1631,14 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
     // (cpg_hip_set_handover); without one the kernel flags the instances whose rho changes (status -2) and the
     // host layer re-solves them through the per-instance factor path
     const bool two_phase = h->S.adaptive_rho && h->S.adaptive_rho_interval > 0 && h->linked != nullptr;
+    if (h->S.adaptive_rho && h->S.adaptive_rho_interval > 0 && h->linked == nullptr && !h->flag_rho_changes) {
+        // a shared factor cannot follow a rho change: without a linked per-instance factor handle every instance whose rho
+        // estimate leaves the tolerance band would come back UNSOLVED under the internal status -2 -- refuse instead
+        set_error("rho adaptation is on and this shared-factor handle has no per-instance factor handle linked (cpg_hip_set_handover): "
+                  "link one, or turn it off (cpg_hip_set_build_option(h, \"adaptive_rho\", 0)), or accept instances flagged "
+                  "CPG_STATUS_NEEDS_REFACTOR (-2) with cpg_hip_set_build_option(h, \"flag_rho_changes\", 1)");
+        return CPG_E_UNSUPPORTED;
+    }
     if (two_phase && !h->linked->refactor_mode) { set_error("linked handle has no per-instance factor tables (cpg_hip_set_refactor)"); return CPG_E_BADARG; }
     const int G = h->inst_per_wave;
     const size_t N = (size_t)(h->F.n + h->F.m);

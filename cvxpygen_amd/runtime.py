@@ -367,6 +367,7 @@ class BatchResult:
     sol_x: Optional[np.ndarray] = None      # canonical solution (full_output solvers only)
     sol_y: Optional[np.ndarray] = None
     state: Optional[np.ndarray] = None      # workspace after the solve (solve(..., return_state=True))
+    ctype: Optional[np.ndarray] = None      # ... and the row classes it holds ([B, m] int8; solve(..., ctype_in=...))
 
     def status_str(self) -> List[str]:
         return [STATUS_STRINGS.get(int(s), 'unknown') for s in self.status]
@@ -413,6 +414,7 @@ class BatchSolver:
         keep = self._keep
         D = np.ascontiguousarray(o.scaling.D[p.ordx]); E = np.ascontiguousarray(o.scaling.E[p.ordz])
         ctype = np.ascontiguousarray(o.constr_type[p.ordz], dtype=np.int8)
+        self._family_ctype = np.asarray(o.constr_type, dtype=np.int8)      # canonical order (BatchSolver.row_classes)
         fpos = np.ascontiguousarray(p.kkt.final_pos, dtype=np.uint16)
         prim_idx = np.ascontiguousarray(p.posx if full_output else p.prim_idx, dtype=np.int32)
         dual_idx = np.ascontiguousarray(p.posz if full_output else p.dual_idx, dtype=np.int32)
@@ -918,9 +920,14 @@ class BatchSolver:
     def solve(self, params: Optional[Dict[str, np.ndarray]] = None,
               updated_params: Optional[Sequence[str]] = None, B: Optional[int] = None,
               theta_var: Optional[np.ndarray] = None, state_in: Optional[np.ndarray] = None,
-              return_state: bool = False, **kwargs) -> BatchResult:
+              return_state: bool = False, ctype_in: Optional[np.ndarray] = None, **kwargs) -> BatchResult:
         """state_in / return_state: the workspace a sequential caller carries from solve to solve
-        ([B, n + 2 m + 1]: scaled iterates x | z | y in canonical order, then rho; include/cpg_hip.h)."""
+        ([B, n + 2 m + 1]: scaled iterates x | z | y in canonical order, then rho; include/cpg_hip.h).
+        ctype_in [B, m] (int8): the row classes that workspace held (`BatchResult.ctype` of its previous solve; default:
+        the family's, i.e. a workspace that never saw a class change).  OSQP's update_rho_vec rebuilds rho_vec from
+        settings->rho -- the family's rho, restored by every cpg_solve -- when a bound moved a row to another class
+        (oracle/osqp_oracle.c set_rho_vec): instances whose classes differ from ctype_in therefore start from that rho,
+        not from the adapted one in state_in."""
         if not (updated_params is None and theta_var is not None and self._update_key is not None):
             self.set_updated(updated_params)      # None = every parameter, as in the reference
         self.apply_settings(**kwargs)
@@ -930,6 +937,15 @@ class BatchSolver:
         Bn = theta_var.shape[0] if theta_var.ndim == 2 and self.np_var else (B or theta_var.shape[0])
         if self.np_var and theta_var.shape != (Bn, self.np_var):
             raise ValueError(f'theta_var must have shape (B, {self.np_var})')
+        ctype = None
+        if (state_in is not None or return_state) and self.desc.solver == 'OSQP':
+            ctype = self.row_classes(theta_var, Bn)
+            if state_in is not None:
+                prev = self._family_ctype[None, :] if ctype_in is None else np.asarray(ctype_in).reshape(Bn, -1)
+                moved = (ctype != prev).any(axis=1)
+                if moved.any():
+                    state_in = np.array(state_in, dtype=np.float64)
+                    state_in[moved, -1] = min(max(self.plan.osqp.settings['rho'], 1e-6), 1e6)
         t0 = time.time()
         out = self._solve_on(self.h, theta_var, Bn, state_in, return_state)
         t1 = time.time()
@@ -938,7 +954,27 @@ class BatchSolver:
         self._resolve_class_changes(theta_var, out, state_in)
         res = self._result(*out[:7], t1 - t0, ms.value)
         res.state = out[7]
+        res.ctype = ctype
         return res
+
+    def row_classes(self, theta_var: np.ndarray, Bn: int) -> np.ndarray:
+        """[B, m] int8 classes of the constraint rows at these parameter values, as OSQP's update_rho_vec sees them
+        (-1 free, 1 equality, 0 inequality) with the scaling E of the family.  (After a matrix update the workspace's
+        E is the instance's own; a bound of +-1e30 and l == u classify the same under any admissible E in
+        [1e-4, 1e4], only a row with 0 < E (u - l) < 1e-4 could differ.)"""
+        d, o = self.desc, self.plan.osqp
+        th = np.tile(self._th_fixed[:d.NP + 1], (Bn, 1))
+        if self.np_var:
+            th[:, self._var_cols] = theta_var
+        E = np.asarray(o.scaling.E, dtype=np.float64)
+        u = np.clip(np.asarray((sp.csr_matrix(d.maps['u']) @ th.T).T), -CPG_INF, CPG_INF)
+        l = np.full_like(u, -CPG_INF)
+        if d.n_eq:
+            l[:, :d.n_eq] = np.clip(np.asarray((sp.csr_matrix(d.maps['l']) @ th.T).T), -CPG_INF, CPG_INF)
+        ls, us = l * E, u * E
+        free = (ls < -CPG_INF * 1e-4) & (us > CPG_INF * 1e-4)
+        eq = ~free & (us - ls < 1e-4)
+        return np.where(free, -1, np.where(eq, 1, 0)).astype(np.int8)
 
     def _solve_on(self, hh, theta_var, Bn, state_in, return_state):
         n_prim, n_dual = self.n_out_prim, self.n_out_dual
@@ -971,6 +1007,7 @@ class BatchSolver:
         # update_rho_vec refactors K, nothing else): the workspace's matrices, a factor per instance
         self._set_refactor(self._var_cols, self._th_fixed, self._q_setup, shared_mats=True)
         self._apply_settings_to(self.h_rs)
+        # (state_in: `solve` has already put the family's rho where the classes differ from the ones the workspace held)
         sub = self._solve_on(self.h_rs, np.ascontiguousarray(theta_var[bad]), len(bad),
                              None if state_in is None else state_in[bad], out[7] is not None)
         for k in range(8):

@@ -161,8 +161,8 @@ class GeneratedSolver:
             bs.set_updated(None, q_setup=ws['q_setup'], path=path)
             # the workspace always goes in: warm_starting = 0 (osqp_cold_start) zeroes the iterates only, the rho
             # its last adapt_rho left -- and the factor that goes with it -- stay (the kernels read the setting)
-            res = bs.solve(theta_var=theta_var, B=1, state_in=ws['state'], return_state=True, **kwargs)
-            ws['state'] = res.state
+            res = bs.solve(theta_var=theta_var, B=1, state_in=ws['state'], return_state=True, ctype_in=ws.get('ctype'), **kwargs)
+            ws['state'], ws['ctype'] = res.state, res.ctype
             if 'q' in ws['outdated']:
                 ws['q_ws'] = np.asarray(desc.canon_at(ws['theta'])['q'], dtype=np.float64)
         ws['outdated'] = set()

@@ -285,7 +285,15 @@ int cpg_hip_set_build_option(cpg_handle_t h, const char *name, double value);
  * TWO kernels back to back on h's stream: the shared-factor kernel serves every instance until OSQP's adapt_rho
  * changes its rho (iterations 1 .. interval always; for as long as the estimate stays inside [rho / tolerance,
  * rho * tolerance] after that) and hands the others -- workspace, iteration count -- to the per-instance factor
- * kernel, which refactors K for the new rho and continues.  per_instance == NULL unlinks. */
+ * kernel, which refactors K for the new rho and continues.  per_instance == NULL unlinks.
+ *
+ * !! A handle from cpg_hip_create_osqp has adaptive_rho ON (the library default the reference links).  Solving on a
+ * !! shared-factor handle (cpg_hip_set_update) with it on and NO handle linked here is refused with CPG_E_UNSUPPORTED by
+ * !! every solve entry point (cpg_hip_solve_batch, _device, the pipelined one): a shared factor cannot follow a rho change,
+ * !! so those instances could only come back unsolved.  Either link a per-instance factor handle, or switch adaptation
+ * !! off (cpg_hip_set_build_option(h, "adaptive_rho", 0)), or opt in to the flagging protocol with
+ * !! cpg_hip_set_build_option(h, "flag_rho_changes", 1): the solve then returns CPG_OK and every instance whose rho would
+ * !! have changed carries status CPG_STATUS_NEEDS_REFACTOR (-2) and NO solution -- the caller must re-solve those. */
 int cpg_hip_set_handover(cpg_handle_t h, cpg_handle_t per_instance);
 /* split of the most recent solve on `h`: kernel time of the two phases and the number of instances handed over
  * (0 / 0 when the solve ran one kernel) */

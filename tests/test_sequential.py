@@ -186,6 +186,32 @@ def test_drop_in_sequence_on_a_vector_only_family(sim_lib, oracle_lib, tmp_path)
     assert iters[2] <= iters[0]                                       # a nearby problem does not converge slower warm
 
 
+def test_row_class_change_after_an_adapted_rho_restarts_from_the_family_rho(sim_lib, oracle_lib, tmp_path):
+    """call 1 adapts the workspace's rho (0.1 -> 1.66); call 2 frees the upper bound (ub = 1e30: the row changes class):
+    OSQP's update_rho_vec rebuilds rho_vec from settings->rho -- 0.1 again after the per-call reset of the settings --
+    and not from the adapted value the workspace carries; call 3 makes the bound finite again (oracle/osqp_oracle.c
+    set_rho_vec; cvxpygen/solvers/osqp.py:100-101)"""
+    d = families.toy_box()
+    prob = LiteProblem.from_descriptor(d)
+    cpg.generate_code(prob, code_dir=str(tmp_path / 'seq_cls'), solver='OSQP', wrapper=False)
+    mod = cpg.load_generated(str(tmp_path / 'seq_cls'), prob)
+    mod._SOLVER.lib_path = sim_lib
+    ses = oracle_lib.CpgSession(d)
+    seq = [({'a': 1000.0, 'lb': -1.0, 'ub': 1.0}, None), ({'ub': 1e30}, ['ub']), ({'ub': 2.0}, ['ub'])]
+    rhos = []
+    for k, (upd, names) in enumerate(seq):
+        for nm, v in upd.items():
+            prob.param_dict[nm].value = np.array(v)
+        val = prob.solve(method='CPG', updated_params=names, eps_abs=1e-9, eps_rel=1e-9)
+        o = ses.solve({nm: np.array(v) for nm, v in upd.items()}, eps_abs=1e-9, eps_rel=1e-9)
+        assert prob._solution.attr['num_iters'] == o['iter'] and prob.status == 'solved', k
+        assert abs(val - o['obj_val']) <= 1e-9 * max(1.0, abs(o['obj_val'])), k
+        ws = mod._SOLVER._workspace()['state']
+        assert abs(ws[0, -1] - o['rho']) <= 1e-9 * o['rho'], k
+        rhos.append(o['rho'])
+    assert rhos[0] > 1.0 and rhos[1] < 0.1                             # adapted up, then restarted at 0.1 and adapted down
+
+
 def _three_call_sequence_with_a_rho_change(lib_path, oracle_lib, tmp_path, wrapper):
     """the reference's static workspace under OSQP >= 1.0 (solvers/osqp.py:100-101): every call resets the SETTINGS
     (rho back to 0.1), the workspace keeps the rho and factor of its last adapt_rho.  Call 1 adapts rho (MPC: the

@@ -291,3 +291,50 @@ def test_shared_mode_plan_follows_the_library(sim_lib, tmp_path):
         bs.solve({'x_init': x0}, updated_params=['x_init'])
         assert bs._hybrid and bs._rplan_s.sol.fingerprint() == want
         bs.close()
+
+
+def test_raw_entry_points_refuse_rho_adaptation_on_a_shared_factor_handle_without_a_linked_one(sim_lib, oracle_lib):
+    """the C entry points driven WITHOUT the host layer's re-solve (device and pipelined paths): a shared-factor handle
+    with rho adaptation on and no per-instance factor handle linked is refused (CPG_E_UNSUPPORTED, loud message) instead
+    of returning CPG_OK with unsolved status -2 rows; opting in (build option flag_rho_changes) gives exactly the rows
+    whose rho changed as -2; with adaptation off every row is solved (include/cpg_hip.h, cpg_hip_set_handover)"""
+    import ctypes as C
+    from cvxpygen_amd.runtime import DeviceBatch, PinnedStream
+    d = families.mpc(6, 3, 10)
+    B = 6
+    x0 = -2 + 4 * np.random.default_rng(3).random((B, 6))
+    bs = BatchSolver(d, lib_path=sim_lib)
+    bs.set_updated(['x_init'])
+    L = bs.lib.L
+    dev = DeviceBatch(bs, B)
+    dev.upload(x0)
+
+    def raw_status():
+        bs.solve_device(dev); bs.synchronize()
+        st = np.empty(B, dtype=np.int32)
+        bs.lib.check(L.cpg_hip_memcpy_d2h(bs.h, st.ctypes.data_as(C.c_void_p), dev._ptrs['status'], st.nbytes), 'd2h')
+        it = np.empty(B, dtype=np.int32)
+        bs.lib.check(L.cpg_hip_memcpy_d2h(bs.h, it.ctypes.data_as(C.c_void_p), dev._ptrs['iter'], it.nbytes), 'd2h')
+        return st, it
+    o, _, _ = _oracle_flat(oracle_lib, d, _theta(d, 'x_init', x0), ['x_init'])
+    st, it = raw_status()                                   # linked (what the host layer sets up): two kernels, nothing flagged
+    assert st.tolist() == o['status'].tolist() and it.tolist() == o['iter'].tolist() and (o['iter'] > 50).any()
+    bs.lib.check(L.cpg_hip_set_handover(bs.h_shared, None), 'cpg_hip_set_handover')
+    with pytest.raises(RuntimeError, match=r'\(-4\).*cpg_hip_set_handover'):
+        bs.solve_device(dev)
+    ps = PinnedStream(bs, B, 2)
+    ps.theta[:] = np.tile(x0, (2, 1))
+    with pytest.raises(RuntimeError, match='cpg_hip_set_handover'):
+        ps.run()
+    bs.lib.check(L.cpg_hip_set_build_option(bs.h_shared, b'flag_rho_changes', 1.0), 'cpg_hip_set_build_option')
+    st2, _ = raw_status()
+    assert (st2 == -2).any() and ((st2 == -2) <= (o['iter'] > 50)).all()      # only instances that reached the first adaptation
+    keep = st2 != -2
+    assert st2[keep].tolist() == o['status'][keep].tolist()
+    bs.lib.check(L.cpg_hip_set_build_option(bs.h_shared, b'flag_rho_changes', 0.0), 'cpg_hip_set_build_option')
+    bs.lib.check(L.cpg_hip_set_build_option(bs.h_shared, b'adaptive_rho', 0.0), 'cpg_hip_set_build_option')
+    st3, _ = raw_status()
+    assert (st3 == 1).all()
+    ps.run()
+    assert (np.array(ps.status) == 1).all()
+    ps.free(); dev.free(); bs.close()
