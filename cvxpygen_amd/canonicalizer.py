@@ -115,7 +115,11 @@ def descriptor_from_reduced(name: str, solver: str, n_var: int, n_eq: int, n_ine
 
 
 def descriptor_from_cvxpy(problem, solver: str = 'OSQP', solver_opts=None, name: str = 'problem') -> FamilyDescriptor:
-    """`Canonicalizer._extract` (`canonicalizer.py:86-122`) for the OSQP and CLARABEL forms."""
+    """`Canonicalizer._extract` (`canonicalizer.py:86-122`) for the OSQP, CLARABEL and ECOS forms.  `solver_opts` has the
+    reference's meaning: cvxpy canonicalisation options, forwarded verbatim to `get_problem_data` (`canonicalizer.py:89-95`);
+    its `use_quad_obj` entry also decides whether a conic solver keeps a quadratic objective (`canonicalizer.py:418-426`).
+    ECOS (`solvers/ecos.py:20-22, 75-84`): the chain of cvxpy's ECOS interface hands over the same [A | b] data as any conic
+    solver; the rows of the zero cone become A x = b, the others G x + s = h (`_interface.py:132-173`, `ecos_front.py`)."""
     import warnings
     import cvxpy as cp
     from cvxpy.reductions.solvers.conic_solvers.conic_solver import ConicSolver
@@ -128,17 +132,19 @@ def descriptor_from_cvxpy(problem, solver: str = 'OSQP', solver_opts=None, name:
         from cvxpy.reductions.solvers.solving_chain import SolverInverseData
     except ImportError:                                     # older cvxpy
         SolverInverseData = ()
-    if solver not in ('OSQP', 'CLARABEL'):
+    if solver not in ('OSQP', 'CLARABEL', 'ECOS'):
         raise ValueError(f'Unsupported solver: {solver}.')
     data, _, inverse_data = problem.get_problem_data(solver=solver, gp=False, enforce_dpp=True, verbose=False,
                                                      solver_opts=solver_opts)
     pp = data['param_prob']
     if not pp.parameters:
         raise ValueError('Solution does not depend on parameters. Aborting code generation.')
-    conic = solver == 'CLARABEL'
+    conic = solver in ('CLARABEL', 'ECOS')
     cones = None
     if conic:
         cd = pp.cone_dims
+        if solver == 'ECOS' and cd.exp > 0:                  # `solvers/ecos.py:121-125`
+            raise ValueError('Code generation with ECOS and exponential cones is not supported yet.')
         if cd.exp or len(cd.psd) or len(getattr(cd, 'p3d', [])):
             raise NotImplementedError('exponential / PSD / power cones are not supported by the HIP interior-point kernel')
         n_var, n_eq, n_ineq = int(pp.x.size), int(cd.zero), int(data['A'].shape[0]) - int(cd.zero)
@@ -211,12 +217,20 @@ def descriptor_from_cvxpy(problem, solver: str = 'OSQP', solver_opts=None, name:
         duals.append(UserDual(f'd{k}', (off_of[did] + np.arange(c.size)).astype(np.int32), shape, 'z' if conic else 'y'))
 
     P_index = pp.reduced_P.problem_data_index
-    quad = P_index is not None and (not conic or problem.objective.expr.has_quadratic_term())
-    return descriptor_from_reduced(
-        name, solver, n_var, n_eq, n_ineq,
+    # `canonicalizer.py:418-426`: quadratic solvers always; conic ones when they support it (Clarabel does, ECOS does
+    # not: `supports_quad_obj`), the user did not switch it off and the objective has a quadratic term
+    use_quad_obj = solver_opts.get('use_quad_obj', True) if solver_opts else True
+    quad = P_index is not None and (not conic or (bool(use_quad_obj) and solver == 'CLARABEL'
+                                                  and problem.objective.expr.has_quadratic_term()))
+    desc = descriptor_from_reduced(
+        name, 'CLARABEL' if conic else solver, n_var, n_eq, n_ineq,
         pp.reduced_P.reduced_mat if quad else None, P_index if quad else None,
         pp.q, pp.reduced_A.reduced_mat, pp.reduced_A.problem_data_index, theta0, params, variables, duals,
         isinstance(problem.objective, cp.Maximize), cones)
+    if solver == 'ECOS':
+        from .ecos_front import ecos_from_conic
+        desc = ecos_from_conic(desc)
+    return desc
 
 
 def reduced_from_descriptor(desc: FamilyDescriptor):

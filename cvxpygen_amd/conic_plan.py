@@ -81,12 +81,6 @@ def matrix_views(P: sp.csc_matrix, A: sp.csc_matrix):
 
 
 def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
-    from .solve_program import PLAN_LOCK as _lock
-    with _lock:                       # the planner's stage costs are module state: one plan at a time (solve_program.PLAN_LOCK)
-        return _build_conic_plan_unlocked(desc, ordering)
-
-
-def _build_conic_plan_unlocked(desc, ordering: str = 'auto') -> ConicPlan:
     if not desc.cones:
         raise ValueError('not a conic family')
     for key, val in desc.cones.items():

@@ -281,12 +281,6 @@ def shared_mode_plan(Ps: sp.csc_matrix, As: sp.csc_matrix, osqp: _setup.OsqpPlan
 
 
 def build_refactor_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPlan, stage_scale: Optional[float] = None) -> RefactorPlan:
-    from .solve_program import PLAN_LOCK as _lock
-    with _lock:                       # the planner's stage costs are module state: one plan at a time (solve_program.PLAN_LOCK)
-        return _build_refactor_plan_unlocked(P, A, osqp, stage_scale)
-
-
-def _build_refactor_plan_unlocked(P: sp.csc_matrix, A: sp.csc_matrix, osqp: _setup.OsqpPlan, stage_scale: Optional[float] = None) -> RefactorPlan:
     n, m = P.shape[0], A.shape[0]
     N = n + m
     P, A = sp.csc_matrix(P), sp.csc_matrix(A)

@@ -160,12 +160,11 @@ class ResidentPlan:
 
 def build_resident_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp, stage_scale: Optional[float] = None,
                         groups: Optional[List[Tuple[int, int]]] = None) -> ResidentPlan:
-    with _sp.PLAN_LOCK:
-        return _build(P, A, osqp, stage_scale, groups)
+    return _build(P, A, osqp, stage_scale, groups)
 
 
 def _build(P, A, osqp, stage_scale, groups) -> ResidentPlan:
-    base = _rp._build_refactor_plan_unlocked(P, A, osqp)
+    base = _rp.build_refactor_plan(P, A, osqp)
     n, m, nnzL = base.n, base.m, base.nnzL
     N = n + m
     Lp, Li, Lcol = base.Lp.astype(np.int64), base.Li.astype(np.int64), base.Lcol.astype(np.int64)

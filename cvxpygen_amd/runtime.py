@@ -42,7 +42,7 @@ STATUS_NEEDS_REFACTOR = -2
 # OSQP settings the generated shim has no setter for: the defaults of the OSQP library the solver is linked
 # with, restored by every cpg_solve (osqp_set_default_settings, cvxpygen/solvers/osqp.py:100-101).  The reference
 # requires osqp >= 1.0 (pyproject.toml:26; its emitted calls are the 1.0 API): rho adapted every 50 iterations,
-# tolerance 5, duality-gap test.  `build_options` / generate_code(solver_opts=...) override.
+# tolerance 5, duality-gap test.  `build_options` / generate_code(osqp_build_options=...) override.
 BUILD_OPTIONS = ('adaptive_rho', 'adaptive_rho_interval', 'adaptive_rho_tolerance', 'check_dualgap')
 BUILD_OPTION_DEFAULTS = {'adaptive_rho': 1, 'adaptive_rho_interval': 50, 'adaptive_rho_tolerance': 5.0, 'check_dualgap': 1}
 # the other reading of the reference's default (a solver generated against an OSQP whose codegen never adapts rho)
@@ -262,13 +262,6 @@ def _instance_fingerprints(lib_path: str, stem: str = 'cpg_instance', prefix: st
 
 
 def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
-                      setup_settings: Optional[Dict[str, float]] = None, bank_layout: bool = True) -> FamilyPlan:
-    from .solve_program import PLAN_LOCK as _lock
-    with _lock:                       # the planner's stage costs are module state: one plan at a time (solve_program.PLAN_LOCK)
-        return _build_family_plan_unlocked(desc, ordering, merge, setup_settings, bank_layout)
-
-
-def _build_family_plan_unlocked(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
                       setup_settings: Optional[Dict[str, float]] = None, bank_layout: bool = True) -> FamilyPlan:
     t0 = time.time()
     n, m, n_eq = desc.n_var, desc.m, desc.n_eq

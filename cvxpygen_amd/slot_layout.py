@@ -67,6 +67,24 @@ def store_groups(out_slots: np.ndarray, no_row: int) -> List[np.ndarray]:
     return out
 
 
+_SOURCE_VERSION = None
+
+
+def _source_version() -> bytes:
+    """digest of this module's source: part of the disk cache key of `optimise`, so that a change of the annealer
+    (temperatures, move rule, best-seen logic) cannot silently reuse layouts -- and with them family-library
+    fingerprints -- of the version before"""
+    global _SOURCE_VERSION
+    if _SOURCE_VERSION is None:
+        import hashlib
+        try:
+            with open(__file__, 'rb') as f:
+                _SOURCE_VERSION = hashlib.sha256(f.read()).digest()
+        except OSError:
+            _SOURCE_VERSION = b'unknown'
+    return _SOURCE_VERSION
+
+
 def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed: int = 0,
              stores: List[np.ndarray] = ()) -> Tuple[np.ndarray, int, int]:
     """Returns (pi, cost before, cost after).  pi[slot] = new position; pi permutes the slots of every
@@ -81,6 +99,7 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
     import hashlib
     import os
     hsh = hashlib.sha256()
+    hsh.update(_source_version())               # the annealer itself: a cached layout of another version of this file is not reused
     for a_ in (np.ascontiguousarray(step_slots, dtype=np.int64), np.ascontiguousarray(region, dtype=np.int64),
                np.asarray([sweeps, seed, BANK_PAIRS, STORE_BANK_PAIRS], dtype=np.int64),
                *[np.ascontiguousarray(g_, dtype=np.int64) for g_ in stores]):

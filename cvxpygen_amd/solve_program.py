@@ -42,12 +42,15 @@ import scipy.sparse as sp
 import os as _os
 import threading as _threading
 
-# The planner's stage costs are module state that pack_ragged(stage_scale=...) changes for the duration of a call, and
-# __graft_entry__.build() / generate_code plan several families from worker threads: without this lock one family's
-# solve program was planned with another call's scaled costs (a header whose fingerprint no later process reproduces:
-# "this library was generated for a different problem family"), or the costs stayed scaled for good.
-_PLAN_LOCK = _threading.RLock()
-PLAN_LOCK = _PLAN_LOCK          # held by the plan builders around a whole plan (runtime.build_family_plan, refactor_plan, conic_plan)
+# The planner's stage costs: pack_ragged(stage_scale=...) changes them for the duration of a call, and
+# __graft_entry__.build() / generate_code plan several families from worker threads.  They are therefore PER THREAD
+# (`_costs`): a scaled call of one thread is invisible to the plans the others are building, and no plan builder has to
+# serialise on a lock (round 3 held one around every whole plan, annealing included).
+class _Costs(_threading.local):
+    def __init__(self):
+        self.stage = STAGE_COST
+        self.group = GROUP_STAGE_COST
+
 
 LANES = 64
 # cost model of the packer, in units of one multiply-add step of a wavefront (environment overrides are
@@ -115,7 +118,7 @@ def _chunk_plan(lens: Sequence[int]) -> Tuple[float, int, List[Tuple[int, int, L
                 ln = int(-(-lens[sel].max() // gv)) if len(sel) else 0
                 ln = max(ln, 1)
                 chunks.append((int(gv), ln, [int(v) for v in sel]))
-                cost += ln + CHUNK_COST + GROUP_STAGE_COST * np.log2(gv)
+                cost += ln + CHUNK_COST + _costs.group * np.log2(gv)
         if best is None or cost < best[0]:
             best = (cost, len(chunks), chunks)
     return best
@@ -345,8 +348,7 @@ def assign_slots(phases: List[Phase], N: int, slot_perm: Optional[np.ndarray] = 
 
 def pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None,
          slot_perm: Optional[np.ndarray] = None) -> PackedProgram:
-    with _PLAN_LOCK:               # (reads the stage costs: see pack_ragged)
-        return _pack(phases, natural, N, slot_perm)
+    return _pack(phases, natural, N, slot_perm)
 
 
 def _pack(phases: List[Phase], natural: bool = False, N: Optional[int] = None,
@@ -475,7 +477,8 @@ class RaggedProgram:
 DPP_ROW = 16            # cross-lane shifts of the segmented reduction stay inside 16-lane DPP rows
 SEG_KMAX = 8            # lanes per row in a balanced chunk (3 mask bits next to a 13-bit slot)
 AUTO_BALANCED_MARGIN = float(_os.environ.get('CPG_AUTO_BALANCED_MARGIN', 0.9))
-STAGE_COST = float(_os.environ.get('CPG_STAGE_COST', 1.0))       # one stage of the segmented reduction
+STAGE_COST = float(_os.environ.get('CPG_STAGE_COST', 1.0))       # one stage of the segmented reduction (default of _costs.stage)
+_costs = _Costs()
 
 
 def _balanced_layout(lens: np.ndarray, seg_len: int):
@@ -537,7 +540,7 @@ def _balanced_plan(lens: Sequence[int]):
         cost = 0.0
         for ch in chunks:
             kmax = max(k for (_, _, k, _) in ch)
-            cost += ch[0][3] + CHUNK_COST + STAGE_COST * int(np.ceil(np.log2(kmax))) if kmax > 1 else ch[0][3] + CHUNK_COST
+            cost += ch[0][3] + CHUNK_COST + _costs.stage * int(np.ceil(np.log2(kmax))) if kmax > 1 else ch[0][3] + CHUNK_COST
         if best is None or cost < best[0]:
             best = (cost, chunks)
     return best
@@ -547,8 +550,7 @@ def _balanced_plan(lens: Sequence[int]):
 
 def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0,
                 slot_perm: Optional[np.ndarray] = None) -> RaggedProgram:
-    with _PLAN_LOCK:
-        return _pack_ragged(phases, N, balanced, stage_scale, slot_perm)
+    return _pack_ragged(phases, N, balanced, stage_scale, slot_perm)
 
 
 def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0,
@@ -559,14 +561,13 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
     stage_scale scales what the planner charges for a reduction stage relative to a step: the
     executors whose steps are memory requests (run_program_stream) want fewer, wider steps than the
     LDS-resident one the defaults were tuned on."""
-    global STAGE_COST, GROUP_STAGE_COST
     if stage_scale != 1.0:
-        saved = (STAGE_COST, GROUP_STAGE_COST)
-        STAGE_COST, GROUP_STAGE_COST = saved[0] * stage_scale, saved[1] * stage_scale
+        saved = (_costs.stage, _costs.group)
+        _costs.stage, _costs.group = saved[0] * stage_scale, saved[1] * stage_scale
         try:
             return _pack_ragged(phases, N, balanced, slot_perm=slot_perm)
         finally:
-            STAGE_COST, GROUP_STAGE_COST = saved
+            _costs.stage, _costs.group = saved
     outs, ins, n_slots, final_pos = assign_slots(phases, N, slot_perm)
     if n_slots * 8 > 0xFFFF:
         raise NotImplementedError('work vector too large for 16-bit byte offsets')

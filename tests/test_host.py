@@ -341,9 +341,10 @@ def test_coefficient_register_sharing_of_the_instance_executor(make):
 
 def test_plans_built_from_worker_threads_equal_the_sequential_ones():
     """__graft_entry__.build() and generate_code plan families from worker threads while pack_ragged(stage_scale=...)
-    changes the planner's module-level stage costs for the duration of a call: every plan builder holds one lock
-    (solve_program.PLAN_LOCK).  Without it a family's solve program came out planned with another call's costs -- a
-    header whose fingerprint no later process reproduces ("generated for a different problem family")."""
+    changes the planner's stage costs for the duration of a call: the costs are per thread (solve_program._costs), so the
+    plans of concurrent builders do not see each other's scaled values and nobody serialises on a lock.  With module-level
+    costs a family's solve program came out planned with another call's costs -- a header whose fingerprint no later
+    process reproduces ("generated for a different problem family")."""
     from concurrent.futures import ThreadPoolExecutor
     from cvxpygen_amd import refactor_plan as _rp, solve_program as _spm
     from cvxpygen_amd.conic_plan import build_conic_plan
@@ -359,7 +360,8 @@ def test_plans_built_from_worker_threads_equal_the_sequential_ones():
                 _rp.build_refactor_plan(d.P, d.A, plan.osqp).sol.fingerprint())
     seq = [prints(mk) for mk in makes]
     conic = build_conic_plan(families.adp()).sol.fingerprint()
-    costs = (_spm.STAGE_COST, _spm.GROUP_STAGE_COST)
+    costs = (_spm._costs.stage, _spm._costs.group)
+    assert costs == (_spm.STAGE_COST, _spm.GROUP_STAGE_COST)
     for _ in range(2):
         with ThreadPoolExecutor(max_workers=7) as ex:
             futs = [ex.submit(prints, mk) for mk in makes + makes]
@@ -367,4 +369,71 @@ def test_plans_built_from_worker_threads_equal_the_sequential_ones():
             got = [f.result() for f in futs]
             assert fc.result() == conic
         assert got == seq + seq
-        assert (_spm.STAGE_COST, _spm.GROUP_STAGE_COST) == costs           # nothing left scaled
+        assert (_spm._costs.stage, _spm._costs.group) == costs            # nothing left scaled
+
+
+def test_cvxpy_front_door_forwards_solver_opts_and_routes_ecos(tmp_path):
+    """`generate_code(cvxpy.Problem, solver=..., solver_opts=...)`: solver_opts are cvxpy's canonicalisation options and
+    reach `problem.get_problem_data` verbatim (cvxpygen/canonicalizer.py:86-94), the OSQP build options travel under
+    their own keyword; solver='ECOS' goes through cvxpy's ECOS chain and comes out in the ECOS form c, d, A, b, G, h
+    with y / z duals (solvers/ecos.py:20-22, 75-84); `use_quad_obj` is honoured (canonicalizer.py:418-426).  cvxpy is
+    not in the image: the problem objects are the test double of tests/sim/fake_cvxpy.py, built from hand-canonicalised
+    families, so this checks the front door's plumbing, not cvxpy's canonicalisation."""
+    import json
+    import warnings
+    from sim import fake_cvxpy
+    from cvxpygen_amd import cpg
+    from cvxpygen_amd.descriptor import FamilyDescriptor
+    from cvxpygen_amd.ecos_front import ecos_from_conic
+    remove = fake_cvxpy.install()
+    try:
+        def same(a, b):
+            assert (a.solver, a.n_var, a.n_eq, a.n_ineq, a.is_maximization) == (b.solver, b.n_var, b.n_eq, b.n_ineq, b.is_maximization)
+            assert set(a.maps) == set(b.maps)
+            for k in a.maps:
+                assert abs(sp.csr_matrix(a.maps[k]) - sp.csr_matrix(b.maps[k])).max() == 0, k
+            assert np.array_equal(a.A.indices, b.A.indices) and np.array_equal(a.A.indptr, b.A.indptr)
+            assert [(v.name, v.indices.tolist()) for v in a.variables] == [(v.name, v.indices.tolist()) for v in b.variables]
+            assert [(u.vec, np.ravel(u.indices).tolist()) for u in a.duals] == [(u.vec, np.ravel(u.indices).tolist()) for u in b.duals]
+            assert [(q.name, q.col, q.size) for q in a.params] == [(q.name, q.col, q.size) for q in b.params]
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            # OSQP: solver_opts forwarded, build options under their own keyword
+            d = families.mpc(2, 1, 3)
+            prob = fake_cvxpy.Problem(d)
+            opts = {'use_quad_obj': True, 'some_cvxpy_option': 7}
+            cpg.generate_code(prob, code_dir=str(tmp_path / 'q'), solver='OSQP', solver_opts=opts, wrapper=False,
+                              osqp_build_options={'adaptive_rho': 0, 'check_dualgap': 0})
+            assert prob.calls == [dict(solver='OSQP', gp=False, enforce_dpp=True, verbose=False, solver_opts=opts)]
+            same(FamilyDescriptor.load(str(tmp_path / 'q' / 'descriptor.npz')), d)
+            assert json.load(open(tmp_path / 'q' / 'osqp_build.json')) == {'adaptive_rho': 0.0, 'check_dualgap': 0.0}
+            prob2 = fake_cvxpy.Problem(d)                        # solver_opts are NOT read as build options any more
+            cpg.generate_code(prob2, code_dir=str(tmp_path / 'q2'), solver='OSQP', solver_opts={'adaptive_rho': 0}, wrapper=False)
+            assert json.load(open(tmp_path / 'q2' / 'osqp_build.json')) == {}
+            with pytest.raises(ValueError, match='unknown OSQP build option'):
+                cpg.generate_code(fake_cvxpy.Problem(d), code_dir=str(tmp_path / 'q3'), solver='OSQP', wrapper=False,
+                                  osqp_build_options={'use_quad_obj': False})
+            # CLARABEL and ECOS from the same conic problem
+            c = families.adp()
+            pc = fake_cvxpy.Problem(c)
+            cpg.generate_code(pc, code_dir=str(tmp_path / 'c'), solver='CLARABEL', wrapper=False)
+            assert pc.calls[0]['solver'] == 'CLARABEL' and pc.calls[0]['solver_opts'] is None
+            same(FamilyDescriptor.load(str(tmp_path / 'c' / 'descriptor.npz')), c)
+            c = families.adp_norm(tie=True)                    # (no quadratic objective: ECOS has none)
+            pe = fake_cvxpy.Problem(c)
+            cpg.generate_code(pe, code_dir=str(tmp_path / 'e'), solver='ECOS', solver_opts={'x': 1}, wrapper=False)
+            assert pe.calls == [dict(solver='ECOS', gp=False, enforce_dpp=True, verbose=False, solver_opts={'x': 1})]
+            e = FamilyDescriptor.load(str(tmp_path / 'e' / 'descriptor.npz'))
+            assert e.solver == 'ECOS' and set(e.maps) == {'c', 'd', 'A', 'b', 'G', 'h'} and {u.vec for u in e.duals} <= {'y', 'z'}
+            same(e, ecos_from_conic(c))
+    finally:
+        remove()
+    # the same routing from the cvxpy-free front door: a conic LiteProblem asked for solver='ECOS'
+    from cvxpygen_amd.lite import LiteProblem
+    c = families.adp_norm(tie=True)
+    lp = LiteProblem.from_descriptor(c)
+    cpg.generate_code(lp, code_dir=str(tmp_path / 'le'), solver='ECOS', wrapper=False)
+    e = FamilyDescriptor.load(str(tmp_path / 'le' / 'descriptor.npz'))
+    assert e.solver == 'ECOS' and e.n_eq == c.cones['zero'] and e.n_ineq == c.m - c.cones['zero']
+    with pytest.raises(ValueError, match='canonicalised for OSQP'):
+        cpg.generate_code(LiteProblem.from_descriptor(families.mpc(2, 1, 3)), code_dir=str(tmp_path / 'bad'), solver='ECOS', wrapper=False)
