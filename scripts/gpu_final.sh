@@ -1,0 +1,54 @@
+#!/bin/bash
+# THE measurement session of the current tree (run last in a round, on the final sources):
+#   gpurun --timeout 2700 -- 'CPG_OUT=r4final bash scripts/gpu_final.sh'
+# GPU test tier with its full log, smoke, the bench line of every BASELINE config (default mode; fixed-rho fork of configs 2 / 3),
+# rocprofv3 kernel stats and PMC passes (FETCH_SIZE, WRITE_SIZE, SQ activity, instruction mix -- one pass each, never combined
+# with a trace domain) of config 2, config 3 and the all-parameters MPC, and the traffic records bench.py replays
+# (profiles/hbm_traffic.json, stamped with the fingerprint of these sources).  Copy what should be judged from
+# gpurun_out/$CPG_OUT into profiles/.  CPG_SKIP="tests pmc" leaves parts out.
+set -u
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd $R
+OUT=gpurun_out/${CPG_OUT:-final}; mkdir -p $OUT; export TMPDIR=/tmp
+SKIP=" ${CPG_SKIP:-} "
+P="import sys,json; d=json.loads(sys.stdin.read()); ph=d.get('phases') or {}; print(round(d['value']), round(d['ms_per_step'],2), d['config'].get('mean_iter'), d['config'].get('solved'), d['roofline']['kernel'], {k:(round(v['ms'],2), v['instances']) for k,v in ph.items()}, (d.get('fixed_rho') or {}).get('value'), d.get('wall_pcie',{}).get('value'), (d.get('cpu_baseline') or {}).get('value'), d.get('adjoint'), d.get('check'))"
+if [[ "$SKIP" != *" tests "* ]]; then
+  echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -rA 2>&1 | grep -v "^$" | tail -80 | tee $OUT/pytest_gpu.txt | tail -4
+  echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt
+fi
+B="timeout 600 python $R/bench.py --no-cpu-baseline --no-wall --no-fixed-rho-leg"
+echo "== config 2 default mode (cpu baseline, wall, fixed-rho leg, check)"; timeout 900 python bench.py --check 2>&1 | tail -1 | tee $OUT/bench_config2.json | python -c "$P"
+echo "== config 2 fixed-rho fork"; $B --fixed-rho 2>&1 | tail -1 | tee $OUT/bench_config2_fixed_rho.json | python -c "$P"
+echo "== config 3 portfolio 20k (cpu baseline, check)"; timeout 900 python bench.py --no-wall --no-fixed-rho-leg --workload portfolio --batch 20000 --steps 3 --warmup 1 --check 2>&1 | tail -1 | tee $OUT/bench_config3_20k.json | python -c "$P"
+echo "== config 3 portfolio 125k shard"; $B --workload portfolio --batch 125000 --steps 2 --warmup 1 2>&1 | tail -1 | tee $OUT/bench_config3_125k.json | python -c "$P"
+echo "== config 3 fixed-rho fork 20k"; $B --workload portfolio --batch 20000 --steps 3 --warmup 1 --fixed-rho 2>&1 | tail -1 | tee $OUT/bench_config3_20k_fixed_rho.json | python -c "$P"
+echo "== config 4 ADP (cpu baseline)"; timeout 600 python bench.py --no-wall --workload adp 2>&1 | tail -1 | tee $OUT/bench_config4.json | python -c "$P"
+echo "== config 5 adjoint"; $B --adjoint 2>&1 | tail -1 | tee $OUT/bench_config5.json | python -c "$P"
+echo "== mpc12 all parameters"; $B --all-params --batch 20000 --steps 3 --warmup 1 2>&1 | tail -1 | tee $OUT/bench_allparams.json | python -c "$P"
+if [[ "$SKIP" != *" pmc "* ]]; then
+  C="python $R/bench.py --no-cpu-baseline --no-wall --no-fixed-rho-leg"
+  prof() {   # prof <tag> <rocprofv3 args ...> -- <bench args>: one pass, db summarised by the caller
+    local tag=$1; shift; ( cd /tmp && timeout 400 rocprofv3 "$@" > $R/$OUT/$tag.log 2>&1 ); }
+  W2=""; W3="--workload portfolio --batch 20000"; WA="--all-params --batch 20000"
+  for cfg in 2 3 A; do
+    eval "W=\$W$cfg"
+    prof prof$cfg --kernel-trace --stats -d $R/$OUT/prof$cfg -o trace -- $C $W --steps 3 --warmup 1
+    prof pmc_f$cfg --pmc FETCH_SIZE -d $R/$OUT/pmc_f$cfg -o pmc -- $C $W --steps 2 --warmup 1
+    prof pmc_w$cfg --pmc WRITE_SIZE -d $R/$OUT/pmc_w$cfg -o pmc -- $C $W --steps 2 --warmup 1
+    prof pmc_a$cfg --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $R/$OUT/pmc_a$cfg -o pmc -- $C $W --steps 2 --warmup 1
+    prof pmc_b$cfg --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU -d $R/$OUT/pmc_b$cfg -o pmc -- $C $W --steps 2 --warmup 1
+    name=config$cfg; [ $cfg = A ] && name=allparams
+    f=$(find $OUT/prof$cfg -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocpd_summary.py $f | tee $OUT/kernel_stats_$name.txt
+    for d in f w a b; do f=$(find $OUT/pmc_$d$cfg -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocpd_pmc.py $f '%osqp%'; done | tee $OUT/pmc_$name.txt
+    rm -rf $OUT/prof$cfg $OUT/pmc_f$cfg $OUT/pmc_w$cfg $OUT/pmc_a$cfg $OUT/pmc_b$cfg
+  done
+  SRC="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on python bench.py --no-cpu-baseline --no-wall --no-fixed-rho-leg"
+  python scripts/record_traffic.py mpc12 100000 $OUT/pmc_config2.txt "$SRC --steps 2 --warmup 1, session $OUT"
+  python scripts/record_traffic.py portfolio 20000 $OUT/pmc_config3.txt "$SRC $W3 --steps 2 --warmup 1, session $OUT"
+  python scripts/record_traffic.py mpc12_all_params 20000 $OUT/pmc_allparams.txt "$SRC $WA --steps 2 --warmup 1, session $OUT"
+  cp profiles/hbm_traffic.json $OUT/hbm_traffic.json
+  echo "== bench lines with the stamped traffic"
+  $B 2>&1 | tail -1 | tee $OUT/bench_config2_traffic.json | python -c "$P"
+  $B $W3 --steps 3 --warmup 1 2>&1 | tail -1 | tee $OUT/bench_config3_20k_traffic.json | python -c "$P"
+  $B $WA --steps 3 --warmup 1 2>&1 | tail -1 | tee $OUT/bench_allparams_traffic.json | python -c "$P"
+fi
+echo "== done"
