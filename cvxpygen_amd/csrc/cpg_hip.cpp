@@ -600,8 +600,8 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     else if (s == "adaptive_rho_tolerance") *v = h->S.adaptive_rho_tolerance;
     else if (s == "check_dualgap") *v = h->S.check_dualgap;
     // (read-only facts about the handle) 1: per-instance solves of this handle run the generated instance executor
-    else if (s == "resident_executor") *v = (h->refactor_mode && h->Rs.ok && h->program_in_lds != 0) ? 1.0 : 0.0;
-    else if (s == "generated_instance_executor") *v = (h->refactor_mode && h->R.gi_ok && h->program_in_lds != 0) ? 1.0 : 0.0;
+    else if (s == "resident_executor") *v = (h->refactor_mode && h->Rs.ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
+    else if (s == "generated_instance_executor") *v = (h->refactor_mode && h->R.gi_ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
 }
@@ -1468,7 +1468,7 @@ static int ensure(DevBuf &b, size_t bytes) {
 }
 
 int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds) {
-    if (!h || in_lds < -1 || in_lds > 1) { set_error("in_lds must be -1, 0 or 1"); return CPG_E_BADARG; }
+    if (!h || in_lds < -1 || in_lds > 2) { set_error("in_lds must be -1, 0, 1 or 2"); return CPG_E_BADARG; }
     h->program_in_lds = in_lds;
     return CPG_OK;
 }
@@ -1487,7 +1487,7 @@ static cpg::DevBatch make_batch(int64_t B, const double *d_theta, const double *
 static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, cpg::DevBatch &Bt) {
     const int W = 4;
 #ifdef CPG_GENR_HEADER
-    if (h->Rs.ok && !h->R.shared_mats && h->program_in_lds != 0) {
+    if (h->Rs.ok && !h->R.shared_mats && h->program_in_lds != 0 && h->program_in_lds != 2) {
         // resident kernel: one workgroup per CU, as many wavefronts (<= 4: one per SIMD) as slices fit the LDS
         const size_t tab = (size_t)(((CPG_GENR_NSTEPS + 3) / 4) * 256 + ((CPG_GENR_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
         const size_t slice = (size_t)h->Rs.slice_doubles * sizeof(double);
@@ -1508,7 +1508,7 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
     }
 #endif
 #ifdef CPG_GENI_HEADER
-    if (h->R.gi_ok && h->program_in_lds != 0) {
+    if (h->R.gi_ok && h->program_in_lds != 0 && h->program_in_lds != 2) {
         const int W = 8;                               // one workgroup of eight wavefronts per CU shares the tables       // generated instance executor (cpg_hip_set_program_placement(0): the streaming one)
         const size_t tab = (size_t)(((CPG_GENI_NSTEPS + 3) / 4) * 256 + ((CPG_GENI_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
         const size_t nq = (size_t)(h->F.n + h->F.m);
@@ -1674,12 +1674,13 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
     // table-driven kernels, automatic placement: the streaming executor (program through L2, operands
     // of eight steps in flight, more resident waves) beats the LDS-resident table walk -- 1.44 M vs
     // 1.10 M instances/s on MPC 12/4/10; the LDS-resident form remains for G = 2 and on request
+    const int placement = h->program_in_lds == 2 ? -1 : h->program_in_lds;     // (2 concerns per-instance factor handles only)
 #ifdef CPG_GEN_HEADER
     const bool prefer_stream = false;   // family library: the generated executor works on the LDS-resident program
 #else
-    const bool prefer_stream = h->program_in_lds == -1 && G == 1 && h->F.kkt_stream.n_pairs > 0;
+    const bool prefer_stream = placement == -1 && G == 1 && h->F.kkt_stream.n_pairs > 0;
 #endif
-    if (h->program_in_lds != 0 && R.n_chunks > 0 && !prefer_stream) {
+    if (placement != 0 && R.n_chunks > 0 && !prefer_stream) {
         const size_t fixed = N * 8 + prog_bytes;
         int wfit = fixed < h->lds_limit ? (int)((h->lds_limit - fixed) / per_wave) : 0;
         // every slot class has an LDS kernel for <= 8 waves (<= 4 for G = 2 on the larger classes);
@@ -1694,10 +1695,10 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
         }
 #endif
         if (wfit > wcap) wfit = wcap;
-        if (wfit >= 4 || (h->program_in_lds == 1 && wfit >= 1)) {
+        if (wfit >= 4 || (placement == 1 && wfit >= 1)) {
             in_lds = true;
             if (W <= 0 || W > wfit) W = wfit;
-        } else if (h->program_in_lds == 1) {
+        } else if (placement == 1) {
             set_error("solve program does not fit into LDS next to the work vectors"); return CPG_E_UNSUPPORTED;
         }
     }

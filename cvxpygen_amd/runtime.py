@@ -697,7 +697,8 @@ class BatchSolver:
                 self.lib.check(self.lib.L.cpg_hip_set_launch(hh, *self._launch), 'set_launch')
 
     def set_program_placement(self, in_lds: int = -1):
-        """-1 automatic, 0 stream the solve program from L2/HBM, 1 keep it resident in LDS"""
+        """-1 automatic, 0 stream the solve program from L2/HBM, 1 keep it resident in LDS, 2 (per-instance factor
+        handles) the streaming executor with its entry words in LDS instead of a generated executor"""
         self._placement = in_lds
         for hh in (self.h_shared, self.h_ref, self.h_rs):
             if hh is not None and hh.value:

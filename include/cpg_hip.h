@@ -362,7 +362,10 @@ int cpg_hip_last_kernel_ms(cpg_handle_t h, float *ms);
 int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, int blocks_per_cu);
 /* where the solve program lives: 0 = streamed through L2, 1 = resident in LDS (one workgroup per
  * CU; fails if it does not fit), -1 = the library's choice (family library with a generated executor:
- * LDS resident; table-driven kernels: streamed for one instance per wave, which measures faster) */
+ * LDS resident; table-driven kernels: streamed for one instance per wave, which measures faster);
+ * 2 = per-instance factor handles only: the streaming executor with its shared entry words in LDS even when the
+ * library carries a generated (instance / resident) executor for the family -- the kernel those replaced, kept
+ * selectable for comparison */
 int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds);
 
 /* ---- device memory helpers for the device-resident variant ---------------------------------------- */
