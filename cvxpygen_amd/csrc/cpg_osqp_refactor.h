@@ -534,6 +534,13 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         double rho_stg = F0.rho;        // (a resumed instance: see where `iter` starts)
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
+        // (experiments, generated instance kernel only, debug_stage 20: 100 MHz time stamps of the instance's stages replace
+        // its first primal results -- scripts/gpu_probe_instance.py)
+        const bool probe = GENI && __builtin_expect(S.debug_stage == 20, 0);
+        unsigned long long ts[8];
+        int n_ts = 0;
+#define CPG_INST_PROBE() do { if (GENI && probe && n_ts < 8) ts[n_ts++] = cpgw::clock100(); } while (0)
+        CPG_INST_PROBE();
         // ---- 1. canonicalise (unscaled; scaled in shared-matrix mode): P, A values, q, u, d
         if (!shared) {
             for (unsigned k = (unsigned)lane; k < (unsigned)R.nnzA; k += 64u) cpgw::gst(B.A, k, csr_row(R.map_A, k, theta, cpgw::gld(R.A_base, k)));
@@ -673,11 +680,13 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             cpgw::lds_order();
         };
         if (__builtin_expect(S.debug_stage == 2, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }     // (row classes, rho_vec)
+        CPG_INST_PROBE();          // 1: canonicalised, row classes
         if (GENI) factor_in_lds();
         else
 #endif
         factor_generic();
         if (__builtin_expect(S.debug_stage == 3, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }     // (factorised, coefficients loaded)
+        CPG_INST_PROBE();          // 2: factorised, coefficients in registers
 
         // ---- 6. ADMM from cold start with the instance's own factor
         DevFamily F = F0;
@@ -759,6 +768,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             cpgw::lds_order();
         };
         const int chk_int = S.check_termination, ad_int = S.adaptive_rho ? S.adaptive_rho_interval : 0;
+        CPG_INST_PROBE();          // 3: workspace loaded
         // The iterations between two events (termination check, rho adaptation, max_iter) run in their own
         // inner loop: the check (row products, norms, infeasibility tests) needs many registers, and with
         // its code inside the hot loop the iterates were spilled and reloaded in every iteration.
@@ -773,6 +783,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 iter++;
                 admm_iteration(true);
             }
+            CPG_INST_PROBE();      // 4 (6, ...): iterations up to the next event
             const bool can_check = chk_int > 0 && iter > 0 && iter % chk_int == 0;
             const bool adapt = ad_int > 0 && iter > 0 && iter % ad_int == 0;
             const bool last = iter >= S.max_iter;
@@ -781,6 +792,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             if (can_check) {
                 o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
                 have_info = true;
+                CPG_INST_PROBE();  // 5 (7, ...): termination test
                 if (o.status != 11) break;
             }
             if (adapt) {
@@ -810,6 +822,11 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             }
         }
         finalize<NSX, NSZ, GENI>(F, Bt, x, z, y, dconst, b, w, lane, iter, o, rho);     // (per-call lane id in the generated instance kernel, see InstCtx)
+        if (GENI && probe) {
+            CPG_INST_PROBE();      // last: results written
+            if (lane == 0) for (int k = 0; k < n_ts && k < F0.n_prim; k++) Bt.prim[(size_t)b * F0.n_prim + k] = (double)(ts[k] - ts[0]);
+            if (lane == 0 && n_ts < F0.n_prim) Bt.prim[(size_t)b * F0.n_prim + n_ts] = -1.0;
+        }
     }
 }
 
