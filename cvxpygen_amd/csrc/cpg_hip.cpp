@@ -1122,7 +1122,12 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
 #ifdef CPG_GENI_HEADER
     std::vector<unsigned short> gcols, grows, glcol;
     std::vector<unsigned> gsrc;
-    if (r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
+#ifdef CPG_GENI_N
+    const bool geni_dims = h->F.n == CPG_GENI_N && h->F.m == CPG_GENI_M && h->F.n_eq == CPG_GENI_NEQ;
+#else
+    const bool geni_dims = true;
+#endif
+    if (geni_dims && r->shared_mats && r->sol_chunks == CPG_GENI_NCHUNKS && r->sol_nnz == CPG_GENI_NNZ && r->sol_slots == CPG_GENI_NSLOTS) {
         const unsigned hsh = program_fingerprint(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz);
         static const int steps[][4] = CPG_GENI_STEPS;             // {first entry, active lanes, coefficient register, lane shift} in execution order
         static const int chunk_shift[] = CPG_GENI_CHUNK_SHIFT;

@@ -460,11 +460,29 @@ CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, 
 // instances, 4 bytes next to every 8-byte coefficient) get a block-shared LDS copy, one workgroup of eight wavefronts
 // per CU.  With the per-instance coefficient streams of the resident wavefronts flowing through it the L2 does not keep
 // that table: config 3 refetched it for every instance and iteration (a third of its FETCH_SIZE).
+// a value every lane holds alike (rho: loaded per lane from the instance's workspace, or computed from wave-wide norms), moved
+// to scalar registers: the step sizes derived from it then cost no VGPRs in the ADMM loop of the generated instance kernel
+CPG_DEV double uniform_double(double v) {
+    int w2[2];
+    __builtin_memcpy(w2, &v, 8);
+    w2[0] = cpgw::read_first_lane(w2[0]); w2[1] = cpgw::read_first_lane(w2[1]);
+    __builtin_memcpy(&v, w2, 8);
+    return v;
+}
+
 template <int NSX, int NSZ, bool GENI = false, bool SHARED = GENI, bool CRLDS = false>
 CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const DevSettings &S,
                                 const DevBatch &Bt, double *lds, int wave_global) {
     const int lane = cpgw::lane_id();
-    const unsigned n = (unsigned)F0.n, m = (unsigned)F0.m, N = n + m;
+    // generated instance kernel: the family's dimensions are compile-time facts of its library (cpg_hip_set_refactor checks
+    // them with the fingerprint) -- the bound tests of full 64-row slots, the class of the equality slots and every
+    // address computation on n / m fold (the resident kernel's lesson)
+#if defined(CPG_GENI_HEADER) && defined(CPG_GENI_N)
+    const unsigned n = GENI ? (unsigned)CPG_GENI_N : (unsigned)F0.n, m = GENI ? (unsigned)CPG_GENI_M : (unsigned)F0.m, N = n + m;
+    const unsigned n_eq = GENI ? (unsigned)CPG_GENI_NEQ : (unsigned)R.n_eq;
+#else
+    const unsigned n = (unsigned)F0.n, m = (unsigned)F0.m, N = n + m, n_eq = (unsigned)R.n_eq;
+#endif
     const unsigned *cr_tab = R.sol_cr;
     if (CRLDS) {
         unsigned *lc = (unsigned *)lds;
@@ -531,6 +549,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         const double *state_in = (Bt.state_in && (S.warm_starting || Bt.resume)) ? Bt.state_in + (size_t)b * state_len : nullptr;
         double rho = Bt.state_in ? cpgw::gld(Bt.state_in + (size_t)b * state_len, n + 2u * m) : F0.rho;     // (osqp_cold_start resets the iterates only)
         rho = cpgw::dmin2(cpgw::dmax2(rho, CPG_RHO_MIN), CPG_RHO_MAX);
+        if (GENI) rho = uniform_double(rho);
         double rho_stg = F0.rho;        // (a resumed instance: see where `iter` starts)
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
@@ -634,9 +653,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         const int lane_rc = GENI ? cpgw::opaque(lane) : lane;      // (generated instance kernel: addresses local to this block, see InstCtx)
 #pragma unroll
         for (int s = 0; s < NSZ; s++) {
-            const unsigned i = (unsigned)lane_rc + 64u * (unsigned)s;
+            const unsigned i = (unsigned)lane_rc + 64u * (unsigned)s;         // addresses
+            const unsigned ic = (unsigned)lane + 64u * (unsigned)s;           // tests (range known: they fold on full slots when m, n_eq are constants)
             ct[s] = 0;
-            if (i < m) {
+            if (ic < m) {
                 double uu = cpgw::gld((const double *)B.u, i);      // shared-matrix mode: already E u
                 if (!shared) {
                     const double ei = w[n + i];
@@ -644,12 +664,23 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                     cpgw::gst(B.E, i, ei); cpgw::gst(B.Einv, i, 1.0 / ei); cpgw::gst(B.u, i, uu);
                 }
                 // equality rows (l = u) are the first n_eq rows of the canonical form
-                ct[s] = i < (unsigned)R.n_eq ? 1 : (uu > CPG_INFTY * CPG_MIN_SCALING ? -1 : 0);
+                ct[s] = ic < n_eq ? 1 : (uu > CPG_INFTY * CPG_MIN_SCALING ? -1 : 0);
                 cpgw::gst(B.rinv, i, ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr));
             }
         }
         cpgw::lds_order();
         cpgw::mem_order();
+        // generated instance kernel: the step sizes of the slots whose class is not a compile-time fact (a slot below n_eq is
+        // all equalities) as per-lane values, set here and after an adapt_rho -- the ADMM loop then selects nothing
+        double rvv[NSZ], riv[NSZ];
+        auto set_steps = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < NSZ; s++) {
+                rvv[s] = ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr);
+                riv[s] = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+            }
+        };
+        if (GENI) set_steps();
 
         // ---- 4. numeric LDL' through the dot-product schedule, 5. coefficients of the substitution program
         auto factor_generic = [&]() __attribute__((always_inline)) {
@@ -731,7 +762,8 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 #pragma unroll
             for (int s = 0; s < NSZ; s++) {
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-                const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+                const bool ceq = GENI && 64u * (unsigned)(s + 1) <= n_eq;       // (a compile-time fact per unrolled slot)
+                const double ri = !GENI ? (ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr)) : (ceq ? ri_eq : riv[s]);
                 if (i < m) w[n + i] = z[s] - ri * y[s];
             }
             cpgw::lds_order();
@@ -743,6 +775,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 #pragma unroll
             for (int s = 0; s < NSX; s++) {
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                if (chk) dxr[s] = 0.0;           // (defined on every lane: nothing of the old steps stays live across the iterations)
                 if (i < n) {
                     const double xn = F.alpha * w[GENI ? i : (unsigned)fpx[s]] + (1.0 - F.alpha) * x[s];     // (generated program: solved in place)
                     if (chk) dxr[s] = xn - x[s];
@@ -752,14 +785,17 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
 #pragma unroll
             for (int s = 0; s < NSZ; s++) {
                 const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+                if (chk) dyr[s] = 0.0;
                 if (i < m) {
-                    const double rv = ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr);
-                    const double ri = ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr);
+                    const bool ceq = GENI && 64u * (unsigned)(s + 1) <= n_eq;
+                    const double rv = !GENI ? (ct[s] == 1 ? rho_eq : (ct[s] == 0 ? rho_in : rho_fr)) : (ceq ? rho_eq : rvv[s]);
+                    const double ri = !GENI ? (ct[s] == 1 ? ri_eq : (ct[s] == 0 ? ri_in : ri_fr)) : (ceq ? ri_eq : riv[s]);
                     const double zp = z[s], yp = y[s];
                     const double zt = (zp - ri * yp) + ri * w[GENI ? n + i : (unsigned)fpz[s]];
                     const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
                     const double uu = cx.u(s, i);
-                    const double zn = ct[s] == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
+                    const double zc = cpgw::dmin2(zr + ri * yp, uu);        // (computed on every lane: a select, not a branch, in a slot of mixed classes)
+                    const double zn = ceq ? uu : (ct[s] == 1 ? uu : zc);
                     const double dyv = rv * (zr - zn);
                     z[s] = zn; y[s] = yp + dyv;
                     if (chk) dyr[s] = dyv;
@@ -799,9 +835,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 // adapt_rho (OSQP paper sec. 5.2): rho <- rho sqrt(normalised primal / dual residual); a new
                 // factorisation only when it changed by more than adaptive_rho_tolerance
                 if (!have_info) (void)check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr}, InfeasVerdict{false, false}, w, lane, false, &sn);
-                const double rn = rho_estimate(sn, rho_stg);
+                const double rn = GENI ? uniform_double(rho_estimate(sn, rho_stg)) : rho_estimate(sn, rho_stg);
                 if (rn > rho_stg * S.adaptive_rho_tolerance || rn < rho_stg / S.adaptive_rho_tolerance) {
                     rho = rn; rho_stg = rn; rho_eq = 1e3 * rho; rho_in = rho; ri_eq = 1.0 / rho_eq; ri_in = 1.0 / rho_in;
+                    if (GENI) set_steps();
 #pragma unroll
                     for (int s = 0; s < NSZ; s++) {
                         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
