@@ -1089,6 +1089,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
         if ((rc = upload<double>(h, own, r->E, m, &R.Es))) return rc;
         if ((rc = upload<double>(h, own, einv.data(), m, &R.Einvs))) return rc;
     }
+    R.gf_tri = nullptr; R.gf_dk = nullptr;
     R.gi_ok = 0; R.gi_cols = R.gi_rows = nullptr; R.gi_src = nullptr; R.gi_lcol = nullptr; R.fac_kc = nullptr; R.fac_krow = nullptr; R.fac_kc_cl = nullptr; R.fac_krow_cl = nullptr; R.fac_kind_cl = nullptr; R.fac_idx_cl = nullptr;
     std::vector<double> fkc, fkc_cl;                              // alive until the sync below
     std::vector<int> fkrow, fkrow_cl;
@@ -1121,7 +1122,8 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     }
 #ifdef CPG_GENI_HEADER
     std::vector<unsigned short> gcols, grows, glcol;
-    std::vector<unsigned> gsrc;
+    std::vector<unsigned> gsrc, gdk;
+    std::vector<unsigned long long> gtri;
 #ifdef CPG_GENI_N
     const bool geni_dims = h->F.n == CPG_GENI_N && h->F.m == CPG_GENI_M && h->F.n_eq == CPG_GENI_NEQ;
 #else
@@ -1163,6 +1165,58 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
                 }
             }
         }
+#ifdef CPG_GENI_FAC_NSTEPS
+        if (ok) {
+            // tables of the generated factorisation: its header fixes (steps, level end, group width) per chunk and the term
+            // counts per lane (fingerprint); the operand positions and destinations are packed from the plan handed in here
+            static const int fch[][3] = CPG_GENI_FAC_CHUNKS;
+            const size_t nd = (size_t)r->nnzL + N;
+            unsigned hsh = 0x811C9DC5u;
+            auto mix = [&](unsigned v) { for (int k = 0; k < 4; k++) { hsh = (hsh ^ ((v >> (8 * k)) & 0xFFu)) * 0x01000193u; } };
+            ok = r->fac_chunks == CPG_GENI_FAC_NCHUNKS && nd == (size_t)CPG_GENI_FAC_ZERO && nd < 0xFFFFu;
+            for (int c = 0; ok && c < r->fac_chunks; c++) { mix((unsigned)r->fac_ctab[4 * c]); mix((unsigned)r->fac_ctab[4 * c + 1]); mix((unsigned)r->fac_ctab[4 * c + 3]); }
+            for (size_t e = 0; ok && e < (size_t)r->fac_chunks * 64; e++) mix(r->fac_len[e]);
+            ok = ok && hsh == CPG_GENI_FAC_FINGERPRINT;
+            if (ok) {
+                const unsigned long long Z = (unsigned long long)nd;
+                gtri.assign((size_t)CPG_GENI_FAC_NSTEPS * 64, Z | (Z << 16) | (Z << 32));
+                gdk.assign((size_t)r->fac_chunks * 64, 0xFFFFu);
+                size_t step = 0;
+                for (int c = 0; ok && c < r->fac_chunks; c++) {
+                    const int L = r->fac_ctab[4 * c];
+                    size_t base = (size_t)r->fac_ctab[4 * c + 2];
+                    if (L != fch[c][0]) { ok = false; break; }
+                    for (int s = 0; ok && s < L; s++, step++) {
+                        int cnt = 0;
+                        for (int l = 0; l < 64; l++) {
+                            const unsigned ln = r->fac_len[(size_t)c * 64 + l];
+                            if ((int)(ln & 0xFFFFu) <= s) continue;
+                            const size_t e = base + (size_t)l;        // (lanes with entries at step s form a prefix of the chunk)
+                            if (l != cnt || e >= (size_t)r->fac_triples) { ok = false; break; }
+                            cnt++;
+                            if ((int)(ln >> 16) > s) {
+                                const unsigned a = r->fac_a[e], b = r->fac_b[e], k = r->fac_k[e];
+                                if (a >= (unsigned)r->nnzL || b >= (unsigned)r->nnzL || k >= (unsigned)N) { ok = false; break; }
+                                gtri[step * 64 + (size_t)l] = (unsigned long long)a | ((unsigned long long)b << 16) | ((unsigned long long)((unsigned)r->nnzL + k) << 32);
+                            }
+                        }
+                        base += (size_t)cnt;
+                    }
+                    for (int l = 0; ok && l < 64; l++) {
+                        const unsigned t = r->fac_task[(size_t)c * 64 + l];
+                        if (t == 0xFFFFFFFFu) continue;
+                        const int kr = fkrow_cl[(size_t)c * 64 + l];
+                        gdk[(size_t)c * 64 + l] = t | ((unsigned)(kr + 1) << 16);
+                    }
+                }
+                if (ok && step != (size_t)CPG_GENI_FAC_NSTEPS) ok = false;
+            }
+            if (ok) {
+                if ((rc = upload<unsigned long long>(h, own, gtri.data(), gtri.size(), &R.gf_tri))) return rc;
+                if ((rc = upload<unsigned>(h, own, gdk.data(), gdk.size(), &R.gf_dk))) return rc;
+            }
+        }
+#endif
         if (ok) {
             if ((rc = upload<unsigned short>(h, own, glcol.data(), glcol.size(), &R.gi_lcol))) return rc;
             if ((rc = upload<unsigned short>(h, own, gcols.data(), gcols.size(), &R.gi_cols))) return rc;
@@ -1518,7 +1572,11 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
         const size_t tab = (size_t)(((CPG_GENI_NSTEPS + 3) / 4) * 256 + ((CPG_GENI_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
         const size_t nq = (size_t)(h->F.n + h->F.m);
         size_t per_wave = (size_t)(CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS) + nq + (nq & 1);   // work vector | q | u ...
+#ifdef CPG_GENI_FAC_NSTEPS
+        const size_t fac = (size_t)h->R.nnzL + nq + 1;                                        // ... or the factor (+ a zero slot) while it is computed
+#else
         const size_t fac = (size_t)h->R.nnzL + nq;                                            // ... or the factor while it is computed
+#endif
         if (per_wave < fac) per_wave = fac + (fac & 1);
         const size_t lds = tab + (size_t)W * per_wave * sizeof(double);
         if (lds <= h->lds_limit) {

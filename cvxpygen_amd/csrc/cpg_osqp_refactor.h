@@ -82,6 +82,10 @@ struct DevRefactor {
     const unsigned short *gi_cols, *gi_rows;
     const unsigned *gi_src;
     const unsigned short *gi_lcol;      // [step][lane] column of the L entry behind a kind-2 coefficient
+    // generated factorisation of shared-matrix mode (numeric_ldl_gen of the family's cpg_instance_<name>.h): operand positions
+    // a | b << 16 | k << 32 per (step, lane), destination | (rho row + 1) << 16 per (chunk, lane); see codegen.emit_factor_program
+    const unsigned long long *gf_tri;
+    const unsigned *gf_dk;
     // shared-matrix mode: the KKT value of every destination of the factorisation is a family constant (fac_kc; sigma
     // included on the pivots) except the -1 / rho_vec of the (2,2) diagonal: fac_krow = its row, -1 elsewhere
     const double *fac_kc;
@@ -511,7 +515,12 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
     // per wavefront: the work vector, and with the generated executor the instance's q and u behind it; the same
     // slice holds the factor (M [nnzL] | 1 / d [N]) while numeric_ldl_lds runs -- nothing in it is live then
     size_t per_wave = (size_t)ldw + (GENI ? (size_t)(N + (N & 1u)) : 0u);
-    if (GENI && per_wave < (size_t)R.nnzL + N) per_wave = (size_t)R.nnzL + N + (((size_t)R.nnzL + N) & 1u);
+#ifdef CPG_GENI_FAC_NSTEPS
+    const size_t fac_doubles = (size_t)R.nnzL + N + 1u;       // (+ the zero slot idle lanes of the generated factorisation read)
+#else
+    const size_t fac_doubles = (size_t)R.nnzL + N;
+#endif
+    if (GENI && per_wave < fac_doubles) per_wave = fac_doubles + (fac_doubles & 1u);
     double *w = lds + (size_t)cpgw::wave_in_block() * per_wave;
     double *qs = w + ldw, *us = qs + n;
     constexpr bool shared = SHARED || GENI;
@@ -700,7 +709,13 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         double cf[CPG_GENI_NREGS];           // (dead, hence free, in the streaming instantiation)
         auto factor_in_lds = [&]() __attribute__((always_inline)) {
             cpgw::mem_order();                // B.rinv
+#ifdef CPG_GENI_FAC_NSTEPS
+            if (lane == 0) w[CPG_GENI_FAC_ZERO] = 0.0;
+            cpgw::lds_order();
+            numeric_ldl_gen(R.gf_tri, R.gf_dk, R.fac_kc_cl, (const double *)B.rinv, w, lane);
+#else
             numeric_ldl_m<true>(R, w, w + R.nnzL, (const double *)B.rinv, lane);
+#endif
             load_instance_coefficients(R, w, w + R.nnzL, cf, lane);
             cpgw::lds_order();
             // the slice goes back to its ADMM use: idle lanes of a step gather the zero slot, idle lanes of a chunk
