@@ -209,37 +209,25 @@ def cpu_baseline_portfolio(desc, target_seconds: float = 12.0, **mode):
     return _cpu_sweep(run, 8, target_seconds, 20000, 'QP instances/s', 'per-instance osqp_update_data_mat')
 
 
-def _adp_chunk(args):
-    desc, th = args
-    from oracle import clarabel_numpy as cl
-    r = cl.cpg_solve_batch(desc, th)
-    return int((r['status'] == 1).sum())
-
-
 def cpu_baseline_adp(desc, target_seconds: float = 10.0):
-    """config 4 on the host: the numpy interior-point oracle (pure-Python restatement), one process per host core
-    (instances are independent: the same split the reference's users would make)"""
-    import multiprocessing as mp
-    os.environ.setdefault('OMP_NUM_THREADS', '1'); os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
-    cores = max(1, min(os.cpu_count() or 1, 128))
-    from oracle import clarabel_numpy as cl
-    B = 32
-    pv = adp_params(B, 1)
-    th = np.stack([desc.theta_from_values({k: v[i] for k, v in pv.items()}) for i in range(B)])
-    t0 = time.time(); cl.cpg_solve_batch(desc, th); t1 = (time.time() - t0) / B          # one core, seconds per instance
-    per = int(max(8, min(400, target_seconds / max(t1, 1e-6))))                          # instances per process
-    B2 = per * cores
-    pv = adp_params(B2, 2)
-    th = np.stack([desc.theta_from_values({k: v[i] for k, v in pv.items()}) for i in range(B2)])
-    ctx = mp.get_context('spawn')          # (the parent holds an initialised HIP runtime: no fork)
-    with ctx.Pool(cores) as pool:
-        pool.map(_adp_chunk, [(desc, th[:cores])] )                                      # start the workers outside the timed region
+    """config 4 on the host: the interior-point restatement in C (oracle/clarabel_oracle.c, the algorithm of
+    oracle/clarabel_numpy.py statement for statement), OpenMP over the instances -- a new solver per instance as the
+    reference's generated code builds one (solvers/clarabel.py:201-204)"""
+    from oracle import binding as ob
+    ob.build()
+
+    def run(B, seed, threads):
+        pv = adp_params(B, seed)
+        th = np.stack([desc.theta_from_values({k: v[i] for k, v in pv.items()}) for i in range(B)])
         t0 = time.time()
-        solved = sum(pool.map(_adp_chunk, [(desc, th[k * per:(k + 1) * per]) for k in range(cores)]))
-        t = time.time() - t0
-    return {'value': B2 / t, 'unit': 'SOCP instances/s', 'cores': int(cores), 'kind': 'port',
-            'sample': f'{B2} instances of the same workload ({solved} solved), dense numpy restatement, one process per core '
-                      f'({cores} processes x {per} instances), {t:.1f} s wall; single core: {1.0 / t1:.0f} instances/s'}
+        r = ob.clarabel_solve_batch(desc, th, nthreads=threads)
+        dt = time.time() - t0
+        if not (r['status'] == 1).all():
+            raise RuntimeError('cpu baseline: the conic oracle did not solve its sample')
+        return dt
+    out = _cpu_sweep(run, 256, target_seconds, 400000, 'SOCP instances/s', 'a new solver per instance, default settings')
+    out['sample'] = out['sample'].replace('OpenMP static', 'C restatement of the interior-point method, OpenMP dynamic')
+    return out
 
 
 def main():

@@ -737,6 +737,9 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         // ---- 6. ADMM from cold start with the instance's own factor
         DevFamily F = F0;
         F.D = B.D; F.Dinv = B.Dinv; F.E = B.E; F.Einv = B.Einv; F.c = cs; F.cinv = 1.0 / cs;
+        // (F.n / F.m stay run-time values: as literals they shrink the termination test and the retrieval, but the allocation of
+        // the whole kernel shifts and the ADMM loop reloads six values from scratch per iteration -- tried, measured by
+        // scripts/isa_hot_loops.py, dropped)
         StreamProg ST;
         ST.stab = R.sol_stab; ST.cr = cr_tab; ST.vals = B.sv;
         ST.n_pairs = R.sol_pairs; ST.dummy = (unsigned)R.sol_nnz / 2u - 1u;

@@ -24,8 +24,8 @@ _ip = C.POINTER(C.c_int)
 
 def build(force=False):
     so = os.path.join(_HERE, 'liboracle.so')
-    src = os.path.join(_HERE, 'osqp_oracle.c')
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ('osqp_oracle.c', 'clarabel_oracle.c', 'Makefile')]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'],
                               stdout=subprocess.DEVNULL)
     return so
@@ -35,8 +35,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, 'liboracle.so')
-        if not os.path.exists(so):
-            build()
+        build()
         L = C.CDLL(so)
         L.oracle_setup.restype = C.c_void_p
         L.oracle_setup.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp]
@@ -58,6 +57,11 @@ def lib():
             C.c_void_p, C.c_int, _ip, C.POINTER(_ip), C.POINTER(_ip), C.POINTER(_dp), _ip, C.c_int,
             C.c_int, C.c_long, _dp, _dp, _dp, _dp, C.c_int]
         L.oracle_num_threads.restype = C.c_int
+        L.clarabel_oracle_solve_batch.restype = C.c_int
+        L.clarabel_oracle_solve_batch.argtypes = [
+            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _ip,
+            _ip, C.POINTER(_ip), C.POINTER(_ip), C.POINTER(_dp), C.c_int, C.c_int, C.c_int, C.c_long, _dp, _dp,
+            _dp, _dp, _dp, C.c_int]
         _LIB = L
     return _LIB
 
@@ -266,3 +270,62 @@ class CpgSession:
         ov = r['obj_val'] + d
         r['obj_val'] = -ov if desc.is_maximization else ov
         return r
+
+
+CLARABEL_SETTING_ORDER = [
+    'max_iter', 'max_step_fraction', 'tol_gap_abs', 'tol_gap_rel', 'tol_feas', 'tol_infeas_abs', 'tol_infeas_rel', 'tol_ktratio',
+    'reduced_tol_gap_abs', 'reduced_tol_gap_rel', 'reduced_tol_feas', 'reduced_tol_infeas_abs', 'reduced_tol_infeas_rel',
+    'reduced_tol_ktratio', 'equilibrate_enable', 'equilibrate_max_iter', 'equilibrate_min_scaling', 'equilibrate_max_scaling',
+    'linesearch_backtrack_step', 'min_switch_step_length', 'min_terminate_step_length', 'static_regularization_enable',
+    'static_regularization_constant', 'static_regularization_proportional', 'dynamic_regularization_enable',
+    'dynamic_regularization_eps', 'dynamic_regularization_delta', 'iterative_refinement_enable', 'iterative_refinement_reltol',
+    'iterative_refinement_abstol', 'iterative_refinement_max_iter', 'iterative_refinement_stop_ratio']
+
+
+def clarabel_solve_batch(desc, theta, nthreads=0, **settings):
+    """The conic restatement in C (oracle/clarabel_oracle.c: the algorithm of oracle/clarabel_numpy.py statement for
+    statement) on a batch of one conic family: per instance canonicalise, NEW solver, solve, retrieve.  Same result dict as
+    clarabel_numpy.cpg_solve_batch.  Settings not given take clarabel_numpy.DEFAULTS."""
+    from oracle import clarabel_numpy as cl
+    L = lib()
+    if list(cl.DEFAULTS) != CLARABEL_SETTING_ORDER:
+        raise RuntimeError('clarabel_numpy.DEFAULTS and the C settings vector disagree')
+    stg = dict(cl.DEFAULTS)
+    for k, v in settings.items():
+        if k not in stg:
+            raise KeyError(k)
+        stg[k] = v
+    sv = np.array([float(stg[k]) for k in CLARABEL_SETTING_ORDER])
+    theta = np.asarray(theta, dtype=np.float64)
+    B = theta.shape[0]
+    if theta.shape[1] == desc.NP:
+        theta = np.concatenate([theta, np.ones((B, 1))], axis=1)
+    theta = np.ascontiguousarray(theta)
+    n, m = desc.n_var, desc.m
+    soc = np.ascontiguousarray(desc.cones['soc'], dtype=np.int32)
+    P, A = desc.P.tocsc(), desc.A.tocsc()
+    keep = [np.ascontiguousarray(P.indptr, dtype=np.int32), np.ascontiguousarray(P.indices, dtype=np.int32),
+            np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32)]
+    ids = ['P', 'q', 'd', 'A', 'b']
+    rows = np.zeros(5, dtype=np.int32)
+    ps, is_, xs = (_ip * 5)(), (_ip * 5)(), (_dp * 5)()
+    for k, pid in enumerate(ids):
+        Cm = desc.maps[pid].tocsr()
+        a = np.ascontiguousarray(Cm.indptr, dtype=np.int32)
+        b = np.ascontiguousarray(Cm.indices, dtype=np.int32)
+        c = np.ascontiguousarray(Cm.data, dtype=np.float64)
+        keep += [a, b, c]
+        rows[k] = Cm.shape[0]
+        ps[k], is_[k], xs[k] = _i(a), _i(b), _d(c)
+    sol_x, sol_z, info = np.zeros((B, n)), np.zeros((B, m)), np.zeros((B, 5))
+    rc = L.clarabel_oracle_solve_batch(n, m, int(desc.cones['zero']), int(desc.cones['nonneg']), len(soc), _i(soc) if len(soc) else None,
+                                       _i(keep[0]), _i(keep[1]), _i(keep[2]), _i(keep[3]), _i(rows), ps, is_, xs,
+                                       int(desc.is_maximization), int(bool(desc.nonzero_d)), desc.NP + 1, B, _d(theta), _d(sv),
+                                       _d(sol_x), _d(sol_z), _d(info), int(nthreads))
+    if rc:
+        raise RuntimeError('clarabel_oracle_solve_batch: cone dimensions do not add up to m')
+    out = dict(sol_x=sol_x, sol_z=sol_z, obj_val=info[:, 0].copy(), iter=info[:, 1].astype(np.int32),
+               status=info[:, 2].astype(np.int32), pri_res=info[:, 3].copy(), dua_res=info[:, 4].copy())
+    out['prim'] = {v.name: sol_x[:, v.indices] for v in desc.variables}
+    out['dual'] = {d.name: sol_z[:, d.indices] for d in desc.duals}
+    return out

@@ -443,3 +443,30 @@ def test_adp_full_batch_properties():
     r2 = bs.solve({'f': f[perm], 'G': G[perm]}, updated_params=['f', 'G'])
     assert (r2.iter == r.iter[perm]).all() and np.array_equal(r2.prim_flat, r.prim_flat[perm])
     bs.close()
+
+
+def test_c_restatement_of_the_conic_oracle_follows_the_numpy_one():
+    """oracle/clarabel_oracle.c (the CPU baseline of the conic workload) against oracle/clarabel_numpy.py, which shares no
+    code with it beyond the algorithm: identical iteration counts and statuses, solutions to round-off on the ADP family of
+    BASELINE config 4 (quadratic objective), objective and duals on the norm form whose optimum sits at a kink of the
+    cones (x there is determined to ~1e-5 only), an infeasible instance, and a settings override"""
+    from oracle import binding as ob
+    from oracle import clarabel_numpy as cl
+    rs = np.random.RandomState(11)
+    states = -2 + 4 * rs.rand(10, 6)
+    for d, xtol in ((families.adp(), 1e-10), (families.adp_norm(tie=True), 1e-4), (families.adp_norm(tie=False), 1e-4)):
+        th = np.stack([d.theta_from_values(families.adp_values(s_)) for s_ in states])
+        o = cl.cpg_solve_batch(d, th)
+        c = ob.clarabel_solve_batch(d, th, nthreads=2)
+        assert c['iter'].tolist() == o['iter'].tolist() and c['status'].tolist() == o['status'].tolist()
+        assert np.abs(c['obj_val'] - o['obj_val']).max() <= 1e-9 * max(1.0, np.abs(o['obj_val']).max())
+        assert np.abs(c['sol_x'] - o['sol_x']).max() <= xtol * max(1.0, np.abs(o['sol_x']).max())
+        assert np.abs(c['sol_z'] - o['sol_z']).max() <= 1e-7 * max(1.0, np.abs(o['sol_z']).max())
+        assert np.allclose(c['pri_res'], o['pri_res'], rtol=1e-2, atol=1e-10) and np.allclose(c['dua_res'], o['dua_res'], rtol=1e-2, atol=1e-10)   # (round-off-level figures)
+    d = families.adp()
+    th = np.stack([d.theta_from_values(families.adp_values(s_)) for s_ in states[:3]])
+    o = cl.cpg_solve_batch(d, th, max_iter=3)
+    c = ob.clarabel_solve_batch(d, th, max_iter=3)
+    assert c['iter'].tolist() == o['iter'].tolist() == [3, 3, 3] and c['status'].tolist() == o['status'].tolist()
+    with pytest.raises(KeyError):
+        ob.clarabel_solve_batch(d, th, no_such_setting=1)
