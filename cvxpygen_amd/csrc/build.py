@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['cpg_hip.cpp']
-HEADERS = ['cpg_osqp_kernel.h', 'cpg_osqp_refactor.h', 'cpg_wave.h', 'cpg_wave_gfx950.h', os.path.join('..', '..', 'include', 'cpg_hip.h'), 'cpg_clarabel_kernel.h']
+HEADERS = ['cpg_osqp_kernel.h', 'cpg_osqp_refactor.h', 'cpg_osqp_resident.h', 'cpg_wave.h', 'cpg_wave_gfx950.h', os.path.join('..', '..', 'include', 'cpg_hip.h'), 'cpg_clarabel_kernel.h']
 
 
 def lib_path(tag: str = '') -> str:

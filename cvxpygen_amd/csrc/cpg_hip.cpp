@@ -1365,15 +1365,40 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         for (int k = r->Ap[j]; k < r->Ap[j + 1]; k++) entA[k] = (unsigned)r->Ai[k] | ((unsigned)j << 16);
         for (int k = r->Pp[j]; k < r->Pp[j + 1]; k++) entP[k] = (unsigned)r->Pi[k] | ((unsigned)j << 16);
     }
-    // ---- products of the termination test in the streaming executor's layout
+    // ---- products of the termination test: generated row executors of the family's header, or the streaming executor's layout
     StreamTables st3[3];
     std::vector<int> src3[3];
+    std::vector<unsigned short> rcols3[3], rrows3[3];
     const cpg_rows_program_t *rows3[3] = {&rs->rows_A, &rs->rows_P, &rs->rows_At};
     cpg::DevStreamTab *dst3[3] = {&Rs.pA, &Rs.pP, &Rs.pAt};
     const int w_slots = std::max(rs->out_ax + m, rs->out_aty + n);
     for (int k = 0; k < 3; k++) {
         const cpg_rows_program_t &p = *rows3[k];
         for (int c = 0; c < p.n_chunks; c++) if (p.ctab[4 * c + 3] & ~1) { set_error("cpg_hip_set_resident: row program with an unsupported chunk kind"); return CPG_E_BADARG; }
+#ifdef CPG_GENRA_NSTEPS
+        {
+            static const int stA[][4] = CPG_GENRA_STEPS, stP[][4] = CPG_GENRP_STEPS, stT[][4] = CPG_GENRT_STEPS;
+            const int (*steps)[4] = k == 0 ? stA : (k == 1 ? stP : stT);
+            const int T = k == 0 ? CPG_GENRA_NSTEPS : (k == 1 ? CPG_GENRP_NSTEPS : CPG_GENRT_NSTEPS);
+            const int nch = k == 0 ? CPG_GENRA_NCHUNKS : (k == 1 ? CPG_GENRP_NCHUNKS : CPG_GENRT_NCHUNKS);
+            const int nz = k == 0 ? CPG_GENRA_NNZ : (k == 1 ? CPG_GENRP_NNZ : CPG_GENRT_NNZ);
+            const unsigned fp = k == 0 ? CPG_GENRA_FINGERPRINT : (k == 1 ? CPG_GENRP_FINGERPRINT : CPG_GENRT_FINGERPRINT);
+            if (p.n_chunks != nch || p.nnz != nz || program_fingerprint(p.ctab, p.desc, p.cols, p.n_chunks, p.nnz) != fp) {
+                set_error("cpg_hip_set_resident: this library's row executors were generated for a different family"); return CPG_E_BADARG; }
+            // idle lanes gather the zero slot of the substitution program's work vector and store to its dummy slots
+            if (!generated_tables(p.ctab, p.desc, p.cols, p.n_chunks, p.nnz, CPG_GENR_NSLOTS, steps, T, rcols3[k], rrows3[k])) {
+                set_error("cpg_hip_set_resident: row program does not fit the generated executor's tables"); return CPG_E_BADARG; }
+            const int lim = k == 1 ? r->nnzP : r->nnzA;
+            src3[k].assign((size_t)p.nnz + 64, -1);               // (a step's idle lanes read the entries behind it: finite padding)
+            for (int e = 0; e < p.nnz; e++) { const int v = p.ent[e]; if (v >= lim) { set_error("cpg_hip_set_resident: matrix entry out of range"); return CPG_E_BADARG; } src3[k][e] = v; }
+            cpg::DevStreamTab &D = *dst3[k];
+            D.n_pairs = 0; D.n_entries = (int)src3[k].size(); D.dummy = 0; D.stab = nullptr; D.cr = nullptr;
+            if ((rc = upload<int>(h, own, src3[k].data(), src3[k].size(), &D.src))) return rc;
+            if ((rc = upload<unsigned short>(h, own, rcols3[k].data(), rcols3[k].size(), &D.gcols))) return rc;
+            if ((rc = upload<unsigned short>(h, own, rrows3[k].data(), rrows3[k].size(), &D.grows))) return rc;
+            continue;
+        }
+#endif
         if ((rc = build_stream_tables(p.ctab, p.desc, p.cols, p.n_chunks, w_slots, st3[k], CPG_RES_PRODUCT_DEPTH / 2))) return rc;
         src3[k].resize(st3[k].src.size());
         const int lim = k == 1 ? r->nnzP : r->nnzA;
@@ -1385,6 +1410,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
             src3[k][e] = v;
         }
         cpg::DevStreamTab &D = *dst3[k];
+        D.gcols = nullptr; D.grows = nullptr;
         D.n_pairs = st3[k].n_pairs; D.n_entries = (int)st3[k].cr.size(); D.dummy = (unsigned)st3[k].cr.size() / 2u - 1u;
         if ((rc = upload<unsigned>(h, own, st3[k].st.data(), st3[k].st.size(), &D.stab))) return rc;
         if ((rc = upload<unsigned>(h, own, st3[k].cr.data(), st3[k].cr.size(), &D.cr))) return rc;

@@ -37,6 +37,9 @@ struct DevStreamTab {             // a ragged program in the layout of run_progr
     const int *src;               // [n_entries] entry of the instance's matrix behind entry e (-1: padding)
     int n_pairs, n_entries;
     unsigned dummy;
+    // generated row executors (run_rows_a / _p / _t of the family's cpg_resident_<name>.h): the values sit in program-entry
+    // order (n_entries = nnz + 64 zeros of padding), operand offsets / output slots in the layout of run_program_res's tables
+    const unsigned short *gcols, *grows;
 };
 struct DevEll {                   // out[k] = base[k] + sum_j coef[j * rows + k] * theta[idx[j * rows + k]]
     int J, rows;
@@ -86,7 +89,7 @@ struct ResBuf { double *A, *P, *D, *Dinv, *E, *Einv, *q, *u, *rinv, *cA, *cP, *c
 // every pointer of a struct that arrived through a call, marked as global memory (cpgw::as_global)
 #define CPG_G(x) x = cpgw::as_global(x)
 CPG_DEV void globalise(ResBuf &B) { CPG_G(B.A); CPG_G(B.P); CPG_G(B.D); CPG_G(B.Dinv); CPG_G(B.E); CPG_G(B.Einv); CPG_G(B.q); CPG_G(B.u); CPG_G(B.rinv); CPG_G(B.cA); CPG_G(B.cP); CPG_G(B.cAt); CPG_G(B.cf); }
-CPG_DEV void globalise(DevStreamTab &T) { CPG_G(T.stab); CPG_G(T.cr); CPG_G(T.src); }
+CPG_DEV void globalise(DevStreamTab &T) { CPG_G(T.stab); CPG_G(T.cr); CPG_G(T.src); CPG_G(T.gcols); CPG_G(T.grows); }
 CPG_DEV void globalise(DevEll &E) { CPG_G(E.idx); CPG_G(E.coef); }
 CPG_DEV void globalise(DevResident &Rs) {
     CPG_G(Rs.f_ctl); CPG_G(Rs.f_ent); CPG_G(Rs.k_src); CPG_G(Rs.g_src); CPG_G(Rs.g_lcol); CPG_G(Rs.g_cols); CPG_G(Rs.g_rows);
@@ -198,6 +201,7 @@ struct ResidentCtx {
     unsigned w_off;               // ... as an offset into the workgroup's LDS window (for the calls)
     const double *qm, *um;
     int lane;
+    int skip_products;            // (experiments, debug_stage 21: the termination test without its three products)
     CPG_DEV double q(int, unsigned i) const { return qm[i]; }
     CPG_DEV double u(int, unsigned i) const { return um[i]; }
     // Scaling vectors: with one wavefront per SIMD a global load per 64-entry slot inside the test's loops is a memory
@@ -221,7 +225,14 @@ struct ResidentCtx {
         }
         cpgw::lds_order();
     }
-    CPG_DEV void run(const DevStreamTab &T, const double *vals) const {
+    CPG_DEV void run(const DevStreamTab &T, const double *vals, int k) const {
+#ifdef CPG_GENRA_NSTEPS
+        CPG_LDS double *wl = cpgw::lds_window3() + w_off;
+        if (k == 0) run_rows_a(vals, T.gcols, T.grows, wl, lane);
+        else if (k == 1) run_rows_p(vals, T.gcols, T.grows, wl, lane);
+        else run_rows_t(vals, T.gcols, T.grows, wl, lane);
+        return;
+#endif
         StreamProg ST;
         ST.stab = T.stab; ST.cr = T.cr; ST.vals = vals; ST.n_pairs = T.n_pairs; ST.dummy = T.dummy;
         run_program_stream<CPG_RES_PRODUCT_DEPTH>(ST, w, lane);
@@ -230,6 +241,7 @@ struct ResidentCtx {
         // rows without an entry are never written by their program, and A x shares the slots of P x | A' y: clear first
         // (behind every lane's last read of the previous product).  (As a real call -- one copy of the executor instead of
         // one per call site -- a test took 2.27 instead of 1.69 ms per 20 000 instances: profiles/r4_s4c_*.)
+        if (__builtin_expect(skip_products, 0)) return;
         cpgw::lds_order();
         if (which & 1) for (unsigned i = (unsigned)lane; i < (unsigned)F.m; i += 64u) w[(unsigned)Rs.out_ax + i] = 0.0;
         if (which & 2) for (unsigned i = (unsigned)lane; i < (unsigned)F.n; i += 64u) w[(unsigned)Rs.out_px + i] = 0.0;
@@ -237,7 +249,7 @@ struct ResidentCtx {
         cpgw::lds_order();
 #pragma nounroll
         for (int k = 0; k < 3; k++)
-            if ((which >> k) & 1) run(k == 0 ? Rs.pA : (k == 1 ? Rs.pP : Rs.pAt), k == 0 ? B.cA : (k == 1 ? B.cP : B.cAt));
+            if ((which >> k) & 1) run(k == 0 ? Rs.pA : (k == 1 ? Rs.pP : Rs.pAt), k == 0 ? B.cA : (k == 1 ? B.cP : B.cAt), k);
         cpgw::lds_order();
     }
     CPG_DEV double ax(int s) const { const unsigned i = (unsigned)lane + 64u * (unsigned)s; return i < (unsigned)F.m ? w[(unsigned)Rs.out_ax + i] : 0.0; }
@@ -666,7 +678,7 @@ CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F_, const DevResident 
     ScaledNorms *sn = &sn_local;
     double *w = cpgw::lds_window() + sl_off;
     const double *qs = w + (CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + CPG_GENR_N;
-    const CtxT cx{F, Rs, B, w, sl_off, qs, us, lane};
+    const CtxT cx{F, Rs, B, w, sl_off, qs, us, lane, S.debug_stage == 21};
     const CheckOut o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr},
                                                                            InfeasVerdict{false, false}, w, lane, approximate, sn);
     if (sn_) *sn_ = sn_local;
@@ -733,7 +745,7 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
         // (experiments, debug_stage 20: the 100 MHz time stamps of the instance's stages replace its primal results)
-        const bool probe = __builtin_expect(S.debug_stage == 20, 0);
+        const bool probe = __builtin_expect(S.debug_stage == 20 || S.debug_stage == 21, 0);
         unsigned long long ts[8];
         int n_ts = 0;
 #define CPG_RES_PROBE() do { if (probe && n_ts < 8) ts[n_ts++] = cpgw::clock100(); } while (0)

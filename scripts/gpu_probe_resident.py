@@ -15,7 +15,7 @@ plan = build_family_plan(d)
 lib = os.path.join(ROOT, 'cvxpygen_amd', 'generated', 'portfolio', os.environ.get('CPG_PROBE_LIB', 'libcpg_portfolio.so'))
 pv = bench.portfolio_params(d, B, 1000)
 bs = BatchSolver(d, lib_path=lib, plan=plan)
-r = bs.solve(pv, updated_params=list(pv.keys()), debug_stage=20, **stg)
+r = bs.solve(pv, updated_params=list(pv.keys()), debug_stage=int(os.environ.get('CPG_PROBE_STAGE', '20')), **stg)
 ts = r.prim_flat[:, :8] * 0.01            # microseconds since the instance started
 names = ['start', 'setup', 'factor', 'store', 'iterate', 'check', 'next', 'next2']
 d_ = np.diff(ts, axis=1)
