@@ -86,18 +86,20 @@ def adp_params(B: int, seed: int):
 
 
 BINDING = {
-    # (workload, all parameters per instance, fixed-rho fork)
-    ('mpc12', False, False): 'latency: the dominant kernel (per-instance factor phase, osqp_instance_kernel) keeps no unit busy -- VALU 55 %, LDS 31 %, '
-                             '49 % of the wave cycles waiting, two wavefronts per SIMD at 256 VGPRs; the shared-factor kernel in front of it: LDS pipe '
-                             '81 % busy, 26 % of it bank conflicts (profiles/r3_final7_pmc_config2.txt)',
+    # (workload, all parameters per instance, fixed-rho fork) -> what binds the dominant kernel, from the PMC passes under profiles/
+    # (busy fractions: counter x 4 / (1024 SIMDs x kernel cycles) for the quad-cycle counters, / (256 CUs x cycles) for the LDS ones)
+    ('mpc12', False, False): 'LDS throughput, then latency: the shared-factor kernel (12.2 of the 22.4 ms) keeps the LDS pipe 83 % busy, 26 % of '
+                             'it bank conflicts, VALU 50 %; the per-instance factor kernel behind it (10.2 ms) keeps no unit busy -- VALU 49 %, '
+                             'LDS pipe 54 %, 50 % of the wave cycles waiting at two wavefronts per SIMD and 256 VGPRs (profiles/r4_final_pmc_config2.txt)',
     ('mpc12', False, True): 'LDS throughput: SQ_LDS_IDX_ACTIVE 84 % of the CU cycles, 24 % of it bank conflicts; VALU 50 % (profiles/r2_final6_pmc_config2.txt)',
-    ('mpc6', False, False): 'latency (as mpc12: per-instance factor phase behind an LDS-bound shared-factor kernel)',
-    ('portfolio', False, False): 'latency: resident per-instance factor kernel at one wavefront per SIMD (three per CU), a chain of LDS / register '
-                                 'dependencies per ADMM iteration and of memory round trips in its set-up / termination tests; HBM-side traffic 1.3 TB/s = '
-                                 '16 % of the peak (profiles/r4_pmc_config3.txt, r4_probe_stages_config3.txt)',
+    ('mpc6', False, False): 'as mpc12: an LDS-bound shared-factor kernel in front of a latency-bound per-instance factor kernel',
+    ('portfolio', False, False): 'latency: resident per-instance factor kernel at ONE wavefront per SIMD on three of the four SIMDs of a CU: VALU 22 % of '
+                                 'all SIMD cycles (30 % of the occupied ones), LDS pipe 22 %, 43 % of the wave cycles waiting; HBM-side traffic '
+                                 '78.6 GB per launch = 1.45 TB/s = 18 % of the peak (profiles/r4_final_pmc_config3.txt, r4_s10_probe_resident.txt)',
     ('portfolio', False, True): 'latency (as the default mode; fewer termination tests and no refactorisations)',
-    ('mpc12', True, False): 'HBM stream + dependent chunk ends: per-instance substitution coefficients read in every iteration on a 242-level chain '
-                            '(profiles/r3_final7_bench_allparams.json)',
+    ('mpc12', True, False): 'dependent memory round trips: 484 level-scheduled phases per iteration, each waiting for its coefficient stream -- 61 % of the '
+                            'wave cycles waiting, VALU 41 %, FETCH 342 GB per launch = 3.2 TB/s = 40 % of the HBM peak, 0.8 scalar instructions per '
+                            'vector one (profiles/r4_final_pmc_allparams.txt)',
     ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 83 % of the SIMD cycles (profiles/r3_conic_pmc_config4.txt)',
 }
 
