@@ -1341,6 +1341,48 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         Rs.fac_steps = (int)(ctl.size() / 2);
         for (int t = 0; t < 2 * DP; t++) { ctl.push_back(Rs.f_dummy); ctl.push_back(0u); }
     }
+#ifdef CPG_GENR_FAC_NSTEPS
+    // ---- tables of the generated factorisation: the header fixes (steps, level end, group width) per chunk and the per-lane
+    //      term counts (fingerprint); positions and destinations are packed from the plan handed in here
+    std::vector<unsigned long long> gftri;
+    std::vector<unsigned> gfdk;
+    {
+        static const int fch[][3] = CPG_GENR_FAC_CHUNKS;
+        unsigned hsh = 0x811C9DC5u;
+        auto mix = [&](unsigned v) { for (int k = 0; k < 4; k++) { hsh = (hsh ^ ((v >> (8 * k)) & 0xFFu)) * 0x01000193u; } };
+        bool ok = rs->fac_chunks == CPG_GENR_FAC_NCHUNKS && ZERO == CPG_GENR_FAC_ZERO && Rs.fac_len < 0xFFFF;
+        for (int c = 0; ok && c < rs->fac_chunks; c++) { mix((unsigned)rs->f_ctab[4 * c]); mix((unsigned)rs->f_ctab[4 * c + 1]); mix((unsigned)rs->f_ctab[4 * c + 3]); }
+        for (size_t e = 0; ok && e < (size_t)rs->fac_chunks * 64; e++) mix(rs->f_len[e]);
+        if (!ok || hsh != CPG_GENR_FAC_FINGERPRINT) { set_error("cpg_hip_set_resident: this library's factorisation was generated for a different family"); return CPG_E_BADARG; }
+        const unsigned long long Z = (unsigned long long)ZERO;
+        gftri.assign((size_t)CPG_GENR_FAC_NSTEPS * 64, Z | (Z << 16) | (Z << 32));
+        gfdk.assign((size_t)rs->fac_chunks * 64, 0xFFFFu);
+        size_t step = 0;
+        for (int c = 0; c < rs->fac_chunks; c++) {
+            const int L = rs->f_ctab[4 * c];
+            size_t base = (size_t)rs->f_ctab[4 * c + 2];
+            if (L != fch[c][0]) { set_error("cpg_hip_set_resident: factorisation chunk differs from the generated one"); return CPG_E_BADARG; }
+            for (int s = 0; s < L; s++, step++) {
+                int cnt = 0;
+                for (int l = 0; l < 64; l++) {
+                    const unsigned lw = rs->f_len[(size_t)c * 64 + l];
+                    if ((int)(lw & 0xFFFFu) <= s) continue;
+                    const size_t e = base + (size_t)l;            // (validated above: active lanes are a prefix, positions in range)
+                    cnt++;
+                    if ((int)(lw >> 16) > s)
+                        gftri[step * 64 + (size_t)l] = (unsigned long long)rs->f_a[e] | ((unsigned long long)rs->f_b[e] << 16) | ((unsigned long long)rs->f_k[e] << 32);
+                }
+                base += (size_t)cnt;
+            }
+            for (int l = 0; l < 64; l++) {
+                const unsigned t = rs->f_task[(size_t)c * 64 + l];
+                if (t == 0xFFFFFFFFu || !(rs->f_len[(size_t)c * 64 + l] & 0xFFFFu)) continue;       // (no term: the destination is final)
+                gfdk[(size_t)c * 64 + l] = (t & 0xFFFFu) | ((t & 0x80000000u) ? 0x10000u : 0u);
+            }
+        }
+        if (step != (size_t)CPG_GENR_FAC_NSTEPS) { set_error("cpg_hip_set_resident: factorisation steps differ from the generated ones"); return CPG_E_BADARG; }
+    }
+#endif
     // ---- coalesced canonicalisation maps, entry tables
     struct EllHost { std::vector<int> idx; std::vector<double> coef; int J = 0, rows = 0; };
     auto make_ell = [&](const cpg_csr_t &M, int rows, EllHost &E) {
@@ -1426,6 +1468,11 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }
     Rs.slice_doubles = (int)slice;
     Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64LL * CPG_GENR_NREGS + 64;
+    Rs.gf_tri = nullptr; Rs.gf_dk = nullptr;
+#ifdef CPG_GENR_FAC_NSTEPS
+    if ((rc = upload<unsigned long long>(h, own, gftri.data(), gftri.size(), &Rs.gf_tri))) return rc;
+    if ((rc = upload<unsigned>(h, own, gfdk.data(), gfdk.size(), &Rs.gf_dk))) return rc;
+#endif
     if ((rc = upload<unsigned>(h, own, ctl.data(), ctl.size(), &Rs.f_ctl))) return rc;
     if ((rc = upload<cpg::ResEntry>(h, own, ent.data(), ent.size(), &Rs.f_ent))) return rc;
     if ((rc = upload<unsigned>(h, own, ksrc.data(), ksrc.size(), &Rs.k_src))) return rc;

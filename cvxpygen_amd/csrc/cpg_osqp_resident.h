@@ -63,6 +63,10 @@ struct DevResident {
     const unsigned short *g_cols, *g_rows; // operand offsets / output slots of the generated executor (LDS tables)
     DevEll eP, eA, eq, eu;
     const unsigned *entA, *entP;           // row | column << 16 of every stored entry
+    // generated factorisation (resident_factor_gen of the family's header): operand positions a | b << 16 | k << 32 per
+    // (step, lane), destination | pivot << 16 per (chunk, lane) (0xFFFF: none)
+    const unsigned long long *gf_tri;
+    const unsigned *gf_dk;
     DevStreamTab pA, pP, pAt;              // A x, P x, A' y on the work vector [x | y | .. | A x | P x | A' y]
     int out_ax, out_px, out_aty;           // first slot of the products' results (A x shares the slots of P x | A' y)
     int out_sc;                            // ... and of 1 / D (n) | 1 / E (m): the residuals of every termination test unscale with them
@@ -93,7 +97,7 @@ CPG_DEV void globalise(DevStreamTab &T) { CPG_G(T.stab); CPG_G(T.cr); CPG_G(T.sr
 CPG_DEV void globalise(DevEll &E) { CPG_G(E.idx); CPG_G(E.coef); }
 CPG_DEV void globalise(DevResident &Rs) {
     CPG_G(Rs.f_ctl); CPG_G(Rs.f_ent); CPG_G(Rs.k_src); CPG_G(Rs.g_src); CPG_G(Rs.g_lcol); CPG_G(Rs.g_cols); CPG_G(Rs.g_rows);
-    globalise(Rs.eP); globalise(Rs.eA); globalise(Rs.eq); globalise(Rs.eu); CPG_G(Rs.entA); CPG_G(Rs.entP);
+    globalise(Rs.eP); globalise(Rs.eA); globalise(Rs.eq); globalise(Rs.eu); CPG_G(Rs.entA); CPG_G(Rs.entP); CPG_G(Rs.gf_tri); CPG_G(Rs.gf_dk);
     globalise(Rs.pA); globalise(Rs.pP); globalise(Rs.pAt);
 }
 CPG_DEV void globalise(DevRefactor &R) {     // (the members the resident path reads)
@@ -511,7 +515,11 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R_, const DevResiden
             }
             for (unsigned d = nd + (unsigned)lane; d < (unsigned)Rs.fac_len; d += 64u) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
             cpgw::lds_order();
+#ifdef CPG_GENR_FAC_NSTEPS
+            resident_factor_gen(Rs.gf_tri, Rs.gf_dk, sl, lane);
+#else
             resident_factor(Rs, sl, lane);
+#endif
     }
 }
 
