@@ -178,17 +178,29 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
 CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, const double *fac, int lane) {
     const unsigned ln = (unsigned)cpgw::opaque(lane);            // (see load_instance_coefficients: addresses local to this block)
     const unsigned nnzL = (unsigned)R.nnzL, X0 = (unsigned)(Rs.fac_len - 2 - Rs.nnzX);
-#pragma unroll 16
-    for (int t = 0; t < CPG_GENR_NREGS; t++) {
-        const unsigned code = cpgw::gld(Rs.g_src, (unsigned)t * 64u + ln);
-        const unsigned col = (unsigned)cpgw::gld(Rs.g_lcol, (unsigned)t * 64u + ln);
-        const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
-        double v = 0.0;
-        if (kind == 1u) v = 1.0;
-        else if (kind == 2u) v = -(fac[idx] * fac[nnzL + col]);
-        else if (kind == 3u) v = fac[nnzL + idx];
-        else if (kind == 4u) v = fac[X0 + idx];
-        cpgw::gst(B.cf, (unsigned)t * 64u + ln, v);
+    // (the source words of 48 registers requested together: with one wavefront per SIMD every batch is an exposed round trip)
+    constexpr int NB = 48;
+#pragma unroll
+    for (int t0 = 0; t0 < CPG_GENR_NREGS; t0 += NB) {
+        unsigned code[NB], col[NB];
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int t = t0 + u;
+            code[u] = t < CPG_GENR_NREGS ? cpgw::gld(Rs.g_src, (unsigned)t * 64u + ln) : 0u;
+            col[u] = t < CPG_GENR_NREGS ? (unsigned)cpgw::gld(Rs.g_lcol, (unsigned)t * 64u + ln) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int t = t0 + u;
+            if (t >= CPG_GENR_NREGS) break;
+            const unsigned kind = code[u] >> 28, idx = code[u] & 0x0FFFFFFFu;
+            double v = 0.0;
+            if (kind == 1u) v = 1.0;
+            else if (kind == 2u) v = -(fac[idx] * fac[nnzL + col[u]]);
+            else if (kind == 3u) v = fac[nnzL + idx];
+            else if (kind == 4u) v = fac[X0 + idx];
+            cpgw::gst(B.cf, (unsigned)t * 64u + ln, v);
+        }
     }
 }
 
@@ -538,18 +550,20 @@ CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R_, const D
     double *w = sl, *qs = w + ldw, *us = qs + n;
     for (unsigned t = (unsigned)lane; t < (unsigned)Rs.slice_doubles; t += 64u) w[t] = 0.0;
     cpgw::lds_order();
-    // q | u and 1 / D | 1 / E of the instance, eight loads in flight
-    auto fill = [&](double *dst, const double *a, unsigned na, const double *b2, unsigned nb) __attribute__((always_inline)) {
-        for (unsigned i0 = 0; i0 < na + nb; i0 += 512u) {
-            double v[8];
+    // q | u and 1 / D | 1 / E of the instance: all loads of both in flight together (the dimensions are literals)
+    {
+        constexpr int KV = (int)((n + m + 63u) / 64u);
+        double vq[KV], vs[KV];
 #pragma unroll
-            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; v[u_] = i < na ? cpgw::gld(a, i) : (i < na + nb ? cpgw::gld(b2, i - na) : 0.0); }
-#pragma unroll
-            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; if (i < na + nb) dst[i] = v[u_]; }
+        for (int u_ = 0; u_ < KV; u_++) {
+            const unsigned i = 64u * (unsigned)u_ + (unsigned)lane;
+            vq[u_] = i < n ? cpgw::gld((const double *)B.q, i) : (i < n + m ? cpgw::gld((const double *)B.u, i - n) : 0.0);
+            vs[u_] = i < n ? cpgw::gld((const double *)B.Dinv, i) : (i < n + m ? cpgw::gld((const double *)B.Einv, i - n) : 0.0);
         }
-    };
-    fill(qs, (const double *)B.q, n, (const double *)B.u, m);
-    fill(w + (unsigned)Rs.out_sc, (const double *)B.Dinv, n, (const double *)B.Einv, m);
+        double *sc = w + (unsigned)Rs.out_sc;
+#pragma unroll
+        for (int u_ = 0; u_ < KV; u_++) { const unsigned i = 64u * (unsigned)u_ + (unsigned)lane; if (i < n + m) { qs[i] = vq[u_]; sc[i] = vs[u_]; } }
+    }
     cpgw::lds_order();
     cpgw::mem_order();
 }
