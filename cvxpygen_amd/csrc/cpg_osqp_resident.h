@@ -232,12 +232,12 @@ struct ResidentCtx {
         const double *src = which == 1 ? (const double *)B.E : (const double *)B.D;
         const unsigned cnt = which == 1 ? (unsigned)F.m : (unsigned)F.n;
         cpgw::lds_order();
-        for (unsigned i0 = 0; i0 < cnt; i0 += 512u) {
-            double v[8];
+        for (unsigned i0 = 0; i0 < cnt; i0 += 1024u) {        // (16 loads in flight: one round trip for up to 1 024 rows)
+            double v[16];
 #pragma unroll
-            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; v[u_] = i < cnt ? cpgw::gld(src, i) : 0.0; }
+            for (int u_ = 0; u_ < 16; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; v[u_] = i < cnt ? cpgw::gld(src, i) : 0.0; }
 #pragma unroll
-            for (int u_ = 0; u_ < 8; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; if (i < cnt) w[(unsigned)Rs.out_ax + i] = v[u_]; }
+            for (int u_ = 0; u_ < 16; u_++) { const unsigned i = i0 + 64u * (unsigned)u_ + (unsigned)lane; if (i < cnt) w[(unsigned)Rs.out_ax + i] = v[u_]; }
         }
         cpgw::lds_order();
     }
@@ -313,12 +313,12 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &R
         double qr[NSX], ur[NSZ];
         {
             double *th = Dl;
-            for (unsigned t0 = 0; t0 < (unsigned)R.np_var; t0 += 512u) {
-                double tv[8];
+            for (unsigned t0 = 0; t0 < (unsigned)R.np_var; t0 += 2048u) {      // (32 loads in flight: one round trip for up to 2 048 parameters)
+                double tv[32];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const unsigned t = t0 + 64u * (unsigned)u + (unsigned)lane; tv[u] = t < (unsigned)R.np_var ? cpgw::gld(theta, t) : 0.0; }
+                for (int u = 0; u < 32; u++) { const unsigned t = t0 + 64u * (unsigned)u + (unsigned)lane; tv[u] = t < (unsigned)R.np_var ? cpgw::gld(theta, t) : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const unsigned t = t0 + 64u * (unsigned)u + (unsigned)lane; if (t < (unsigned)R.np_var) th[t] = tv[u]; }
+                for (int u = 0; u < 32; u++) { const unsigned t = t0 + 64u * (unsigned)u + (unsigned)lane; if (t < (unsigned)R.np_var) th[t] = tv[u]; }
             }
             cpgw::lds_order();
 #pragma unroll
@@ -471,12 +471,12 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &R
         cpgw::lds_order();
         auto copy_values = [&](const DevStreamTab &T, double *dst, const double *src) __attribute__((always_inline)) {
 #pragma nounroll
-            for (unsigned e0 = 0; e0 < (unsigned)T.n_entries; e0 += 512u) {
-                int kk[8];
+            for (unsigned e0 = 0; e0 < (unsigned)T.n_entries; e0 += 1536u) {      // (24 source words in flight)
+                int kk[24];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const unsigned e = e0 + 64u * (unsigned)u + (unsigned)lane; kk[u] = e < (unsigned)T.n_entries ? cpgw::gld(T.src, e) : -1; }
+                for (int u = 0; u < 24; u++) { const unsigned e = e0 + 64u * (unsigned)u + (unsigned)lane; kk[u] = e < (unsigned)T.n_entries ? cpgw::gld(T.src, e) : -1; }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < 24; u++) {
                     const unsigned e = e0 + 64u * (unsigned)u + (unsigned)lane;
                     if (e < (unsigned)T.n_entries) cpgw::gst(dst, e, kk[u] >= 0 ? src[(unsigned)kk[u]] : 0.0);
                 }
@@ -501,15 +501,16 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R_, const DevResiden
     {
             constexpr unsigned nd = CPG_GENR_NNZL + CPG_GENR_N + CPG_GENR_M;
             constexpr int KD = (int)((nd + 63u) / 64u);
+            constexpr int KB = 40;           // (two dependent loads per destination: every batch is two exposed round trips)
             const unsigned lk = (unsigned)cpgw::opaque(lane);
 #pragma unroll
-            for (int t0 = 0; t0 < KD; t0 += 16) {            // KKT values of the destinations: 16 independent sources at a time
-                unsigned code[16];
-                double v[16];
+            for (int t0 = 0; t0 < KD; t0 += KB) {            // KKT values of the destinations: KB independent sources at a time
+                unsigned code[KB];
+                double v[KB];
 #pragma unroll
-                for (int u = 0; u < 16; u++) { const unsigned d = lk + 64u * (unsigned)(t0 + u); code[u] = (t0 + u < KD && d < nd) ? cpgw::gld(Rs.k_src, d) : 0u; }
+                for (int u = 0; u < KB; u++) { const unsigned d = lk + 64u * (unsigned)(t0 + u); code[u] = (t0 + u < KD && d < nd) ? cpgw::gld(Rs.k_src, d) : 0u; }
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
+                for (int u = 0; u < KB; u++) {
                     const unsigned kind = (code[u] >> 28) & 7u, idx = code[u] & 0x0FFFFFFFu;
                     v[u] = 0.0;
                     if (kind == CPG_K_P) v[u] = cpgw::gld((const double *)B.P, idx);
@@ -517,7 +518,7 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R_, const DevResiden
                     else if (kind == CPG_K_RHO) v[u] = -cpgw::gld((const double *)B.rinv, idx);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
+                for (int u = 0; u < KB; u++) {
                     const unsigned d = lk + 64u * (unsigned)(t0 + u), kind = (code[u] >> 28) & 7u;
                     double vv = v[u];
                     if (kind == CPG_K_P) vv = vv + (d >= (unsigned)CPG_GENR_NNZL ? sigma : 0.0);
