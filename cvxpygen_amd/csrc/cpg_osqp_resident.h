@@ -284,13 +284,15 @@ struct ResSetupOut {
     double cs, dconst;
     unsigned free_rows;           // bit s: row lane + 64 s is free (infinite bound)
     signed char ct[NSZ];          // row classes for check(): 1 equality, 0 inequality, -1 free
+    unsigned long long ts[3];     // (experiments, debug_stage 22: time stamps after canonicalisation, equilibration, scaled data)
 };
 
 // steps 1 - 3 of an instance: canonicalise, equilibrate, scaled data (the wavefront's buffer B, program-order copies)
 template <int NSX, int NSZ>
 CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, unsigned sl_off_v, const double *theta_v,
-                                     double ri_eq, double ri_in, double ri_fr, int, ResSetupOut<NSZ> &out) {
-    const int lane = cpgw::lane_id();      // (not the argument: the compiler knows this one's range, and folds the bounds tests of full slots)
+                                     double ri_eq, double ri_in, double ri_fr, int probe_v, ResSetupOut<NSZ> &out) {
+    const int lane = cpgw::lane_id();      // (the compiler knows this one's range, and folds the bounds tests of full slots)
+    const bool probe = cpgw::read_first_lane(probe_v) != 0;
     const DevRefactor R = uniform_global_copy(R_); const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
     const double *theta = nullptr;
@@ -363,6 +365,7 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &R
             }
         }
         const double dconst = csr_row(R.map_d, 0, theta, R.d_base);
+        if (probe) out.ts[0] = cpgw::clock100();
         double qsu[NSX];                       // q of the code-generation-time workspace (cost scaling)
 #pragma unroll
         for (int s = 0; s < NSX; s++) { const unsigned j = (unsigned)lane + 64u * (unsigned)s; qsu[s] = j < n ? cpgw::gld(R.q_setup, j) : 0.0; }
@@ -433,6 +436,7 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &R
             cs = cs * (1.0 / lim_scaling(cpgw::dmax2(cm, qn)));
             cpgw::lds_order();
         }
+        if (probe) out.ts[1] = cpgw::clock100();
         // ---- 3. scaled data: matrices (LDS for the copies below; the wavefront's buffer: the factorisations read their
         //         KKT values there, the termination tests their program-order copies), scaling vectors, q, u, row classes
 #pragma unroll
@@ -469,6 +473,7 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &R
 #pragma unroll
         for (int t = 0; t < KP; t++) { const unsigned k = (unsigned)lane + 64u * (unsigned)t; if (k < nnzP) { Pl[k] = pv[t]; cpgw::gst(B.P, k, pv[t]); } }
         cpgw::lds_order();
+        if (probe) out.ts[2] = cpgw::clock100();
         auto copy_values = [&](const DevStreamTab &T, double *dst, const double *src) __attribute__((always_inline)) {
 #pragma nounroll
             for (unsigned e0 = 0; e0 < (unsigned)T.n_entries; e0 += 1536u) {      // (24 source words in flight)
@@ -576,10 +581,17 @@ struct ResState { double x[NSX], z[NSZ], y[NSZ], dx[NSX], dy[NSZ]; };
 struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
 
 // One ADMM iteration on the instance's registers.
+// CPG_RES_STEP_VALUES 1: the step sizes of a slot as per-lane values selected once per call instead of selected from `rr` in every
+// iteration (what removes 18 of the loop's 22 scratch reloads -- the compiler turns the select between members of `rr` into a
+// select between their stack addresses and a load).  Measured A/B on one box (profiles/r4_s14_ab_step_values.txt): 121 instead
+// of 118 us per 25 iterations, and the OTHER stages 3 - 8 % slower with it too; the reloads are overlapped.  Off.
+#ifndef CPG_RES_STEP_VALUES
+#define CPG_RES_STEP_VALUES 0
+#endif
 template <int NSX, int NSZ>
 CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ], const double (&cf)[CPG_GENR_NREGS],
                            const CPG_LDS unsigned short *lc, const CPG_LDS unsigned short *lr, CPG_LDS double *w, const CPG_LDS double *qs,
-                           const CPG_LDS double *us, const ResRho &rr, unsigned free_rows, int lane) {
+                           const CPG_LDS double *us, const ResRho &rr, const double (&riv)[NSZ], const double (&rvv)[NSZ], unsigned free_rows, int lane) {
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
     double qt[NSX];
 #pragma unroll
@@ -589,7 +601,11 @@ CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ],
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+#if CPG_RES_STEP_VALUES
+        const double ri = riv[s];
+#else
         const double ri = i < n_eq ? rr.ri_eq : (((free_rows >> s) & 1u) ? rr.ri_fr : rr.ri_in);
+#endif
         if (i < m) w[n + i] = z[s] - ri * y[s];
     }
     cpgw::lds_order();
@@ -603,9 +619,14 @@ CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ],
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
-        const bool eq = i < n_eq, fr = (free_rows >> s) & 1u;
+        const bool eq = i < n_eq;
+#if CPG_RES_STEP_VALUES
+        const double rv = rvv[s], ri = riv[s];
+#else
+        const bool fr = (free_rows >> s) & 1u;
         const double rv = eq ? rr.rho_eq : (fr ? rr.rho_fr : rr.rho_in);
         const double ri = eq ? rr.ri_eq : (fr ? rr.ri_fr : rr.ri_in);
+#endif
         const double zp = z[s], yp = y[s];
         const double zt = (zp - ri * yp) + ri * (i < m ? w[n + i] : 0.0);
         const double zr = rr.alpha * zt + (1.0 - rr.alpha) * zp;
@@ -639,6 +660,15 @@ CPG_RES_ITERATE_LINKAGE void resident_iterate(ResState<NSX, NSZ> &st, const ResR
     CPG_LDS double *w = cpgw::lds_window3() + sl_off;
     const CPG_LDS double *qs = w + ldw, *us = qs + n;
     const ResRho rr = uniform_copy(rr_);
+    // (step sizes per slot as per-lane values: only read with CPG_RES_STEP_VALUES, see resident_step)
+    double riv[NSZ], rvv[NSZ];
+#pragma unroll
+    for (int s = 0; s < NSZ; s++) {
+        const unsigned i = (unsigned)lane + 64u * (unsigned)s;
+        const bool eq = i < n_eq, fr = (free_rows >> s) & 1u;
+        riv[s] = eq ? rr.ri_eq : (fr ? rr.ri_fr : rr.ri_in);
+        rvv[s] = eq ? rr.rho_eq : (fr ? rr.rho_fr : rr.rho_in);
+    }
     // The coefficients: ~2 registers per step and lane, loaded once per call (one call = the iterations between two
     // termination tests; 74 KB per call on the portfolio family) and held in the wavefront's 512 registers -- which of them
     // are VGPRs and which AGPR copies read through v_accvgpr_read at their use is the compiler's business, in a function
@@ -658,7 +688,7 @@ CPG_RES_ITERATE_LINKAGE void resident_iterate(ResState<NSX, NSZ> &st, const ResR
     for (int pass = 0; pass < 2; pass++) {
         const int nk = pass == 0 ? count - 1 : (count > 0 ? 1 : 0);
 #pragma nounroll
-        for (int k = 0; k < nk; k++) resident_step<NSX, NSZ>(x, z, y, cf, lc, lr, w, qs, us, rr, free_rows, lane);
+        for (int k = 0; k < nk; k++) resident_step<NSX, NSZ>(x, z, y, cf, lc, lr, w, qs, us, rr, riv, rvv, free_rows, lane);
         if (pass == 0) {
 #pragma unroll
             for (int s = 0; s < NSX; s++) st.dx[s] = x[s];
@@ -768,14 +798,15 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
 
         // (experiments, debug_stage 20: the 100 MHz time stamps of the instance's stages replace its primal results)
-        const bool probe = __builtin_expect(S.debug_stage == 20 || S.debug_stage == 21, 0);
+        const bool probe = __builtin_expect(S.debug_stage >= 20 && S.debug_stage <= 22, 0);
         unsigned long long ts[8];
         int n_ts = 0;
 #define CPG_RES_PROBE() do { if (probe && n_ts < 8) ts[n_ts++] = cpgw::clock100(); } while (0)
         CPG_RES_PROBE();
         ResSetupOut<NSZ> su;
-        resident_setup<NSX, NSZ>(R, Rs, B, sl_off, theta, ri_eq, ri_in, ri_fr, lane, su);
+        resident_setup<NSX, NSZ>(R, Rs, B, sl_off, theta, ri_eq, ri_in, ri_fr, S.debug_stage == 22 ? 1 : 0, su);
         const double cs = su.cs, dconst = su.dconst;
+        if (__builtin_expect(S.debug_stage == 22, 0)) { for (int k = 0; k < 3 && n_ts < 8; k++) ts[n_ts++] = su.ts[k]; }
         // (experiments: leave the instance after stage k of its life: 1 set-up, 2 factorisation, 3 coefficients, 4 first iterations)
 #define CPG_RES_STOP_AFTER(k) if (__builtin_expect(S.debug_stage == (k), 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }
         CPG_RES_STOP_AFTER(1)
