@@ -95,7 +95,7 @@ BINDING = {
     ('mpc6', False, False): 'as mpc12: an LDS-bound shared-factor kernel in front of a latency-bound per-instance factor kernel',
     ('portfolio', False, False): 'latency: resident per-instance factor kernel at ONE wavefront per SIMD on three of the four SIMDs of a CU: VALU 22 % of '
                                  'all SIMD cycles (30 % of the occupied ones), LDS pipe 22 %, 43 % of the wave cycles waiting; HBM-side traffic '
-                                 '78.6 GB per launch = 1.45 TB/s = 18 % of the peak (profiles/r4_final_pmc_config3.txt, r4_s10_probe_resident.txt)',
+                                 '80.6 GB per launch = 1.59 TB/s = 20 % of the peak (profiles/r4_final_pmc_config3.txt, r4_s13_probe_resident.txt)',
     ('portfolio', False, True): 'latency (as the default mode; fewer termination tests and no refactorisations)',
     ('mpc12', True, False): 'dependent memory round trips: 484 level-scheduled phases per iteration, each waiting for its coefficient stream -- 61 % of the '
                             'wave cycles waiting, VALU 41 %, FETCH 342 GB per launch = 3.2 TB/s = 40 % of the HBM peak, 0.8 scalar instructions per '
