@@ -437,3 +437,43 @@ def test_cvxpy_front_door_forwards_solver_opts_and_routes_ecos(tmp_path):
     assert e.solver == 'ECOS' and e.n_eq == c.cones['zero'] and e.n_ineq == c.m - c.cones['zero']
     with pytest.raises(ValueError, match='canonicalised for OSQP'):
         cpg.generate_code(LiteProblem.from_descriptor(families.mpc(2, 1, 3)), code_dir=str(tmp_path / 'bad'), solver='ECOS', wrapper=False)
+
+
+def test_library_staleness_is_decided_by_content_not_by_times(tmp_path):
+    """codegen.compile_if_stale: a library is rebuilt when the command or the CONTENT of a dependency changed -- digests taken
+    before the compiler starts -- and not otherwise: a header edited while a long compile runs leaves a library that is newer
+    than the edit without containing it (times alone called it fresh), and a copy of the checkout to another box changes every
+    time stamp (and possibly the path) without changing anything that matters"""
+    import time
+    from cvxpygen_amd import codegen
+    src = tmp_path / 'a.c'
+    hdr = tmp_path / 'a.h'
+    out = str(tmp_path / 'liba.so')
+    hdr.write_text('#define V 1\n')
+    src.write_text('#include "a.h"\nint v(void) { return V; }\n')
+    cmd = ['gcc', '-shared', '-fPIC', '-o', out, str(src)]
+
+    def build2():
+        before = os.stat(out).st_mtime_ns if os.path.exists(out) else None
+        time.sleep(0.02)
+        codegen.compile_if_stale(cmd, out, [str(src), str(hdr)])
+        return before is None or os.stat(out).st_mtime_ns != before
+    assert build2()                                   # first build
+    time.sleep(0.05)
+    assert not build2()                               # nothing changed
+    os.utime(hdr, None); os.utime(src, None)          # newer time stamps, same content (a copied checkout)
+    assert not build2()
+    # an edit "during the compile": the library ends up NEWER than the header and must still count as stale
+    hdr.write_text('#define V 2\n')
+    os.utime(out, None)
+    assert os.path.getmtime(out) >= os.path.getmtime(hdr)
+    assert build2()
+    assert not build2()
+    # another command (flags) -> rebuild; an interrupted build leaves no stamp behind
+    cmd.insert(1, '-O1')
+    assert build2()
+    bad = ['gcc', '-shared', '-fPIC', '-o', out, str(tmp_path / 'missing.c')]
+    with pytest.raises(Exception):
+        codegen.compile_if_stale(bad, out, [str(src), str(hdr)])
+    assert not os.path.exists(out + '.flags')
+    assert build2()
