@@ -1047,6 +1047,28 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     // accordingly (build_stream_tables above).
     StreamTables stt;                                             // alive until the sync below
     std::vector<int> kind2, idx2;
+    R.gs_cols = nullptr; R.gs_rows = nullptr; R.gs_kind = nullptr; R.gs_idx = nullptr; R.gs_ok = 0; R.gs_nnz = 0;
+#ifdef CPG_GENS_HEADER
+    std::vector<unsigned short> gscols, gsrows;
+    std::vector<int> gskind, gsidx;
+    if (!r->shared_mats && r->sol_chunks == CPG_GENS_NCHUNKS && r->sol_nnz == CPG_GENS_NNZ && r->sol_slots == CPG_GENS_NSLOTS &&
+        program_fingerprint(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz) == CPG_GENS_FINGERPRINT) {
+        // this library runs THIS per-instance-matrix program as generated straight-line code: next to the streaming layout
+        // (the adjoint kernel reads that one) the value sources in program-entry order, 64 zeros behind them (a step's idle
+        // lanes read the entries that follow), and the executor's offset / slot tables
+        static const int gsteps[][4] = CPG_GENS_STEPS;
+        if (generated_tables(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_nnz, r->sol_slots, gsteps, CPG_GENS_NSTEPS, gscols, gsrows)) {
+            gskind.assign((size_t)r->sol_nnz + 64, 0); gsidx.assign((size_t)r->sol_nnz + 64, 0);
+            for (int e = 0; e < r->sol_nnz; e++) { gskind[e] = r->sol_kind[e]; gsidx[e] = r->sol_idx[e]; }
+            R.gs_nnz = r->sol_nnz + 64;
+            if ((rc = upload<unsigned short>(h, own, gscols.data(), gscols.size(), &R.gs_cols))) return rc;
+            if ((rc = upload<unsigned short>(h, own, gsrows.data(), gsrows.size(), &R.gs_rows))) return rc;
+            if ((rc = upload<int>(h, own, gskind.data(), gskind.size(), &R.gs_kind))) return rc;
+            if ((rc = upload<int>(h, own, gsidx.data(), gsidx.size(), &R.gs_idx))) return rc;
+            R.gs_ok = 1;
+        }
+    }
+#endif
     {
         if ((rc = build_stream_tables(r->sol_ctab, r->sol_desc, r->sol_cols, r->sol_chunks, r->sol_slots, stt))) return rc;
         kind2.resize(stt.src.size()); idx2.resize(stt.src.size());
@@ -1070,7 +1092,7 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     if ((rc = upload_csr(h, own, r->map_q, &R.map_q))) return rc;
     if ((rc = upload_csr(h, own, r->map_u, &R.map_u))) return rc;
     if ((rc = upload_csr(h, own, r->map_d, &R.map_d))) return rc;
-    R.buf_doubles = (long long)(r->nnzP + 2 * r->nnzA + 3 * n + 4 * m + r->nnzL + 2 * N + R.sol_nnz + 64);   // see carve()
+    R.buf_doubles = (long long)(r->nnzP + 2 * r->nnzA + 3 * n + 4 * m + r->nnzL + 2 * N + std::max(R.sol_nnz, R.gs_nnz) + 64);   // see carve()
     R.shared_mats = r->shared_mats ? 1 : 0; R.cs = 1.0;
     R.Ps = R.As = R.Ars = R.Ds = R.Dinvs = R.Es = R.Einvs = nullptr;
     std::vector<double> ars, dinv, einv;                          // alive until the sync below
@@ -1685,7 +1707,13 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
         }
     }
 #endif
+#ifdef CPG_GENS_HEADER
+    if (!h->R.shared_mats && !h->R.gs_ok) {
+        set_error("this library's per-instance substitution program was generated for a different family"); return CPG_E_BADARG; }
+    const size_t lds = (size_t)W * (size_t)(h->R.shared_mats ? h->R.sol_slots : h->R.sol_slots + CPG_GEN_EXTRA_SLOTS) * sizeof(double);
+#else
     const size_t lds = (size_t)W * h->R.sol_slots * sizeof(double);
+#endif
     if (lds > h->lds_limit) { set_error("work vectors do not fit the LDS"); return CPG_E_UNSUPPORTED; }
     int per_cu = h->blocks_per_cu > 0 ? h->blocks_per_cu : CPG_REFACTOR_WAVES_PER_SIMD;    // workgroups of 4 waves
     if (per_cu > CPG_REFACTOR_WAVES_PER_SIMD) per_cu = CPG_REFACTOR_WAVES_PER_SIMD;

@@ -22,6 +22,14 @@
 // registers (cvxpygen_amd/codegen.py::emit_instance_program)
 #include CPG_GENI_HEADER
 #endif
+#ifdef CPG_GENS_HEADER
+// straight-line executor of the family's per-instance substitution program on per-instance matrices: coefficients and tables
+// from global memory at static addresses (cvxpygen_amd/codegen.py::stream_header)
+#include CPG_GENS_HEADER
+#define CPG_GENS_ACTIVE(geni, shared, crlds) (!(geni) && !(shared) && !(crlds))
+#else
+#define CPG_GENS_ACTIVE(geni, shared, crlds) false
+#endif
 
 namespace cpg {
 
@@ -86,6 +94,11 @@ struct DevRefactor {
     // a | b << 16 | k << 32 per (step, lane), destination | (rho row + 1) << 16 per (chunk, lane); see codegen.emit_factor_program
     const unsigned long long *gf_tri;
     const unsigned *gf_dk;
+    // generated streaming executor (run_program_gens of cpg_stream_<name>.h, per-instance-matrix mode): operand offsets
+    // [step / 4][lane][4] and output slots [chunk / 4][lane][4] in global memory; the coefficients stay in program-entry order
+    const unsigned short *gs_cols, *gs_rows;
+    const int *gs_kind, *gs_idx;        // value sources in program-entry order (+ 64 entries of kind 0)
+    int gs_ok, gs_nnz;
     // shared-matrix mode: the KKT value of every destination of the factorisation is a family constant (fac_kc; sigma
     // included on the pivots) except the -1 / rho_vec of the (2,2) diagonal: fac_krow = its row, -1 elsewhere
     const double *fac_kc;
@@ -115,7 +128,7 @@ CPG_DEV InstBuf carve(double *b, const DevFamily &F, const DevRefactor &R) {
     o.D = b; b += n; o.Dinv = b; b += n; o.E = b; b += m; o.Einv = b; b += m;
     o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
     o.Lx = b; b += R.nnzL; o.Dg = b; b += N; o.Dginv = b; b += N;
-    o.sv = b; b += R.sol_nnz;
+    o.sv = b; b += R.sol_nnz > R.gs_nnz ? R.sol_nnz : R.gs_nnz;
     o.Ar = b; b += R.nnzA;
     return o;
 }
@@ -323,11 +336,14 @@ CPG_DEV void numeric_ldl(const DevRefactor &R, const InstBuf &B, double reg, int
 }
 // Coefficients of the substitution program from the factor (1, -L_ij or 1 / d_j per entry).  MFORM: B.Lx holds the
 // undivided entries of numeric_ldl_m (l_ij = M_ij / d_j), B.Dginv the reciprocal pivots.
-template <bool MFORM = false>
+template <bool MFORM = false, bool GENS = false>
 CPG_DEV void substitution_values(const DevRefactor &R, const InstBuf &B, int lane) {
-    for (unsigned e = (unsigned)lane; e < (unsigned)R.sol_nnz; e += 64u) {
-        const int kind = cpgw::gld(R.sol_kind, e);
-        const unsigned idx = (unsigned)cpgw::gld(R.sol_idx, e);
+    // (GENS: program-entry order for the generated streaming executor, else the streaming executor's own layout)
+    const int *kinds = GENS ? R.gs_kind : R.sol_kind, *idxs = GENS ? R.gs_idx : R.sol_idx;
+    const unsigned cnt = GENS ? (unsigned)R.gs_nnz : (unsigned)R.sol_nnz;
+    for (unsigned e = (unsigned)lane; e < cnt; e += 64u) {
+        const int kind = cpgw::gld(kinds, e);
+        const unsigned idx = (unsigned)cpgw::gld(idxs, e);
         double v = 0.0;
         if (kind == 1) v = 1.0;
         else if (kind == 2) v = MFORM ? -(cpgw::gld((const double *)B.Lx, idx) * cpgw::gld((const double *)B.Dginv, (unsigned)cpgw::gld(R.Lcol, idx)))
@@ -497,7 +513,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         lds += (ncr + 1u) / 2u;
     }
 #ifdef CPG_GENI_HEADER
-    const int ldw = GENI ? CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS : R.sol_slots;
+    const int ldw = GENI ? CPG_GENI_NSLOTS + CPG_GEN_EXTRA_SLOTS : (CPG_GENS_ACTIVE(GENI, SHARED, CRLDS) ? R.sol_slots + CPG_GEN_EXTRA_SLOTS : R.sol_slots);
     // block-shared copies of the executor's offset / output-slot tables in front of the work vectors
     constexpr unsigned gi_ncols = ((CPG_GENI_NSTEPS + 3u) / 4u) * 256u, gi_nrows = ((CPG_GENI_NCHUNKS + 3u) / 4u) * 256u;
     const unsigned short *gi_lc = nullptr, *gi_lr = nullptr;
@@ -510,7 +526,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         lds += (gi_ncols + gi_nrows) / 4u;
     }
 #else
-    const int ldw = R.sol_slots;
+    const int ldw = CPG_GENS_ACTIVE(GENI, SHARED, CRLDS) ? R.sol_slots + CPG_GEN_EXTRA_SLOTS : R.sol_slots;
 #endif
     // per wavefront: the work vector, and with the generated executor the instance's q and u behind it; the same
     // slice holds the factor (M [nnzL] | 1 / d [N]) while numeric_ldl_lds runs -- nothing in it is live then
@@ -524,6 +540,11 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
     double *w = lds + (size_t)cpgw::wave_in_block() * per_wave;
     double *qs = w + ldw, *us = qs + n;
     constexpr bool shared = SHARED || GENI;
+#ifdef CPG_GENS_HEADER
+    constexpr bool GENS = !shared && !CRLDS;          // (this library's per-instance-matrix program is the generated one: cpg_hip_set_refactor checked)
+#else
+    constexpr bool GENS = false;
+#endif
     InstBuf B = carve(Bt.scratch + (size_t)wave_global * (size_t)R.buf_doubles, F0, R);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
     const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
@@ -702,7 +723,7 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
                 // instance's P / A measured SLOWER on this kernel -- config 3 161 -> 147 k/s, all parameters 200 -> 190 k/s,
                 // profiles/r3_s13_*: its extra live values push the ADMM loop's allocation over the edge)
                 numeric_ldl(R, B, F0.sigma, lane);
-                substitution_values<false>(R, B, lane);
+                substitution_values<false, GENS>(R, B, lane);
             }
         };
 #ifdef CPG_GENI_HEADER
@@ -734,6 +755,12 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
         if (__builtin_expect(S.debug_stage == 3, 0)) { if (lane == 0) { Bt.status[b] = 11; Bt.iter[b] = 0; } continue; }     // (factorised, coefficients loaded)
         CPG_INST_PROBE();          // 2: factorised, coefficients in registers
 
+#ifdef CPG_GENS_HEADER
+        if (GENS) {    // the zero slot idle lanes of the generated executor gather (its dummy store targets sit next to it)
+            if (lane == 0) w[CPG_GENS_NSLOTS + CPG_GEN_DUMMY_SLOTS] = 0.0;
+            cpgw::lds_order();
+        }
+#endif
         // ---- 6. ADMM from cold start with the instance's own factor
         DevFamily F = F0;
         F.D = B.D; F.Dinv = B.Dinv; F.E = B.E; F.Einv = B.Einv; F.c = cs; F.cinv = 1.0 / cs;
@@ -787,6 +814,10 @@ CPG_DEV void osqp_refactor_body(const DevFamily &F0, const DevRefactor &R, const
             cpgw::lds_order();
 #ifdef CPG_GENI_HEADER
             if (GENI) run_program_inst(cf, gi_lc, gi_lr, w, lane);
+            else
+#endif
+#ifdef CPG_GENS_HEADER
+            if (GENS) run_program_gens((const double *)B.sv, R.gs_cols, R.gs_rows, w, lane);
             else
 #endif
             run_program_stream(ST, w, lane);

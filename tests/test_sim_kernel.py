@@ -338,3 +338,42 @@ def test_raw_entry_points_refuse_rho_adaptation_on_a_shared_factor_handle_withou
     ps.run()
     assert (np.array(ps.status) == 1).all()
     ps.free(); dev.free(); bs.close()
+
+
+def test_generated_streaming_executor_for_per_instance_matrices(sim_lib, oracle_lib, tmp_path, monkeypatch):
+    """a family whose parameters enter P / A and whose merged program does not fit the resident kernel (an MPC chain): with
+    CPG_GENS=1 its family library runs the per-instance substitution program as generated straight-line code with
+    coefficients and tables from global memory (cpg_stream_<name>.h, CPG_GENS_HEADER) -- every parameter varying, against
+    the oracle, against the table-driven streaming executor of the generic library, and through a rho adaptation.  (Off by
+    default: slower than the table-driven executor on the GPU, codegen.stream_header says why; the path stays correct.)"""
+    monkeypatch.setenv('CPG_GENS', '1')
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sim import build_sim
+    from cvxpygen_amd import codegen
+    from cvxpygen_amd.runtime import build_family_plan
+    d = families.mpc(8, 3, 7)
+    plan = build_family_plan(d)
+    _, defs = codegen.family_library_defs(plan, str(tmp_path), 'mpc8')
+    if not any('CPG_GENS_HEADER' in x for x in defs):
+        pytest.skip('this family fits the resident kernel')
+    lib = build_sim.build_family(plan, str(tmp_path), 'mpc8')
+    rng = np.random.default_rng(2)
+    B = 3
+    th = np.tile(d.theta0, (B, 1))
+    th[:, :d.NP] *= 1 + 0.05 * rng.standard_normal((B, d.NP))
+    p = d.param('x_init')
+    th[:, p.col:p.col + p.size] = -2 + 4 * rng.random((B, p.size))
+    B = 2; th = th[:2]
+    vals = {q.name: th[:, q.col:q.col + q.size] for q in d.params}
+    out = {}
+    for tag, path in (('family', lib), ('generic', sim_lib)):
+        bs = BatchSolver(d, lib_path=path, plan=plan if tag == 'family' else None)
+        for stg in ({}, dict(eps_abs=1e-7, eps_rel=1e-7)):
+            r = bs.solve(vals, **stg)
+            o, prim, dual = _oracle_flat(oracle_lib, d, th, None, **stg)
+            _assert_parity(r, o, prim, dual, tol=1e-8)
+        out[tag] = r
+        bs.close()
+    assert out['family'].iter.tolist() == out['generic'].iter.tolist()
+    assert np.abs(out['family'].prim_flat - out['generic'].prim_flat).max() < 1e-9
