@@ -1484,8 +1484,15 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     const int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     if (rs->out_ax < ldw + N || rs->out_px < ldw + N || rs->out_aty < rs->out_px + n) { set_error("cpg_hip_set_resident: result slots overlap the work vector"); return CPG_E_BADARG; }
     Rs.out_sc = w_slots;                                  // 1 / D | 1 / E of the instance behind the products' results
+#ifdef CPG_GENR_TABLES_GLOBAL
+    // four wavefronts per CU: 1 / E alone behind the products' results; the set-up's D, E, norms and theta alias the space of the
+    // scaled matrices (cpg_osqp_resident.h)
+    long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots + m);
+    slice = std::max<long long>(slice, std::max<long long>((long long)r->nnzA + r->nnzP, std::max<long long>(r->np_var, (long long)N + std::max(n, m))));
+#else
     long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots + N);
     slice = std::max<long long>(slice, (long long)r->nnzA + r->nnzP + std::max<long long>(r->np_var, (long long)N + std::max(n, m)));
+#endif
     slice += slice & 1;
     if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }
     Rs.slice_doubles = (int)slice;
@@ -1643,7 +1650,11 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
 #ifdef CPG_GENR_HEADER
     if (h->Rs.ok && !h->R.shared_mats && h->program_in_lds != 0 && h->program_in_lds != 2) {
         // resident kernel: one workgroup per CU, as many wavefronts (<= 4: one per SIMD) as slices fit the LDS
+#ifdef CPG_GENR_TABLES_GLOBAL
+        const size_t tab = 0;                          // (the executor's tables stay in global memory)
+#else
         const size_t tab = (size_t)(((CPG_GENR_NSTEPS + 3) / 4) * 256 + ((CPG_GENR_NCHUNKS + 3) / 4) * 256) * sizeof(unsigned short);
+#endif
         const size_t slice = (size_t)h->Rs.slice_doubles * sizeof(double);
         int NW = h->waves_per_block > 0 ? h->waves_per_block : 4;
         if (NW > 4) NW = 4;

@@ -224,8 +224,16 @@ struct ResidentCtx {
     // round trip each (~60 of them per test, most of its 96 us: profiles/r4_s3_*).  1 / D and 1 / E sit in the slice; D / E,
     // which only the infeasibility tests read, are staged into the products' result slots when such a test starts (one
     // batch of loads) and consumed before the test's first product overwrites them.
+#ifdef CPG_GENR_TABLES_GLOBAL
+    // (four wavefronts per CU: 1 / E alone stays in the slice; 1 / D sits in registers of the test, loaded at its entry --
+    // i = lane + 64 s with lane < 64, so i >> 6 is the literal s after unrolling)
+    const double (&dinv_r)[NSX];
+    CPG_DEV double sDinv(unsigned i) const { return dinv_r[i >> 6]; }
+    CPG_DEV double sEinv(unsigned i) const { return w[(unsigned)Rs.out_sc + i]; }
+#else
     CPG_DEV double sDinv(unsigned i) const { return w[(unsigned)Rs.out_sc + i]; }
     CPG_DEV double sEinv(unsigned i) const { return w[(unsigned)Rs.out_sc + (unsigned)F.n + i]; }
+#endif
     CPG_DEV double sE(unsigned i) const { return w[(unsigned)Rs.out_ax + i]; }
     CPG_DEV double sD(unsigned i) const { return w[(unsigned)Rs.out_ax + i]; }
     CPG_DEV void stage(int which) const {
@@ -301,7 +309,13 @@ CPG_DEV_NOINLINE void resident_setup(const DevRefactor &R_, const DevResident &R
     theta = cpgw::as_global(theta);
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, N = n + m, n_eq = CPG_GENR_NEQ;
     double *sl = cpgw::lds_window() + sl_off;
+#ifdef CPG_GENR_TABLES_GLOBAL
+    // (four wavefronts per CU: the scaling vectors, the norms and theta use the space the scaled matrices take once D and E are
+    // dead -- step 3 below writes A, P behind a fence, after every read of D and E)
+    double *Al = sl, *Pl = Al + CPG_GENR_NNZA, *Dl = sl, *El = Dl + n;
+#else
     double *Al = sl, *Pl = Al + CPG_GENR_NNZA, *Dl = Pl + CPG_GENR_NNZP, *El = Dl + n;
+#endif
     unsigned long long *nrm = (unsigned long long *)(El + m);
     {
         // ---- 1. theta -> LDS; canonicalise P, A, q, u (registers: entry k = lane + 64 t of a matrix, entry i = lane + 64 s
@@ -568,7 +582,17 @@ CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R_, const D
         }
         double *sc = w + (unsigned)Rs.out_sc;
 #pragma unroll
-        for (int u_ = 0; u_ < KV; u_++) { const unsigned i = 64u * (unsigned)u_ + (unsigned)lane; if (i < n + m) { qs[i] = vq[u_]; sc[i] = vs[u_]; } }
+        for (int u_ = 0; u_ < KV; u_++) {
+            const unsigned i = 64u * (unsigned)u_ + (unsigned)lane;
+            if (i < n + m) {
+                qs[i] = vq[u_];
+#ifdef CPG_GENR_TABLES_GLOBAL
+                if (i >= n) sc[i - n] = vs[u_];             // (1 / E only: 1 / D is read into registers by the test)
+#else
+                sc[i] = vs[u_];
+#endif
+            }
+        }
     }
     cpgw::lds_order();
     cpgw::mem_order();
@@ -580,6 +604,11 @@ template <int NSX, int NSZ>
 struct ResState { double x[NSX], z[NSZ], y[NSZ], dx[NSX], dy[NSZ]; };
 struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
 
+#ifdef CPG_GENR_TABLES_GLOBAL
+#define CPG_RES_TAB                 // the executor's tables in global memory
+#else
+#define CPG_RES_TAB CPG_LDS         // ... in a block-shared LDS copy
+#endif
 // One ADMM iteration on the instance's registers.
 // CPG_RES_STEP_VALUES 1: the step sizes of a slot as per-lane values selected once per call instead of selected from `rr` in every
 // iteration (what removes 18 of the loop's 22 scratch reloads -- the compiler turns the select between members of `rr` into a
@@ -590,7 +619,7 @@ struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha
 #endif
 template <int NSX, int NSZ>
 CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ], const double (&cf)[CPG_GENR_NREGS],
-                           const CPG_LDS unsigned short *lc, const CPG_LDS unsigned short *lr, CPG_LDS double *w, const CPG_LDS double *qs,
+                           const CPG_RES_TAB unsigned short *lc, const CPG_RES_TAB unsigned short *lr, CPG_LDS double *w, const CPG_LDS double *qs,
                            const CPG_LDS double *us, const ResRho &rr, const double (&riv)[NSZ], const double (&rvv)[NSZ], unsigned free_rows, int lane) {
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
     double qt[NSX];
@@ -648,7 +677,7 @@ CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ],
 // loop holds no scratch access (scripts/isa_resident.py checks it).
 template <int NSX, int NSZ>
 CPG_RES_ITERATE_LINKAGE void resident_iterate(ResState<NSX, NSZ> &st, const ResRho &rr_, const double *cfg, unsigned free_rows, unsigned sl_off_v,
-                                       int count_v, int) {
+                                       int count_v, int, const unsigned short *gcols_v = nullptr, const unsigned short *grows_v = nullptr) {
     const int lane = cpgw::lane_id();      // (range known: bounds tests of full slots fold away)
     // (arguments arrive in VGPRs: tell the compiler which of them are wave-uniform)
     const unsigned sl_off = (unsigned)cpgw::read_first_lane((int)sl_off_v);
@@ -656,7 +685,16 @@ CPG_RES_ITERATE_LINKAGE void resident_iterate(ResState<NSX, NSZ> &st, const ResR
     constexpr unsigned n = CPG_GENR_N, m = CPG_GENR_M, n_eq = CPG_GENR_NEQ;
     constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u;
+#ifdef CPG_GENR_TABLES_GLOBAL
+    auto uniform_ptr = [](const unsigned short *p) __attribute__((always_inline)) {
+        const unsigned long long a = (unsigned long long)p;
+        return cpgw::as_global((const unsigned short *)(((unsigned long long)(unsigned)cpgw::read_first_lane((int)(a >> 32)) << 32) | (unsigned)cpgw::read_first_lane((int)a)));
+    };
+    const unsigned short *lc = uniform_ptr(gcols_v), *lr = uniform_ptr(grows_v);
+    (void)t_ncols;
+#else
     const CPG_LDS unsigned short *lc = (const CPG_LDS unsigned short *)cpgw::lds_window3(), *lr = lc + t_ncols;
+#endif
     CPG_LDS double *w = cpgw::lds_window3() + sl_off;
     const CPG_LDS double *qs = w + ldw, *us = qs + n;
     const ResRho rr = uniform_copy(rr_);
@@ -731,7 +769,14 @@ CPG_DEV_NOINLINE CheckOut resident_check(const DevFamily &F_, const DevResident 
     ScaledNorms *sn = &sn_local;
     double *w = cpgw::lds_window() + sl_off;
     const double *qs = w + (CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + CPG_GENR_N;
+#ifdef CPG_GENR_TABLES_GLOBAL
+    double dinv_r[NSX];
+#pragma unroll
+    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane + 64u * (unsigned)s; dinv_r[s] = i < (unsigned)CPG_GENR_N ? cpgw::gld((const double *)B.Dinv, i) : 0.0; }
+    const CtxT cx{F, Rs, B, w, sl_off, qs, us, lane, S.debug_stage == 21, dinv_r};
+#else
     const CtxT cx{F, Rs, B, w, sl_off, qs, us, lane, S.debug_stage == 21};
+#endif
     const CheckOut o = check<NSX, NSZ, CtxT, RegDelta<NSX>, RegDelta<NSZ>>(F, cx, ct, S, x, z, y, RegDelta<NSX>{dxr}, RegDelta<NSZ>{dyr},
                                                                            InfeasVerdict{false, false}, w, lane, approximate, sn);
     if (sn_) *sn_ = sn_local;
@@ -765,16 +810,22 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
     constexpr int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     // block-shared copies of the executor's offset / output-slot tables in front of the wavefronts' slices
     constexpr unsigned t_ncols = ((CPG_GENR_NSTEPS + 3u) / 4u) * 256u, t_nrows = ((CPG_GENR_NCHUNKS + 3u) / 4u) * 256u;
+#ifdef CPG_GENR_TABLES_GLOBAL
+    constexpr unsigned tab_doubles = 0u;             // (four wavefronts per CU: the tables are read from global memory)
+    (void)t_ncols; (void)t_nrows; (void)lds;
+#else
+    constexpr unsigned tab_doubles = (t_ncols + t_nrows) / 4u;
     unsigned short *lc = (unsigned short *)lds, *lr = lc + t_ncols;
     for (unsigned t = cpgw::thread_in_block(); t < t_ncols; t += cpgw::block_threads()) lc[t] = cpgw::gld(Rs.g_cols, t);
     for (unsigned t = cpgw::thread_in_block(); t < t_nrows; t += cpgw::block_threads()) lr[t] = cpgw::gld(Rs.g_rows, t);
     cpgw::block_sync();
-    lds += (t_ncols + t_nrows) / 4u;
+    lds += tab_doubles;
+#endif
     // The wavefront's slice, three lives:
     //   set-up    A (nnzA) | P (nnzP) | D (n) | E (m) | norms (max(n, m))      theta is staged where D starts
     //   factor    fac = M (nnzL) | 1/d (N) | X | 1.0 | 0.0
     //   ADMM      w (ldw) | q (n) | u (m) | A x (m)  or  P x (n) | A' y (n) | 1 / D (n) | 1 / E (m)
-    const unsigned sl_off = (t_ncols + t_nrows) / 4u + (unsigned)cpgw::wave_in_block() * (unsigned)Rs.slice_doubles;
+    const unsigned sl_off = tab_doubles + (unsigned)cpgw::wave_in_block() * (unsigned)Rs.slice_doubles;
     const ResBuf B = res_carve(Bt.scratch + (size_t)wave_global * (size_t)Rs.buf_doubles, F0, R, Rs);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
     const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
@@ -845,9 +896,9 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
                 if (ad_int > 0) { const int c = (iter / ad_int + 1) * ad_int; if (c < next_ev) next_ev = c; }
                 const ResRho rr{rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, F0.sigma, F0.alpha};
                 if (__builtin_expect(S.debug_stage == 7, 0)) {        // (experiments: one call per iteration)
-                    for (int k = iter; k < next_ev; k++) resident_iterate<NSX, NSZ>(st, rr, B.cf, su.free_rows, sl_off, 1, lane);
+                    for (int k = iter; k < next_ev; k++) resident_iterate<NSX, NSZ>(st, rr, B.cf, su.free_rows, sl_off, 1, lane, Rs.g_cols, Rs.g_rows);
                 } else
-                resident_iterate<NSX, NSZ>(st, rr, B.cf, su.free_rows, sl_off, next_ev - iter, lane);
+                resident_iterate<NSX, NSZ>(st, rr, B.cf, su.free_rows, sl_off, next_ev - iter, lane, Rs.g_cols, Rs.g_rows);
                 iter = next_ev;
                 CPG_RES_PROBE();
                 if (__builtin_expect(S.debug_stage == 4, 0)) break;

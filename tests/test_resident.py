@@ -108,7 +108,8 @@ def _resident_in_use(bs) -> bool:
     return v.value == 1.0
 
 
-def test_resident_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path):
+@pytest.mark.parametrize('four_waves', [False, True])
+def test_resident_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path, monkeypatch, four_waves):
     """the kernel sources of the resident path (set-up in LDS, combined factorisation + inverse stream, merged program
     through the generated executor, termination test through the streamed row programs) in a family library of a small
     portfolio family: the oracle's iterates, iteration counts and statuses in the default mode (rho adapted at 50, 100 ...),
@@ -116,11 +117,15 @@ def test_resident_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path):
     library gives the same counts"""
     from sim import build_sim
     from test_sim_kernel import _assert_parity, _oracle_flat
+    # (four_waves: the layout with the executor's tables in global memory and four slices per CU -- correct, slower on the GPU,
+    # off by default: codegen.resident_four_waves)
+    monkeypatch.setenv('CPG_RES_FOUR_WAVES', '1' if four_waves else '0')
     n, m, B = 20, 3, 3
     d = families.portfolio(n, m)
     plan = build_family_plan(d)
     _, defs = codegen.family_library_defs(plan, str(tmp_path), 'pf20')
     assert any('CPG_GENR_HEADER' in x for x in defs)
+    assert ('CPG_GENR_TABLES_GLOBAL' in open(str(tmp_path / 'cpg_resident_pf20.h')).read()) == four_waves
     lib = build_sim.build_family(plan, str(tmp_path), 'pf20')
     vals, th, upd = _portfolio_values(d, B, n, m)
     bs = BatchSolver(d, lib_path=lib, plan=plan)
