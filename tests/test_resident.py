@@ -179,3 +179,34 @@ def test_config3_family_runs_the_resident_kernel_vs_oracle(oracle_lib):
     assert not _resident_in_use(bs)
     assert r2.iter.tolist() == r.iter.tolist() and np.abs(r2.prim_flat - r.prim_flat).max() < 1e-8
     bs.close()
+
+
+@pytest.mark.gpu
+def test_config3_full_shard_is_its_64_distinct_instances_repeated(oracle_lib):
+    """BASELINE config 3 at its full per-GPU shard (125 000 instances): a size-independent property -- the shard is 64 distinct
+    instances repeated, every copy must come back bit-identical to the first (instances share nothing but read-only tables and
+    are handed to wavefronts in an order that depends on the run), and the 64 equal the oracle's (counts exact, 1e-6)"""
+    import os
+    from test_sim_kernel import _assert_parity, _oracle_flat
+    d = families.portfolio(100, 10)
+    plan = build_family_plan(d)
+    out = os.path.join(os.path.dirname(os.path.abspath(codegen.__file__)), 'generated', 'portfolio')
+    lib = codegen.build_family_library(plan, out, 'portfolio')
+    K, B = 64, 125_000
+    vals, th, upd = _portfolio_values(d, K, 100, 10, seed=11)
+    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    bs.set_updated(upd)
+    tv = bs.theta_var(vals)                                   # [K, np_var]
+    reps = -(-B // K)
+    tv_full = np.ascontiguousarray(np.tile(tv, (reps, 1))[:B])
+    r = bs.solve(theta_var=tv_full, B=B)
+    assert _resident_in_use(bs)
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, upd)
+    first = type('R', (), dict(iter=r.iter[:K], status=r.status[:K], prim_flat=r.prim_flat[:K], dual_flat=r.dual_flat[:K],
+                               obj_val=r.obj_val[:K], pri_res=r.pri_res[:K], dua_res=r.dua_res[:K]))()
+    _assert_parity(first, o, prim, dual, tol=1e-6)
+    idx = np.arange(B) % K
+    assert np.array_equal(r.iter, r.iter[:K][idx]) and np.array_equal(r.status, r.status[:K][idx])
+    assert np.array_equal(r.prim_flat, r.prim_flat[:K][idx]) and np.array_equal(r.dual_flat, r.dual_flat[:K][idx])
+    assert np.array_equal(r.obj_val, r.obj_val[:K][idx])
+    bs.close()
