@@ -14,6 +14,7 @@
 #include "cpg_osqp_kernel.h"
 #include "cpg_osqp_refactor.h"
 #include "cpg_osqp_resident.h"
+#include "cpg_osqp_team.h"
 #include "cpg_clarabel_kernel.h"
 
 // ------------------------------------------------------------------------------------ runtime layer
@@ -332,6 +333,24 @@ static int launch_resident_t(cpg_handle_t h, rt_stream_t stream, const cpg::DevS
     return CPG_OK;
 }
 #endif
+#ifdef CPG_GENT_HEADER
+// team per-instance factor kernel (cpg_osqp_team.h): one workgroup of CPG_GENT_W wavefronts per instance.  Up to four
+// wavefronts: one per SIMD, each with the SIMD's whole unified register file (512 registers); eight: two per SIMD (256).
+__global__ void __launch_bounds__(CPG_GENT_W * 64)
+osqp_team_kernel(cpg::DevFamily F, cpg::DevRefactor R, cpg::DevResident Rs, cpg::DevSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    constexpr int NX = (CPG_GENT_N + CPG_GENT_W * 64 - 1) / (CPG_GENT_W * 64), NZ = (CPG_GENT_M + CPG_GENT_W * 64 - 1) / (CPG_GENT_W * 64);
+    cpg::osqp_team_body<(NX > 0 ? NX : 1), (NZ > 0 ? NZ : 1)>(F, R, Rs, S, Bt, cpg_lds, (int)blockIdx.x);
+}
+static int launch_team(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, const cpg::DevBatch &Bt, int blocks, size_t lds) {
+    auto kern = osqp_team_kernel;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(CPG_GENT_W * 64), lds, stream, h->F, h->R, h->Rs, S, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#endif
 #ifndef CPG_KERNELS_REFACTOR
 #define CPG_KERNELS_REFACTOR(Z) Z(1, 1) Z(4, 4) Z(8, 8) Z(16, 16)
 #endif
@@ -600,6 +619,7 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     else if (s == "adaptive_rho_tolerance") *v = h->S.adaptive_rho_tolerance;
     else if (s == "check_dualgap") *v = h->S.check_dualgap;
     // (read-only facts about the handle) 1: per-instance solves of this handle run the generated instance executor
+    else if (s == "team_executor") *v = (h->refactor_mode && h->Rs.ok == 2 && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else if (s == "resident_executor") *v = (h->refactor_mode && h->Rs.ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else if (s == "generated_instance_executor") *v = (h->refactor_mode && h->R.gi_ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
@@ -1254,6 +1274,49 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *r) {
     return CPG_OK;
 }
 
+#if defined(CPG_GENT_HEADER)
+#define CPG_RX(x) CPG_GENT_##x
+#define CPG_RX_PRESENT 1
+#define CPG_RX_FAC 1
+#elif defined(CPG_GENR_HEADER)
+#define CPG_RX(x) CPG_GENR_##x
+#define CPG_RX_PRESENT 1
+#ifdef CPG_GENR_FAC_NSTEPS
+#define CPG_RX_FAC 1
+#endif
+#endif
+#ifdef CPG_GENT_HEADER
+// Register images of a team executor (codegen.emit_team_program): per wavefront of the team the operand offsets of ITS steps
+// (two 16-bit byte offsets per word, step j of the wavefront in half j & 1 of word j / 2) and the output slots of ITS
+// chunks, from the [step / 4][lane][4] / [chunk / 4][lane][4] tables generated_tables builds; unused halves: the zero slot /
+// a dummy slot.
+static bool team_tables(const std::vector<unsigned short> &gcols, const std::vector<unsigned short> &grows, int T, int n_chunks,
+                        const int *step_wave, const int *step_local, const int *chunk_wave, const int *chunk_local, int W, int n_off, int n_row,
+                        int n_slots, std::vector<unsigned> &toff, std::vector<unsigned> &trow) {
+    const unsigned zero_off = (unsigned)(n_slots + CPG_GEN_DUMMY_SLOTS) * 8u, dummy = (unsigned)n_slots;
+    toff.assign((size_t)W * n_off * 64, zero_off | (zero_off << 16));
+    trow.assign((size_t)W * n_row * 64, dummy | (dummy << 16));
+    for (int t = 0; t < T; t++) {
+        const int wv = step_wave[t], j = step_local[t];
+        if (wv < 0 || wv >= W || j < 0 || j / 2 >= n_off) return false;
+        for (int l = 0; l < 64; l++) {
+            unsigned &wd = toff[((size_t)wv * n_off + (size_t)(j / 2)) * 64 + l];
+            const unsigned v = gcols[((size_t)(t / 4) * 64 + l) * 4 + (t % 4)];
+            wd = (j & 1) ? ((wd & 0xFFFFu) | (v << 16)) : ((wd & 0xFFFF0000u) | v);
+        }
+    }
+    for (int c = 0; c < n_chunks; c++) {
+        const int wv = chunk_wave[c], j = chunk_local[c];
+        if (wv < 0 || wv >= W || j < 0 || j / 2 >= n_row) return false;
+        for (int l = 0; l < 64; l++) {
+            unsigned &wd = trow[((size_t)wv * n_row + (size_t)(j / 2)) * 64 + l];
+            const unsigned v = grows[((size_t)(c >> 2) * 64 + l) * 4 + (c & 3)];
+            wd = (j & 1) ? ((wd & 0xFFFFu) | (v << 16)) : ((wd & 0xFFFF0000u) | v);
+        }
+    }
+    return true;
+}
+#endif
 // Tables of the resident per-instance factor kernel (cpg_osqp_resident.h); see include/cpg_hip.h.
 int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg_osqp_resident_t *rs) {
     int rc = cpg_hip_set_refactor(h, r);
@@ -1261,31 +1324,43 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     free_list(h->resident_owned);
     h->Rs = cpg::DevResident{};
     if (!rs) { set_error("null argument"); return CPG_E_BADARG; }
-#ifdef CPG_GENR_HEADER
+#ifdef CPG_RX_PRESENT
     if (r->shared_mats) return CPG_OK;
     std::vector<void *> &own = h->resident_owned;
     cpg::DevResident &Rs = h->Rs;
     const int n = h->F.n, m = h->F.m, N = n + m, nnzL = r->nnzL;
-    if (n != CPG_GENR_N || m != CPG_GENR_M || h->F.n_eq != CPG_GENR_NEQ || r->nnzA != CPG_GENR_NNZA || r->nnzP != CPG_GENR_NNZP ||
-        nnzL != CPG_GENR_NNZL || rs->nnzX != CPG_GENR_NNZX ||
-        rs->sol_chunks != CPG_GENR_NCHUNKS || rs->sol_nnz != CPG_GENR_NNZ || rs->sol_slots != CPG_GENR_NSLOTS ||
-        program_fingerprint(rs->sol_ctab, rs->sol_desc, rs->sol_cols, rs->sol_chunks, rs->sol_nnz) != CPG_GENR_FINGERPRINT)
+    if (n != CPG_RX(N) || m != CPG_RX(M) || h->F.n_eq != CPG_RX(NEQ) || r->nnzA != CPG_RX(NNZA) || r->nnzP != CPG_RX(NNZP) ||
+        nnzL != CPG_RX(NNZL) || rs->nnzX != CPG_RX(NNZX) ||
+        rs->sol_chunks != CPG_RX(NCHUNKS) || rs->sol_nnz != CPG_RX(NNZ) || rs->sol_slots != CPG_RX(NSLOTS) ||
+        program_fingerprint(rs->sol_ctab, rs->sol_desc, rs->sol_cols, rs->sol_chunks, rs->sol_nnz) != CPG_RX(FINGERPRINT))
         return CPG_OK;                                    // another family's library: the streaming kernel serves this handle
-    static const int steps[][4] = CPG_GENR_STEPS;         // {first entry, active lanes, coefficient register, lane shift}
-    static const int chunk_shift[] = CPG_GENR_CHUNK_SHIFT;
+    static const int steps[][4] = CPG_RX(STEPS);         // {first entry, active lanes, coefficient register, lane shift}
+    static const int chunk_shift[] = CPG_RX(CHUNK_SHIFT);
     std::vector<unsigned short> gcols, grows, glcol;
     std::vector<unsigned> gsrc;
-    if (!generated_tables(rs->sol_ctab, rs->sol_desc, rs->sol_cols, rs->sol_chunks, rs->sol_nnz, rs->sol_slots, steps, CPG_GENR_NSTEPS, gcols, grows, chunk_shift)) {
+    if (!generated_tables(rs->sol_ctab, rs->sol_desc, rs->sol_cols, rs->sol_chunks, rs->sol_nnz, rs->sol_slots, steps, CPG_RX(NSTEPS), gcols, grows, chunk_shift)) {
         set_error("cpg_hip_set_resident: the merged program does not fit the generated executor's tables"); return CPG_E_BADARG; }
-    gsrc.assign((size_t)CPG_GENR_NREGS * 64, 0u); glcol.assign((size_t)CPG_GENR_NREGS * 64, (unsigned short)0);
+#ifdef CPG_GENT_HEADER
+    // team kernel: coefficient registers, operand offsets and output slots per WAVEFRONT of the team
+    static const int step_wave[] = CPG_GENT_STEP_WAVE, step_local[] = CPG_GENT_STEP_LOCAL, chunk_wave[] = CPG_GENT_CHUNK_WAVE, chunk_local[] = CPG_GENT_CHUNK_LOCAL;
+    constexpr int TW = CPG_GENT_W;
+    std::vector<unsigned> toff, trow;
+    if (!team_tables(gcols, grows, CPG_GENT_NSTEPS, CPG_GENT_NCHUNKS, step_wave, step_local, chunk_wave, chunk_local, TW, CPG_GENT_NOFF, CPG_GENT_NROW,
+                     CPG_GENT_NSLOTS, toff, trow)) { set_error("cpg_hip_set_resident: bad team tables"); return CPG_E_BADARG; }
+#else
+    constexpr int TW = 1;
+    static const int step_wave[1] = {0};
+#endif
+    gsrc.assign((size_t)TW * CPG_RX(NREGS) * 64, 0u); glcol.assign((size_t)TW * CPG_RX(NREGS) * 64, (unsigned short)0);
     {
-        std::vector<char> taken((size_t)CPG_GENR_NREGS * 64, 0);
-        for (int t = 0; t < CPG_GENR_NSTEPS; t++) {
+        std::vector<char> taken((size_t)TW * CPG_RX(NREGS) * 64, 0);
+        for (int t = 0; t < CPG_RX(NSTEPS); t++) {
             const int e = steps[t][0], cnt = steps[t][1], reg = steps[t][2], sh = steps[t][3];
-            if (reg < 0 || reg >= CPG_GENR_NREGS) { set_error("cpg_hip_set_resident: coefficient register out of range"); return CPG_E_BADARG; }
+            const int wv = TW > 1 ? step_wave[TW > 1 ? t : 0] : 0;
+            if (reg < 0 || reg >= CPG_RX(NREGS) || wv < 0 || wv >= TW) { set_error("cpg_hip_set_resident: coefficient register out of range"); return CPG_E_BADARG; }
             for (int l = 0; l < cnt; l++) {
                 const int kind = rs->sol_kind[e + l], idx = rs->sol_idx[e + l], lc = rs->sol_lcol[e + l];
-                const size_t at = (size_t)reg * 64 + (size_t)(l + sh);
+                const size_t at = ((size_t)wv * CPG_RX(NREGS) + (size_t)reg) * 64 + (size_t)(l + sh);
                 const bool ok = kind >= 0 && kind <= 4 && idx >= 0 && idx < (1 << 28) && !taken[at] &&
                                 (kind != 2 || (idx < nnzL && lc >= 0 && lc < N)) && (kind != 3 || idx < N) && (kind != 4 || idx < rs->nnzX);
                 if (!ok) { set_error("cpg_hip_set_resident: bad coefficient source"); return CPG_E_BADARG; }
@@ -1363,21 +1438,21 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         Rs.fac_steps = (int)(ctl.size() / 2);
         for (int t = 0; t < 2 * DP; t++) { ctl.push_back(Rs.f_dummy); ctl.push_back(0u); }
     }
-#ifdef CPG_GENR_FAC_NSTEPS
+#ifdef CPG_RX_FAC
     // ---- tables of the generated factorisation: the header fixes (steps, level end, group width) per chunk and the per-lane
     //      term counts (fingerprint); positions and destinations are packed from the plan handed in here
     std::vector<unsigned long long> gftri;
     std::vector<unsigned> gfdk;
     {
-        static const int fch[][3] = CPG_GENR_FAC_CHUNKS;
+        static const int fch[][3] = CPG_RX(FAC_CHUNKS);
         unsigned hsh = 0x811C9DC5u;
         auto mix = [&](unsigned v) { for (int k = 0; k < 4; k++) { hsh = (hsh ^ ((v >> (8 * k)) & 0xFFu)) * 0x01000193u; } };
-        bool ok = rs->fac_chunks == CPG_GENR_FAC_NCHUNKS && ZERO == CPG_GENR_FAC_ZERO && Rs.fac_len < 0xFFFF;
+        bool ok = rs->fac_chunks == CPG_RX(FAC_NCHUNKS) && ZERO == CPG_RX(FAC_ZERO) && Rs.fac_len < 0xFFFF;
         for (int c = 0; ok && c < rs->fac_chunks; c++) { mix((unsigned)rs->f_ctab[4 * c]); mix((unsigned)rs->f_ctab[4 * c + 1]); mix((unsigned)rs->f_ctab[4 * c + 3]); }
         for (size_t e = 0; ok && e < (size_t)rs->fac_chunks * 64; e++) mix(rs->f_len[e]);
-        if (!ok || hsh != CPG_GENR_FAC_FINGERPRINT) { set_error("cpg_hip_set_resident: this library's factorisation was generated for a different family"); return CPG_E_BADARG; }
+        if (!ok || hsh != CPG_RX(FAC_FINGERPRINT)) { set_error("cpg_hip_set_resident: this library's factorisation was generated for a different family"); return CPG_E_BADARG; }
         const unsigned long long Z = (unsigned long long)ZERO;
-        gftri.assign((size_t)CPG_GENR_FAC_NSTEPS * 64, Z | (Z << 16) | (Z << 32));
+        gftri.assign((size_t)CPG_RX(FAC_NSTEPS) * 64, Z | (Z << 16) | (Z << 32));
         gfdk.assign((size_t)rs->fac_chunks * 64, 0xFFFFu);
         size_t step = 0;
         for (int c = 0; c < rs->fac_chunks; c++) {
@@ -1402,7 +1477,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
                 gfdk[(size_t)c * 64 + l] = (t & 0xFFFFu) | ((t & 0x80000000u) ? 0x10000u : 0u);
             }
         }
-        if (step != (size_t)CPG_GENR_FAC_NSTEPS) { set_error("cpg_hip_set_resident: factorisation steps differ from the generated ones"); return CPG_E_BADARG; }
+        if (step != (size_t)CPG_RX(FAC_NSTEPS)) { set_error("cpg_hip_set_resident: factorisation steps differ from the generated ones"); return CPG_E_BADARG; }
     }
 #endif
     // ---- coalesced canonicalisation maps, entry tables
@@ -1439,18 +1514,23 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     for (int k = 0; k < 3; k++) {
         const cpg_rows_program_t &p = *rows3[k];
         for (int c = 0; c < p.n_chunks; c++) if (p.ctab[4 * c + 3] & ~1) { set_error("cpg_hip_set_resident: row program with an unsupported chunk kind"); return CPG_E_BADARG; }
-#ifdef CPG_GENRA_NSTEPS
+#if defined(CPG_GENRA_NSTEPS) || defined(CPG_GENT_HEADER)
         {
-            static const int stA[][4] = CPG_GENRA_STEPS, stP[][4] = CPG_GENRP_STEPS, stT[][4] = CPG_GENRT_STEPS;
+#ifdef CPG_GENT_HEADER
+#define CPG_RXR(which, x) CPG_GENT##which##_##x
+#else
+#define CPG_RXR(which, x) CPG_GENR##which##_##x
+#endif
+            static const int stA[][4] = CPG_RXR(A, STEPS), stP[][4] = CPG_RXR(P, STEPS), stT[][4] = CPG_RXR(T, STEPS);
             const int (*steps)[4] = k == 0 ? stA : (k == 1 ? stP : stT);
-            const int T = k == 0 ? CPG_GENRA_NSTEPS : (k == 1 ? CPG_GENRP_NSTEPS : CPG_GENRT_NSTEPS);
-            const int nch = k == 0 ? CPG_GENRA_NCHUNKS : (k == 1 ? CPG_GENRP_NCHUNKS : CPG_GENRT_NCHUNKS);
-            const int nz = k == 0 ? CPG_GENRA_NNZ : (k == 1 ? CPG_GENRP_NNZ : CPG_GENRT_NNZ);
-            const unsigned fp = k == 0 ? CPG_GENRA_FINGERPRINT : (k == 1 ? CPG_GENRP_FINGERPRINT : CPG_GENRT_FINGERPRINT);
+            const int T = k == 0 ? CPG_RXR(A, NSTEPS) : (k == 1 ? CPG_RXR(P, NSTEPS) : CPG_RXR(T, NSTEPS));
+            const int nch = k == 0 ? CPG_RXR(A, NCHUNKS) : (k == 1 ? CPG_RXR(P, NCHUNKS) : CPG_RXR(T, NCHUNKS));
+            const int nz = k == 0 ? CPG_RXR(A, NNZ) : (k == 1 ? CPG_RXR(P, NNZ) : CPG_RXR(T, NNZ));
+            const unsigned fp = k == 0 ? CPG_RXR(A, FINGERPRINT) : (k == 1 ? CPG_RXR(P, FINGERPRINT) : CPG_RXR(T, FINGERPRINT));
             if (p.n_chunks != nch || p.nnz != nz || program_fingerprint(p.ctab, p.desc, p.cols, p.n_chunks, p.nnz) != fp) {
                 set_error("cpg_hip_set_resident: this library's row executors were generated for a different family"); return CPG_E_BADARG; }
             // idle lanes gather the zero slot of the substitution program's work vector and store to its dummy slots
-            if (!generated_tables(p.ctab, p.desc, p.cols, p.n_chunks, p.nnz, CPG_GENR_NSLOTS, steps, T, rcols3[k], rrows3[k])) {
+            if (!generated_tables(p.ctab, p.desc, p.cols, p.n_chunks, p.nnz, CPG_RX(NSLOTS), steps, T, rcols3[k], rrows3[k])) {
                 set_error("cpg_hip_set_resident: row program does not fit the generated executor's tables"); return CPG_E_BADARG; }
             const int lim = k == 1 ? r->nnzP : r->nnzA;
             src3[k].assign((size_t)p.nnz + 64, -1);               // (a step's idle lanes read the entries behind it: finite padding)
@@ -1458,8 +1538,26 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
             cpg::DevStreamTab &D = *dst3[k];
             D.n_pairs = 0; D.n_entries = (int)src3[k].size(); D.dummy = 0; D.stab = nullptr; D.cr = nullptr;
             if ((rc = upload<int>(h, own, src3[k].data(), src3[k].size(), &D.src))) return rc;
+#ifdef CPG_GENT_HEADER
+            {
+                // the team's row executors read 32-bit register images per wavefront, like the substitution executor
+                static const int swA[] = CPG_GENTA_STEP_WAVE, slA[] = CPG_GENTA_STEP_LOCAL, cwA[] = CPG_GENTA_CHUNK_WAVE, clA[] = CPG_GENTA_CHUNK_LOCAL;
+                static const int swP[] = CPG_GENTP_STEP_WAVE, slP[] = CPG_GENTP_STEP_LOCAL, cwP[] = CPG_GENTP_CHUNK_WAVE, clP[] = CPG_GENTP_CHUNK_LOCAL;
+                static const int swT[] = CPG_GENTT_STEP_WAVE, slT[] = CPG_GENTT_STEP_LOCAL, cwT[] = CPG_GENTT_CHUNK_WAVE, clT[] = CPG_GENTT_CHUNK_LOCAL;
+                const int noff = k == 0 ? CPG_GENTA_NOFF : (k == 1 ? CPG_GENTP_NOFF : CPG_GENTT_NOFF), nrow = k == 0 ? CPG_GENTA_NROW : (k == 1 ? CPG_GENTP_NROW : CPG_GENTT_NROW);
+                std::vector<unsigned> to, tr_;
+                if (!team_tables(rcols3[k], rrows3[k], T, nch, k == 0 ? swA : (k == 1 ? swP : swT), k == 0 ? slA : (k == 1 ? slP : slT),
+                                 k == 0 ? cwA : (k == 1 ? cwP : cwT), k == 0 ? clA : (k == 1 ? clP : clT), CPG_GENT_W, noff, nrow, CPG_GENT_NSLOTS, to, tr_)) {
+                    set_error("cpg_hip_set_resident: bad team tables of a row program"); return CPG_E_BADARG; }
+                const unsigned *d_to = nullptr, *d_tr = nullptr;
+                if ((rc = upload<unsigned>(h, own, to.data(), to.size(), &d_to))) return rc;
+                if ((rc = upload<unsigned>(h, own, tr_.data(), tr_.size(), &d_tr))) return rc;
+                D.gcols = (const unsigned short *)d_to; D.grows = (const unsigned short *)d_tr;
+            }
+#else
             if ((rc = upload<unsigned short>(h, own, rcols3[k].data(), rcols3[k].size(), &D.gcols))) return rc;
             if ((rc = upload<unsigned short>(h, own, rrows3[k].data(), rrows3[k].size(), &D.grows))) return rc;
+#endif
             continue;
         }
 #endif
@@ -1481,7 +1579,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         if ((rc = upload<int>(h, own, src3[k].data(), src3[k].size(), &D.src))) return rc;
     }
     Rs.out_ax = rs->out_ax; Rs.out_px = rs->out_px; Rs.out_aty = rs->out_aty;
-    const int ldw = CPG_GENR_NSLOTS + CPG_GEN_EXTRA_SLOTS;
+    const int ldw = CPG_RX(NSLOTS) + CPG_GEN_EXTRA_SLOTS;
     if (rs->out_ax < ldw + N || rs->out_px < ldw + N || rs->out_aty < rs->out_px + n) { set_error("cpg_hip_set_resident: result slots overlap the work vector"); return CPG_E_BADARG; }
     Rs.out_sc = w_slots;                                  // 1 / D | 1 / E of the instance behind the products' results
 #ifdef CPG_GENR_TABLES_GLOBAL
@@ -1494,11 +1592,17 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     slice = std::max<long long>(slice, (long long)r->nnzA + r->nnzP + std::max<long long>(r->np_var, (long long)N + std::max(n, m)));
 #endif
     slice += slice & 1;
+#ifdef CPG_GENT_HEADER
+    // (one slice per workgroup behind the team's scratch; the factor positions are 16-bit ELEMENT numbers, the executor's
+    // operand offsets 16-bit byte offsets into the work vector at the front of the slice)
+    if (Rs.fac_len >= 0xFFFF || ((long long)w_slots + N) * 8 > 0x7FFFFFFFLL) { set_error("cpg_hip_set_resident: team slice too large"); return CPG_E_UNSUPPORTED; }
+#else
     if (slice * 8 > 0xFFFF) { set_error("cpg_hip_set_resident: LDS slice beyond 16-bit offsets"); return CPG_E_UNSUPPORTED; }
+#endif
     Rs.slice_doubles = (int)slice;
-    Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64LL * CPG_GENR_NREGS + 64;
+    Rs.buf_doubles = (long long)r->nnzA + r->nnzP + 3LL * n + 4LL * m + Rs.pA.n_entries + Rs.pP.n_entries + Rs.pAt.n_entries + 64LL * TW * CPG_RX(NREGS) + 64;
     Rs.gf_tri = nullptr; Rs.gf_dk = nullptr;
-#ifdef CPG_GENR_FAC_NSTEPS
+#ifdef CPG_RX_FAC
     if ((rc = upload<unsigned long long>(h, own, gftri.data(), gftri.size(), &Rs.gf_tri))) return rc;
     if ((rc = upload<unsigned>(h, own, gfdk.data(), gfdk.size(), &Rs.gf_dk))) return rc;
 #endif
@@ -1511,8 +1615,12 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     if ((rc = upload<unsigned short>(h, own, grows.data(), grows.size(), &Rs.g_rows))) return rc;
     if ((rc = upload<unsigned>(h, own, entA.data(), entA.size(), &Rs.entA))) return rc;
     if ((rc = upload<unsigned>(h, own, entP.data(), entP.size(), &Rs.entP))) return rc;
+#ifdef CPG_GENT_HEADER
+    if ((rc = upload<unsigned>(h, own, toff.data(), toff.size(), &Rs.t_off))) return rc;
+    if ((rc = upload<unsigned>(h, own, trow.data(), trow.size(), &Rs.t_row))) return rc;
+#endif
     if ((rc = rt_sync(h))) return rc;
-    Rs.ok = 1;
+    Rs.ok = TW > 1 ? 2 : 1;
 #endif
     return CPG_OK;
 }
@@ -1647,6 +1755,24 @@ static cpg::DevBatch make_batch(int64_t B, const double *d_theta, const double *
 // per-instance factor kernel of handle `h` (its tables, its scratch) on `stream` with settings `S`
 static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::DevSettings &S, cpg::DevBatch &Bt) {
     const int W = 4;
+#ifdef CPG_GENT_HEADER
+    if (h->Rs.ok == 2 && !h->R.shared_mats && h->program_in_lds != 0 && h->program_in_lds != 2) {
+        // team kernel: one instance per workgroup; as many workgroups per CU as their LDS (scratch + slice) allows
+        const size_t lds = ((size_t)CPG_TEAM_SLICE_OFF + (size_t)h->Rs.slice_doubles) * sizeof(double);
+        if (lds <= h->lds_limit) {
+            long long per_cu = (long long)(h->lds_limit / lds);
+            if (per_cu * CPG_GENT_W > 16) per_cu = 16 / CPG_GENT_W;
+            if (h->blocks_per_cu > 0 && per_cu > h->blocks_per_cu) per_cu = h->blocks_per_cu;
+            long long blocks = Bt.B;
+            if (blocks > (long long)h->num_cu * per_cu) blocks = (long long)h->num_cu * per_cu;
+            if (blocks < 1) blocks = 1;
+            int rc;
+            if ((rc = ensure(h->scratch, (size_t)blocks * (size_t)h->Rs.buf_doubles * sizeof(double)))) return rc;
+            Bt.scratch = (double *)h->scratch.p;
+            return launch_team(h, stream, S, Bt, (int)blocks, lds);
+        }
+    }
+#endif
 #ifdef CPG_GENR_HEADER
     if (h->Rs.ok && !h->R.shared_mats && h->program_in_lds != 0 && h->program_in_lds != 2) {
         // resident kernel: one workgroup per CU, as many wavefronts (<= 4: one per SIMD) as slices fit the LDS

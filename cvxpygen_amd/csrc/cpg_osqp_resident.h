@@ -72,9 +72,14 @@ struct DevResident {
     int out_sc;                            // ... and of 1 / D (n) | 1 / E (m): the residuals of every termination test unscale with them
     int slice_doubles;                     // LDS doubles per wavefront
     long long buf_doubles;                 // per-wavefront buffer in global memory
+    // team kernel (cpg_osqp_team.h; ok == 2): per wavefront of the team the operand offsets of its steps and the output slots
+    // of its chunks as the 32-bit register images the generated executor keeps (two 16-bit words each), [wave][NOFF | NROW][lane];
+    // g_src / g_lcol are [wave][NREGS][lane] then, and pA / pP / pAt carry the same two tables of the row executors (gcols / grows
+    // reinterpreted as 32-bit words)
+    const unsigned *t_off, *t_row;
 };
 
-#ifdef CPG_GENR_HEADER
+#if defined(CPG_GENR_HEADER) || defined(CPG_GENT_HEADER)
 // A wave-uniform struct that arrives by reference (the caller's stack): one batch of loads, and every word through
 // v_readfirstlane -- the compiler then knows the pointers in it are uniform (scalar base addresses, s_load for the tables)
 // instead of reloading a field from the stack, as a per-lane value, in front of each use.
@@ -112,17 +117,22 @@ CPG_DEV void globalise(DevBatch &Bt) {
 #undef CPG_G
 template <class T>
 CPG_DEV T uniform_global_copy(const T &src) { T d = uniform_copy(src); globalise(d); return d; }
-CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, const DevResident &Rs) {
+CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, const DevResident &Rs, const int n_coef_regs) {
     ResBuf o;
     const size_t n = (size_t)F.n, m = (size_t)F.m;
     o.A = b; b += R.nnzA; o.P = b; b += R.nnzP;
     o.D = b; b += n; o.Dinv = b; b += n; o.E = b; b += m; o.Einv = b; b += m;
     o.q = b; b += n; o.u = b; b += m; o.rinv = b; b += m;
     o.cA = b; b += Rs.pA.n_entries; o.cP = b; b += Rs.pP.n_entries; o.cAt = b; b += Rs.pAt.n_entries;
-    o.cf = b; b += 64 * CPG_GENR_NREGS;
+    o.cf = b; b += 64 * n_coef_regs;
     return o;
 }
 
+// the iterates of an instance between two calls / the step sizes of an ADMM iteration (both kernels)
+struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
+#endif  // CPG_GENR_HEADER || CPG_GENT_HEADER
+
+#ifdef CPG_GENR_HEADER
 // Numeric LDL' of the instance's KKT matrix in the M-form of numeric_ldl_m (undivided column entries, reciprocal
 // pivots), followed by the inverses X = L_GG^-1 of the merged groups' diagonal blocks -- one flat stream of dot-product
 // steps over `fac` (LDS), whose destinations were preloaded with their KKT values (zeros for X).  An entry is the
@@ -602,7 +612,6 @@ CPG_DEV_NOINLINE void resident_store_coefficients(const DevRefactor &R_, const D
 // the last checked iteration.
 template <int NSX, int NSZ>
 struct ResState { double x[NSX], z[NSZ], y[NSZ], dx[NSX], dy[NSZ]; };
-struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
 
 #ifdef CPG_GENR_TABLES_GLOBAL
 #define CPG_RES_TAB                 // the executor's tables in global memory
@@ -826,7 +835,7 @@ CPG_DEV void osqp_resident_body(const DevFamily &F0, const DevRefactor &R, const
     //   factor    fac = M (nnzL) | 1/d (N) | X | 1.0 | 0.0
     //   ADMM      w (ldw) | q (n) | u (m) | A x (m)  or  P x (n) | A' y (n) | 1 / D (n) | 1 / E (m)
     const unsigned sl_off = tab_doubles + (unsigned)cpgw::wave_in_block() * (unsigned)Rs.slice_doubles;
-    const ResBuf B = res_carve(Bt.scratch + (size_t)wave_global * (size_t)Rs.buf_doubles, F0, R, Rs);
+    const ResBuf B = res_carve(Bt.scratch + (size_t)wave_global * (size_t)Rs.buf_doubles, F0, R, Rs, CPG_GENR_NREGS);
     const double rho_fr = CPG_RHO_MIN, ri_fr = 1.0 / rho_fr;
     const size_t state_len = (size_t)n + 2u * (size_t)m + 1u;
     const unsigned n_work = Bt.list_count ? cpgw::sld(Bt.list_count, 0u) : 0u;

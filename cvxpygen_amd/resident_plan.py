@@ -148,6 +148,7 @@ class ResidentPlan:
     rows_A_ent: np.ndarray; rows_P_ent: np.ndarray; rows_At_ent: np.ndarray
     out_ax: int; out_px: int; out_aty: int; w_slots: int
     stats: Dict[str, float] = field(default_factory=dict)
+    team: int = 1                                 # wavefronts per instance the programs were planned for (1: the resident kernel)
 
     @property
     def fac_len(self) -> int:                      # [M | 1/d | X | 1.0 | 0.0]
@@ -159,11 +160,13 @@ class ResidentPlan:
 
 
 def build_resident_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp, stage_scale: Optional[float] = None,
-                        groups: Optional[List[Tuple[int, int]]] = None) -> ResidentPlan:
-    return _build(P, A, osqp, stage_scale, groups)
+                        groups: Optional[List[Tuple[int, int]]] = None, team: int = 1) -> ResidentPlan:
+    """team = W > 1: the substitution program and the row programs planned for a team of W wavefronts per instance
+    (csrc/cpg_osqp_team.h): everything else -- groups, schedules, sources -- is the plan of the resident kernel."""
+    return _build(P, A, osqp, stage_scale, groups, int(team))
 
 
-def _build(P, A, osqp, stage_scale, groups) -> ResidentPlan:
+def _build(P, A, osqp, stage_scale, groups, team=1) -> ResidentPlan:
     base = _rp.build_refactor_plan(P, A, osqp)
     n, m, nnzL = base.n, base.m, base.nnzL
     N = n + m
@@ -260,6 +263,16 @@ def _build(P, A, osqp, stage_scale, groups) -> ResidentPlan:
             for x, (i, j) in enumerate(zip(x_row, x_col)):
                 if grp_of[i] == gi:
                     byrow.setdefault(i, []).append((j, x))
+            if team > 1:
+                # (a team of wavefronts: the in-place form below would need a barrier between the last gather and the first
+                # store of the phase; y_G goes to slots of its own instead -- assign_slots' `intra` phases -- with the unit
+                # diagonal of X as an explicit coefficient: one barrier per phase, solution not in place (sol.final_pos))
+                for i in G:
+                    ent = byrow.get(int(i), [])
+                    rr.append(int(i)); cs.append(perm[np.array([int(i)] + [j for j, _ in ent])])
+                    vs.append(np.array([code(SRC_ONE, 0)] + [code(SRC_X, x) for _, x in ent]))
+                phases.append(_sp.Phase(perm[np.array(rr)], cs, vs, True, f'FX{a}-{b}'))
+                continue
             for i in sorted(byrow):
                 rr.append(i); cs.append(perm[np.array([j for j, _ in byrow[i]])]); vs.append(np.array([code(SRC_X, x) for _, x in byrow[i]]))
             if rr:
@@ -282,11 +295,19 @@ def _build(P, A, osqp, stage_scale, groups) -> ResidentPlan:
                 if grp_of[i] == gi:
                     bycol.setdefault(j, []).append((i, x))
             rr, cs, vs = [], [], []
+            if team > 1:
+                for j in G:
+                    ent = bycol.get(int(j), [])
+                    rr.append(int(j)); cs.append(perm[np.array([int(j)] + [i for i, _ in ent])])
+                    vs.append(np.array([code(SRC_ONE, 0)] + [code(SRC_X, x) for _, x in ent]))
+                phases.append(_sp.Phase(perm[np.array(rr)], cs, vs, True, f'BX{a}-{b}'))
+                continue
             for j in sorted(bycol):
                 rr.append(j); cs.append(perm[np.array([i for i, _ in bycol[j]])]); vs.append(np.array([code(SRC_X, x) for _, x in bycol[j]]))
             if rr:
                 phases.append(_sp.Phase(perm[np.array(rr)], cs, vs, False, f'BX{a}-{b}', accumulate=True, deferred=True))
-    sol = _sp._pack_ragged(phases, N, balanced='auto', stage_scale=RESIDENT_STAGE_SCALE if stage_scale is None else stage_scale)
+    sol = _sp._pack_ragged(phases, N, balanced='auto', stage_scale=RESIDENT_STAGE_SCALE if stage_scale is None else stage_scale,
+                           team=team)
     codes = sol.vals.astype(np.int64)
     sol_kind = (codes >> 32).astype(np.int32); sol_idx = (codes & 0xFFFFFFFF).astype(np.int32)
     sol_lcol = np.where(sol_kind == SRC_NEG_L, Lcol[np.where(sol_kind == SRC_NEG_L, sol_idx, 0)], 0).astype(np.int32)
@@ -307,7 +328,8 @@ def _build(P, A, osqp, stage_scale, groups) -> ResidentPlan:
         vs = [M.data[M.indptr[r]:M.indptr[r + 1]].astype(np.float64) for r in range(M.shape[0])]
         keep = [r for r in range(M.shape[0]) if len(cs[r])]
         ph = _sp.Phase(rows[keep], [cs[r] for r in keep], [vs[r] for r in keep], False, name)
-        prog = _sp._pack_ragged([ph], w_slots, balanced='auto', stage_scale=_rp.STREAM_STAGE_SCALE)
+        prog = _sp._pack_ragged([ph], w_slots, balanced='auto', stage_scale=_rp.STREAM_STAGE_SCALE if team <= 1 else RESIDENT_STAGE_SCALE,
+                                team=team)
         return prog, (prog.vals.astype(np.int64) - 1).astype(np.int32)      # entry behind every coefficient (-1: padding)
     rows_A, rows_A_ent = product(Acsr, 0, out_ax, 'A')
     pr = base.Pi.astype(np.int64); pc = np.repeat(np.arange(n), np.diff(base.Pp)).astype(np.int64)
@@ -327,7 +349,8 @@ def _build(P, A, osqp, stage_scale, groups) -> ResidentPlan:
                         k_kind=base.ksrc_kind.copy(), k_idx=base.ksrc_idx.copy(),
                         sol=sol, sol_kind=sol_kind, sol_idx=sol_idx, sol_lcol=sol_lcol,
                         rows_A=rows_A, rows_P=rows_P, rows_At=rows_At, rows_A_ent=rows_A_ent, rows_P_ent=rows_P_ent,
-                        rows_At_ent=rows_At_ent, out_ax=out_ax, out_px=out_px, out_aty=out_aty, w_slots=w_slots, stats=stats)
+                        rows_At_ent=rows_At_ent, out_ax=out_ax, out_px=out_px, out_aty=out_aty, w_slots=w_slots, stats=stats,
+                        team=team)
 
 
 # ------------------------------------------------------------------------------------------------

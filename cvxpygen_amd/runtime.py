@@ -261,6 +261,21 @@ def _instance_fingerprints(lib_path: str, stem: str = 'cpg_instance', prefix: st
     return out
 
 
+def _team_widths(lib_path: str):
+    """CPG_GENT_W of the generated team headers next to a library"""
+    import glob
+    import re
+    out = set()
+    for h in glob.glob(os.path.join(os.path.dirname(os.path.abspath(lib_path)), 'cpg_team_*.h')):
+        try:
+            m = re.search(r'#define CPG_GENT_W (\d+)', open(h).read(4096))
+        except OSError:
+            m = None
+        if m:
+            out.add(int(m.group(1)))
+    return out
+
+
 def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: bool = True,
                       setup_settings: Optional[Dict[str, float]] = None, bank_layout: bool = True) -> FamilyPlan:
     t0 = time.time()
@@ -516,7 +531,18 @@ class BatchSolver:
                 # register-resident coefficients) -- when the library has one for this family; its `base` is the plan
                 # every other library streams
                 self._rplan_res = None
-                if _instance_fingerprints(self.lib.path, 'cpg_resident', 'GENR'):
+                fps_t = _instance_fingerprints(self.lib.path, 'cpg_team', 'GENT')
+                if fps_t:
+                    # ... or the team executor (csrc/cpg_osqp_team.h): the same plan with its programs planned for W wavefronts
+                    # per instance -- W is what the header next to the library says
+                    from . import codegen as _cg
+                    for Wt in sorted(_team_widths(self.lib.path)):
+                        cand = _cg.build_team_plan(desc, o, Wt)
+                        if cand.sol.fingerprint() in fps_t:
+                            self._rplan_res = cand
+                            rplan = cand.base
+                            break
+                if rplan is None and _instance_fingerprints(self.lib.path, 'cpg_resident', 'GENR'):
                     from . import resident_plan as _rs
                     cand = _rs.build_resident_plan(desc.P, desc.A, o)
                     if cand.sol.fingerprint() in _instance_fingerprints(self.lib.path, 'cpg_resident', 'GENR'):

@@ -50,6 +50,7 @@ class _Costs(_threading.local):
     def __init__(self):
         self.stage = STAGE_COST
         self.group = GROUP_STAGE_COST
+        self.team = 1           # wavefronts that share a phase (pack_ragged(team=W)): chunk costs add up per wavefront only
 
 
 LANES = 64
@@ -91,6 +92,21 @@ def _levels(N: int, Lp: np.ndarray, Li: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------
+def _team_cost(costs: Sequence[float]) -> float:
+    """What the chunks of one phase cost: their sum on one wavefront; with a TEAM of W wavefronts per instance
+    (pack_ragged(team=W), csrc/cpg_osqp_team.h) the chunks of a phase run side by side, longest first to the least
+    loaded wavefront, and the phase takes as long as the busiest one."""
+    W = int(_costs.team)
+    if W <= 1 or len(costs) <= 1:
+        return float(sum(costs))
+    loads = [0.0] * W
+    for c in sorted(costs, reverse=True):
+        k = loads.index(min(loads))
+        loads[k] += c
+    # (a little for the total too: of two plans with the same busiest wavefront the one with fewer steps)
+    return max(loads) + 1e-3 * float(sum(costs))
+
+
 def _chunk_plan(lens: Sequence[int]) -> Tuple[float, int, List[Tuple[int, int, List[int]]]]:
     """Best split of rows with `lens` multiply-adds into chunks.  Returns (cost, n_chunks,
     [(g, len, [row positions]) ...])."""
@@ -101,14 +117,14 @@ def _chunk_plan(lens: Sequence[int]) -> Tuple[float, int, List[Tuple[int, int, L
     best = None
     total = int(lens.sum())
     cand = sorted(set([1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128,
-                       max(1, -(-total // LANES)), int(lens.max())]))
+                       max(1, -(-total // LANES)), max(1, -(-total // (LANES * max(1, int(_costs.team))))), int(lens.max())]))
     for T in cand:
         g = np.ones(R, dtype=np.int64)
         need = -(-lens // T)
         g = np.where(need <= 1, 1, 2 ** np.ceil(np.log2(np.maximum(need, 1))).astype(np.int64))
         g = np.minimum(g, LANES)
         chunks = []
-        cost = 0.0
+        costs = []
         for gv in np.unique(g):
             idx = np.nonzero(g == gv)[0]
             idx = idx[np.argsort(-lens[idx], kind='stable')]
@@ -118,7 +134,8 @@ def _chunk_plan(lens: Sequence[int]) -> Tuple[float, int, List[Tuple[int, int, L
                 ln = int(-(-lens[sel].max() // gv)) if len(sel) else 0
                 ln = max(ln, 1)
                 chunks.append((int(gv), ln, [int(v) for v in sel]))
-                cost += ln + CHUNK_COST + _costs.group * np.log2(gv)
+                costs.append(ln + CHUNK_COST + _costs.group * np.log2(gv))
+        cost = _team_cost(costs)
         if best is None or cost < best[0]:
             best = (cost, len(chunks), chunks)
     return best
@@ -537,10 +554,11 @@ def _balanced_plan(lens: Sequence[int]):
     mx = int(max(lens.max(), 1))
     for seg_len in sorted(set(list(range(1, min(mx, 24) + 1)) + [mx, -(-mx // 2), -(-mx // 3), -(-mx // 4)])):
         chunks = _balanced_layout(lens, seg_len)
-        cost = 0.0
+        costs = []
         for ch in chunks:
             kmax = max(k for (_, _, k, _) in ch)
-            cost += ch[0][3] + CHUNK_COST + _costs.stage * int(np.ceil(np.log2(kmax))) if kmax > 1 else ch[0][3] + CHUNK_COST
+            costs.append(ch[0][3] + CHUNK_COST + _costs.stage * int(np.ceil(np.log2(kmax))) if kmax > 1 else ch[0][3] + CHUNK_COST)
+        cost = _team_cost(costs)
         if best is None or cost < best[0]:
             best = (cost, chunks)
     return best
@@ -549,23 +567,33 @@ def _balanced_plan(lens: Sequence[int]):
 
 
 def pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0,
-                slot_perm: Optional[np.ndarray] = None) -> RaggedProgram:
-    return _pack_ragged(phases, N, balanced, stage_scale, slot_perm)
+                slot_perm: Optional[np.ndarray] = None, team: int = 1) -> RaggedProgram:
+    return _pack_ragged(phases, N, balanced, stage_scale, slot_perm, team)
 
 
 def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float = 1.0,
-                 slot_perm: Optional[np.ndarray] = None) -> RaggedProgram:
+                 slot_perm: Optional[np.ndarray] = None, team: int = 1) -> RaggedProgram:
     """balanced=False: rows of a chunk are split over a uniform power-of-two number of lanes;
     balanced=True: variable number of adjacent lanes per row + segmented reduction (fewer steps when
     row lengths are uneven); balanced='auto': per phase whichever of the two the cost model prefers.
     stage_scale scales what the planner charges for a reduction stage relative to a step: the
     executors whose steps are memory requests (run_program_stream) want fewer, wider steps than the
-    LDS-resident one the defaults were tuned on."""
+    LDS-resident one the defaults were tuned on.
+    team = W > 1: the program is planned for a team of W wavefronts per instance (csrc/cpg_osqp_team.h) -- the chunks of
+    a phase are spread over the wavefronts (team_assignment), so the planner prefers plans whose BUSIEST wavefront
+    is done first: more, shorter chunks per phase."""
+    if int(team) != int(_costs.team):
+        saved_team = _costs.team
+        _costs.team = int(team)
+        try:
+            return _pack_ragged(phases, N, balanced, stage_scale, slot_perm, team)
+        finally:
+            _costs.team = saved_team
     if stage_scale != 1.0:
         saved = (_costs.stage, _costs.group)
         _costs.stage, _costs.group = saved[0] * stage_scale, saved[1] * stage_scale
         try:
-            return _pack_ragged(phases, N, balanced, slot_perm=slot_perm)
+            return _pack_ragged(phases, N, balanced, slot_perm=slot_perm, team=team)
         finally:
             _costs.stage, _costs.group = saved
     outs, ins, n_slots, final_pos = assign_slots(phases, N, slot_perm)
@@ -749,6 +777,23 @@ def execution_steps(prog: RaggedProgram):
                 if s_ < len(lst):
                     steps.append(lst[s_])
     return steps
+
+
+def team_assignment(prog: RaggedProgram, W: int) -> np.ndarray:
+    """Wavefront of every chunk when a team of W wavefronts executes the program (csrc/cpg_osqp_team.h, codegen.
+    emit_team_program): inside a phase the chunk with the most steps goes to the least loaded wavefront (the lowest
+    numbered one on ties)."""
+    wave = np.zeros(prog.n_chunks, dtype=np.int32)
+    phases = {}
+    for c in range(prog.n_chunks):
+        phases.setdefault(int(prog.chunk_phase[c]), []).append(c)
+    for p in sorted(phases):
+        loads = [0.0] * W
+        for c in sorted(phases[p], key=lambda c_: (-int(prog.ctab[c_, 0]), c_)):
+            k = min(range(W), key=lambda k_: (loads[k_], k_))
+            loads[k] += int(prog.ctab[c, 0]) + CHUNK_COST
+            wave[c] = k
+    return wave
 
 
 def padded_offsets_fit(prog: RaggedProgram, N: int, waves: int = 8, lds_bytes: int = 160 * 1024) -> bool:

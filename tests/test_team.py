@@ -1,0 +1,88 @@
+"""Team per-instance factor kernel (csrc/cpg_osqp_team.h): the path of the resident kernel -- `osqp_update_data_mat` +
+`osqp_solve` per instance (cvxpygen/solvers/osqp.py:20-62) -- with one WORKGROUP of W wavefronts per instance, for families
+whose merged substitution program does not fit one wavefront's registers (MPC 12/4/10 with every parameter per instance).
+
+CPU tier: the team plan's algebra (programs planned for W wavefronts, products with the block inverses out of place), the
+wavefront assignment, and the kernel SOURCES on the lock-step emulator against the C oracle.  GPU tier: the all-parameters
+MPC 12/4/10 family through the C-ABI against the oracle."""
+import ctypes as C
+import dataclasses
+
+import numpy as np
+import pytest
+
+from cvxpygen_amd import codegen, families, resident_plan as rs, solve_program as spm
+from cvxpygen_amd.runtime import BatchSolver, build_family_plan
+
+from test_resident import _dense_kkt, _portfolio_values, _random_values
+
+
+def _team_in_use(bs) -> bool:
+    v = C.c_double(-1)
+    bs.lib.check(bs.lib.L.cpg_hip_get_setting(bs.h_ref, b'team_executor', C.byref(v)), 'cpg_hip_get_setting')
+    return v.value == 1.0
+
+
+@pytest.mark.parametrize('fam', ['portfolio', 'mpc6'])
+@pytest.mark.parametrize('W', [2, 4])
+def test_team_plan_solves_the_kkt_system(fam, W):
+    """the programs planned for a team: no deferred (in-place) phases -- the products with the inverses of merged diagonal
+    blocks write to slots of their own and the solution still comes out in place --, every chunk belongs to one wavefront,
+    the busiest wavefront has fewer steps than the single-wavefront plan, and the program == a dense solve"""
+    d = families.portfolio(30, 4) if fam == 'portfolio' else families.mpc(6, 3, 10)
+    plan = build_family_plan(d, bank_layout=False)
+    pl1 = rs.build_resident_plan(d.P, d.A, plan.osqp)
+    pl = rs.build_resident_plan(d.P, d.A, plan.osqp, team=W)
+    b = pl.base
+    N = b.n + b.m
+    assert pl.team == W and pl.nnzX == pl1.nnzX and pl.groups == pl1.groups
+    assert not (pl.sol.ctab[:, 3] & 4).any() and (pl1.sol.ctab[:, 3] & 4).any()
+    assert np.array_equal(pl.sol.final_pos, np.arange(N)) and pl.sol.n_slots > N
+    steps, sw, sl, cw, cl = codegen.team_steps(pl.sol, W)
+    assert len(steps) == int(pl.sol.ctab[:, 0].sum())
+    for v in range(W):
+        mine = np.nonzero(sw == v)[0]
+        assert np.array_equal(np.sort(sl[mine]), np.arange(len(mine)))          # a wavefront's steps are numbered 0 ..
+        assert all(cw[steps[t][1]] == v for t in mine)
+    per_phase = {}
+    for t, (p, c, e, cnt) in enumerate(steps):
+        per_phase.setdefault(p, np.zeros(W, dtype=int))[sw[t]] += 1
+    assert sum(int(v.max()) for v in per_phase.values()) < int(pl1.sol.ctab[:, 0].sum())
+    rng, Ps, As, rho_inv = _random_values(b, d.n_eq)
+    fac = rs.replay_factor(pl, Ps, As, 1e-6, rho_inv)
+    _, _, K = _dense_kkt(b, Ps, As, 1e-6, rho_inv)
+    rhs = rng.standard_normal(N)
+    w = np.zeros(pl.sol.n_slots); w[:N] = rhs
+    w = spm.execute_ragged(dataclasses.replace(pl.sol, vals=rs.replay_solve_vals(pl, fac)), w)
+    xr = np.linalg.solve(K, rhs)
+    assert np.abs(w[:N] - xr).max() <= 1e-9 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize('W', [2, 4])
+def test_team_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path, monkeypatch, W):
+    """the kernel sources of the team path (set-up on 64 W threads, factorisation on wavefront 0, per-wavefront coefficient /
+    offset / slot registers, one barrier per phase, team reductions of the termination test) in a family library of a small
+    portfolio family: the oracle's iterates, iteration counts and statuses in the default mode (rho adapted at 50, 100 ...),
+    at a cut-off between two tests (approximate second test) and with tight tolerances; the streaming kernel of the same
+    library gives the same counts"""
+    from sim import build_sim
+    from test_sim_kernel import _assert_parity, _oracle_flat
+    monkeypatch.setattr(codegen, 'TEAM_WAVES', W)
+    n, m, B = 20, 3, 3
+    d = families.portfolio(n, m)
+    plan = build_family_plan(d)
+    _, defs = codegen.family_library_defs(plan, str(tmp_path), 'pf20')
+    assert any('CPG_GENT_HEADER' in x for x in defs) and not any('CPG_GENR_HEADER' in x for x in defs)
+    lib = build_sim.build_family(plan, str(tmp_path), 'pf20')
+    vals, th, upd = _portfolio_values(d, B, n, m)
+    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    for stg in ({}, dict(max_iter=60), dict(eps_abs=1e-7, eps_rel=1e-7)):
+        r = bs.solve(vals, updated_params=upd, **stg)
+        assert _team_in_use(bs)
+        o, prim, dual = _oracle_flat(oracle_lib, d, th, upd, **stg)
+        _assert_parity(r, o, prim, dual, tol=1e-8)
+    bs.set_program_placement(0)                       # the streaming kernel (unmerged program from HBM)
+    r2 = bs.solve(vals, updated_params=upd, eps_abs=1e-7, eps_rel=1e-7)
+    assert not _team_in_use(bs)
+    assert r2.iter.tolist() == r.iter.tolist() and np.abs(r2.prim_flat - r.prim_flat).max() < 1e-8
+    bs.close()
