@@ -1587,6 +1587,11 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     // scaled matrices (cpg_osqp_resident.h)
     long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots + m);
     slice = std::max<long long>(slice, std::max<long long>((long long)r->nnzA + r->nnzP, std::max<long long>(r->np_var, (long long)N + std::max(n, m))));
+#elif defined(CPG_GENT_HEADER)
+    // team kernel: 1 / D | 1 / E are not kept in the slice (the termination test reads them into registers), the set-up's scaling
+    // vectors, norms and theta alias the space of the scaled matrices (cpg_osqp_team.h)
+    long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots);
+    slice = std::max<long long>(slice, std::max<long long>((long long)r->nnzA + r->nnzP, std::max<long long>(r->np_var, (long long)N + std::max(n, m))));
 #else
     long long slice = std::max<long long>(Rs.fac_len, (long long)w_slots + N);
     slice = std::max<long long>(slice, (long long)r->nnzA + r->nnzP + std::max<long long>(r->np_var, (long long)N + std::max(n, m)));
@@ -1620,7 +1625,11 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     if ((rc = upload<unsigned>(h, own, trow.data(), trow.size(), &Rs.t_row))) return rc;
 #endif
     if ((rc = rt_sync(h))) return rc;
-    Rs.ok = TW > 1 ? 2 : 1;
+#ifdef CPG_GENT_HEADER
+    Rs.ok = 2;          // the team kernel's tables
+#else
+    Rs.ok = 1;
+#endif
 #endif
     return CPG_OK;
 }
@@ -1762,6 +1771,7 @@ static int launch_per_instance(cpg_handle_t h, rt_stream_t stream, const cpg::De
         if (lds <= h->lds_limit) {
             long long per_cu = (long long)(h->lds_limit / lds);
             if (per_cu * CPG_GENT_W > 16) per_cu = 16 / CPG_GENT_W;
+            if (CPG_GENT_W <= 4 && per_cu * CPG_GENT_W > 4) per_cu = 4 / CPG_GENT_W;       // (kernels built for one wavefront per SIMD)
             if (h->blocks_per_cu > 0 && per_cu > h->blocks_per_cu) per_cu = h->blocks_per_cu;
             long long blocks = Bt.B;
             if (blocks > (long long)h->num_cu * per_cu) blocks = (long long)h->num_cu * per_cu;

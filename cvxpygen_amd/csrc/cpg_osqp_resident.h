@@ -128,11 +128,6 @@ CPG_DEV ResBuf res_carve(double *b, const DevFamily &F, const DevRefactor &R, co
     return o;
 }
 
-// the iterates of an instance between two calls / the step sizes of an ADMM iteration (both kernels)
-struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
-#endif  // CPG_GENR_HEADER || CPG_GENT_HEADER
-
-#ifdef CPG_GENR_HEADER
 // Numeric LDL' of the instance's KKT matrix in the M-form of numeric_ldl_m (undivided column entries, reciprocal
 // pivots), followed by the inverses X = L_GG^-1 of the merged groups' diagonal blocks -- one flat stream of dot-product
 // steps over `fac` (LDS), whose destinations were preloaded with their KKT values (zeros for X).  An entry is the
@@ -183,6 +178,11 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
     cpgw::lds_order();
 }
 
+// the iterates of an instance between two calls / the step sizes of an ADMM iteration (both kernels)
+struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
+#endif  // CPG_GENR_HEADER || CPG_GENT_HEADER
+
+#ifdef CPG_GENR_HEADER
 // the instance's coefficients of the generated executor from `fac`: -l_ij = -M_ij / d_j, 1 / d_i, X_ij or 1 per (coefficient
 // register, lane), to the wavefront's buffer in the layout the iteration function loads them in ([register][lane])
 CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, const double *fac, int lane) {

@@ -28,9 +28,9 @@ namespace cpg {
 
 #define CPG_TEAM_W CPG_GENT_W
 #define CPG_TEAM_T (64 * CPG_GENT_W)
-// LDS of a team: [0, 8) broadcast words, [8, 8 + 2 * 8 * 8) two buffers of 8 partial results per wavefront, then the slice
+// LDS of a team: [0, 8) broadcast words, [8, 8 + 2 * 8 W) two buffers of 8 partial results per wavefront, then the slice
 #define CPG_TEAM_RED_OFF 8u
-#define CPG_TEAM_SLICE_OFF (8u + 2u * 8u * 8u)
+#define CPG_TEAM_SLICE_OFF (8u + 16u * (unsigned)CPG_GENT_W)
 
 // Reduction over the team: every wavefront reduces its lanes, lane 0 leaves the partial result in LDS, after ONE barrier
 // every thread combines the W partial results in wavefront order (the same value, bit for bit, on every thread: the
@@ -40,7 +40,7 @@ struct TeamRed { unsigned par; };
 template <int K, bool SUM>
 CPG_DEV void team_reduce(double (&v)[K], TeamRed &tr, int lane, int wave) {
     static_assert(K <= 8, "at most 8 values per reduction");
-    double *buf = cpgw::lds_window() + CPG_TEAM_RED_OFF + tr.par * 64u;
+    double *buf = cpgw::lds_window() + CPG_TEAM_RED_OFF + tr.par * (8u * (unsigned)CPG_TEAM_W);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const double r = SUM ? cpgw::wave_sum(v[k]) : cpgw::wave_max_nonneg(v[k]);
@@ -86,7 +86,9 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
     constexpr int KA = (int)((nnzA + T - 1) / T) > 0 ? (int)((nnzA + T - 1) / T) : 1, KP = (int)((nnzP + T - 1) / T) > 0 ? (int)((nnzP + T - 1) / T) : 1;
     TeamRed tr{0u};
     double *sl = cpgw::lds_window() + CPG_TEAM_SLICE_OFF;
-    double *Al = sl, *Pl = Al + nnzA, *Dl = Pl + nnzP, *El = Dl + n;
+    // (the scaling vectors, the norms and theta use the space the scaled matrices take once D and E are dead: step 3 below writes
+    // A, P behind a barrier, after every read of D and E)
+    double *Al = sl, *Pl = Al + nnzA, *Dl = sl, *El = Dl + n;
     unsigned long long *nrm = (unsigned long long *)(El + m);
     // ---- 1. theta -> LDS; canonicalise P, A, q, u into registers (entry k = tid + T t of a matrix, entry i = tid + T s of a vector)
     unsigned ea[KA], ep[KP];           // row | column << 16
@@ -306,12 +308,17 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
     }
     for (unsigned d = nd + (unsigned)tid; d < (unsigned)Rs.fac_len; d += T) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
     cpgw::block_sync();
+#ifdef CPG_TEAM_TABLE_FACTOR
+    if (wave == 0) resident_factor(Rs, sl, lane);        // (experiments: the flat table-driven stream instead of straight-line code)
+#else
     if (wave == 0) team_factor_gen(Rs.gf_tri, Rs.gf_dk, sl, lane);
+#endif
     cpgw::block_sync();
 }
 
 // ---- step 5: every wavefront's coefficients (-l_ij = -M_ij / d_j, 1 / d_i, X_ij or 1 per register and lane) to the team's
 //      buffer in the layout the iteration function loads them in ([wave][register][lane]); the slice back to its ADMM use
+//      (work vector | q | u | results of the termination test's products; 1 / D and 1 / E are read into registers by the test)
 CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_) {
     const int tid = (int)cpgw::thread_in_block(), lane = cpgw::lane_id(), wave = cpgw::read_first_lane(cpgw::wave_in_block());
     constexpr unsigned T = CPG_TEAM_T;
@@ -354,18 +361,16 @@ CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevRe
     cpgw::block_sync();
     {
         constexpr int KV = (int)((n + m + T - 1) / T);
-        double vq[KV], vs[KV];
+        double vq[KV];
 #pragma unroll
         for (int u_ = 0; u_ < KV; u_++) {
             const unsigned i = T * (unsigned)u_ + (unsigned)tid;
             vq[u_] = i < n ? cpgw::gld((const double *)B.q, i) : (i < n + m ? cpgw::gld((const double *)B.u, i - n) : 0.0);
-            vs[u_] = i < n ? cpgw::gld((const double *)B.Dinv, i) : (i < n + m ? cpgw::gld((const double *)B.Einv, i - n) : 0.0);
         }
-        double *sc = w + (unsigned)Rs.out_sc;
 #pragma unroll
         for (int u_ = 0; u_ < KV; u_++) {
             const unsigned i = T * (unsigned)u_ + (unsigned)tid;
-            if (i < n + m) { qs[i] = vq[u_]; sc[i] = vs[u_]; }
+            if (i < n + m) qs[i] = vq[u_];
         }
     }
     cpgw::mem_order();
@@ -488,9 +493,11 @@ struct TeamCheck {
     const signed char (&ct)[NZ];
     TeamRed &tr;
     int tid, lane, wave;
+    const double (&dinv_r)[NX];          // 1 / D, 1 / E of the thread's entries (loaded at the test's entry)
+    const double (&einv_r)[NZ];
     static constexpr unsigned n = CPG_GENT_N, m = CPG_GENT_M, T = CPG_TEAM_T;
-    CPG_DEV double sDinv(unsigned i) const { return w[(unsigned)Rs.out_sc + i]; }
-    CPG_DEV double sEinv(unsigned i) const { return w[(unsigned)Rs.out_sc + n + i]; }
+    CPG_DEV double sDinv(int s) const { return dinv_r[s]; }
+    CPG_DEV double sEinv(int s) const { return einv_r[s]; }
     CPG_DEV double staged(unsigned i) const { return w[(unsigned)Rs.out_ax + i]; }
     CPG_DEV void stage(int which) const {          // D (2) or E (1) into the products' result slots (consumed before a product runs)
         const double *src = which == 1 ? (const double *)B.E : (const double *)B.D;
@@ -555,7 +562,7 @@ struct TeamCheck {
         for (int s = 0; s < NX; s++) {
             const unsigned i = (unsigned)tid + T * (unsigned)s;
             const double t = atx(i);
-            if (i < n) r[0] = cpgw::dmax2(r[0], fabs(unsc ? sDinv(i) * t : t));
+            if (i < n) r[0] = cpgw::dmax2(r[0], fabs(unsc ? sDinv(s) * t : t));
         }
         team_reduce<1, false>(r, tr, lane, wave);
         return r[0] < eps * nrm[0];
@@ -586,7 +593,7 @@ struct TeamCheck {
         for (int s = 0; s < NX; s++) {
             const unsigned i = (unsigned)tid + T * (unsigned)s;
             const double t = px(i);
-            if (i < n) r[0] = cpgw::dmax2(r[0], fabs(unsc ? sDinv(i) * t : t));
+            if (i < n) r[0] = cpgw::dmax2(r[0], fabs(unsc ? sDinv(s) * t : t));
         }
         team_reduce<1, false>(r, tr, lane, wave);
         bool res = false;
@@ -598,7 +605,7 @@ struct TeamCheck {
                 const unsigned i = (unsigned)tid + T * (unsigned)s;
                 const double a = ax(i);
                 if (i < m) {
-                    const double av = unsc ? sEinv(i) * a : a;
+                    const double av = unsc ? sEinv(s) * a : a;
                     if ((um[i] < CPG_INFTY * CPG_MIN_SCALING && av > eps * nrm[0]) || (ct[s] == 1 && av < -eps * nrm[0])) viol = true;
                 }
             }
@@ -624,7 +631,12 @@ CPG_DEV_NOINLINE CheckOut team_check(const DevFamily &F_, const DevResident &Rs_
     double *w = cpgw::lds_window() + CPG_TEAM_SLICE_OFF;
     const double *qs = w + (CPG_GENT_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + n;
     TeamRed tr{0u};
-    const TeamCheck<NX, NZ> cx{F, Rs, B, w, qs, us, ct, tr, tid, lane, wave};
+    double dinv_r[NX], einv_r[NZ];
+#pragma unroll
+    for (int s = 0; s < NX; s++) { const unsigned i = (unsigned)tid + T * (unsigned)s; dinv_r[s] = i < n ? cpgw::gld((const double *)B.Dinv, i) : 0.0; }
+#pragma unroll
+    for (int s = 0; s < NZ; s++) { const unsigned i = (unsigned)tid + T * (unsigned)s; einv_r[s] = i < m ? cpgw::gld((const double *)B.Einv, i) : 0.0; }
+    const TeamCheck<NX, NZ> cx{F, Rs, B, w, qs, us, ct, tr, tid, lane, wave, dinv_r, einv_r};
     const bool unsc = !S.scaled_termination;
     const double mult = approximate ? 10.0 : 1.0;
     const double ea = S.eps_abs * mult, er = S.eps_rel * mult;
@@ -641,7 +653,7 @@ CPG_DEV_NOINLINE CheckOut team_check(const DevFamily &F_, const DevResident &Rs_
         const unsigned i = (unsigned)tid + T * (unsigned)s;
         const double ax = cx.ax(i);
         if (i < m) {
-            const double ei = unsc ? cx.sEinv(i) : 1.0;
+            const double ei = unsc ? cx.sEinv(s) : 1.0;
             mx1[0] = cpgw::dmax2(mx1[0], fabs(ei * (ax - Iz[s])));
             mx1[1] = cpgw::dmax2(mx1[1], fabs(ei * Iz[s]));
             mx1[2] = cpgw::dmax2(mx1[2], fabs(ei * ax));
@@ -661,7 +673,7 @@ CPG_DEV_NOINLINE CheckOut team_check(const DevFamily &F_, const DevResident &Rs_
         const unsigned i = (unsigned)tid + T * (unsigned)s;
         const double px = cx.px(i), aty = cx.atx(i);
         if (i < n) {
-            const double di = unsc ? cx.sDinv(i) : 1.0;
+            const double di = unsc ? cx.sDinv(s) : 1.0;
             const double qq = qs[i];
             mx2[0] = cpgw::dmax2(mx2[0], fabs(di * (qq + px + aty)));
             mx2[1] = cpgw::dmax2(mx2[1], fabs(di * qq));

@@ -160,13 +160,15 @@ class ResidentPlan:
 
 
 def build_resident_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp, stage_scale: Optional[float] = None,
-                        groups: Optional[List[Tuple[int, int]]] = None, team: int = 1) -> ResidentPlan:
+                        groups: Optional[List[Tuple[int, int]]] = None, team: int = 1, inplace_x: Optional[bool] = None) -> ResidentPlan:
     """team = W > 1: the substitution program and the row programs planned for a team of W wavefronts per instance
-    (csrc/cpg_osqp_team.h): everything else -- groups, schedules, sources -- is the plan of the resident kernel."""
-    return _build(P, A, osqp, stage_scale, groups, int(team))
+    (csrc/cpg_osqp_team.h): everything else -- groups, schedules, sources -- is the plan of the resident kernel.
+    inplace_x (default: team <= 1): the products with the inverses of merged diagonal blocks as in-place (`deferred`) phases;
+    False: to slots of their own (what the team kernel's executor runs, also with a team of one)."""
+    return _build(P, A, osqp, stage_scale, groups, int(team), (int(team) <= 1) if inplace_x is None else bool(inplace_x))
 
 
-def _build(P, A, osqp, stage_scale, groups, team=1) -> ResidentPlan:
+def _build(P, A, osqp, stage_scale, groups, team=1, inplace_x=True) -> ResidentPlan:
     base = _rp.build_refactor_plan(P, A, osqp)
     n, m, nnzL = base.n, base.m, base.nnzL
     N = n + m
@@ -263,7 +265,7 @@ def _build(P, A, osqp, stage_scale, groups, team=1) -> ResidentPlan:
             for x, (i, j) in enumerate(zip(x_row, x_col)):
                 if grp_of[i] == gi:
                     byrow.setdefault(i, []).append((j, x))
-            if team > 1:
+            if not inplace_x:
                 # (a team of wavefronts: the in-place form below would need a barrier between the last gather and the first
                 # store of the phase; y_G goes to slots of its own instead -- assign_slots' `intra` phases -- with the unit
                 # diagonal of X as an explicit coefficient: one barrier per phase, solution not in place (sol.final_pos))
@@ -295,7 +297,7 @@ def _build(P, A, osqp, stage_scale, groups, team=1) -> ResidentPlan:
                 if grp_of[i] == gi:
                     bycol.setdefault(j, []).append((i, x))
             rr, cs, vs = [], [], []
-            if team > 1:
+            if not inplace_x:
                 for j in G:
                     ent = bycol.get(int(j), [])
                     rr.append(int(j)); cs.append(perm[np.array([int(j)] + [i for i, _ in ent])])

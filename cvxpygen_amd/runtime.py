@@ -262,17 +262,19 @@ def _instance_fingerprints(lib_path: str, stem: str = 'cpg_instance', prefix: st
 
 
 def _team_widths(lib_path: str):
-    """CPG_GENT_W of the generated team headers next to a library"""
+    """(CPG_GENT_W, CPG_GENT_MAX_GROUP_ROWS) of the generated team headers next to a library: what their plans were built with"""
     import glob
     import re
     out = set()
     for h in glob.glob(os.path.join(os.path.dirname(os.path.abspath(lib_path)), 'cpg_team_*.h')):
         try:
-            m = re.search(r'#define CPG_GENT_W (\d+)', open(h).read(4096))
+            txt = open(h).read(4096)
         except OSError:
-            m = None
+            continue
+        m = re.search(r'#define CPG_GENT_W (\d+)', txt)
+        g = re.search(r'#define CPG_GENT_MAX_GROUP_ROWS (\d+)', txt)
         if m:
-            out.add(int(m.group(1)))
+            out.add((int(m.group(1)), int(g.group(1)) if g else None))
     return out
 
 
@@ -536,8 +538,8 @@ class BatchSolver:
                     # ... or the team executor (csrc/cpg_osqp_team.h): the same plan with its programs planned for W wavefronts
                     # per instance -- W is what the header next to the library says
                     from . import codegen as _cg
-                    for Wt in sorted(_team_widths(self.lib.path)):
-                        cand = _cg.build_team_plan(desc, o, Wt)
+                    for Wt, Gt in sorted(_team_widths(self.lib.path), key=lambda t_: (t_[0], t_[1] or 0)):
+                        cand = _cg.build_team_plan(desc, o, Wt, Gt)
                         if cand.sol.fingerprint() in fps_t:
                             self._rplan_res = cand
                             rplan = cand.base

@@ -24,7 +24,7 @@ def _team_in_use(bs) -> bool:
 
 
 @pytest.mark.parametrize('fam', ['portfolio', 'mpc6'])
-@pytest.mark.parametrize('W', [2, 4])
+@pytest.mark.parametrize('W', [1, 2, 4])
 def test_team_plan_solves_the_kkt_system(fam, W):
     """the programs planned for a team: no deferred (in-place) phases -- the products with the inverses of merged diagonal
     blocks write to slots of their own and the solution still comes out in place --, every chunk belongs to one wavefront,
@@ -32,7 +32,7 @@ def test_team_plan_solves_the_kkt_system(fam, W):
     d = families.portfolio(30, 4) if fam == 'portfolio' else families.mpc(6, 3, 10)
     plan = build_family_plan(d, bank_layout=False)
     pl1 = rs.build_resident_plan(d.P, d.A, plan.osqp)
-    pl = rs.build_resident_plan(d.P, d.A, plan.osqp, team=W)
+    pl = rs.build_resident_plan(d.P, d.A, plan.osqp, team=W, inplace_x=False)
     b = pl.base
     N = b.n + b.m
     assert pl.team == W and pl.nnzX == pl1.nnzX and pl.groups == pl1.groups
@@ -47,7 +47,8 @@ def test_team_plan_solves_the_kkt_system(fam, W):
     per_phase = {}
     for t, (p, c, e, cnt) in enumerate(steps):
         per_phase.setdefault(p, np.zeros(W, dtype=int))[sw[t]] += 1
-    assert sum(int(v.max()) for v in per_phase.values()) < int(pl1.sol.ctab[:, 0].sum())
+    if W > 1:
+        assert sum(int(v.max()) for v in per_phase.values()) < int(pl1.sol.ctab[:, 0].sum())
     rng, Ps, As, rho_inv = _random_values(b, d.n_eq)
     fac = rs.replay_factor(pl, Ps, As, 1e-6, rho_inv)
     _, _, K = _dense_kkt(b, Ps, As, 1e-6, rho_inv)
@@ -58,7 +59,7 @@ def test_team_plan_solves_the_kkt_system(fam, W):
     assert np.abs(w[:N] - xr).max() <= 1e-9 * np.abs(xr).max()
 
 
-@pytest.mark.parametrize('W', [2, 4])
+@pytest.mark.parametrize('W', [1, 2, 4])
 def test_team_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path, monkeypatch, W):
     """the kernel sources of the team path (set-up on 64 W threads, factorisation on wavefront 0, per-wavefront coefficient /
     offset / slot registers, one barrier per phase, team reductions of the termination test) in a family library of a small
@@ -85,4 +86,30 @@ def test_team_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path, monkeypatch
     r2 = bs.solve(vals, updated_params=upd, eps_abs=1e-7, eps_rel=1e-7)
     assert not _team_in_use(bs)
     assert r2.iter.tolist() == r.iter.tolist() and np.abs(r2.prim_flat - r.prim_flat).max() < 1e-8
+    bs.close()
+
+
+def test_team_kernel_all_parameters_mpc_on_the_emulator(oracle_lib, tmp_path, monkeypatch):
+    """MPC 6/3/10 with EVERY parameter per instance (the shape of the family the kernel was built for: a chain of levels,
+    several merged groups) on the emulator, a team of four wavefronts: iteration counts / statuses = oracle, 1e-8"""
+    from sim import build_sim
+    from test_sim_kernel import _assert_parity, _oracle_flat
+    monkeypatch.setattr(codegen, 'TEAM_WAVES', 4)
+    d = families.mpc(6, 3, 10)
+    plan = build_family_plan(d)
+    _, defs = codegen.family_library_defs(plan, str(tmp_path), 'mpc6t')
+    assert any('CPG_GENT_HEADER' in x for x in defs)
+    lib = build_sim.build_family(plan, str(tmp_path), 'mpc6t')
+    B = 2
+    rng = np.random.default_rng(17)
+    th = np.tile(d.theta0, (B, 1))
+    th[:, :d.NP] *= 1 + 0.1 * rng.standard_normal((B, d.NP))
+    p = d.param('x_init')
+    th[:, p.col:p.col + p.size] = -2 + 4 * rng.random((B, p.size))
+    vals = {q.name: th[:, q.col:q.col + q.size] for q in d.params}
+    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    r = bs.solve(vals)
+    assert _team_in_use(bs)
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
+    _assert_parity(r, o, prim, dual, tol=1e-8)
     bs.close()
