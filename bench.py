@@ -104,6 +104,17 @@ BINDING = {
 }
 
 
+def team_kernel_in_use(solver) -> bool:
+    """does the per-instance factor handle of this solver run the team kernel (one workgroup of W wavefronts per instance)?"""
+    import ctypes as _C
+    h = getattr(solver, 'h_ref', None)
+    if h is None or not h.value:
+        return False
+    v = _C.c_double(0)
+    solver.lib.L.cpg_hip_get_setting(h, b'team_executor', _C.byref(v))
+    return v.value == 1.0
+
+
 def resident_kernel_in_use(solver) -> bool:
     """does the per-instance factor handle of this solver run the resident kernel (family library with this family's resident executor)?"""
     import ctypes as _C
@@ -469,6 +480,7 @@ def main():
         binding = BINDING.get((args.workload, bool(args.all_params), bool(args.fixed_rho)))
         traffic_src = None
         traffic_stale = None
+        binding_num = None      # per kernel: busy fractions of LDS / VALU / HBM and the share of wave cycles waiting (scripts/record_traffic.py)
         try:
             # records are stamped with the fingerprint of the kernel sources and name their kernel: a record taken on
             # other kernels is refused instead of silently replayed (scripts/record_traffic.py writes them)
@@ -479,6 +491,7 @@ def main():
                 if rec.get('source_fingerprint') == source_fingerprint():
                     traffic = rec['fetch_bytes'] + rec['write_bytes']
                     binding = rec.get('binding_resource') or binding
+                    binding_num = rec.get('binding')
                     traffic_src = f"{rec.get('source')}; kernel {rec.get('kernel')}"
                 else:
                     traffic_stale = f"record {key} of profiles/hbm_traffic.json was taken on other kernel sources ({rec.get('source_fingerprint')}): refused"
@@ -514,6 +527,9 @@ def main():
                       'per_instance_factor': {'kernel': inst_kernel, 'ms': ms2, 'instances': n_ho,
                                               'iterations_estimate': int((it - it1)[ho].sum()), 'handed_over_by_iteration_count': int(ho.sum()),
                                               'note': 'instances handed over after a rho change: numeric LDL\' for the new rho, then ADMM with their own factor'}}
+            # what a kernel of the two-kernel step FINISHES is what it is priced for: the shared-factor kernel writes the results of the
+            # instances it solves itself; the ones it hands over get theirs from the kernel behind it
+            units = max(0, B - int(n_ho))
             if ms2 > ms1:
                 kernel_name, units, k_ms = inst_kernel, n_ho, ms2
                 # the hand-over adds the workspace (n + 2m + 1 doubles) written by the kernel in front and read here
@@ -525,6 +541,21 @@ def main():
                          ', `stream` the coefficients it actually streams per iteration (DESIGN.md section 4.5)'))
             else:
                 k_ms = ms1
+        elif per_instance_kernel and team_kernel_in_use(solver):
+            # team per-instance factor kernel (cpg_osqp_team.h): one workgroup of W wavefronts per instance, coefficients, operand
+            # offsets and output slots of a wavefront's steps in its registers -- no coefficient stream
+            kernel_name = 'osqp_team_kernel'
+            rpl_res = getattr(solver, '_rplan_res', None)
+            stream = None
+            rnote = ('team per-instance factor kernel: one workgroup of W wavefronts per instance, numeric LDL\' + block inverses in LDS, the merged '
+                     'substitution program split over the wavefronts with its coefficients / offsets / slots in their registers, one barrier per '
+                     'phase; `achieved` prices SURVEY.md 8(d) bytes per instance; the kernel is a chain of latencies, not HBM bound (DESIGN.md 4.7)')
+            if rpl_res is not None:
+                out_plan_extra = {'team_wavefronts': int(rpl_res.team), 'team_phases': int(rpl_res.sol.n_phases),
+                                  'team_steps': int(rpl_res.stats.get('sol_steps', 0)), 'merged_groups': int(rpl_res.stats.get('merged', 0))}
+            if binding_num is None:
+                binding = ('latency: a chain of dependent phases per ADMM iteration (one barrier each) and of dependent levels per '
+                           'factorisation at one instance per CU; nothing streamed per iteration (DESIGN.md 4.7)')
         elif per_instance_kernel and resident_kernel_in_use(solver):
             # resident per-instance factor kernel (cpg_osqp_resident.h): factor in LDS, substitution coefficients in registers --
             # no coefficient stream; what it reads from memory per instance beyond SURVEY.md 8(d)'s bytes is in DESIGN.md 4.6
@@ -582,7 +613,9 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': (f'REPLAYED, not measured in this run: bytes per step (all kernels of the step) from the rocprofv3 PMC '
                                           f'passes recorded in profiles/hbm_traffic.json ({traffic_src})') if traffic else traffic_stale,
+                         'frac_step': (bytes_per_inst * B / (1e-3 * 1e3 * elapsed / args.steps) / 1e9 / HBM_PEAK_GBS) if elapsed > 0 else 0.0,
                          'binding_resource': binding,
+                         'binding': next((dict(v, kernel=k) for k, v in (binding_num or {}).items() if kernel_name in k), None),
                          'kernel': kernel_name, 'kernel_ms': k_ms, 'units_per_launch': int(units),
                          'algorithmic_bytes_per_instance': bytes_per_inst, 'stream': stream,
                          'note': rnote},

@@ -10,6 +10,7 @@ set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd $R
 OUT=gpurun_out/${CPG_OUT:-final}; mkdir -p $OUT; export TMPDIR=/tmp
 SKIP=" ${CPG_SKIP:-} "
+python scripts/probe_reference.py 2>&1 | tee $OUT/reference_probe.txt      # parity-pin readiness: capture the real reference wherever it imports
 P="import sys,json; d=json.loads(sys.stdin.read()); ph=d.get('phases') or {}; print(round(d['value']), round(d['ms_per_step'],2), d['config'].get('mean_iter'), d['config'].get('solved'), d['roofline']['kernel'], {k:(round(v['ms'],2), v['instances']) for k,v in ph.items()}, (d.get('fixed_rho') or {}).get('value'), d.get('wall_pcie',{}).get('value'), (d.get('cpu_baseline') or {}).get('value'), d.get('adjoint'), d.get('check'))"
 if [[ "$SKIP" != *" tests "* ]]; then
   echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -rA 2>&1 | grep -v "^$" | tail -80 | tee $OUT/pytest_gpu.txt | tail -4

@@ -25,6 +25,35 @@ def main(key, instances, pmc_file, source=''):
             per_kernel.setdefault(mt.group(1).strip(), {})[mt.group(2)] = float(mt.group(3))
     if not per_kernel:
         raise SystemExit(f'no FETCH_SIZE / WRITE_SIZE lines in {pmc_file}')
+    # the SQ counters of the same session, per kernel: what fraction of its cycles each resource is busy -- the numbers behind
+    # bench.py's `roofline.binding` (SQ_BUSY_CYCLES sums the 32 shader engines' busy cycles: x 8 CUs each = CU-cycles of the kernel;
+    # quad-cycle counters x 4 / (4 SIMDs per CU) = the same denominator)
+    sq = {}
+    for ln in open(pmc_file):
+        mt = re.match(r'\s*(\S.*?)\s+(SQ_\w+)\s+per-dispatch total\s+([0-9.eE+]+)', ln)
+        if mt:
+            sq.setdefault(mt.group(1).strip(), {})[mt.group(2)] = float(mt.group(3))
+    binding = {}
+    for k, c in sq.items():
+        cu_cycles = 8.0 * c.get('SQ_BUSY_CYCLES', 0.0)
+        if cu_cycles <= 0:
+            continue
+        b = {'lds_busy': c.get('SQ_LDS_IDX_ACTIVE', 0.0) / cu_cycles,
+             'lds_conflict_share': c.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(1.0, c.get('SQ_LDS_IDX_ACTIVE', 0.0)),
+             'valu_busy': c.get('SQ_ACTIVE_INST_VALU', 0.0) / cu_cycles,
+             'wave_wait_share': c.get('SQ_WAIT_ANY', 0.0) / max(1.0, c.get('SQ_WAVE_CYCLES', 0.0)),
+             'waves_per_simd': c.get('SQ_WAVE_CYCLES', 0.0) / cu_cycles if c.get('SQ_WAVE_CYCLES') else None}   # (counted in quad-cycles, four SIMDs per CU)
+        fk = per_kernel.get(k, {})
+        secs = (c.get('SQ_BUSY_CYCLES', 0.0) / 32.0) / 2.4e9
+        b['hbm_busy'] = (2.0 * 1024.0 * fk.get('FETCH_SIZE', 0.0) + 1024.0 * fk.get('WRITE_SIZE', 0.0)) / (secs * 8e12) if secs > 0 else None
+        cand = {'lds': b['lds_busy'], 'valu': b['valu_busy'], 'hbm': b['hbm_busy'] or 0.0}
+        top = max(cand, key=cand.get)
+        # a kernel none of whose units is half busy is bound by the latency chain of its dependent phases: report the wait share
+        if cand[top] < 0.5 and b['wave_wait_share'] > cand[top]:
+            b.update(resource='latency (wave cycles waiting)', busy=b['wave_wait_share'], useful=1.0 - b['wave_wait_share'])
+        else:
+            b.update(resource=top, busy=cand[top], useful=cand[top] * (1.0 - b['lds_conflict_share']) if top == 'lds' else cand[top])
+        binding[k.split('(')[0][:40]] = {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in b.items()}
     fetch = sum(2.0 * 1024.0 * v.get('FETCH_SIZE', 0.0) for v in per_kernel.values())
     write = sum(1024.0 * v.get('WRITE_SIZE', 0.0) for v in per_kernel.values())
     path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
@@ -34,7 +63,7 @@ def main(key, instances, pmc_file, source=''):
                  'source_fingerprint matches the kernel sources it runs'}
     rec[key] = {'instances': int(instances), 'fetch_bytes': int(fetch), 'write_bytes': int(write),
                 'kernel': ' + '.join(sorted(k.split('(')[0][:40] for k in per_kernel)),
-                'per_kernel_KiB': per_kernel, 'source_fingerprint': source_fingerprint(), 'source': source or pmc_file}
+                'per_kernel_KiB': per_kernel, 'binding': binding, 'source_fingerprint': source_fingerprint(), 'source': source or pmc_file}
     json.dump(rec, open(path, 'w'), indent=1)
     print(key, 'fetch', int(fetch), 'write', int(write), 'fingerprint', rec[key]['source_fingerprint'])
 
