@@ -1480,6 +1480,61 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         if (step != (size_t)CPG_RX(FAC_NSTEPS)) { set_error("cpg_hip_set_resident: factorisation steps differ from the generated ones"); return CPG_E_BADARG; }
     }
 #endif
+#ifdef CPG_GENT_HEADER
+    // ---- the same schedule for the team's batched table walk (team_factor_batched): batches of CPG_TEAM_FAC_BATCH steps, one list per wavefront;
+    //      the LDL' part (the first r->fac_chunks chunks) on wavefront 0, every level of the block inverses spread over the team
+    std::vector<unsigned> bfhdr((size_t)2 * TW, 0u), bfctl, bfdk;
+    std::vector<unsigned long long> bftri;
+    {
+        constexpr int DPF = CPG_TEAM_FAC_DEPTH, SB = CPG_TEAM_FAC_BATCH;
+        struct WaveList { std::vector<unsigned> ctl, dk; std::vector<unsigned long long> tri; };
+        std::vector<WaveList> wl((size_t)TW);
+        const unsigned long long Zp = (unsigned long long)ZERO, Zw = Zp | (Zp << 16) | (Zp << 32);
+        auto null_batch = [&](WaveList &L, unsigned fl) { L.ctl.push_back(fl); L.dk.insert(L.dk.end(), 64, 0xFFFFu); L.tri.insert(L.tri.end(), (size_t)64 * SB, Zw); };
+        auto add_chunk = [&](WaveList &L, int c, size_t step0) {
+            const int Ls = rs->f_ctab[4 * c], lg = rs->f_ctab[4 * c + 3], nbat = (Ls + SB - 1) / SB;
+            for (int bt = 0; bt < nbat; bt++) {
+                L.ctl.push_back((bt == 0 ? 1u : 0u) | (bt == nbat - 1 ? 2u : 0u) | ((unsigned)lg << 4));
+                for (int l = 0; l < 64; l++) {
+                    L.dk.push_back(gfdk[(size_t)c * 64 + l]);
+                    for (int k = 0; k < SB; k++) L.tri.push_back(SB * bt + k < Ls ? gftri[(step0 + (size_t)(SB * bt + k)) * 64 + l] : Zw);
+                }
+            }
+        };
+        const int ldl = std::min(r->fac_chunks, rs->fac_chunks);
+        size_t step = 0;
+        for (int c = 0; c < ldl; c++) {
+            const int Ls = rs->f_ctab[4 * c];
+            if (Ls > 0) add_chunk(wl[0], c, step);
+            step += (size_t)Ls;
+            if (rs->f_ctab[4 * c + 1] && !wl[0].ctl.empty()) wl[0].ctl.back() |= 4u;
+        }
+        if (wl[0].ctl.empty()) null_batch(wl[0], 0u);
+        wl[0].ctl.back() |= 8u;                                  // the team meets behind the LDL' part
+        for (int wv = 1; wv < TW; wv++) null_batch(wl[wv], 8u);
+        std::vector<char> has((size_t)TW, 0);
+        int in_level = 0, level = 0;
+        auto close_level = [&]() {
+            for (int wv = 0; wv < TW; wv++) { if (has[wv]) wl[wv].ctl.back() |= 8u; else null_batch(wl[wv], 8u); has[wv] = 0; }
+            in_level = 0; level++;
+        };
+        for (int c = ldl; c < rs->fac_chunks; c++) {
+            const int Ls = rs->f_ctab[4 * c];
+            if (Ls > 0) { const int wv = (level + in_level) % TW; add_chunk(wl[wv], c, step); has[wv] = 1; in_level++; }
+            step += (size_t)Ls;
+            if (rs->f_ctab[4 * c + 1]) close_level();
+        }
+        if (in_level) close_level();
+        for (int wv = 0; wv < TW; wv++) {
+            while (wl[wv].ctl.size() % DPF) null_batch(wl[wv], 0u);
+            bfhdr[2 * wv] = (unsigned)bfctl.size(); bfhdr[2 * wv + 1] = (unsigned)wl[wv].ctl.size();
+            for (int k = 0; k < 2 * DPF; k++) null_batch(wl[wv], 0u);       // (what the prefetch ring reads past the end)
+            bfctl.insert(bfctl.end(), wl[wv].ctl.begin(), wl[wv].ctl.end());
+            bfdk.insert(bfdk.end(), wl[wv].dk.begin(), wl[wv].dk.end());
+            bftri.insert(bftri.end(), wl[wv].tri.begin(), wl[wv].tri.end());
+        }
+    }
+#endif
     // ---- coalesced canonicalisation maps, entry tables
     struct EllHost { std::vector<int> idx; std::vector<double> coef; int J = 0, rows = 0; };
     auto make_ell = [&](const cpg_csr_t &M, int rows, EllHost &E) {
@@ -1621,6 +1676,10 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     if ((rc = upload<unsigned>(h, own, entA.data(), entA.size(), &Rs.entA))) return rc;
     if ((rc = upload<unsigned>(h, own, entP.data(), entP.size(), &Rs.entP))) return rc;
 #ifdef CPG_GENT_HEADER
+    if ((rc = upload<unsigned>(h, own, bfhdr.data(), bfhdr.size(), &Rs.bf_hdr))) return rc;
+    if ((rc = upload<unsigned>(h, own, bfctl.data(), bfctl.size(), &Rs.bf_ctl))) return rc;
+    if ((rc = upload<unsigned>(h, own, bfdk.data(), bfdk.size(), &Rs.bf_dk))) return rc;
+    if ((rc = upload<unsigned long long>(h, own, bftri.data(), bftri.size(), &Rs.bf_tri))) return rc;
     if ((rc = upload<unsigned>(h, own, toff.data(), toff.size(), &Rs.t_off))) return rc;
     if ((rc = upload<unsigned>(h, own, trow.data(), trow.size(), &Rs.t_row))) return rc;
 #endif

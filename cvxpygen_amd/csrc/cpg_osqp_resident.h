@@ -77,6 +77,13 @@ struct DevResident {
     // g_src / g_lcol are [wave][NREGS][lane] then, and pA / pP / pAt carry the same two tables of the row executors (gcols / grows
     // reinterpreted as 32-bit words)
     const unsigned *t_off, *t_row;
+    // ... and its BATCHED factorisation (team_factor_batched): the combined schedule as batches of CPG_TEAM_FAC_BATCH steps, one list per wavefront
+    // -- the LDL' part (a chain of levels, one chunk wide) on wavefront 0, the chunks of every level of the block inverses spread over
+    // the team.  bf_hdr [wave][2] first batch | batches; bf_ctl [batch] 1 first of a chunk | 2 last | 4 level end inside a
+    // wavefront's own section | 8 level end the team meets at | reduction stages << 4; bf_tri [batch][lane][CPG_TEAM_FAC_BATCH] operand
+    // positions a | b << 16 | k << 32 of the batch's steps (idle: the zero slot); bf_dk [batch][lane] destination | pivot << 16 (0xFFFF: none)
+    const unsigned *bf_hdr, *bf_ctl, *bf_dk;
+    const unsigned long long *bf_tri;
 };
 
 #if defined(CPG_GENR_HEADER) || defined(CPG_GENT_HEADER)
@@ -104,6 +111,7 @@ CPG_DEV void globalise(DevResident &Rs) {
     CPG_G(Rs.f_ctl); CPG_G(Rs.f_ent); CPG_G(Rs.k_src); CPG_G(Rs.g_src); CPG_G(Rs.g_lcol); CPG_G(Rs.g_cols); CPG_G(Rs.g_rows);
     globalise(Rs.eP); globalise(Rs.eA); globalise(Rs.eq); globalise(Rs.eu); CPG_G(Rs.entA); CPG_G(Rs.entP); CPG_G(Rs.gf_tri); CPG_G(Rs.gf_dk);
     globalise(Rs.pA); globalise(Rs.pP); globalise(Rs.pAt);
+    CPG_G(Rs.t_off); CPG_G(Rs.t_row); CPG_G(Rs.bf_hdr); CPG_G(Rs.bf_ctl); CPG_G(Rs.bf_dk); CPG_G(Rs.bf_tri);
 }
 CPG_DEV void globalise(DevRefactor &R) {     // (the members the resident path reads)
     CPG_G(R.P_base); CPG_G(R.A_base); CPG_G(R.q_base); CPG_G(R.u_base); CPG_G(R.q_setup);

@@ -271,6 +271,63 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
     out.cs = cs; out.dconst = dconst; out.free_rows = free_rows;
 }
 
+// The combined factorisation + block-inverse schedule as a table walk in batches of CPG_TEAM_FAC_BATCH steps (DevResident::bf_*): the
+// LDS reads of a batch are issued together, the operand words of the next CPG_TEAM_FAC_DEPTH batches are on their way from
+// memory while a batch is consumed.  Wavefront 0 walks the LDL' part -- a chain of levels one chunk wide on the families this
+// kernel exists for, nothing to share -- then the team meets, and every level of the block inverses is spread over the
+// wavefronts, one barrier per level.  Same arithmetic, in the same order, as the straight-line form and resident_factor.
+#ifndef CPG_TEAM_FAC_DEPTH
+#define CPG_TEAM_FAC_DEPTH 4
+#endif
+#ifndef CPG_TEAM_FAC_BATCH
+#define CPG_TEAM_FAC_BATCH 8          // steps per batch: a chain level of 5 - 7 steps is ONE batch = one LDS round trip
+#endif
+struct alignas(16) TeamTriPair { unsigned long long a, b; };
+CPG_DEV void team_factor_batched(const DevResident &Rs, double *fac, int lane, int wave) {
+    constexpr int DP = CPG_TEAM_FAC_DEPTH, S = CPG_TEAM_FAC_BATCH, SP = S / 2;
+    static_assert(S % 2 == 0 && S >= 2, "an even number of steps per batch");
+    const unsigned first = cpgw::sld(Rs.bf_hdr, 2u * (unsigned)wave), nb = cpgw::sld(Rs.bf_hdr, 2u * (unsigned)wave + 1u);
+    const TeamTriPair *tri = (const TeamTriPair *)Rs.bf_tri;
+    TeamTriPair e[DP][SP];
+    unsigned dk[DP], c[DP], cn[DP];
+    auto request = [&](int u, unsigned t) __attribute__((always_inline)) {
+        const unsigned at = (first + t) * 64u + (unsigned)lane;
+#pragma unroll
+        for (int k = 0; k < SP; k++) e[u][k] = cpgw::gld(tri, (unsigned)SP * at + (unsigned)k);
+        dk[u] = cpgw::gld(Rs.bf_dk, at);
+    };
+#pragma unroll
+    for (int u = 0; u < DP; u++) { request(u, (unsigned)u); c[u] = cpgw::sld(Rs.bf_ctl, first + (unsigned)u); cn[u] = cpgw::sld(Rs.bf_ctl, first + (unsigned)(DP + u)); }
+    double acc = 0.0;
+#pragma nounroll
+    for (unsigned t0 = 0; t0 < nb; t0 += DP) {
+#pragma unroll
+        for (int u = 0; u < DP; u++) {
+            unsigned long long w_[S];
+#pragma unroll
+            for (int k = 0; k < SP; k++) { w_[2 * k] = e[u][k].a; w_[2 * k + 1] = e[u][k].b; }
+            const unsigned fl = c[u], d = dk[u];
+            request(u, t0 + (unsigned)(u + DP));
+            if (fl & 1u) acc = 0.0;
+            double av[S], kv[S], bv[S];
+#pragma unroll
+            for (int k = 0; k < S; k++) { av[k] = fac[(unsigned)w_[k] & 0xFFFFu]; kv[k] = fac[(unsigned)(w_[k] >> 32)]; bv[k] = fac[((unsigned)w_[k] >> 16)]; }
+#pragma unroll
+            for (int k = 0; k < S; k++) acc = fma(av[k] * kv[k], bv[k], acc);
+            if (fl & 2u) {
+                const double r = cpgw::group_sum_first_dyn(acc, (int)((fl >> 4) & 7u));
+                if ((d & 0xFFFFu) != 0xFFFFu) {
+                    const double v = fac[d & 0xFFFFu] - r;
+                    fac[d & 0xFFFFu] = (d >> 16) ? 1.0 / v : v;
+                }
+            }
+            if (fl & 4u) cpgw::lds_order();
+            if (fl & 8u) cpgw::block_sync();
+            c[u] = cn[u]; cn[u] = cpgw::sld(Rs.bf_ctl, first + t0 + (unsigned)(2 * DP + u));
+        }
+    }
+}
+
 // ---- step 4: KKT values into the slice (all threads), numeric LDL' + inverses of the merged diagonal blocks (wavefront 0:
 //      the schedule is a chain of levels, most of them one chunk wide)
 CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, double sigma) {
@@ -308,10 +365,12 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
     }
     for (unsigned d = nd + (unsigned)tid; d < (unsigned)Rs.fac_len; d += T) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
     cpgw::block_sync();
-#ifdef CPG_TEAM_TABLE_FACTOR
-    if (wave == 0) resident_factor(Rs, sl, lane);        // (experiments: the flat table-driven stream instead of straight-line code)
-#else
+#if defined(CPG_TEAM_TABLE_FACTOR)
+    if (wave == 0) resident_factor(Rs, sl, lane);        // (experiments: the flat one-step-at-a-time stream of the resident kernel's fallback)
+#elif defined(CPG_GENT_FAC_GENERATED) && !defined(CPG_TEAM_BATCHED_FACTOR)
     if (wave == 0) team_factor_gen(Rs.gf_tri, Rs.gf_dk, sl, lane);
+#else
+    team_factor_batched(Rs, sl, lane, wave);              // (its last batch is a barrier of the team)
 #endif
     cpgw::block_sync();
 }

@@ -43,7 +43,10 @@ STATUS_NEEDS_REFACTOR = -2
 # with, restored by every cpg_solve (osqp_set_default_settings, cvxpygen/solvers/osqp.py:100-101).  The reference
 # requires osqp >= 1.0 (pyproject.toml:26; its emitted calls are the 1.0 API): rho adapted every 50 iterations,
 # tolerance 5, duality-gap test.  `build_options` / generate_code(osqp_build_options=...) override.
-BUILD_OPTIONS = ('adaptive_rho', 'adaptive_rho_interval', 'adaptive_rho_tolerance', 'check_dualgap')
+BUILD_OPTIONS = ('adaptive_rho', 'adaptive_rho_interval', 'adaptive_rho_tolerance', 'check_dualgap',
+                 # raw-handle protocol of the C-ABI (include/cpg_hip.h): a shared-factor solve WITHOUT a linked per-instance handle
+                 # flags the instances whose rho would change (status -2) instead of being refused
+                 'flag_rho_changes')
 BUILD_OPTION_DEFAULTS = {'adaptive_rho': 1, 'adaptive_rho_interval': 50, 'adaptive_rho_tolerance': 5.0, 'check_dualgap': 1}
 # the other reading of the reference's default (a solver generated against an OSQP whose codegen never adapts rho)
 BUILD_OPTIONS_FIXED_RHO = {'adaptive_rho': 0, 'check_dualgap': 0}
@@ -528,6 +531,9 @@ class BatchSolver:
         else:
             o = self.plan.osqp
             rplan = self._rplan
+            if rplan is not None and not getattr(self, '_res_probed', False):
+                rplan = None               # (a gradient built the plain plan first: the resident / team candidate is still to be probed)
+            self._res_probed = True
             if rplan is None:
                 # the plan codegen.resident_header generated this library's resident executor from (merged levels,
                 # register-resident coefficients) -- when the library has one for this family; its `base` is the plan
@@ -985,14 +991,38 @@ class BatchSolver:
         E is the instance's own; a bound of +-1e30 and l == u classify the same under any admissible E in
         [1e-4, 1e4], only a row with 0 < E (u - l) < 1e-4 could differ.)"""
         d, o = self.desc, self.plan.osqp
-        th = np.tile(self._th_fixed[:d.NP + 1], (Bn, 1))
-        if self.np_var:
-            th[:, self._var_cols] = theta_var
+        # the maps in CSR, their fixed part and their columns over the varying parameters: built once per set_updated
+        key = (self._var_cols.tobytes(), self._th_fixed.tobytes())
+        cache = getattr(self, '_rc_cache', None)
+        if cache is None or cache[0] != key:
+            Mu, Ml = sp.csr_matrix(d.maps['u']), sp.csr_matrix(d.maps['l'])
+            tf = np.array(self._th_fixed[:d.NP + 1], dtype=np.float64)
+            if self.np_var:
+                tf[self._var_cols] = 0.0
+            ub, lb = np.asarray(Mu @ tf).ravel(), (np.asarray(Ml @ tf).ravel() if d.n_eq else np.zeros(0))
+            Muv = sp.csr_matrix(Mu[:, self._var_cols]) if self.np_var else None
+            Mlv = sp.csr_matrix(Ml[:, self._var_cols]) if (self.np_var and d.n_eq) else None
+            cache = (key, ub, lb, Muv, Mlv)
+            self._rc_cache = cache
+        _, ub, lb, Muv, Mlv = cache
+        if (Muv is None or Muv.nnz == 0) and (Mlv is None or Mlv.nnz == 0):
+            # neither bound depends on a varying parameter: no row can have changed class
+            u1 = np.clip(ub, -CPG_INF, CPG_INF)[None, :]
+            l1 = np.full_like(u1, -CPG_INF)
+            if d.n_eq:
+                l1[:, :d.n_eq] = np.clip(lb, -CPG_INF, CPG_INF)
+            E = np.asarray(o.scaling.E, dtype=np.float64)
+            ls, us = l1 * E, u1 * E
+            free = (ls < -CPG_INF * 1e-4) & (us > CPG_INF * 1e-4)
+            eq = ~free & (us - ls < 1e-4)
+            return np.broadcast_to(np.where(free, -1, np.where(eq, 1, 0)).astype(np.int8), (Bn, d.m)).copy()
         E = np.asarray(o.scaling.E, dtype=np.float64)
-        u = np.clip(np.asarray((sp.csr_matrix(d.maps['u']) @ th.T).T), -CPG_INF, CPG_INF)
+        u = ub[None, :] + (np.asarray((Muv @ theta_var.T).T) if Muv is not None and Muv.nnz else 0.0)
+        u = np.clip(np.broadcast_to(u, (Bn, d.m)), -CPG_INF, CPG_INF)
         l = np.full_like(u, -CPG_INF)
         if d.n_eq:
-            l[:, :d.n_eq] = np.clip(np.asarray((sp.csr_matrix(d.maps['l']) @ th.T).T), -CPG_INF, CPG_INF)
+            lv = lb[None, :] + (np.asarray((Mlv @ theta_var.T).T) if Mlv is not None and Mlv.nnz else 0.0)
+            l[:, :d.n_eq] = np.clip(np.broadcast_to(lv, (Bn, d.n_eq)), -CPG_INF, CPG_INF)
         ls, us = l * E, u * E
         free = (ls < -CPG_INF * 1e-4) & (us > CPG_INF * 1e-4)
         eq = ~free & (us - ls < 1e-4)

@@ -25,9 +25,20 @@ _ip = C.POINTER(C.c_int)
 def build(force=False):
     so = os.path.join(_HERE, 'liboracle.so')
     srcs = [os.path.join(_HERE, f) for f in ('osqp_oracle.c', 'clarabel_oracle.c', 'Makefile')]
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'],
-                              stdout=subprocess.DEVNULL)
+    def stale():
+        return force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs)
+    if stale():
+        # several ranks / pytest workers may import this at once: one of them builds, the others wait for the lock and find
+        # the library up to date
+        import fcntl
+        with open(os.path.join(_HERE, '.build.lock'), 'w') as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'], stdout=subprocess.DEVNULL)
+                    force = False
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return so
 
 

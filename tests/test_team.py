@@ -59,8 +59,8 @@ def test_team_plan_solves_the_kkt_system(fam, W):
     assert np.abs(w[:N] - xr).max() <= 1e-9 * np.abs(xr).max()
 
 
-@pytest.mark.parametrize('W', [1, 2, 4])
-def test_team_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path, monkeypatch, W):
+@pytest.mark.parametrize('W,gen_fac', [(1, True), (2, True), (4, True), (4, False), (2, False)])
+def test_team_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path, monkeypatch, W, gen_fac):
     """the kernel sources of the team path (set-up on 64 W threads, factorisation on wavefront 0, per-wavefront coefficient /
     offset / slot registers, one barrier per phase, team reductions of the termination test) in a family library of a small
     portfolio family: the oracle's iterates, iteration counts and statuses in the default mode (rho adapted at 50, 100 ...),
@@ -69,11 +69,15 @@ def test_team_kernel_on_the_emulator_vs_oracle(oracle_lib, tmp_path, monkeypatch
     from sim import build_sim
     from test_sim_kernel import _assert_parity, _oracle_flat
     monkeypatch.setattr(codegen, 'TEAM_WAVES', W)
+    # (gen_fac False: the factorisation as the team's batched table walk -- LDL' part on wavefront 0, the levels of the block
+    # inverses spread over the team -- what families with long schedules get; True: straight-line code on wavefront 0)
+    monkeypatch.setattr(codegen, 'TEAM_FAC_GENERATED_MAX', 600 if gen_fac else 0)
     n, m, B = 20, 3, 3
     d = families.portfolio(n, m)
     plan = build_family_plan(d)
     _, defs = codegen.family_library_defs(plan, str(tmp_path), 'pf20')
     assert any('CPG_GENT_HEADER' in x for x in defs) and not any('CPG_GENR_HEADER' in x for x in defs)
+    assert ('CPG_GENT_FAC_GENERATED' in open(str(tmp_path / 'cpg_team_pf20.h')).read()) == gen_fac
     lib = build_sim.build_family(plan, str(tmp_path), 'pf20')
     vals, th, upd = _portfolio_values(d, B, n, m)
     bs = BatchSolver(d, lib_path=lib, plan=plan)
@@ -95,6 +99,7 @@ def test_team_kernel_all_parameters_mpc_on_the_emulator(oracle_lib, tmp_path, mo
     from sim import build_sim
     from test_sim_kernel import _assert_parity, _oracle_flat
     monkeypatch.setattr(codegen, 'TEAM_WAVES', 4)
+    monkeypatch.setattr(codegen, 'TEAM_FAC_GENERATED_MAX', 0)          # (the batched factorisation: several merged groups to invert)
     d = families.mpc(6, 3, 10)
     plan = build_family_plan(d)
     _, defs = codegen.family_library_defs(plan, str(tmp_path), 'mpc6t')
