@@ -1483,22 +1483,45 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
 #ifdef CPG_GENT_HEADER
     // ---- the same schedule for the team's batched table walk (team_factor_batched): batches of CPG_TEAM_FAC_BATCH steps, one list per wavefront;
     //      the LDL' part (the first r->fac_chunks chunks) on wavefront 0, every level of the block inverses spread over the team
-    std::vector<unsigned> bfhdr((size_t)2 * TW, 0u), bfctl, bfdk;
-    std::vector<unsigned long long> bftri;
+    std::vector<unsigned> bfhdr((size_t)2 * TW, 0u), bfctl, bfdk, bftri;
     {
         constexpr int DPF = CPG_TEAM_FAC_DEPTH, SB = CPG_TEAM_FAC_BATCH;
-        struct WaveList { std::vector<unsigned> ctl, dk; std::vector<unsigned long long> tri; };
+        const unsigned long long Zp = (unsigned long long)ZERO;
+        constexpr int NQ = (3 * SB / 2 + 3) / 4, NWD = 3 * SB / 2;
+        struct WaveList { std::vector<unsigned> ctl, dk, tri; };
         std::vector<WaveList> wl((size_t)TW);
-        const unsigned long long Zp = (unsigned long long)ZERO, Zw = Zp | (Zp << 16) | (Zp << 32);
-        auto null_batch = [&](WaveList &L, unsigned fl) { L.ctl.push_back(fl); L.dk.insert(L.dk.end(), 64, 0xFFFFu); L.tri.insert(L.tri.end(), (size_t)64 * SB, Zw); };
+        const unsigned Zb = (unsigned)ZERO * 8u;
+        // tri of a batch: [quad][lane][4] words; three words per two steps: a | b << 16, k | a' << 16, b' | k' << 16 (element numbers)
+        const unsigned Zh = (unsigned)ZERO | ((unsigned)ZERO << 16);
+        auto put_batch = [&](WaveList &L, unsigned fl, const unsigned (*words)[3 * SB / 2], const unsigned *dks) {
+            L.ctl.push_back(fl);
+            for (int l = 0; l < 64; l++) L.dk.push_back(dks ? dks[l] : (Zb | 0x40000000u));
+            for (int q = 0; q < NQ; q++) for (int l = 0; l < 64; l++) for (int k = 0; k < 4; k++) {
+                const int wd = 4 * q + k;
+                L.tri.push_back((words && wd < NWD) ? words[l][wd] : Zh);
+            }
+        };
+        auto null_batch = [&](WaveList &L, unsigned fl) { put_batch(L, fl, nullptr, nullptr); };
         auto add_chunk = [&](WaveList &L, int c, size_t step0) {
             const int Ls = rs->f_ctab[4 * c], lg = rs->f_ctab[4 * c + 3], nbat = (Ls + SB - 1) / SB;
+            unsigned dks[64];
+            bool pivot = false;
+            for (int l = 0; l < 64; l++) {
+                const unsigned g = gfdk[(size_t)c * 64 + l];
+                if ((g & 0xFFFFu) == 0xFFFFu) dks[l] = Zb | 0x40000000u;
+                else { dks[l] = ((g & 0xFFFFu) * 8u) | ((g >> 16) ? 0x80000000u : 0u); pivot |= (g >> 16) != 0; }
+            }
+            static unsigned words[64][3 * SB / 2];
             for (int bt = 0; bt < nbat; bt++) {
-                L.ctl.push_back((bt == 0 ? 1u : 0u) | (bt == nbat - 1 ? 2u : 0u) | ((unsigned)lg << 4));
-                for (int l = 0; l < 64; l++) {
-                    L.dk.push_back(gfdk[(size_t)c * 64 + l]);
-                    for (int k = 0; k < SB; k++) L.tri.push_back(SB * bt + k < Ls ? gftri[(step0 + (size_t)(SB * bt + k)) * 64 + l] : Zw);
+                for (int l = 0; l < 64; l++) for (int k = 0; k < SB; k += 2) {
+                    unsigned f[6];
+                    for (int q = 0; q < 2; q++) {
+                        const unsigned long long t = SB * bt + k + q < Ls ? gftri[(step0 + (size_t)(SB * bt + k + q)) * 64 + l] : (Zp | (Zp << 16) | (Zp << 32));
+                        f[3 * q] = (unsigned)(t & 0xFFFFu); f[3 * q + 1] = (unsigned)((t >> 16) & 0xFFFFu); f[3 * q + 2] = (unsigned)((t >> 32) & 0xFFFFu);
+                    }
+                    words[l][3 * (k / 2)] = f[0] | (f[1] << 16); words[l][3 * (k / 2) + 1] = f[2] | (f[3] << 16); words[l][3 * (k / 2) + 2] = f[4] | (f[5] << 16);
                 }
+                put_batch(L, (bt == 0 ? 1u : 0u) | (bt == nbat - 1 ? 2u : 0u) | (pivot ? 16u : 0u) | ((unsigned)lg << 5), words, dks);
             }
         };
         const int ldl = std::min(r->fac_chunks, rs->fac_chunks);
@@ -1679,7 +1702,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     if ((rc = upload<unsigned>(h, own, bfhdr.data(), bfhdr.size(), &Rs.bf_hdr))) return rc;
     if ((rc = upload<unsigned>(h, own, bfctl.data(), bfctl.size(), &Rs.bf_ctl))) return rc;
     if ((rc = upload<unsigned>(h, own, bfdk.data(), bfdk.size(), &Rs.bf_dk))) return rc;
-    if ((rc = upload<unsigned long long>(h, own, bftri.data(), bftri.size(), &Rs.bf_tri))) return rc;
+    if ((rc = upload<unsigned>(h, own, bftri.data(), bftri.size(), &Rs.bf_tri))) return rc;
     if ((rc = upload<unsigned>(h, own, toff.data(), toff.size(), &Rs.t_off))) return rc;
     if ((rc = upload<unsigned>(h, own, trow.data(), trow.size(), &Rs.t_row))) return rc;
 #endif

@@ -80,10 +80,10 @@ struct DevResident {
     // ... and its BATCHED factorisation (team_factor_batched): the combined schedule as batches of CPG_TEAM_FAC_BATCH steps, one list per wavefront
     // -- the LDL' part (a chain of levels, one chunk wide) on wavefront 0, the chunks of every level of the block inverses spread over
     // the team.  bf_hdr [wave][2] first batch | batches; bf_ctl [batch] 1 first of a chunk | 2 last | 4 level end inside a
-    // wavefront's own section | 8 level end the team meets at | reduction stages << 4; bf_tri [batch][lane][CPG_TEAM_FAC_BATCH] operand
-    // positions a | b << 16 | k << 32 of the batch's steps (idle: the zero slot); bf_dk [batch][lane] destination | pivot << 16 (0xFFFF: none)
-    const unsigned *bf_hdr, *bf_ctl, *bf_dk;
-    const unsigned long long *bf_tri;
+    // wavefront's own section | 8 level end the team meets at | 16 the chunk holds a pivot | reduction stages << 5; bf_tri
+    // [batch][quad][lane][4] positions in the factor of the operands a, b, k of the batch's steps, 16 bits each, three words per two
+    // steps (idle: the zero slot); bf_dk [batch][lane] byte offset of the destination | none << 30 (then: the zero slot) | pivot << 31
+    const unsigned *bf_hdr, *bf_ctl, *bf_dk, *bf_tri;
 };
 
 #if defined(CPG_GENR_HEADER) || defined(CPG_GENT_HEADER)

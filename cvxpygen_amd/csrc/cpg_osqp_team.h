@@ -40,7 +40,7 @@ struct TeamRed { unsigned par; };
 template <int K, bool SUM>
 CPG_DEV void team_reduce(double (&v)[K], TeamRed &tr, int lane, int wave) {
     static_assert(K <= 8, "at most 8 values per reduction");
-    double *buf = cpgw::lds_window() + CPG_TEAM_RED_OFF + tr.par * (8u * (unsigned)CPG_TEAM_W);
+    CPG_LDS double *buf = cpgw::lds_window3() + CPG_TEAM_RED_OFF + tr.par * (8u * (unsigned)CPG_TEAM_W);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const double r = SUM ? cpgw::wave_sum(v[k]) : cpgw::wave_max_nonneg(v[k]);
@@ -85,17 +85,18 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
     constexpr unsigned nnzA = CPG_GENT_NNZA, nnzP = CPG_GENT_NNZP;
     constexpr int KA = (int)((nnzA + T - 1) / T) > 0 ? (int)((nnzA + T - 1) / T) : 1, KP = (int)((nnzP + T - 1) / T) > 0 ? (int)((nnzP + T - 1) / T) : 1;
     TeamRed tr{0u};
-    double *sl = cpgw::lds_window() + CPG_TEAM_SLICE_OFF;
+    // (LDS pointers carry their address space in the type: ds_read / ds_write / ds_max instead of flat accesses)
+    CPG_LDS double *sl = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
     // (the scaling vectors, the norms and theta use the space the scaled matrices take once D and E are dead: step 3 below writes
     // A, P behind a barrier, after every read of D and E)
-    double *Al = sl, *Pl = Al + nnzA, *Dl = sl, *El = Dl + n;
-    unsigned long long *nrm = (unsigned long long *)(El + m);
+    CPG_LDS double *Al = sl, *Pl = Al + nnzA, *Dl = sl, *El = Dl + n;
+    CPG_LDS unsigned long long *nrm = (CPG_LDS unsigned long long *)(El + m);
     // ---- 1. theta -> LDS; canonicalise P, A, q, u into registers (entry k = tid + T t of a matrix, entry i = tid + T s of a vector)
     unsigned ea[KA], ep[KP];           // row | column << 16
     double av[KA], pv[KP];
     double qr[NX], ur[NZ];
     {
-        double *th = Dl;
+        CPG_LDS double *th = Dl;
         for (unsigned t0 = 0; t0 < (unsigned)R.np_var; t0 += 8u * T) {
             double tv[8];
 #pragma unroll
@@ -161,8 +162,8 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
             const unsigned k = (unsigned)tid + T * (unsigned)t, i = ep[t] & 0xFFFFu, j = ep[t] >> 16;
             if (k < nnzP) {
                 const double p = pv[t], di = Dl[i], dj = Dl[j];
-                cpgw::lds_max_u64(nrm + j, fabs(cs * dj * p * di));
-                if (i != j) cpgw::lds_max_u64(nrm + i, fabs(cs * di * p * dj));
+                cpgw::lds_max_u64_l(nrm + j, fabs(cs * dj * p * di));
+                if (i != j) cpgw::lds_max_u64_l(nrm + i, fabs(cs * di * p * dj));
             }
         }
     };
@@ -176,7 +177,7 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
 #pragma unroll
         for (int t = 0; t < KA; t++) { const unsigned r = ea[t] & 0xFFFFu, c = ea[t] >> 16; mag[t] = fabs(El[r] * av[t] * Dl[c]); }
 #pragma unroll
-        for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)tid + T * (unsigned)t; if (k < nnzA) cpgw::lds_max_u64(nrm + (ea[t] >> 16), mag[t]); }
+        for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)tid + T * (unsigned)t; if (k < nnzA) cpgw::lds_max_u64_l(nrm + (ea[t] >> 16), mag[t]); }
         cpgw::block_sync();
 #pragma unroll
         for (int s = 0; s < NX; s++) { const unsigned j = (unsigned)tid + T * (unsigned)s; dn[s] = j < n ? cpgw::u64_as_double(nrm[j]) : 0.0; }
@@ -184,7 +185,7 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
         for (unsigned i = (unsigned)tid; i < m; i += T) nrm[i] = 0ull;
         cpgw::block_sync();
 #pragma unroll
-        for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)tid + T * (unsigned)t; if (k < nnzA) cpgw::lds_max_u64(nrm + (ea[t] & 0xFFFFu), mag[t]); }
+        for (int t = 0; t < KA; t++) { const unsigned k = (unsigned)tid + T * (unsigned)t; if (k < nnzA) cpgw::lds_max_u64_l(nrm + (ea[t] & 0xFFFFu), mag[t]); }
         cpgw::block_sync();
 #pragma unroll
         for (int s = 0; s < NZ; s++) { const unsigned i = (unsigned)tid + T * (unsigned)s; en[s] = i < m ? cpgw::u64_as_double(nrm[i]) : 0.0; }
@@ -250,7 +251,7 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
 #pragma unroll
     for (int t = 0; t < KP; t++) { const unsigned k = (unsigned)tid + T * (unsigned)t; if (k < nnzP) { Pl[k] = pv[t]; cpgw::gst(B.P, k, pv[t]); } }
     cpgw::block_sync();
-    auto copy_values = [&](const DevStreamTab &Tb, double *dst, const double *src) __attribute__((always_inline)) {
+    auto copy_values = [&](const DevStreamTab &Tb, double *dst, const CPG_LDS double *src) __attribute__((always_inline)) {
 #pragma nounroll
         for (unsigned e0 = 0; e0 < (unsigned)Tb.n_entries; e0 += 8u * T) {
             int kk[8];
@@ -282,19 +283,22 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
 #ifndef CPG_TEAM_FAC_BATCH
 #define CPG_TEAM_FAC_BATCH 8          // steps per batch: a chain level of 5 - 7 steps is ONE batch = one LDS round trip
 #endif
-struct alignas(16) TeamTriPair { unsigned long long a, b; };
-CPG_DEV void team_factor_batched(const DevResident &Rs, double *fac, int lane, int wave) {
-    constexpr int DP = CPG_TEAM_FAC_DEPTH, S = CPG_TEAM_FAC_BATCH, SP = S / 2;
-    static_assert(S % 2 == 0 && S >= 2, "an even number of steps per batch");
+struct alignas(16) TeamQuad { unsigned x, y, z, w; };
+CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac, int lane, int wave) {
+    constexpr int DP = CPG_TEAM_FAC_DEPTH, S = CPG_TEAM_FAC_BATCH, NQ = (3 * S / 2 + 3) / 4;
+    static_assert(S % 2 == 0, "an even number of steps per batch: two steps share three words");
     const unsigned first = cpgw::sld(Rs.bf_hdr, 2u * (unsigned)wave), nb = cpgw::sld(Rs.bf_hdr, 2u * (unsigned)wave + 1u);
-    const TeamTriPair *tri = (const TeamTriPair *)Rs.bf_tri;
-    TeamTriPair e[DP][SP];
+    // [batch][NQ][lane]: positions a, b, k of the batch's steps as 16-bit element numbers, three words per TWO steps -- 48 bytes per lane
+    // and batch of eight steps; the tables of a long schedule (MPC 12/4/10 with every parameter: 770 batches) then stay inside an
+    // XCD's 4 MB of L2 (as byte offsets, three words per step, they took 5.6 MB and 81 GB of fetches per 20 000 instances)
+    const TeamQuad *tri = (const TeamQuad *)Rs.bf_tri;
+    const CPG_LDS char *fb = (const CPG_LDS char *)fac;
+    TeamQuad e[DP][NQ];
     unsigned dk[DP], c[DP], cn[DP];
     auto request = [&](int u, unsigned t) __attribute__((always_inline)) {
-        const unsigned at = (first + t) * 64u + (unsigned)lane;
 #pragma unroll
-        for (int k = 0; k < SP; k++) e[u][k] = cpgw::gld(tri, (unsigned)SP * at + (unsigned)k);
-        dk[u] = cpgw::gld(Rs.bf_dk, at);
+        for (int k = 0; k < NQ; k++) e[u][k] = cpgw::gld(tri, ((first + t) * (unsigned)NQ + (unsigned)k) * 64u + (unsigned)lane);
+        dk[u] = cpgw::gld(Rs.bf_dk, (first + t) * 64u + (unsigned)lane);
     };
 #pragma unroll
     for (int u = 0; u < DP; u++) { request(u, (unsigned)u); c[u] = cpgw::sld(Rs.bf_ctl, first + (unsigned)u); cn[u] = cpgw::sld(Rs.bf_ctl, first + (unsigned)(DP + u)); }
@@ -303,23 +307,35 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, double *fac, int lane, i
     for (unsigned t0 = 0; t0 < nb; t0 += DP) {
 #pragma unroll
         for (int u = 0; u < DP; u++) {
-            unsigned long long w_[S];
+            unsigned o_[4 * NQ];
 #pragma unroll
-            for (int k = 0; k < SP; k++) { w_[2 * k] = e[u][k].a; w_[2 * k + 1] = e[u][k].b; }
+            for (int k = 0; k < NQ; k++) { o_[4 * k] = e[u][k].x; o_[4 * k + 1] = e[u][k].y; o_[4 * k + 2] = e[u][k].z; o_[4 * k + 3] = e[u][k].w; }
             const unsigned fl = c[u], d = dk[u];
             request(u, t0 + (unsigned)(u + DP));
             if (fl & 1u) acc = 0.0;
             double av[S], kv[S], bv[S];
+            // (the destination's KKT value is requested with the operands: nothing of this chunk has stored yet, and the value is not
+            // touched before the chunk's own store -- one LDS round trip less on the chain of a level; lanes without a task read the
+            // zero slot their word points at)
+            const double dv = *(const CPG_LDS double *)(fb + (d & 0x3FFFFFu));
 #pragma unroll
-            for (int k = 0; k < S; k++) { av[k] = fac[(unsigned)w_[k] & 0xFFFFu]; kv[k] = fac[(unsigned)(w_[k] >> 32)]; bv[k] = fac[((unsigned)w_[k] >> 16)]; }
+            for (int k = 0; k < S; k += 2) {
+                const unsigned w0 = o_[3 * (k / 2)], w1 = o_[3 * (k / 2) + 1], w2 = o_[3 * (k / 2) + 2];
+                av[k] = fac[w0 & 0xFFFFu]; bv[k] = fac[w0 >> 16]; kv[k] = fac[w1 & 0xFFFFu];
+                av[k + 1] = fac[w1 >> 16]; bv[k + 1] = fac[w2 & 0xFFFFu]; kv[k + 1] = fac[w2 >> 16];
+            }
 #pragma unroll
             for (int k = 0; k < S; k++) acc = fma(av[k] * kv[k], bv[k], acc);
             if (fl & 2u) {
-                const double r = cpgw::group_sum_first_dyn(acc, (int)((fl >> 4) & 7u));
-                if ((d & 0xFFFFu) != 0xFFFFu) {
-                    const double v = fac[d & 0xFFFFu] - r;
-                    fac[d & 0xFFFFu] = (d >> 16) ? 1.0 / v : v;
-                }
+#ifdef CPG_TEAM_FAC_FLAT_REDUCE
+                const double r = cpgw::group_sum_first_flat(acc, (int)((fl >> 5) & 7u));      // (experiments: six masked stages, no branch)
+#else
+                const double r = cpgw::group_sum_first_dyn(acc, (int)((fl >> 5) & 7u));
+#endif
+                const double v = dv - r;
+                double st = v;
+                if (fl & 16u) st = (d >> 31) ? 1.0 / v : v;      // (a chunk without a pivot: no division at all)
+                if (!(d & 0x40000000u)) *(CPG_LDS double *)((CPG_LDS char *)fac + (d & 0x3FFFFFu)) = st;
             }
             if (fl & 4u) cpgw::lds_order();
             if (fl & 8u) cpgw::block_sync();
@@ -335,7 +351,7 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
     constexpr unsigned T = CPG_TEAM_T;
     const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     (void)R_;
-    double *sl = cpgw::lds_window() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *sl = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
     constexpr unsigned nd = CPG_GENT_NNZL + CPG_GENT_N + CPG_GENT_M;
     constexpr int KD = (int)((nd + T - 1) / T);
     constexpr int KB = KD < 16 ? KD : 16;      // (two dependent loads per destination: every batch is two round trips)
@@ -366,9 +382,9 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
     for (unsigned d = nd + (unsigned)tid; d < (unsigned)Rs.fac_len; d += T) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
     cpgw::block_sync();
 #if defined(CPG_TEAM_TABLE_FACTOR)
-    if (wave == 0) resident_factor(Rs, sl, lane);        // (experiments: the flat one-step-at-a-time stream of the resident kernel's fallback)
+    if (wave == 0) resident_factor(Rs, (double *)sl, lane);        // (experiments: the flat one-step-at-a-time stream of the resident kernel's fallback)
 #elif defined(CPG_GENT_FAC_GENERATED) && !defined(CPG_TEAM_BATCHED_FACTOR)
-    if (wave == 0) team_factor_gen(Rs.gf_tri, Rs.gf_dk, sl, lane);
+    if (wave == 0) team_factor_gen(Rs.gf_tri, Rs.gf_dk, (double *)sl, lane);
 #else
     team_factor_batched(Rs, sl, lane, wave);              // (its last batch is a barrier of the team)
 #endif
@@ -383,7 +399,7 @@ CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevRe
     constexpr unsigned T = CPG_TEAM_T;
     const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     (void)R_;
-    double *sl = cpgw::lds_window() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *sl = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
     constexpr unsigned n = CPG_GENT_N, m = CPG_GENT_M;
     constexpr int ldw = CPG_GENT_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     {
@@ -415,7 +431,7 @@ CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevRe
         }
     }
     cpgw::block_sync();                    // (every wavefront has read the factor)
-    double *w = sl, *qs = w + ldw;
+    CPG_LDS double *w = sl, *qs = w + ldw;
     for (unsigned t = (unsigned)tid; t < (unsigned)Rs.slice_doubles; t += T) w[t] = 0.0;
     cpgw::block_sync();
     {
@@ -547,8 +563,8 @@ struct TeamCheck {
     const DevFamily &F;
     const DevResident &Rs;
     const ResBuf &B;
-    double *w;
-    const double *qm, *um;
+    CPG_LDS double *w;
+    const CPG_LDS double *qm, *um;
     const signed char (&ct)[NZ];
     TeamRed &tr;
     int tid, lane, wave;
@@ -578,7 +594,7 @@ struct TeamCheck {
         if (which & 2) for (unsigned i = (unsigned)tid; i < n; i += T) w[(unsigned)Rs.out_px + i] = 0.0;
         if (which & 4) for (unsigned i = (unsigned)tid; i < n; i += T) w[(unsigned)Rs.out_aty + i] = 0.0;
         cpgw::block_sync();
-        CPG_LDS double *wl = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+        CPG_LDS double *wl = w;
         if (which & 1) run_rows_a_team(B.cA, (const unsigned *)Rs.pA.gcols, (const unsigned *)Rs.pA.grows, wl, lane, wave);
         if (which & 2) run_rows_p_team(B.cP, (const unsigned *)Rs.pP.gcols, (const unsigned *)Rs.pP.grows, wl, lane, wave);
         if (which & 4) run_rows_t_team(B.cAt, (const unsigned *)Rs.pAt.gcols, (const unsigned *)Rs.pAt.grows, wl, lane, wave);
@@ -687,8 +703,8 @@ CPG_DEV_NOINLINE CheckOut team_check(const DevFamily &F_, const DevResident &Rs_
     for (int s = 0; s < NX; s++) { Ix[s] = st_.x[s]; dxr[s] = st_.dx[s]; }
 #pragma unroll
     for (int s = 0; s < NZ; s++) { Iz[s] = st_.z[s]; Iy[s] = st_.y[s]; dyr[s] = st_.dy[s]; ct[s] = ct_[s]; }
-    double *w = cpgw::lds_window() + CPG_TEAM_SLICE_OFF;
-    const double *qs = w + (CPG_GENT_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + n;
+    CPG_LDS double *w = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+    const CPG_LDS double *qs = w + (CPG_GENT_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + n;
     TeamRed tr{0u};
     double dinv_r[NX], einv_r[NZ];
 #pragma unroll
@@ -786,7 +802,7 @@ CPG_DEV_NOINLINE void team_finalize(const DevFamily &F_, const DevBatch &Bt_, co
     constexpr unsigned n = CPG_GENT_N, m = CPG_GENT_M, T = CPG_TEAM_T;
     const long long b = ((long long)cpgw::read_first_lane((int)(b_v >> 32)) << 32) | (unsigned)cpgw::read_first_lane((int)b_v);
     const DevFamily F = uniform_global_copy(F_); const DevBatch Bt = uniform_global_copy(Bt_); const CheckOut o = o_;
-    double *w = cpgw::lds_window() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *w = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
     const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
     if (Bt.state_out) {
         double *so = Bt.state_out + (size_t)b * (size_t)(n + 2u * m + 1u);

@@ -97,6 +97,10 @@ CPG_DEV unsigned atomic_next(unsigned *ctr) { return atomicAdd(ctr, 1u); }
 CPG_DEV unsigned long long clock100() { return __builtin_amdgcn_s_memrealtime(); }      // 100 MHz (timing experiments)
 // max of non-negative doubles in LDS (they order like their bit patterns): ds_max_u64, no return value
 CPG_DEV void lds_max_u64(unsigned long long *p, double v) { atomicMax(p, (unsigned long long)__double_as_longlong(v)); }
+// ... the same through an LDS pointer by type (ds_max_u64 instead of a flat atomic)
+CPG_DEV void lds_max_u64_l(CPG_LDS unsigned long long *p, double v) {
+    __hip_atomic_fetch_max(p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 CPG_DEV double u64_as_double(unsigned long long v) { return __longlong_as_double((long long)v); }
 // keeps the instruction scheduler from interleaving unrolled loop bodies (register pressure)
 CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

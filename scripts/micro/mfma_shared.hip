@@ -26,35 +26,55 @@ struct Prog {
     const unsigned short *rb_out;   // [n_rb][16] output slots
 };
 
-__global__ void __launch_bounds__(64) mfma_selftest(const double *A, const double *B, double *D) {
+// one instruction on arbitrary per-lane operands: the host works out which matrix element every lane / register holds
+__global__ void __launch_bounds__(64) mfma_selftest(const double *a_lane, const double *b_lane, double *d_out) {
     const int l = threadIdx.x;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l % 16) * 4 + l / 16], B[(l / 16) * 16 + l % 16], acc, 0, 0, 0);
-    for (int v = 0; v < 4; v++) D[(4 * (l / 16) + v) * 16 + l % 16] = acc[v];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lane[l], b_lane[l], acc, 0, 0, 0);
+    for (int v = 0; v < 4; v++) d_out[l * 4 + v] = acc[v];
 }
 
+// layout of the operands, found by the self-test: lane l holds A[ai(l)][ak(l)], B[bk(l)][bj(l)]; register v of lane l holds D[di(l, v)][dj(l)]
+struct Layout { int a_mode, b_mode, d_mode; };
+__device__ __host__ inline int lay_ai(int m, int l) { return m == 0 ? l % 16 : l / 4; }
+__device__ __host__ inline int lay_ak(int m, int l) { return m == 0 ? l / 16 : l % 4; }
+__device__ __host__ inline int lay_bk(int m, int l) { return m == 0 ? l / 16 : l % 4; }
+__device__ __host__ inline int lay_bj(int m, int l) { return m == 0 ? l % 16 : l / 4; }
+__device__ __host__ inline int lay_di(int m, int l, int v) { return m == 0 ? 4 * (l / 16) + v : (m == 1 ? (l / 16) + 4 * v : l % 16); }
+__device__ __host__ inline int lay_dj(int m, int l, int v) { return m == 2 ? 4 * (l / 16) + v : l % 16; }
+
 template <bool LOAD_TILES>
-__global__ void __launch_bounds__(64) mfma_solve(Prog P, const double *w0, double *w_out, int reps, unsigned long long *cyc) {
-    extern __shared__ double w[];                 // [n_slots][16]
-    const int l = threadIdx.x, j = l & 15, k = l >> 4;
+__global__ void __launch_bounds__(64) mfma_solve(Prog P, Layout L, const double *w0, double *w_out, int reps, unsigned long long *cyc) {
+    extern __shared__ double w[];                 // [n_slots][16] | tile column slots [n_tiles][4] | row block tables
+    unsigned short *tc = (unsigned short *)(w + (size_t)P.n_slots * 16);
+    unsigned short *ro = tc + 4 * (size_t)P.n_tiles;
+    int *rt = (int *)(ro + 16 * (size_t)P.n_rb + 8);
+    const int l = threadIdx.x;
     for (int t = l; t < P.n_slots * 16; t += 64) w[t] = w0[t];
+    for (int t = l; t < 4 * P.n_tiles; t += 64) tc[t] = P.tcols[t];
+    for (int t = l; t < 16 * P.n_rb; t += 64) ro[t] = P.rb_out[t];
+    for (int t = l; t < 2 * P.n_rb; t += 64) rt[t] = P.rb_tiles[t];
     __syncthreads();
+    const int ai = lay_ai(L.a_mode, l), ak = lay_ak(L.a_mode, l), bk = lay_bk(L.b_mode, l), bj = lay_bj(L.b_mode, l);
+    const int a_src = ak * 16 + ai;               // the tile file stores A[i][k] at i + 16 k
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; r++) {
         for (int p = 0; p < P.n_phases; p++) {
             const int rb0 = P.phase_rb[2 * p], nrb = P.phase_rb[2 * p + 1];
             for (int rb = rb0; rb < rb0 + nrb; rb++) {
-                const int tl0 = P.rb_tiles[2 * rb], nt = P.rb_tiles[2 * rb + 1];
+                const int tl0 = rt[2 * rb], nt = rt[2 * rb + 1];
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
-                double a_next = LOAD_TILES && nt ? P.tvals[(size_t)tl0 * 64 + l] : 1.0;
+                // A tiles two ahead (global memory / L2), B operands from LDS
+                double a0 = LOAD_TILES && nt > 0 ? P.tvals[(size_t)tl0 * 64 + a_src] : 1.0;
+                double a1 = LOAD_TILES && nt > 1 ? P.tvals[(size_t)(tl0 + 1) * 64 + a_src] : 1.0;
                 for (int t = tl0; t < tl0 + nt; t++) {
-                    const double a = a_next;
-                    if (LOAD_TILES && t + 1 < tl0 + nt) a_next = P.tvals[(size_t)(t + 1) * 64 + l];
-                    const double b = w[(unsigned)P.tcols[4 * t + k] * 16u + (unsigned)j];
+                    const double a = a0;
+                    a0 = a1;
+                    if (LOAD_TILES && t + 2 < tl0 + nt) a1 = P.tvals[(size_t)(t + 2) * 64 + a_src];
+                    const double b = w[(unsigned)tc[4 * t + bk] * 16u + (unsigned)bj];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
-                // (a row block reads slots written by earlier PHASES only, or spill slots: stores of this phase are safe)
-                for (int v = 0; v < 4; v++) w[(unsigned)P.rb_out[16 * rb + 4 * k + v] * 16u + (unsigned)j] = acc[v];
+                for (int v = 0; v < 4; v++) w[(unsigned)ro[16 * rb + lay_di(L.d_mode, l, v)] * 16u + (unsigned)lay_dj(L.d_mode, l, v)] = acc[v];
             }
             __syncthreads();
         }
@@ -80,16 +100,27 @@ int main(int argc, char **argv) {
     size_t ok = fread(phase_rb.data(), 4, phase_rb.size(), f) + fread(tcols.data(), 2, tcols.size(), f) + fread(tvals.data(), 8, tvals.size(), f) +
                 fread(rb_tiles.data(), 4, rb_tiles.size(), f) + fread(rb_out.data(), 2, rb_out.size(), f) + fread(W0.data(), 8, W0.size(), f) + fread(Wr.data(), 8, Wr.size(), f);
     (void)ok; fclose(f);
-    // ---- layout self-test of one instruction
+    // ---- layout self-test of one instruction: which matrix element does every lane / register hold?
+    Layout L{0, 0, 0};
     {
-        double A[64], B[64], D[256], Dr[256];
-        for (int i = 0; i < 64; i++) { A[i] = sin(1.0 + i); B[i] = cos(2.0 + 3 * i); }
-        for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) { double s = 0; for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 16 + j]; Dr[i * 16 + j] = s; }
-        double *dA = up<double>(A, 64), *dB = up<double>(B, 64), *dD; hipMalloc(&dD, 256 * 8);
-        hipLaunchKernelGGL(mfma_selftest, dim3(1), dim3(64), 0, 0, dA, dB, dD);
-        CK(hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
-        double e = 0; for (int i = 0; i < 256; i++) e = fmax(e, fabs(D[i] - Dr[i]));
-        printf("v_mfma_f64_16x16x4_f64 operand layout self-test: max |D - A B| = %.3e\n", e);
+        double Am[16][4], Bm[4][16], Dr[16][16], al[64], bl[64], dg[256];
+        for (int i = 0; i < 16; i++) for (int k = 0; k < 4; k++) Am[i][k] = sin(1.0 + 7 * i + 3 * k);
+        for (int k = 0; k < 4; k++) for (int j = 0; j < 16; j++) Bm[k][j] = cos(2.0 + 5 * k + 11 * j);
+        for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) { double s = 0; for (int k = 0; k < 4; k++) s += Am[i][k] * Bm[k][j]; Dr[i][j] = s; }
+        double best = 1e300;
+        double *dA, *dB, *dD; hipMalloc(&dA, 64 * 8); hipMalloc(&dB, 64 * 8); hipMalloc(&dD, 256 * 8);
+        for (int am = 0; am < 2; am++) for (int bm = 0; bm < 2; bm++) {
+            for (int l = 0; l < 64; l++) { al[l] = Am[lay_ai(am, l)][lay_ak(am, l)]; bl[l] = Bm[lay_bk(bm, l)][lay_bj(bm, l)]; }
+            hipMemcpy(dA, al, 64 * 8, hipMemcpyHostToDevice); hipMemcpy(dB, bl, 64 * 8, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(mfma_selftest, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+            CK(hipMemcpy(dg, dD, 256 * 8, hipMemcpyDeviceToHost));
+            for (int dm = 0; dm < 3; dm++) {
+                double e = 0;
+                for (int l = 0; l < 64; l++) for (int v = 0; v < 4; v++) e = fmax(e, fabs(dg[l * 4 + v] - Dr[lay_di(dm, l, v)][lay_dj(dm, l, v)]));
+                if (e < best) { best = e; L = Layout{am, bm, dm}; }
+            }
+        }
+        printf("v_mfma_f64_16x16x4_f64 operand layout self-test: A mode %d, B mode %d, D mode %d, max |D - A B| = %.3e\n", L.a_mode, L.b_mode, L.d_mode, best);
     }
     Prog P{np, T, nrb, ns, ni, up<int>(phase_rb.data(), phase_rb.size()), up<unsigned short>(tcols.data(), tcols.size()),
            up<double>(tvals.data(), tvals.size()), up<int>(rb_tiles.data(), rb_tiles.size()), up<unsigned short>(rb_out.data(), rb_out.size())};
@@ -97,12 +128,12 @@ int main(int argc, char **argv) {
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
     const int cus = pr.multiProcessorCount;
     unsigned long long *dc; hipMalloc(&dc, 8 * (size_t)cus * 4);
-    const size_t lds = (size_t)ns * ni * 8;
+    const size_t lds = (size_t)ns * ni * 8 + 8 * (size_t)T + 32 * (size_t)nrb + 16 + 8 * (size_t)nrb + 64;
     CK(hipFuncSetAttribute((const void *)mfma_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void *)mfma_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     printf("%d tiles, %d row blocks, %d phases; LDS per wavefront %.1f KiB (16 instances); %d CUs, %.0f MHz\n", T, nrb, np, lds / 1024.0, cus, pr.clockRate / 1e3);
     // ---- correctness: one solve against the host reference
-    hipLaunchKernelGGL(mfma_solve<true>, dim3(1), dim3(64), lds, 0, P, dW0, dWo, 1, dc);
+    hipLaunchKernelGGL(mfma_solve<true>, dim3(1), dim3(64), lds, 0, P, L, dW0, dWo, 1, dc);
     std::vector<double> Wo(W0.size());
     CK(hipMemcpy(Wo.data(), dWo, Wo.size() * 8, hipMemcpyDeviceToHost));
     double e = 0, sc = 0; for (size_t i = 0; i < Wo.size(); i++) { e = fmax(e, fabs(Wo[i] - Wr[i])); sc = fmax(sc, fabs(Wr[i])); }
@@ -113,8 +144,8 @@ int main(int argc, char **argv) {
         for (int it = 0; it < 2; it++) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0, 0);
-            if (load) hipLaunchKernelGGL(mfma_solve<true>, dim3(cus), dim3(64), lds, 0, P, dW0, dWo, reps, dc);
-            else hipLaunchKernelGGL(mfma_solve<false>, dim3(cus), dim3(64), lds, 0, P, dW0, dWo, reps, dc);
+            if (load) hipLaunchKernelGGL(mfma_solve<true>, dim3(cus), dim3(64), lds, 0, P, L, dW0, dWo, reps, dc);
+            else hipLaunchKernelGGL(mfma_solve<false>, dim3(cus), dim3(64), lds, 0, P, L, dW0, dWo, reps, dc);
             hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
             if (it == 1)

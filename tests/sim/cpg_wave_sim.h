@@ -134,6 +134,7 @@ inline void lds_max_u64(unsigned long long *p, double v) {       // (fibers swit
     unsigned long long b; std::memcpy(&b, &v, 8);
     if (b > *p) *p = b;
 }
+inline void lds_max_u64_l(unsigned long long *p, double v) { lds_max_u64(p, v); }
 inline double u64_as_double(unsigned long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 inline unsigned long long clock100() { return 0ull; }
 inline void mem_order() { wave_sync(); }
