@@ -1495,7 +1495,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         const unsigned Zh = (unsigned)ZERO | ((unsigned)ZERO << 16);
         auto put_batch = [&](WaveList &L, unsigned fl, const unsigned (*words)[3 * SB / 2], const unsigned *dks) {
             L.ctl.push_back(fl);
-            for (int l = 0; l < 64; l++) L.dk.push_back(dks ? dks[l] : (Zb | 0x40000000u));
+            for (int l = 0; l < 64; l++) L.dk.push_back(dks ? dks[l] : (Zb | 0x40000000u));       // (flags: or-ed in when the lists are final)
             for (int q = 0; q < NQ; q++) for (int l = 0; l < 64; l++) for (int k = 0; k < 4; k++) {
                 const int wd = 4 * q + k;
                 L.tri.push_back((words && wd < NWD) ? words[l][wd] : Zh);
@@ -1552,6 +1552,12 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
             while (wl[wv].ctl.size() % DPF) null_batch(wl[wv], 0u);
             bfhdr[2 * wv] = (unsigned)bfctl.size(); bfhdr[2 * wv + 1] = (unsigned)wl[wv].ctl.size();
             for (int k = 0; k < 2 * DPF; k++) null_batch(wl[wv], 0u);       // (what the prefetch ring reads past the end)
+            // the flags of a batch into bits 22 - 29 of every lane's destination word (what the kernel reads them from)
+            for (size_t bt = 0; bt < wl[wv].ctl.size(); bt++) {
+                const unsigned f = wl[wv].ctl[bt];
+                if (f > 0xFFu || Zb >= (1u << 22)) { set_error("cpg_hip_set_resident: factorisation batch flags / offsets out of range"); return CPG_E_BADARG; }
+                for (int l = 0; l < 64; l++) wl[wv].dk[bt * 64 + l] |= f << 22;
+            }
             bfctl.insert(bfctl.end(), wl[wv].ctl.begin(), wl[wv].ctl.end());
             bfdk.insert(bfdk.end(), wl[wv].dk.begin(), wl[wv].dk.end());
             bftri.insert(bftri.end(), wl[wv].tri.begin(), wl[wv].tri.end());

@@ -82,7 +82,7 @@ struct DevResident {
     // the team.  bf_hdr [wave][2] first batch | batches; bf_ctl [batch] 1 first of a chunk | 2 last | 4 level end inside a
     // wavefront's own section | 8 level end the team meets at | 16 the chunk holds a pivot | reduction stages << 5; bf_tri
     // [batch][quad][lane][4] positions in the factor of the operands a, b, k of the batch's steps, 16 bits each, three words per two
-    // steps (idle: the zero slot); bf_dk [batch][lane] byte offset of the destination | none << 30 (then: the zero slot) | pivot << 31
+    // steps (idle: the zero slot); bf_dk [batch][lane] byte offset of the destination | the batch's bf_ctl flags << 22 | none << 30 (then: the zero slot) | pivot << 31
     const unsigned *bf_hdr, *bf_ctl, *bf_dk, *bf_tri;
 };
 

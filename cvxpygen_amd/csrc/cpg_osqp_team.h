@@ -86,7 +86,7 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
     constexpr int KA = (int)((nnzA + T - 1) / T) > 0 ? (int)((nnzA + T - 1) / T) : 1, KP = (int)((nnzP + T - 1) / T) > 0 ? (int)((nnzP + T - 1) / T) : 1;
     TeamRed tr{0u};
     // (LDS pointers carry their address space in the type: ds_read / ds_write / ds_max instead of flat accesses)
-    CPG_LDS double *sl = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *sl = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     // (the scaling vectors, the norms and theta use the space the scaled matrices take once D and E are dead: step 3 below writes
     // A, P behind a barrier, after every read of D and E)
     CPG_LDS double *Al = sl, *Pl = Al + nnzA, *Dl = sl, *El = Dl + n;
@@ -284,7 +284,17 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
 #define CPG_TEAM_FAC_BATCH 8          // steps per batch: a chain level of 5 - 7 steps is ONE batch = one LDS round trip
 #endif
 struct alignas(16) TeamQuad { unsigned x, y, z, w; };
-CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac, int lane, int wave) {
+// (CPG_TEAM_FACTOR_PROBE: experiments only -- two more time stamps inside the factorisation; merely carrying the pointer cost the
+// loop its register allocation: 194 -> 228 us, profiles/r5_s6_team_factor_probe.txt)
+#ifdef CPG_TEAM_FACTOR_PROBE
+#define CPG_TEAM_TS_PARAM , unsigned long long *ts = nullptr
+#define CPG_TEAM_TS_ARG , ts
+#else
+#define CPG_TEAM_TS_PARAM
+#define CPG_TEAM_TS_ARG
+#endif
+CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac_, int lane, int wave CPG_TEAM_TS_PARAM) {
+    CPG_LDS double *fac = cpgw::pin_lds(fac_);
     constexpr int DP = CPG_TEAM_FAC_DEPTH, S = CPG_TEAM_FAC_BATCH, NQ = (3 * S / 2 + 3) / 4;
     static_assert(S % 2 == 0, "an even number of steps per batch: two steps share three words");
     const unsigned first = cpgw::sld(Rs.bf_hdr, 2u * (unsigned)wave), nb = cpgw::sld(Rs.bf_hdr, 2u * (unsigned)wave + 1u);
@@ -294,14 +304,16 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac, int
     const TeamQuad *tri = (const TeamQuad *)Rs.bf_tri;
     const CPG_LDS char *fb = (const CPG_LDS char *)fac;
     TeamQuad e[DP][NQ];
-    unsigned dk[DP], c[DP], cn[DP];
+    unsigned dk[DP];
+    // (the batch's flags ride in bits 22 - 29 of every lane's destination word: a scalar load per batch shares its counter with the
+    // LDS reads -- the compiler drains it in front of the first ds_read of EVERY batch, a scalar-cache miss on the chain of each level)
     auto request = [&](int u, unsigned t) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NQ; k++) e[u][k] = cpgw::gld(tri, ((first + t) * (unsigned)NQ + (unsigned)k) * 64u + (unsigned)lane);
         dk[u] = cpgw::gld(Rs.bf_dk, (first + t) * 64u + (unsigned)lane);
     };
 #pragma unroll
-    for (int u = 0; u < DP; u++) { request(u, (unsigned)u); c[u] = cpgw::sld(Rs.bf_ctl, first + (unsigned)u); cn[u] = cpgw::sld(Rs.bf_ctl, first + (unsigned)(DP + u)); }
+    for (int u = 0; u < DP; u++) request(u, (unsigned)u);
     double acc = 0.0;
 #pragma nounroll
     for (unsigned t0 = 0; t0 < nb; t0 += DP) {
@@ -310,7 +322,7 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac, int
             unsigned o_[4 * NQ];
 #pragma unroll
             for (int k = 0; k < NQ; k++) { o_[4 * k] = e[u][k].x; o_[4 * k + 1] = e[u][k].y; o_[4 * k + 2] = e[u][k].z; o_[4 * k + 3] = e[u][k].w; }
-            const unsigned fl = c[u], d = dk[u];
+            const unsigned d = dk[u], fl = ((unsigned)cpgw::read_first_lane((int)d) >> 22) & 0xFFu;
             request(u, t0 + (unsigned)(u + DP));
             if (fl & 1u) acc = 0.0;
             double av[S], kv[S], bv[S];
@@ -338,23 +350,27 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac, int
                 if (!(d & 0x40000000u)) *(CPG_LDS double *)((CPG_LDS char *)fac + (d & 0x3FFFFFu)) = st;
             }
             if (fl & 4u) cpgw::lds_order();
-            if (fl & 8u) cpgw::block_sync();
-            c[u] = cn[u]; cn[u] = cpgw::sld(Rs.bf_ctl, first + t0 + (unsigned)(2 * DP + u));
+            if (fl & 8u) {
+                cpgw::block_sync();
+#ifdef CPG_TEAM_FACTOR_PROBE
+                if (__builtin_expect(ts != nullptr, 0) && !ts[1]) ts[1] = cpgw::clock100();      // (the LDL' part is done)
+#endif
+            }
         }
     }
 }
 
 // ---- step 4: KKT values into the slice (all threads), numeric LDL' + inverses of the merged diagonal blocks (wavefront 0:
 //      the schedule is a chain of levels, most of them one chunk wide)
-CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, double sigma) {
+CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &Rs_, const ResBuf &B_, double sigma CPG_TEAM_TS_PARAM) {
     const int tid = (int)cpgw::thread_in_block(), lane = cpgw::lane_id(), wave = cpgw::read_first_lane(cpgw::wave_in_block());
     constexpr unsigned T = CPG_TEAM_T;
     const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     (void)R_;
-    CPG_LDS double *sl = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *sl = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     constexpr unsigned nd = CPG_GENT_NNZL + CPG_GENT_N + CPG_GENT_M;
     constexpr int KD = (int)((nd + T - 1) / T);
-    constexpr int KB = KD < 16 ? KD : 16;      // (two dependent loads per destination: every batch is two round trips)
+    constexpr int KB = KD < 32 ? KD : 32;      // (two dependent loads per destination: every batch is two round trips)
     const unsigned lk = (unsigned)cpgw::opaque(tid);
 #pragma unroll
     for (int t0 = 0; t0 < KD; t0 += KB) {
@@ -381,12 +397,15 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
     }
     for (unsigned d = nd + (unsigned)tid; d < (unsigned)Rs.fac_len; d += T) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
     cpgw::block_sync();
+#ifdef CPG_TEAM_FACTOR_PROBE
+    if (__builtin_expect(ts != nullptr, 0)) { ts[0] = cpgw::clock100(); ts[1] = 0ull; }       // (KKT values are in place)
+#endif
 #if defined(CPG_TEAM_TABLE_FACTOR)
     if (wave == 0) resident_factor(Rs, (double *)sl, lane);        // (experiments: the flat one-step-at-a-time stream of the resident kernel's fallback)
 #elif defined(CPG_GENT_FAC_GENERATED) && !defined(CPG_TEAM_BATCHED_FACTOR)
     if (wave == 0) team_factor_gen(Rs.gf_tri, Rs.gf_dk, (double *)sl, lane);
 #else
-    team_factor_batched(Rs, sl, lane, wave);              // (its last batch is a barrier of the team)
+    team_factor_batched(Rs, sl, lane, wave CPG_TEAM_TS_ARG);     // (its last batch is a barrier of the team)
 #endif
     cpgw::block_sync();
 }
@@ -399,7 +418,7 @@ CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevRe
     constexpr unsigned T = CPG_TEAM_T;
     const DevResident Rs = uniform_global_copy(Rs_); const ResBuf B = uniform_global_copy(B_);
     (void)R_;
-    CPG_LDS double *sl = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *sl = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     constexpr unsigned n = CPG_GENT_N, m = CPG_GENT_M;
     constexpr int ldw = CPG_GENT_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     {
@@ -512,7 +531,7 @@ CPG_DEV_NOINLINE void team_iterate(TeamState<NX, NZ> &st, const ResRho &rr_, con
     };
     const double *cfp = cpgw::as_global((const double *)uniform_ptr(cfg));
     const unsigned *offp = cpgw::as_global((const unsigned *)uniform_ptr(offg)), *rowp = cpgw::as_global((const unsigned *)uniform_ptr(rowg));
-    CPG_LDS double *w = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *w = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     const CPG_LDS double *qs = w + ldw, *us = qs + n;
     const ResRho rr = uniform_copy(rr_);
     double cf[CPG_GENT_NREGS];
@@ -703,7 +722,7 @@ CPG_DEV_NOINLINE CheckOut team_check(const DevFamily &F_, const DevResident &Rs_
     for (int s = 0; s < NX; s++) { Ix[s] = st_.x[s]; dxr[s] = st_.dx[s]; }
 #pragma unroll
     for (int s = 0; s < NZ; s++) { Iz[s] = st_.z[s]; Iy[s] = st_.y[s]; dyr[s] = st_.dy[s]; ct[s] = ct_[s]; }
-    CPG_LDS double *w = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *w = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     const CPG_LDS double *qs = w + (CPG_GENT_NSLOTS + CPG_GEN_EXTRA_SLOTS), *us = qs + n;
     TeamRed tr{0u};
     double dinv_r[NX], einv_r[NZ];
@@ -802,7 +821,7 @@ CPG_DEV_NOINLINE void team_finalize(const DevFamily &F_, const DevBatch &Bt_, co
     constexpr unsigned n = CPG_GENT_N, m = CPG_GENT_M, T = CPG_TEAM_T;
     const long long b = ((long long)cpgw::read_first_lane((int)(b_v >> 32)) << 32) | (unsigned)cpgw::read_first_lane((int)b_v);
     const DevFamily F = uniform_global_copy(F_); const DevBatch Bt = uniform_global_copy(Bt_); const CheckOut o = o_;
-    CPG_LDS double *w = cpgw::lds_window3() + CPG_TEAM_SLICE_OFF;
+    CPG_LDS double *w = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     const bool has_sol = o.status == 1 || o.status == 2 || o.status == 7;
     if (Bt.state_out) {
         double *so = Bt.state_out + (size_t)b * (size_t)(n + 2u * m + 1u);
@@ -869,7 +888,7 @@ CPG_DEV void osqp_team_body(const DevFamily &F0, const DevRefactor &R, const Dev
         double rho_stg = F0.rho;
         double rho_eq = 1e3 * rho, rho_in = rho, ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in;
         // (experiments, debug_stage 20: the 100 MHz time stamps of the instance's stages replace its primal results)
-        const bool probe = __builtin_expect(S.debug_stage == 20, 0);
+        const bool probe = __builtin_expect(S.debug_stage == 20 || S.debug_stage == 23, 0);       // (23: two more stamps inside the factorisation)
         unsigned long long ts[8];
         int n_ts = 0;
 #define CPG_TEAM_PROBE() do { if (probe && n_ts < 8) ts[n_ts++] = cpgw::clock100(); } while (0)
@@ -909,7 +928,13 @@ CPG_DEV void osqp_team_body(const DevFamily &F0, const DevRefactor &R, const Dev
 #pragma nounroll
         while (o.status == 11) {
             if (need_factor) {
+#ifdef CPG_TEAM_FACTOR_PROBE
+                unsigned long long fts[2] = {0ull, 0ull};
+                team_factorise(R, Rs, B, F0.sigma, __builtin_expect(S.debug_stage == 23, 0) ? fts : nullptr);
+                if (__builtin_expect(S.debug_stage == 23, 0) && n_ts < 7) { ts[n_ts++] = fts[0]; ts[n_ts++] = fts[1]; }
+#else
                 team_factorise(R, Rs, B, F0.sigma);
+#endif
                 CPG_TEAM_PROBE();
                 team_store_coefficients(R, Rs, B);
                 CPG_TEAM_PROBE();

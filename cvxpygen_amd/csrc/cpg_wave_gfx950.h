@@ -107,6 +107,16 @@ CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and
 // keeping alive) everything derived from it
 CPG_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// An LDS pointer as an opaque value held in a register: inside a function that is a real call the address of
+// the workgroup's dynamic LDS window comes from a table in memory, and under register pressure the compiler re-reads it (s_load)
+// wherever it is used instead of keeping it -- a scalar load shares its counter with the LDS reads, so every such reload is drained
+// in front of the next ds_read.  Laundered through a register constraint it cannot be rematerialised.
+template <class T>
+CPG_DEV CPG_LDS T *pin_lds(CPG_LDS T *p) {
+    unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)p;
+    asm volatile("" : "+v"(a));          // (a vector register: a scalar one was refused inside loops with barriers, "illegal VGPR to SGPR copy")
+    return (CPG_LDS T *)(__attribute__((address_space(3))) void *)(unsigned long long)a;
+}
 // tells the optimiser a fact it lost (e.g. the lane range after opaque()): bounds checks fold again
 CPG_DEV void assume(bool c) { __builtin_assume(c); }
 // Word of a read-only table at a wave-uniform index through the SCALAR cache (s_load): the constant

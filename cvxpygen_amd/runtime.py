@@ -276,8 +276,10 @@ def _team_widths(lib_path: str):
             continue
         m = re.search(r'#define CPG_GENT_W (\d+)', txt)
         g = re.search(r'#define CPG_GENT_MAX_GROUP_ROWS (\d+)', txt)
+        gr = re.search(r'// CPG_GENT_GROUPS ([0-9\- ]+)', txt)
+        groups = tuple(tuple(int(v) for v in it.split('-')) for it in gr.group(1).split()) if gr else None
         if m:
-            out.add((int(m.group(1)), int(g.group(1)) if g else None))
+            out.add((int(m.group(1)), int(g.group(1)) if g else None, groups))
     return out
 
 
@@ -544,8 +546,11 @@ class BatchSolver:
                     # ... or the team executor (csrc/cpg_osqp_team.h): the same plan with its programs planned for W wavefronts
                     # per instance -- W is what the header next to the library says
                     from . import codegen as _cg
-                    for Wt, Gt in sorted(_team_widths(self.lib.path), key=lambda t_: (t_[0], t_[1] or 0)):
-                        cand = _cg.build_team_plan(desc, o, Wt, Gt)
+                    for Wt, Gt, groups in sorted(_team_widths(self.lib.path), key=lambda t_: (t_[0], t_[1] or 0)):
+                        try:
+                            cand = _cg.build_team_plan(desc, o, Wt, Gt, groups=list(groups) if groups else None)
+                        except AssertionError:
+                            continue           # (groups of another family's header)
                         if cand.sol.fingerprint() in fps_t:
                             self._rplan_res = cand
                             rplan = cand.base

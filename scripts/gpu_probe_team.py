@@ -55,6 +55,12 @@ d_ = np.diff(ts, axis=1)
 print('probe instances', Bp, 'kernel ms', round(r.kernel_ms, 2))
 for k in range(7):
     print(f'  {names[k]:8s} mean {d_[:, k].mean():9.1f} us   median {np.median(d_[:, k]):9.1f}   p90 {np.percentile(d_[:, k], 90):9.1f}')
+if os.environ.get('CPG_PROBE_FACTOR', '0') == '1':
+    r = bs.solve(pv, updated_params=upd, debug_stage=23)
+    ts = r.prim_flat[:, :8] * 0.01
+    d_ = np.diff(ts, axis=1)
+    for k, nm in enumerate(['setup', 'KKT values', "LDL' part (wavefront 0)", 'block inverses (team)', 'store', 'iterate', 'check']):
+        print(f'  [factor probe] {nm:26s} mean {d_[:, k].mean():9.1f} us   median {np.median(d_[:, k]):9.1f}')
 pv, upd = params(d, B, 1002)
 for rep in range(3):
     r = bs.solve(pv, updated_params=upd)

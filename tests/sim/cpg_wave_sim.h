@@ -153,6 +153,7 @@ inline unsigned mbcnt(unsigned long long mask) {
 inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
+template <class T> inline T *pin_lds(T *p) { return p; }
 inline void assume(bool) {}
 inline unsigned sld(const unsigned *base, unsigned idx) { return base[idx]; }
 

@@ -102,8 +102,9 @@ def test_infeasible_and_empty_batches(oracle_lib):
     bs.close()
 
 
-def test_full_size_properties():
-    """100 000 instances of the benchmark family: properties that need no oracle."""
+def test_full_size_properties(oracle_lib):
+    """100 000 instances of the benchmark family: properties that need no oracle, and a random sample of 512 instances drawn
+    from inside the big batch against the oracle (counts exact, 1e-6)."""
     d = families.mpc(12, 4, 10)
     B = 100000
     rng = np.random.default_rng(5)
@@ -119,6 +120,11 @@ def test_full_size_properties():
     rr = bs.solve({'x_init': x0[::-1].copy()}, updated_params=['x_init'])
     assert np.array_equal(rr.prim_flat[::-1], r.prim_flat) and np.array_equal(rr.iter[::-1], r.iter)
     assert np.array_equal(rr.dual_flat[::-1], r.dual_flat)
+    # a random sample of the big batch against the oracle: what ran at 100 000 is what the oracle computes, not merely self-consistent
+    pick = np.sort(np.random.default_rng(6).choice(B, 512, replace=False))
+    sub = type('R', (), dict(iter=r.iter[pick], status=r.status[pick], prim_flat=r.prim_flat[pick], dual_flat=r.dual_flat[pick],
+                             obj_val=r.obj_val[pick], pri_res=r.pri_res[pick], dua_res=r.dua_res[pick]))()
+    _check(sub, oracle_lib.cpg_solve_batch(d, _theta(d, 'x_init', x0[pick]), ['x_init']), d)
     # the constraint X[:,0] == x_init holds to the ADMM tolerance; |U| <= 1 likewise
     assert np.abs(r.prim['X'][:, :, 0] - x0).max() < 5e-2
     assert np.abs(r.prim['U']).max() < 1 + 5e-2
@@ -161,6 +167,11 @@ def test_generated_family_library_vs_oracle(oracle_lib, tmp_path):
         assert (r.status == 1).all()
         assert (r.iter == r0.iter).all()
         assert np.abs(r.prim_flat - r0.prim_flat).max() <= 1e-9 * np.abs(r0.prim_flat).max()
+    # ... and a random 512 of the 100 000 against the oracle (the comparison above is GPU against GPU)
+    pick = np.sort(np.random.default_rng(23).choice(len(x0), 512, replace=False))
+    sub = type('R', (), dict(iter=r.iter[pick], status=r.status[pick], prim_flat=r.prim_flat[pick], dual_flat=r.dual_flat[pick],
+                             obj_val=r.obj_val[pick]))()
+    _check(sub, oracle_lib.cpg_solve_batch(d, _theta(d, 'x_init', x0[pick]), ['x_init']), d)
     bs.close()
 
 

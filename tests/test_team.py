@@ -118,3 +118,68 @@ def test_team_kernel_all_parameters_mpc_on_the_emulator(oracle_lib, tmp_path, mo
     o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
     _assert_parity(r, o, prim, dual, tol=1e-8)
     bs.close()
+
+
+@pytest.mark.gpu
+def test_all_parameters_mpc12_runs_the_team_kernel_vs_oracle(oracle_lib):
+    """MPC 12/4/10 with EVERY parameter per instance (sub-mode ii) in its family library on the GPU: the
+    team kernel is what runs (the family's merged program does not fit the resident kernel's single wavefront), iteration
+    counts / statuses = oracle, prim / dual within 1e-6 -- default mode, a cut-off between two tests, and against the streaming
+    kernel of the same library"""
+    import os
+    from test_sim_kernel import _assert_parity, _oracle_flat
+    d = families.mpc(12, 4, 10)
+    plan = build_family_plan(d)
+    out = os.path.join(os.path.dirname(os.path.abspath(codegen.__file__)), 'generated', 'mpc12')
+    lib = codegen.build_family_library(plan, out, 'mpc12')
+    B = 96
+    rng = np.random.default_rng(23)
+    th = np.tile(d.theta0, (B, 1))
+    th[:, :d.NP] *= 1 + 0.05 * rng.standard_normal((B, d.NP))
+    p = d.param('x_init')
+    th[:, p.col:p.col + p.size] = -2 + 4 * rng.random((B, p.size))
+    vals = {q.name: th[:, q.col:q.col + q.size] for q in d.params}
+    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    for stg in ({}, dict(max_iter=60)):
+        r = bs.solve(vals, **stg)
+        assert _team_in_use(bs)
+        o, prim, dual = _oracle_flat(oracle_lib, d, th, None, **stg)
+        _assert_parity(r, o, prim, dual, tol=1e-6)
+    bs.set_program_placement(0)
+    r2 = bs.solve(vals, max_iter=60)
+    assert not _team_in_use(bs)
+    assert r2.iter.tolist() == r.iter.tolist() and np.abs(r2.prim_flat - r.prim_flat).max() < 1e-8
+    bs.close()
+
+
+@pytest.mark.gpu
+def test_all_parameters_full_batch_is_its_distinct_instances_repeated(oracle_lib):
+    """the all-parameters batch at the size the bench line is quoted on (20 000): 50 distinct instances repeated -- every copy
+    comes back bit-identical to the first (teams share nothing but read-only tables and pull instances in an order that depends on
+    the run) and the 50 equal the oracle's (counts exact, 1e-6)"""
+    import os
+    from test_sim_kernel import _assert_parity, _oracle_flat
+    d = families.mpc(12, 4, 10)
+    plan = build_family_plan(d)
+    out = os.path.join(os.path.dirname(os.path.abspath(codegen.__file__)), 'generated', 'mpc12')
+    lib = codegen.build_family_library(plan, out, 'mpc12')
+    K, B = 50, 20_000
+    rng = np.random.default_rng(29)
+    th = np.tile(d.theta0, (K, 1))
+    th[:, :d.NP] *= 1 + 0.05 * rng.standard_normal((K, d.NP))
+    p = d.param('x_init')
+    th[:, p.col:p.col + p.size] = -2 + 4 * rng.random((K, p.size))
+    bs = BatchSolver(d, lib_path=lib, plan=plan)
+    bs.set_updated(None)
+    tv = th[:, bs._var_cols]
+    tv_full = np.ascontiguousarray(np.tile(tv, (B // K, 1)))
+    r = bs.solve(theta_var=tv_full, B=B)
+    assert _team_in_use(bs)
+    o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
+    first = type('R', (), dict(iter=r.iter[:K], status=r.status[:K], prim_flat=r.prim_flat[:K], dual_flat=r.dual_flat[:K],
+                               obj_val=r.obj_val[:K], pri_res=r.pri_res[:K], dua_res=r.dua_res[:K]))()
+    _assert_parity(first, o, prim, dual, tol=1e-6)
+    idx = np.arange(B) % K
+    assert np.array_equal(r.iter, r.iter[:K][idx]) and np.array_equal(r.status, r.status[:K][idx])
+    assert np.array_equal(r.prim_flat, r.prim_flat[:K][idx]) and np.array_equal(r.dual_flat, r.dual_flat[:K][idx])
+    bs.close()
