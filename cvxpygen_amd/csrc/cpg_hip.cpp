@@ -1387,7 +1387,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         std::vector<char> has_dot((size_t)Rs.fac_len, 0);
         size_t level_first = 0;
         for (int c = 0; c < rs->fac_chunks; c++) {
-            const int L = rs->f_ctab[4 * c], last = rs->f_ctab[4 * c + 1], lg = rs->f_ctab[4 * c + 3];
+            const int L = rs->f_ctab[4 * c], last = rs->f_ctab[4 * c + 1] & 1, lg = rs->f_ctab[4 * c + 3];      // (bit 0: level complete; a team plan keeps marks above it)
             unsigned base = (unsigned)rs->f_ctab[4 * c + 2];
             if (L < 0 || lg < 0 || lg > 6) { set_error("cpg_hip_set_resident: bad factorisation chunk"); return CPG_E_BADARG; }
             for (int s = 0; s < L; s++) {
@@ -1526,28 +1526,65 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         };
         const int ldl = std::min(r->fac_chunks, rs->fac_chunks);
         size_t step = 0;
+        // extra bits of a batch's destination words: 0x100000 one more level of the LDL' chain is complete (signal), 0x200000 wait until
+        // the number of complete levels in the word's low bits has been reached
+        auto mark = [&](WaveList &L, unsigned bits) { for (int l = 0; l < 64; l++) L.dk[L.dk.size() - 64 + l] |= bits; };
+        bool marked = false;               // (a plan whose inverse sections follow the chain: resident_plan, CPG_TEAM_GROUP_SECTIONS)
+        for (int c = ldl; c < rs->fac_chunks; c++) if (rs->f_ctab[4 * c + 1] & 2) marked = true;
         for (int c = 0; c < ldl; c++) {
             const int Ls = rs->f_ctab[4 * c];
             if (Ls > 0) add_chunk(wl[0], c, step);
             step += (size_t)Ls;
-            if (rs->f_ctab[4 * c + 1] && !wl[0].ctl.empty()) wl[0].ctl.back() |= 4u;
+            if (rs->f_ctab[4 * c + 1] & 1) {
+                if (wl[0].ctl.empty() || (wl[0].ctl.back() & 4u)) null_batch(wl[0], 0u);     // (a level without a term, or two ends in a row)
+                wl[0].ctl.back() |= 4u;
+                if (TW > 1 && marked) mark(wl[0], 0x100000u);
+            }
         }
-        if (wl[0].ctl.empty()) null_batch(wl[0], 0u);
-        wl[0].ctl.back() |= 8u;                                  // the team meets behind the LDL' part
-        for (int wv = 1; wv < TW; wv++) null_batch(wl[wv], 8u);
+        // the sections of the block inverses (one per merged group, ends marked by bit 1 of the chunk table's second column; a plan
+        // without marks: one section that the team shares level by level behind the chain).  A marked section runs on ONE wavefront,
+        // 1 .. W - 1 in turn, and FOLLOWS the chain: in front of a chunk that needs more complete LDL' levels than the wavefront has
+        // waited for so far (bits 8 .. of the column) sits a batch without work that waits for that count.
+        std::vector<std::pair<int, int>> sections;
+        for (int c = ldl, c0 = ldl; c < rs->fac_chunks; c++)
+            if ((rs->f_ctab[4 * c + 1] & 2) || c == rs->fac_chunks - 1) { sections.push_back({c0, c + 1}); c0 = c + 1; }
+        std::vector<size_t> sec_step(sections.size(), 0);
+        { size_t st = step; for (size_t k = 0; k < sections.size(); k++) { sec_step[k] = st; for (int c = sections[k].first; c < sections[k].second; c++) st += (size_t)rs->f_ctab[4 * c]; } }
+        std::vector<unsigned> waited((size_t)TW, 0u);
+        for (size_t k = 0; marked && k < sections.size(); k++) {
+            const int wv = TW > 1 ? 1 + (int)(k % (size_t)(TW - 1)) : 0;
+            size_t st = sec_step[k];
+            for (int c = sections[k].first; c < sections[k].second; c++) {
+                const int Ls = rs->f_ctab[4 * c];
+                const unsigned need = (unsigned)rs->f_ctab[4 * c + 1] >> 8;
+                if (Ls > 0 && TW > 1 && need > waited[wv]) {
+                    if (need >= (1u << 20)) { set_error("cpg_hip_set_resident: level count out of range"); return CPG_E_BADARG; }
+                    null_batch(wl[wv], 0u);
+                    for (int l = 0; l < 64; l++) wl[wv].dk[wl[wv].dk.size() - 64 + l] = need | 0x200000u | 0x40000000u;
+                    waited[wv] = need;
+                }
+                if (Ls > 0) add_chunk(wl[wv], c, st);
+                st += (size_t)Ls;
+                if ((rs->f_ctab[4 * c + 1] & 1) && !wl[wv].ctl.empty() && !(wl[wv].dk.back() & 0x200000u)) wl[wv].ctl.back() |= 4u;
+            }
+        }
+        for (int wv = 0; wv < TW; wv++) { if (wl[wv].ctl.empty() || (wl[wv].dk.back() & 0x200000u)) null_batch(wl[wv], 0u); wl[wv].ctl.back() |= 8u; }      // the team meets
         std::vector<char> has((size_t)TW, 0);
         int in_level = 0, level = 0;
         auto close_level = [&]() {
             for (int wv = 0; wv < TW; wv++) { if (has[wv]) wl[wv].ctl.back() |= 8u; else null_batch(wl[wv], 8u); has[wv] = 0; }
             in_level = 0; level++;
         };
-        for (int c = ldl; c < rs->fac_chunks; c++) {
-            const int Ls = rs->f_ctab[4 * c];
-            if (Ls > 0) { const int wv = (level + in_level) % TW; add_chunk(wl[wv], c, step); has[wv] = 1; in_level++; }
-            step += (size_t)Ls;
-            if (rs->f_ctab[4 * c + 1]) close_level();
+        if (!marked && !sections.empty()) {
+            size_t st = sec_step[0];
+            for (int c = sections.front().first; c < sections.back().second; c++) {
+                const int Ls = rs->f_ctab[4 * c];
+                if (Ls > 0) { const int wv = (level + in_level) % TW; add_chunk(wl[wv], c, st); has[wv] = 1; in_level++; }
+                st += (size_t)Ls;
+                if (rs->f_ctab[4 * c + 1] & 1) close_level();
+            }
+            if (in_level) close_level();
         }
-        if (in_level) close_level();
         for (int wv = 0; wv < TW; wv++) {
             while (wl[wv].ctl.size() % DPF) null_batch(wl[wv], 0u);
             bfhdr[2 * wv] = (unsigned)bfctl.size(); bfhdr[2 * wv + 1] = (unsigned)wl[wv].ctl.size();
@@ -1555,7 +1592,7 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
             // the flags of a batch into bits 22 - 29 of every lane's destination word (what the kernel reads them from)
             for (size_t bt = 0; bt < wl[wv].ctl.size(); bt++) {
                 const unsigned f = wl[wv].ctl[bt];
-                if (f > 0xFFu || Zb >= (1u << 22)) { set_error("cpg_hip_set_resident: factorisation batch flags / offsets out of range"); return CPG_E_BADARG; }
+                if (f > 0xFFu || Zb >= (1u << 20)) { set_error("cpg_hip_set_resident: factorisation batch flags / offsets out of range"); return CPG_E_BADARG; }
                 for (int l = 0; l < 64; l++) wl[wv].dk[bt * 64 + l] |= f << 22;
             }
             bfctl.insert(bfctl.end(), wl[wv].ctl.begin(), wl[wv].ctl.end());

@@ -315,6 +315,10 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac_, in
 #pragma unroll
     for (int u = 0; u < DP; u++) request(u, (unsigned)u);
     double acc = 0.0;
+    // (the block inverses of a merged group need that group's columns of the factor only: wavefront 0 raises a count in LDS when its
+    // LDL' chain has passed a group, the wavefront that inverts the group waits for it -- no barrier, the chain goes on meanwhile)
+    CPG_LDS unsigned *progress = (CPG_LDS unsigned *)cpgw::lds_window3() + 2;
+    unsigned passed = 0u;
 #pragma nounroll
     for (unsigned t0 = 0; t0 < nb; t0 += DP) {
 #pragma unroll
@@ -322,14 +326,15 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac_, in
             unsigned o_[4 * NQ];
 #pragma unroll
             for (int k = 0; k < NQ; k++) { o_[4 * k] = e[u][k].x; o_[4 * k + 1] = e[u][k].y; o_[4 * k + 2] = e[u][k].z; o_[4 * k + 3] = e[u][k].w; }
-            const unsigned d = dk[u], fl = ((unsigned)cpgw::read_first_lane((int)d) >> 22) & 0xFFu;
+            const unsigned d = dk[u], du = (unsigned)cpgw::read_first_lane((int)d), fl = (du >> 22) & 0xFFu;
             request(u, t0 + (unsigned)(u + DP));
+            if (du & 0x200000u) cpgw::lds_spin_until_ge(progress, du & 0xFFFFFu);      // (a batch without work: its word carries the count)
             if (fl & 1u) acc = 0.0;
             double av[S], kv[S], bv[S];
             // (the destination's KKT value is requested with the operands: nothing of this chunk has stored yet, and the value is not
             // touched before the chunk's own store -- one LDS round trip less on the chain of a level; lanes without a task read the
             // zero slot their word points at)
-            const double dv = *(const CPG_LDS double *)(fb + (d & 0x3FFFFFu));
+            const double dv = *(const CPG_LDS double *)(fb + ((du & 0x200000u) ? 0u : (d & 0xFFFFFu)));
 #pragma unroll
             for (int k = 0; k < S; k += 2) {
                 const unsigned w0 = o_[3 * (k / 2)], w1 = o_[3 * (k / 2) + 1], w2 = o_[3 * (k / 2) + 2];
@@ -347,9 +352,13 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac_, in
                 const double v = dv - r;
                 double st = v;
                 if (fl & 16u) st = (d >> 31) ? 1.0 / v : v;      // (a chunk without a pivot: no division at all)
-                if (!(d & 0x40000000u)) *(CPG_LDS double *)((CPG_LDS char *)fac + (d & 0x3FFFFFu)) = st;
+                if (!(d & 0x40000000u)) *(CPG_LDS double *)((CPG_LDS char *)fac + (d & 0xFFFFFu)) = st;
             }
             if (fl & 4u) cpgw::lds_order();
+            if (du & 0x100000u) {            // the LDL' chain has passed a merged group (its stores are complete: the level end above)
+                passed++;
+                if (lane == 0) cpgw::lds_signal(progress, passed);
+            }
             if (fl & 8u) {
                 cpgw::block_sync();
 #ifdef CPG_TEAM_FACTOR_PROBE
@@ -396,6 +405,7 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
         }
     }
     for (unsigned d = nd + (unsigned)tid; d < (unsigned)Rs.fac_len; d += T) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
+    if (tid == 0) cpgw::lds_signal((CPG_LDS unsigned *)cpgw::lds_window3() + 2, 0u);       // (progress count of team_factor_batched)
     cpgw::block_sync();
 #ifdef CPG_TEAM_FACTOR_PROBE
     if (__builtin_expect(ts != nullptr, 0)) { ts[0] = cpgw::clock100(); ts[1] = 0ull; }       // (KKT values are in place)

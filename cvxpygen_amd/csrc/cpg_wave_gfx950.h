@@ -117,6 +117,13 @@ CPG_DEV CPG_LDS T *pin_lds(CPG_LDS T *p) {
     asm volatile("" : "+v"(a));          // (a vector register: a scalar one was refused inside loops with barriers, "illegal VGPR to SGPR copy")
     return (CPG_LDS T *)(__attribute__((address_space(3))) void *)(unsigned long long)a;
 }
+// A flag in LDS between two wavefronts of one workgroup that do NOT meet at a barrier: the producer has finished a piece of work
+// (its LDS stores are complete: lds_order() in front), the consumer polls.  Release / acquire at workgroup scope.
+CPG_DEV void lds_signal(CPG_LDS unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+CPG_DEV void lds_spin_until_ge(CPG_LDS unsigned *p, unsigned v) {
+    while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // tells the optimiser a fact it lost (e.g. the lane range after opaque()): bounds checks fold again
 CPG_DEV void assume(bool c) { __builtin_assume(c); }
 // Word of a read-only table at a wave-uniform index through the SCALAR cache (s_load): the constant

@@ -169,6 +169,10 @@ def build_resident_plan(P: sp.csc_matrix, A: sp.csc_matrix, osqp, stage_scale: O
 
 
 def _build(P, A, osqp, stage_scale, groups, team=1, inplace_x=True) -> ResidentPlan:
+    # (experiments, CPG_TEAM_GROUP_SECTIONS=1: the block inverses group by group with the marks that let wavefronts 1 .. W - 1 FOLLOW
+    # the LDL' chain level by level -- measured slower than inverting all groups side by side behind the chain, 215 against 204 us per
+    # factorisation: the chain pays a signal per level and the followers do not keep its pace; profiles/r5_s8_*)
+    group_sections = (not inplace_x) and os.environ.get('CPG_TEAM_GROUP_SECTIONS', '0') == '1'
     base = _rp.build_refactor_plan(P, A, osqp)
     n, m, nnzL = base.n, base.m, base.nnzL
     N = n + m
@@ -222,10 +226,6 @@ def _build(P, A, osqp, stage_scale, groups, team=1, inplace_x=True) -> ResidentP
         ta.append(a_); tb.append(b_); tk.append(k_); lens[x] = len(a_)
         assert lens[x] >= 1
     nxl = int(depth.max()) + 1 if nnzX else 0
-    xlevels = [[] for _ in range(nxl)]
-    for x, i in enumerate(x_row):
-        xlevels[depth[i]].append(x)
-    xlevels = [l for l in xlevels if l]
     # ---- combined schedule: the LDL' chunks of the base plan, then the inverse
     fb = base.fac
     f_ctab = [fb.ctab.copy()]
@@ -233,15 +233,49 @@ def _build(P, A, osqp, stage_scale, groups, team=1, inplace_x=True) -> ResidentP
                        np.where(fb.task >= nnzL, fb.task | PIVOT_FLAG, fb.task)).astype(np.uint32)]
     f_len = [fb.tlen.copy()]
     f_a = [base.fac_a.astype(np.int64)]; f_b = [base.fac_b.astype(np.int64)]; f_k = [base.fac_k.astype(np.int64) + nnzL]
-    if nnzX:
-        ft, order = _rp._pack_tasks(xlevels, lens)
-        ct = ft.ctab.copy(); ct[:, 2] += len(base.fac_a)
+
+    def append_inverse(xlv, n_before, need_levels=False):
+        ft, order = _rp._pack_tasks(xlv, lens)
+        ct = ft.ctab.copy(); ct[:, 2] += n_before
+        if need_levels:
+            # (team kernel) a chunk of the inverse can run as soon as the LDL' chain has passed the LAST row it reads the factor of:
+            # number of LDL' levels that must be complete, in the bits above the marks of column 1
+            for c_ in range(ct.shape[0]):
+                tk_ = ft.task[c_][ft.task[c_] != NO_TASK]
+                need = int(max(lev[x_row[int(t_)]] for t_ in tk_)) + 1 if len(tk_) else 0
+                ct[c_, 1] |= need << 8
         f_ctab.append(ct)
         f_task.append(np.where(ft.task == NO_TASK, NO_TASK, ft.task + X0).astype(np.uint32))
         f_len.append(ft.tlen)
         f_a.append(np.array([ta[o[0]][o[1]] if o else 0 for o in order], dtype=np.int64))
         f_b.append(np.array([tb[o[0]][o[1]] if o else 0 for o in order], dtype=np.int64))
         f_k.append(np.array([tk[o[0]][o[1]] if o else nnzL for o in order], dtype=np.int64))
+        return len(order)
+    if nnzX and not group_sections:
+        # every group's inverse level by level side by side: the fewest levels for one wavefront
+        xlevels = [[] for _ in range(nxl)]
+        for x, i in enumerate(x_row):
+            xlevels[depth[i]].append(x)
+        append_inverse([l for l in xlevels if l], len(base.fac_a))
+    elif nnzX:
+        # (team kernel) one SECTION per merged group, in group order: a group's inverse needs the factor's columns of that group
+        # only -- row by row it can FOLLOW the LDL' chain through the group, on another wavefront (cpg_osqp_team.h).  Marks in
+        # column 1 of the chunk table (bit 0 stays "level complete"): 4 on the LDL' chunk that completes a merged group, 2 on
+        # the last chunk of a group's section, and from bit 8 up the number of LDL' levels an inverse chunk waits for.
+        lvl_end = np.nonzero(f_ctab[0][:, 1] != 0)[0]              # chunk that ends LDL' level k
+        n_before = len(base.fac_a)
+        for gi, (a, b) in enumerate(groups):
+            if a == b:
+                continue
+            xs = [x for x, i in enumerate(x_row) if grp_of[i] == gi]
+            if not xs:
+                continue
+            f_ctab[0][lvl_end[b], 1] |= 4
+            xl = [[] for _ in range(nxl)]
+            for x in xs:
+                xl[depth[x_row[x]]].append(x)
+            n_before += append_inverse([l for l in xl if l], n_before, need_levels=True)
+            f_ctab[-1][-1, 1] |= 2
     f_ctab = np.concatenate(f_ctab).astype(np.int32)
     f_task = np.concatenate(f_task).astype(np.uint32); f_len = np.concatenate(f_len).astype(np.uint32)
     f_a = np.concatenate(f_a).astype(np.uint32); f_b = np.concatenate(f_b).astype(np.uint32); f_k = np.concatenate(f_k).astype(np.uint32)
@@ -343,7 +377,7 @@ def _build(P, A, osqp, stage_scale, groups, team=1, inplace_x=True) -> ResidentP
 
     stats = dict(base.stats)
     stats.update(groups=len(groups), merged=sum(1 for a, b in groups if a != b), nnzX=nnzX, phases=sol.n_phases,
-                 sol_steps=int(sol.ctab[:, 0].sum()), sol_chunks=sol.n_chunks, inv_levels=len(xlevels),
+                 sol_steps=int(sol.ctab[:, 0].sum()), sol_chunks=sol.n_chunks, inv_levels=int((np.concatenate(f_ctab)[len(fb.ctab):, 1] != 0).sum()) if isinstance(f_ctab, list) else int((f_ctab[len(fb.ctab):, 1] != 0).sum()),
                  fac_chunks=int(f_ctab.shape[0]), fac_steps=int(f_ctab[:, 0].sum()), fac_len=nnzL + N + nnzX + 2,
                  rows_steps=[int(p.ctab[:, 0].sum()) for p in (rows_A, rows_P, rows_At)])
     return ResidentPlan(base=base, groups=groups, nnzX=nnzX, x_row=np.asarray(x_row, dtype=np.int32), x_col=np.asarray(x_col, dtype=np.int32),

@@ -154,6 +154,8 @@ inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcou
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
 template <class T> inline T *pin_lds(T *p) { return p; }
+inline void lds_signal(unsigned *p, unsigned v) { *(volatile unsigned *)p = v; }
+inline void lds_spin_until_ge(unsigned *p, unsigned v) { while (*(volatile unsigned *)p < v) fiber_yield(); }
 inline void assume(bool) {}
 inline unsigned sld(const unsigned *base, unsigned idx) { return base[idx]; }
 

@@ -407,9 +407,9 @@ def test_cvxpy_front_door_forwards_solver_opts_and_routes_ecos(tmp_path):
             assert prob.calls == [dict(solver='OSQP', gp=False, enforce_dpp=True, verbose=False, solver_opts=opts)]
             same(FamilyDescriptor.load(str(tmp_path / 'q' / 'descriptor.npz')), d)
             assert json.load(open(tmp_path / 'q' / 'osqp_build.json')) == {'adaptive_rho': 0.0, 'check_dualgap': 0.0}
-            prob2 = fake_cvxpy.Problem(d)                        # solver_opts are NOT read as build options any more
-            cpg.generate_code(prob2, code_dir=str(tmp_path / 'q2'), solver='OSQP', solver_opts={'adaptive_rho': 0}, wrapper=False)
-            assert json.load(open(tmp_path / 'q2' / 'osqp_build.json')) == {}
+            # solver_opts are NOT read as build options any more: a build option left there would silently select nothing -> refused
+            with pytest.raises(ValueError, match='osqp_build_options'):
+                cpg.generate_code(fake_cvxpy.Problem(d), code_dir=str(tmp_path / 'q2'), solver='OSQP', solver_opts={'adaptive_rho': 0}, wrapper=False)
             with pytest.raises(ValueError, match='unknown OSQP build option'):
                 cpg.generate_code(fake_cvxpy.Problem(d), code_dir=str(tmp_path / 'q3'), solver='OSQP', wrapper=False,
                                   osqp_build_options={'use_quad_obj': False})
