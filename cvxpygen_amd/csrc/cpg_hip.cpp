@@ -1531,6 +1531,9 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
         auto mark = [&](WaveList &L, unsigned bits) { for (int l = 0; l < 64; l++) L.dk[L.dk.size() - 64 + l] |= bits; };
         bool marked = false;               // (a plan whose inverse sections follow the chain: resident_plan, CPG_TEAM_GROUP_SECTIONS)
         for (int c = ldl; c < rs->fac_chunks; c++) if (rs->f_ctab[4 * c + 1] & 2) marked = true;
+#ifndef CPG_TEAM_FOLLOW_CHAIN
+        if (marked) { set_error("cpg_hip_set_resident: a plan whose block inverses follow the chain needs a library built with CPG_TEAM_FOLLOW_CHAIN"); return CPG_E_UNSUPPORTED; }
+#endif
         for (int c = 0; c < ldl; c++) {
             const int Ls = rs->f_ctab[4 * c];
             if (Ls > 0) add_chunk(wl[0], c, step);

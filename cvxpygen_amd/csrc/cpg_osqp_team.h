@@ -315,10 +315,14 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac_, in
 #pragma unroll
     for (int u = 0; u < DP; u++) request(u, (unsigned)u);
     double acc = 0.0;
-    // (the block inverses of a merged group need that group's columns of the factor only: wavefront 0 raises a count in LDS when its
-    // LDL' chain has passed a group, the wavefront that inverts the group waits for it -- no barrier, the chain goes on meanwhile)
+#ifdef CPG_TEAM_FOLLOW_CHAIN
+    // (experiments, with plans built under CPG_TEAM_GROUP_SECTIONS=1: the block inverses of a merged group need that group's rows of
+    // the factor only -- wavefront 0 counts its complete LDL' levels in LDS, the wavefront that inverts a group follows it level by
+    // level, no barrier.  Measured SLOWER, 215 against 204 us, and the mere presence of these tests in the loop costs 20 us:
+    // profiles/r5_s8_*, r5_s9_team_with_follow_chain_code_in_loop.txt.  Off.)
     CPG_LDS unsigned *progress = (CPG_LDS unsigned *)cpgw::lds_window3() + 2;
     unsigned passed = 0u;
+#endif
 #pragma nounroll
     for (unsigned t0 = 0; t0 < nb; t0 += DP) {
 #pragma unroll
@@ -328,37 +332,53 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac_, in
             for (int k = 0; k < NQ; k++) { o_[4 * k] = e[u][k].x; o_[4 * k + 1] = e[u][k].y; o_[4 * k + 2] = e[u][k].z; o_[4 * k + 3] = e[u][k].w; }
             const unsigned d = dk[u], du = (unsigned)cpgw::read_first_lane((int)d), fl = (du >> 22) & 0xFFu;
             request(u, t0 + (unsigned)(u + DP));
+#ifdef CPG_TEAM_FOLLOW_CHAIN
             if (du & 0x200000u) cpgw::lds_spin_until_ge(progress, du & 0xFFFFFu);      // (a batch without work: its word carries the count)
+#endif
             if (fl & 1u) acc = 0.0;
             double av[S], kv[S], bv[S];
             // (the destination's KKT value is requested with the operands: nothing of this chunk has stored yet, and the value is not
             // touched before the chunk's own store -- one LDS round trip less on the chain of a level; lanes without a task read the
             // zero slot their word points at)
+#ifdef CPG_TEAM_FOLLOW_CHAIN
             const double dv = *(const CPG_LDS double *)(fb + ((du & 0x200000u) ? 0u : (d & 0xFFFFFu)));
+#else
+            const double dv = *(const CPG_LDS double *)(fb + (d & 0xFFFFFu));
+#endif
 #pragma unroll
             for (int k = 0; k < S; k += 2) {
                 const unsigned w0 = o_[3 * (k / 2)], w1 = o_[3 * (k / 2) + 1], w2 = o_[3 * (k / 2) + 2];
+#if defined(CPG_TEAM_FAC_EXPERIMENT) && CPG_TEAM_FAC_EXPERIMENT == 3
+                av[k] = fac[w0 & 0xFFFFu]; bv[k] = 1.0; kv[k] = 1e-3; av[k + 1] = fac[w1 >> 16]; bv[k + 1] = 1.0; kv[k + 1] = 1e-3; (void)w2;
+#else
                 av[k] = fac[w0 & 0xFFFFu]; bv[k] = fac[w0 >> 16]; kv[k] = fac[w1 & 0xFFFFu];
                 av[k + 1] = fac[w1 >> 16]; bv[k + 1] = fac[w2 & 0xFFFFu]; kv[k + 1] = fac[w2 >> 16];
+#endif
             }
 #pragma unroll
             for (int k = 0; k < S; k++) acc = fma(av[k] * kv[k], bv[k], acc);
             if (fl & 2u) {
-#ifdef CPG_TEAM_FAC_FLAT_REDUCE
+#if defined(CPG_TEAM_FAC_EXPERIMENT) && CPG_TEAM_FAC_EXPERIMENT == 2
+                const double r = acc;
+#elif defined(CPG_TEAM_FAC_FLAT_REDUCE)
                 const double r = cpgw::group_sum_first_flat(acc, (int)((fl >> 5) & 7u));      // (experiments: six masked stages, no branch)
 #else
                 const double r = cpgw::group_sum_first_dyn(acc, (int)((fl >> 5) & 7u));
 #endif
                 const double v = dv - r;
                 double st = v;
+#if !defined(CPG_TEAM_FAC_EXPERIMENT) || CPG_TEAM_FAC_EXPERIMENT != 1      // (timing experiments: 1 no division, 2 no reduction, 3 one operand read per step)
                 if (fl & 16u) st = (d >> 31) ? 1.0 / v : v;      // (a chunk without a pivot: no division at all)
+#endif
                 if (!(d & 0x40000000u)) *(CPG_LDS double *)((CPG_LDS char *)fac + (d & 0xFFFFFu)) = st;
             }
             if (fl & 4u) cpgw::lds_order();
-            if (du & 0x100000u) {            // the LDL' chain has passed a merged group (its stores are complete: the level end above)
+#ifdef CPG_TEAM_FOLLOW_CHAIN
+            if (du & 0x100000u) {            // one more level of the LDL' chain is complete (its stores are: the level end above)
                 passed++;
                 if (lane == 0) cpgw::lds_signal(progress, passed);
             }
+#endif
             if (fl & 8u) {
                 cpgw::block_sync();
 #ifdef CPG_TEAM_FACTOR_PROBE
@@ -379,7 +399,10 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
     CPG_LDS double *sl = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     constexpr unsigned nd = CPG_GENT_NNZL + CPG_GENT_N + CPG_GENT_M;
     constexpr int KD = (int)((nd + T - 1) / T);
-    constexpr int KB = KD < 32 ? KD : 32;      // (two dependent loads per destination: every batch is two round trips)
+#ifndef CPG_TEAM_KKT_BATCH
+#define CPG_TEAM_KKT_BATCH 32
+#endif
+    constexpr int KB = KD < CPG_TEAM_KKT_BATCH ? KD : CPG_TEAM_KKT_BATCH;      // (two dependent loads per destination: every batch is two round trips)
     const unsigned lk = (unsigned)cpgw::opaque(tid);
 #pragma unroll
     for (int t0 = 0; t0 < KD; t0 += KB) {
@@ -405,7 +428,9 @@ CPG_DEV_NOINLINE void team_factorise(const DevRefactor &R_, const DevResident &R
         }
     }
     for (unsigned d = nd + (unsigned)tid; d < (unsigned)Rs.fac_len; d += T) sl[d] = d == (unsigned)Rs.fac_len - 2u ? 1.0 : 0.0;
+#ifdef CPG_TEAM_FOLLOW_CHAIN
     if (tid == 0) cpgw::lds_signal((CPG_LDS unsigned *)cpgw::lds_window3() + 2, 0u);       // (progress count of team_factor_batched)
+#endif
     cpgw::block_sync();
 #ifdef CPG_TEAM_FACTOR_PROBE
     if (__builtin_expect(ts != nullptr, 0)) { ts[0] = cpgw::clock100(); ts[1] = 0ull; }       // (KKT values are in place)

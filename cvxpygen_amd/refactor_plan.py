@@ -50,7 +50,7 @@ class RaggedTable:
 NO_TASK = 0xFFFFFFFF
 
 
-def _pack_tasks(levels: List[List[int]], lens: np.ndarray, split: bool = True):
+def _pack_tasks(levels: List[List[int]], lens: np.ndarray, split: bool = True, team: int = 1):
     """levels: lists of task ids (one dot product of lens[t] terms each).  Returns (RaggedTable, entry
     order: list of (task, term) or None for a padding entry).
 
@@ -60,7 +60,8 @@ def _pack_tasks(levels: List[List[int]], lens: np.ndarray, split: bool = True):
     set by the longest dot product divided by g instead of the longest dot product.  Entry addressing
     is `base + lane` over the lanes whose ADDRESSING length (low 16 bits of tlen; the same for all
     lanes of a task, so that lengths stay non-increasing across the chunk) exceeds the step; the high
-    16 bits of tlen are the lane's REAL number of terms, the rest are padding entries."""
+    16 bits of tlen are the lane's REAL number of terms, the rest are padding entries.
+    team: wavefronts that share a level (see below)."""
     ctab, task, tlen, order = [], [], [], []
     first = 0
     for li, tasks in enumerate(levels):
@@ -69,9 +70,11 @@ def _pack_tasks(levels: List[List[int]], lens: np.ndarray, split: bool = True):
         while s0 < len(tasks) or (s0 == 0 and not tasks):
             rest = len(tasks) - s0
             g = 1
-            if split and 0 < rest <= LANES // 2:
+            if split and 0 < rest <= (LANES * max(1, team)) // 2:
+                # (team > 1: the chunks of a level run side by side on the wavefronts of a team -- csrc/cpg_osqp_team.h --, so a level's
+                # dot products are split until they fill 64 * team lanes: fewer steps per chunk, the level's latency, for more chunks)
                 longest = int(lens[tasks[s0]])
-                while 2 * g * rest <= LANES and 2 * g <= max(1, longest):
+                while 2 * g * rest <= LANES * max(1, team) and 2 * g <= max(1, longest) and 2 * g <= LANES:
                     g *= 2
             sel = tasks[s0:s0 + LANES // g]
             T = np.full(LANES, NO_TASK, dtype=np.uint32)

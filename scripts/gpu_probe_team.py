@@ -48,7 +48,8 @@ if check:
           '| prim relerr %.2e dual relerr %.2e' % (np.abs(po - r.prim_flat).max() / np.abs(po).max(), np.abs(do - r.dual_flat).max() / np.abs(do).max()),
           '| iters', sorted(set(r.iter.tolist()))[:6])
 pv, upd = params(d, Bp, 1001)
-r = bs.solve(pv, updated_params=upd, debug_stage=20)
+stg_probe = {'max_iter': 50} if os.environ.get('CPG_PROBE_TIMING_ONLY', '0') == '1' else {}      # (builds that compute garbage on purpose)
+r = bs.solve(pv, updated_params=upd, debug_stage=20, **stg_probe)
 ts = r.prim_flat[:, :8] * 0.01            # microseconds since the instance started
 names = ['setup', 'factor', 'store', 'iterate', 'check', 'next1', 'next2']
 d_ = np.diff(ts, axis=1)
@@ -62,7 +63,7 @@ if os.environ.get('CPG_PROBE_FACTOR', '0') == '1':
     for k, nm in enumerate(['setup', 'KKT values', "LDL' part (wavefront 0)", 'block inverses (team)', 'store', 'iterate', 'check']):
         print(f'  [factor probe] {nm:26s} mean {d_[:, k].mean():9.1f} us   median {np.median(d_[:, k]):9.1f}')
 pv, upd = params(d, B, 1002)
-for rep in range(3):
+for rep in range(0 if os.environ.get('CPG_PROBE_TIMING_ONLY', '0') == '1' else 3):
     r = bs.solve(pv, updated_params=upd)
     print(f'B {B}: kernel {r.kernel_ms:.2f} ms = {B / r.kernel_ms:.1f} k instances/s, mean iter {r.iter.mean():.1f}, solved {(r.status == 1).sum()}')
 bs.close()
