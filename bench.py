@@ -583,8 +583,10 @@ def main():
         achieved = bytes_per_inst * units / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = world * B * args.steps / elapsed
         out = {
-            'metric': ('SOCP instances solved/sec (batched ADP, conic interior point)' if args.workload == 'adp'
-                       else 'QP instances solved/sec (batched MPC QP, OSQP)'),
+            # (BASELINE.json's metric; the driver's contract quotes `value` with the inputs already resident in HBM -- said in the string,
+            # the PCIe-inclusive whole-path rate of SURVEY.md 8(d) is `wall_pcie.value` beside it)
+            'metric': ('SOCP instances solved/sec (batched ADP, conic interior point; inputs resident in HBM)' if args.workload == 'adp'
+                       else 'QP instances solved/sec (batched MPC QP, OSQP; inputs resident in HBM)'),
             'value': value, 'unit': ('SOCP instances/s' if args.workload == 'adp' else 'QP instances/s'), 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',

@@ -480,7 +480,11 @@ CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevRe
                 else if (kind == 2u) v = -(sl[idx] * sl[nnzL + col[u]]);
                 else if (kind == 3u) v = sl[nnzL + idx];
                 else if (kind == 4u) v = sl[X0 + idx];
+#ifdef CPG_TEAM_STREAM_HINTS
+                cpgw::gst_stream(B.cf, base + (unsigned)t * 64u + ln, v);
+#else
                 cpgw::gst(B.cf, base + (unsigned)t * 64u + ln, v);
+#endif
             }
         }
     }
@@ -572,7 +576,11 @@ CPG_DEV_NOINLINE void team_iterate(TeamState<NX, NZ> &st, const ResRho &rr_, con
     double cf[CPG_GENT_NREGS];
     unsigned of[CPG_GENT_NOFF], rw[CPG_GENT_NROW];
 #pragma unroll
+#ifdef CPG_TEAM_STREAM_HINTS
+    for (int t = 0; t < CPG_GENT_NREGS; t++) cf[t] = cpgw::gld_stream(cfp, ((unsigned)wave * (unsigned)CPG_GENT_NREGS + (unsigned)t) * 64u + (unsigned)lane);
+#else
     for (int t = 0; t < CPG_GENT_NREGS; t++) cf[t] = cpgw::gld(cfp, ((unsigned)wave * (unsigned)CPG_GENT_NREGS + (unsigned)t) * 64u + (unsigned)lane);
+#endif
 #pragma unroll
     for (int t = 0; t < CPG_GENT_NOFF; t++) of[t] = cpgw::gld(offp, ((unsigned)wave * (unsigned)CPG_GENT_NOFF + (unsigned)t) * 64u + (unsigned)lane);
 #pragma unroll

@@ -107,6 +107,17 @@ CPG_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // value the optimiser must treat as unknown: stops loop-invariant code motion from hoisting (and
 // keeping alive) everything derived from it
 CPG_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// Global loads / stores of per-instance STREAMS (written once, read once or a few times, by one workgroup: coefficient images,
+// program-order copies) with a 32-bit byte offset per lane, marked non-temporal: they pass the L2 without pushing out the tables every
+// workgroup of the XCD shares.
+template <typename T>
+CPG_DEV T gld_stream(const T *base, unsigned idx) {
+    return __builtin_nontemporal_load((const T *)((const char *)base + (size_t)(idx * (unsigned)sizeof(T))));
+}
+template <typename T>
+CPG_DEV void gst_stream(T *base, unsigned idx, T v) {
+    __builtin_nontemporal_store(v, (T *)((char *)base + (size_t)(idx * (unsigned)sizeof(T))));
+}
 // An LDS pointer as an opaque value held in a register: inside a function that is a real call the address of
 // the workgroup's dynamic LDS window comes from a table in memory, and under register pressure the compiler re-reads it (s_load)
 // wherever it is used instead of keeping it -- a scalar load shares its counter with the LDS reads, so every such reload is drained

@@ -153,6 +153,8 @@ inline unsigned mbcnt(unsigned long long mask) {
 inline unsigned popc64(unsigned long long m) { return (unsigned)__builtin_popcountll(m); }
 inline void sched_fence() {}
 inline int opaque(int v) { return v; }
+template <class T> inline T gld_stream(const T *base, unsigned idx) { return base[idx]; }
+template <class T> inline void gst_stream(T *base, unsigned idx, T v) { base[idx] = v; }
 template <class T> inline T *pin_lds(T *p) { return p; }
 inline void lds_signal(unsigned *p, unsigned v) { *(volatile unsigned *)p = v; }
 inline void lds_spin_until_ge(unsigned *p, unsigned v) { while (*(volatile unsigned *)p < v) fiber_yield(); }
