@@ -97,9 +97,10 @@ BINDING = {
                                  'all SIMD cycles (30 % of the occupied ones), LDS pipe 22 %, 43 % of the wave cycles waiting; HBM-side traffic '
                                  '80.6 GB per launch = 1.59 TB/s = 20 % of the peak (profiles/r4_final_pmc_config3.txt, r4_s13_probe_resident.txt)',
     ('portfolio', False, True): 'latency (as the default mode; fewer termination tests and no refactorisations)',
-    ('mpc12', True, False): 'dependent memory round trips: 484 level-scheduled phases per iteration, each waiting for its coefficient stream -- 61 % of the '
-                            'wave cycles waiting, VALU 41 %, FETCH 342 GB per launch = 3.2 TB/s = 40 % of the HBM peak, 0.8 scalar instructions per '
-                            'vector one (profiles/r4_final_pmc_allparams.txt)',
+    ('mpc12', True, False): 'latency at ONE instance per CU (team kernel, four wavefronts per instance): 17 dependent phases per ADMM iteration (one '
+                            'barrier each, 4.6 us per iteration) and 300 dependent levels per factorisation (0.43 us per level on one wavefront); '
+                            'nothing streamed per iteration (DESIGN.md 4.7; the streaming kernel it replaces: 484 phases per iteration each waiting '
+                            'for HBM, 342 GB of fetches per launch, profiles/r4_final_pmc_allparams.txt)',
     ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 83 % of the SIMD cycles (profiles/r3_conic_pmc_config4.txt)',
 }
 

@@ -100,7 +100,10 @@ class ConicBatchSolver(BatchSolver):
         self.lib.check(L.cpg_hip_set_default_settings(self.h), 'set_default_settings')
         for k, v in kwargs.items():
             name = self.SETTING_ALIASES.get(k, k)
-            if L.cpg_hip_set_setting(self.h, name.encode(), float(v)) != 0:
+            rc = L.cpg_hip_set_setting(self.h, name.encode(), float(v))
+            if rc == -4:           # CPG_E_UNSUPPORTED: a setting of the reference's interface this backend accepts at its default only
+                raise NotImplementedError(L.cpg_hip_last_error().decode())
+            if rc != 0:
                 raise AttributeError(f'Solver setting "{k}" not available.')
 
     def set_program_placement(self, in_lds: int = -1):

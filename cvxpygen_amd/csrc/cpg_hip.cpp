@@ -564,6 +564,12 @@ int cpg_hip_set_setting(cpg_handle_t h, const char *name, double v) {
     if (!h || !name) { set_error("null argument"); return CPG_E_BADARG; }
     std::string s(name);
     if (h->conic) {
+        // settings of the reference's Clarabel interface this backend has no counterpart for are accepted at their DEFAULTS only
+        // (cvxpygen/solvers/clarabel.py:63-119): a batch kernel has no per-instance clock, solves every KKT system directly and runs no
+        // presolve pass -- a value that would change what the reference's solver does is refused, not silently ignored
+        if ((s == "time_limit" && v < 1e10) || (s == "direct_kkt_solver" && (int)v != 1) || (s == "presolve_enable" && (int)v != 1)) {
+            set_error("Solver setting \"" + s + "\" is accepted at its default only (the batched interior-point kernel has no per-instance "
+                      "time limit, no indirect KKT solver and no presolve pass)"); return CPG_E_UNSUPPORTED; }
         if (double *d = conic_double_setting(h, s)) { *d = v; return CPG_OK; }
         if (int *i = conic_int_setting(h, s)) { *i = (int)v; return CPG_OK; }
         set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG;

@@ -3,7 +3,7 @@
 #   gpurun --timeout 2700 -- 'CPG_OUT=r4final bash scripts/gpu_final.sh'
 # GPU test tier with its full log, smoke, the bench line of every BASELINE config (default mode; fixed-rho fork of configs 2 / 3),
 # rocprofv3 kernel stats and PMC passes (FETCH_SIZE, WRITE_SIZE, SQ activity, instruction mix -- one pass each, never combined
-# with a trace domain) of config 2, config 3 and the all-parameters MPC, and the traffic records bench.py replays
+# with a trace domain) of configs 2, 3, 4, 5 and the all-parameters MPC, and the traffic records bench.py replays
 # (profiles/hbm_traffic.json, stamped with the fingerprint of these sources).  Copy what should be judged from
 # gpurun_out/$CPG_OUT into profiles/.  CPG_SKIP="tests pmc" leaves parts out.
 set -u
@@ -29,8 +29,8 @@ if [[ "$SKIP" != *" pmc "* ]]; then
   C="python $R/bench.py --no-cpu-baseline --no-wall --no-fixed-rho-leg"
   prof() {   # prof <tag> <rocprofv3 args ...> -- <bench args>: one pass, db summarised by the caller
     local tag=$1; shift; ( cd /tmp && timeout 400 rocprofv3 "$@" > $R/$OUT/$tag.log 2>&1 ); }
-  W2=""; W3="--workload portfolio --batch 20000"; WA="--all-params --batch 20000"
-  for cfg in 2 3 A; do
+  W2=""; W3="--workload portfolio --batch 20000"; WA="--all-params --batch 20000"; W4="--workload adp"; W5="--adjoint"
+  for cfg in 2 3 A 4 5; do
     eval "W=\$W$cfg"
     prof prof$cfg --kernel-trace --stats -d $R/$OUT/prof$cfg -o trace -- $C $W --steps 3 --warmup 1
     prof pmc_f$cfg --pmc FETCH_SIZE -d $R/$OUT/pmc_f$cfg -o pmc -- $C $W --steps 2 --warmup 1
@@ -39,13 +39,14 @@ if [[ "$SKIP" != *" pmc "* ]]; then
     prof pmc_b$cfg --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU -d $R/$OUT/pmc_b$cfg -o pmc -- $C $W --steps 2 --warmup 1
     name=config$cfg; [ $cfg = A ] && name=allparams
     f=$(find $OUT/prof$cfg -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocpd_summary.py $f | tee $OUT/kernel_stats_$name.txt
-    for d in f w a b; do f=$(find $OUT/pmc_$d$cfg -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocpd_pmc.py $f '%osqp%'; done | tee $OUT/pmc_$name.txt
+    for d in f w a b; do f=$(find $OUT/pmc_$d$cfg -name "*.db" | head -1); [ -n "$f" ] && python scripts/rocpd_pmc.py $f '%_kernel%'; done | tee $OUT/pmc_$name.txt
     rm -rf $OUT/prof$cfg $OUT/pmc_f$cfg $OUT/pmc_w$cfg $OUT/pmc_a$cfg $OUT/pmc_b$cfg
   done
   SRC="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on python bench.py --no-cpu-baseline --no-wall --no-fixed-rho-leg"
   python scripts/record_traffic.py mpc12 100000 $OUT/pmc_config2.txt "$SRC --steps 2 --warmup 1, session $OUT"
   python scripts/record_traffic.py portfolio 20000 $OUT/pmc_config3.txt "$SRC $W3 --steps 2 --warmup 1, session $OUT"
   python scripts/record_traffic.py mpc12_all_params 20000 $OUT/pmc_allparams.txt "$SRC $WA --steps 2 --warmup 1, session $OUT"
+  python scripts/record_traffic.py adp 100000 $OUT/pmc_config4.txt "$SRC $W4 --steps 2 --warmup 1, session $OUT"
   cp profiles/hbm_traffic.json $OUT/hbm_traffic.json
   echo "== bench lines with the stamped traffic"
   $B 2>&1 | tail -1 | tee $OUT/bench_config2_traffic.json | python -c "$P"

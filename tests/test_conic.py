@@ -322,6 +322,19 @@ def test_generate_code_drop_in_for_conic_family(sim_lib, tmp_path):
         cpg.generate_code(d, code_dir=str(tmp_path / 'y'), solver='OSQP')
 
 
+def test_settings_without_a_counterpart_are_accepted_at_their_defaults_only(sim_lib):
+    """`time_limit`, `direct_kkt_solver`, `presolve_enable` of the reference's Clarabel interface (cvxpygen/solvers/clarabel.py:63-119):
+    their defaults pass, a value that would change what the reference's solver does is refused -- not silently ignored"""
+    cs = ConicBatchSolver(families.adp(), lib_path=sim_lib)
+    cs.apply_settings(time_limit=1e10, direct_kkt_solver=1, presolve_enable=1, verbose=0)
+    for bad in (dict(time_limit=0.5), dict(direct_kkt_solver=0), dict(presolve_enable=0)):
+        with pytest.raises(NotImplementedError, match='default only'):
+            cs.apply_settings(**bad)
+    with pytest.raises(AttributeError):
+        cs.apply_settings(no_such_setting=1)
+    cs.close()
+
+
 def test_conic_solver_rejects_wrong_family(sim_lib):
     with pytest.raises(ValueError, match='conic'):
         ConicBatchSolver(families.nonneg_ls(), lib_path=sim_lib)
