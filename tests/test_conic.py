@@ -326,6 +326,7 @@ def test_settings_without_a_counterpart_are_accepted_at_their_defaults_only(sim_
     """`time_limit`, `direct_kkt_solver`, `presolve_enable` of the reference's Clarabel interface (cvxpygen/solvers/clarabel.py:63-119):
     their defaults pass, a value that would change what the reference's solver does is refused -- not silently ignored"""
     cs = ConicBatchSolver(families.adp(), lib_path=sim_lib)
+    cs.set_updated(None)                       # (the handle is created with the first set of updated parameters)
     cs.apply_settings(time_limit=1e10, direct_kkt_solver=1, presolve_enable=1, verbose=0)
     for bad in (dict(time_limit=0.5), dict(direct_kkt_solver=0), dict(presolve_enable=0)):
         with pytest.raises(NotImplementedError, match='default only'):
