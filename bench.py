@@ -528,10 +528,12 @@ def main():
                       'per_instance_factor': {'kernel': inst_kernel, 'ms': ms2, 'instances': n_ho,
                                               'iterations_estimate': int((it - it1)[ho].sum()), 'handed_over_by_iteration_count': int(ho.sum()),
                                               'note': 'instances handed over after a rho change: numeric LDL\' for the new rho, then ADMM with their own factor'}}
-            # what a kernel of the two-kernel step FINISHES is what it is priced for: the shared-factor kernel writes the results of the
-            # instances it solves itself; the ones it hands over get theirs from the kernel behind it
-            units = max(0, B - int(n_ho))
+            # a kernel of the two-kernel step is priced for the algorithmic bytes IT moves: the shared-factor kernel reads theta of every
+            # instance and writes the results of the instances it finishes itself; the ones it hands over get theirs from the kernel behind it
+            units = B
+            algorithmic_bytes_launch = 8 * solver.np_var * B + (bytes_per_inst - 8 * solver.np_var) * max(0, B - int(n_ho))
             if ms2 > ms1:
+                algorithmic_bytes_launch = (bytes_per_inst - 8 * solver.np_var) * int(n_ho)
                 kernel_name, units, k_ms = inst_kernel, n_ho, ms2
                 # the hand-over adds the workspace (n + 2m + 1 doubles) written by the kernel in front and read here
                 it2 = float((it - it1)[ho].mean()) if ho.any() else 0.0
@@ -581,7 +583,9 @@ def main():
             if args.workload == 'portfolio' and traffic_src is None:
                 binding = ('HBM stream + latency: streaming per-instance factor kernel (this library carries no resident executor for the family): '
                            'substitution coefficients re-read from HBM in every ADMM iteration (profiles/r3_final7_pmc_config3.txt)')
-        achieved = bytes_per_inst * units / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        if not hybrid:
+            algorithmic_bytes_launch = bytes_per_inst * units
+        achieved = algorithmic_bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = world * B * args.steps / elapsed
         out = {
             # (BASELINE.json's metric; the driver's contract quotes `value` with the inputs already resident in HBM -- said in the string,
@@ -619,7 +623,7 @@ def main():
                          'frac_step': (bytes_per_inst * B / (1e-3 * 1e3 * elapsed / args.steps) / 1e9 / HBM_PEAK_GBS) if elapsed > 0 else 0.0,
                          'binding_resource': binding,
                          'binding': next((dict(v, kernel=k) for k, v in (binding_num or {}).items() if kernel_name in k), None),
-                         'kernel': kernel_name, 'kernel_ms': k_ms, 'units_per_launch': int(units),
+                         'kernel': kernel_name, 'kernel_ms': k_ms, 'units_per_launch': int(units), 'algorithmic_bytes_per_launch': int(algorithmic_bytes_launch),
                          'algorithmic_bytes_per_instance': bytes_per_inst, 'stream': stream,
                          'note': rnote},
         }
