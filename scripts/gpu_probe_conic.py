@@ -1,0 +1,34 @@
+"""Where does the conic interior-point kernel spend its time?  Kernel time of 100 000 ADP instances with pieces switched off through
+the SETTINGS (no rebuild): iterative refinement, equilibration, a single iteration.  Results change, of course: timing only.
+    python scripts/gpu_probe_conic.py [B]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from cvxpygen_amd import families, codegen
+from cvxpygen_amd.conic_plan import build_conic_plan
+from cvxpygen_amd.conic_runtime import ConicBatchSolver
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+d = families.adp()
+cplan = build_conic_plan(d)
+lib = codegen.build_conic_library(cplan, os.path.join(ROOT, 'cvxpygen_amd', 'generated', 'adp'), 'adp')
+cs = ConicBatchSolver(d, device=0, lib_path=lib, plan=cplan)
+pv = bench.adp_params(B, 1000)
+cs.set_updated(list(pv.keys()))
+theta = cs.theta_var(pv)
+for name, stg in (('defaults', {}), ('no iterative refinement', dict(iterative_refinement_enable=0)), ('no equilibration', dict(equilibrate_enable=0)),
+                  ('max_iter 1', dict(max_iter=1)), ('max_iter 2', dict(max_iter=2)), ('max_iter 3', dict(max_iter=3)),
+                  ('max_iter 1, no equilibration', dict(max_iter=1, equilibrate_enable=0)),
+                  ('no refinement, no static regularisation', dict(iterative_refinement_enable=0, static_regularization_enable=0))):
+    for rep in range(2):
+        r = cs.solve(theta_var=theta, **stg)
+    print(f'{name:42s} kernel {r.kernel_ms:7.3f} ms   mean iter {r.iter.mean():5.2f}   solved {(r.status == 1).sum()}')
+print('-- resident wavefronts per CU (waves per workgroup x workgroups per CU): what a lone pair of waves per SIMD sustains')
+for wpb, bpc in ((0, 0), (8, 1), (6, 1), (4, 1), (6, 2), (4, 2), (4, 3), (2, 1)):
+    cs.set_launch(wpb, 0, bpc)
+    for rep in range(2):
+        r = cs.solve(theta_var=theta)
+    print(f'waves per workgroup {wpb}, workgroups per CU {bpc}: kernel {r.kernel_ms:7.3f} ms')
+cs.close()
