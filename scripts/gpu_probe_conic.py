@@ -26,7 +26,7 @@ for name, stg in (('defaults', {}), ('no iterative refinement', dict(iterative_r
         r = cs.solve(theta_var=theta, **stg)
     print(f'{name:42s} kernel {r.kernel_ms:7.3f} ms   mean iter {r.iter.mean():5.2f}   solved {(r.status == 1).sum()}')
 print('-- resident wavefronts per CU (waves per workgroup x workgroups per CU): what a lone pair of waves per SIMD sustains')
-for wpb, bpc in ((0, 0), (8, 1), (6, 1), (4, 1), (6, 2), (4, 2), (4, 3), (2, 1)):
+for wpb, bpc in ((0, 0), (16, 1), (14, 1), (12, 1), (8, 1), (7, 2), (6, 2), (4, 1)):
     cs.set_launch(wpb, 0, bpc)
     for rep in range(2):
         r = cs.solve(theta_var=theta)
