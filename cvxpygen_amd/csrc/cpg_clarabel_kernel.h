@@ -23,6 +23,14 @@
 #include CPG_GENC_HEADER
 #endif
 
+// (timing experiments, scripts/gpu_probe_conic.py: bit k set = piece k of an iteration is executed TWICE -- every piece is
+// idempotent, so results and control flow stay what they are and the time added is the piece's cost.  1 factorisation, 2 substitution
+// sweeps, 4 refinement residual, 8 NT scaling, 16 step lengths, 32 combined-step offset, 64 step assembly)
+#ifndef CPG_CONIC_TWICE
+#define CPG_CONIC_TWICE 0
+#endif
+#define CPG_CONIC_REPEAT(bit) for (int rep_ = 0; rep_ < ((CPG_CONIC_TWICE & (bit)) ? 2 : 1); rep_++)
+
 namespace cpg {
 
 #define CPG_CK_P 1
@@ -105,27 +113,75 @@ CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
     return o;
 }
 
+#ifndef CPG_GENC_ROWS
+typedef unsigned genc_row_word;      // (no row words in this library: ConicCtx::rows stays null)
+#endif
+
 struct ConicCtx {
     const DevConic &C;
     const DevConicSettings &S;
     ConicBuf B;
     int lane;
     unsigned n, m, N;
+    // The family's own library, specialised kernel: the rows of P, the columns and the rows of A as padded per-lane word lists
+    // (codegen.conic_row_tables; block-shared LDS copy, [step][lane]) -- null: the table-driven loops over the CSR / CSC arrays.
+    // lane = row (n, m <= 64), a row's entries in the order of its loop, so both forms give the same bits.
+    const genc_row_word *rows;
+
+#ifdef CPG_GENC_ROWS
+    static constexpr int ROWS_P = 0, ROWS_AT = CPG_GENC_ROWS_SP * 64, ROWS_A = (CPG_GENC_ROWS_SP + CPG_GENC_ROWS_SAT) * 64;
+    // sum over the lane's list of (entry of P | A) x (operand of v): all words, then all values and operands are requested
+    // before the first multiply-add -- two LDS round trips for the row instead of two per entry
+    template <int S_>
+    CPG_DEV double row_dot(int first, unsigned row, const double *v) const {
+        constexpr int SS = S_ > 0 ? S_ : 1;
+        unsigned w[SS];
+        double a[SS], x[SS];
+#pragma unroll
+        for (int s = 0; s < S_; s++) w[s] = rows[first + s * 64 + (int)row];
+#pragma unroll
+        for (int s = 0; s < S_; s++) { a[s] = B.P[CPG_GENC_ROW_ENT(w[s])]; x[s] = v[CPG_GENC_ROW_OP(w[s])]; }
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < S_; s++) { const double t = fma(a[s], x[s], acc); acc = CPG_GENC_ROW_VALID(w[s]) ? t : acc; }
+        return acc;
+    }
+    // largest |entry| of the lane's list
+    template <int S_>
+    CPG_DEV double row_absmax(int first, unsigned row, double acc) const {
+        constexpr int SS = S_ > 0 ? S_ : 1;
+        unsigned w[SS];
+#pragma unroll
+        for (int s = 0; s < S_; s++) w[s] = rows[first + s * 64 + (int)row];
+#pragma unroll
+        for (int s = 0; s < S_; s++) { const double t = cpgw::dmax2(acc, fabs(B.P[CPG_GENC_ROW_ENT(w[s])])); acc = CPG_GENC_ROW_VALID(w[s]) ? t : acc; }
+        return acc;
+    }
+#endif
 
     // ---- sparse products with the instance's scaled matrices ------------------------------------
     CPG_DEV double row_P(unsigned j, const double *v) const {
+#ifdef CPG_GENC_ROWS
+        if (rows) return row_dot<CPG_GENC_ROWS_SP>(ROWS_P, j, v);
+#endif
         double acc = 0.0;
         const unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
         for (unsigned k = a; k < e; k++) acc = fma(B.P[(unsigned)cpgw::gld(C.Pent, k)], v[(unsigned)cpgw::gld(C.Pcol, k)], acc);
         return acc;
     }
     CPG_DEV double row_A(unsigned i, const double *v) const {
+#ifdef CPG_GENC_ROWS
+        if (rows) return row_dot<CPG_GENC_ROWS_SA>(ROWS_A, i, v);
+#endif
         double acc = 0.0;
         const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
         for (unsigned k = a; k < e; k++) acc = fma(B.A[(unsigned)cpgw::gld(C.Aent, k)], v[(unsigned)cpgw::gld(C.Acol, k)], acc);
         return acc;
     }
     CPG_DEV double col_At(unsigned j, const double *v) const {
+#ifdef CPG_GENC_ROWS
+        if (rows) return row_dot<CPG_GENC_ROWS_SAT>(ROWS_AT, j, v);
+#endif
         double acc = 0.0;
         const unsigned a = (unsigned)cpgw::gld(C.Ap, j), e = (unsigned)cpgw::gld(C.Ap, j + 1u);
         for (unsigned k = a; k < e; k++) acc = fma(B.A[k], v[(unsigned)cpgw::gld(C.Ai, k)], acc);
@@ -136,6 +192,16 @@ struct ConicCtx {
         for (int k = lane; k < C.n_soc; k += 64) {
             const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
             double acc = 0.0;
+#ifdef CPG_GENC_SOC_MAXDIM
+            if (rows) {      // the family's largest cone as a compile-time bound: every load before the first sum (rows past the
+                             // cone's end read the neighbouring vectors of the slice and are not used)
+                double a[CPG_GENC_SOC_MAXDIM], b[CPG_GENC_SOC_MAXDIM];
+#pragma unroll
+                for (int r = 0; r < CPG_GENC_SOC_MAXDIM; r++) { a[r] = B.wv[st + (unsigned)r]; b[r] = v[st + (unsigned)r]; }
+#pragma unroll
+                for (int r = 0; r < CPG_GENC_SOC_MAXDIM; r++) { const double t = acc + a[r] * b[r]; acc = (unsigned)r < dm ? t : acc; }
+            } else
+#endif
             for (unsigned r = 0; r < dm; r++) acc += B.wv[st + r] * v[st + r];
             tmp[st] = acc;
         }
@@ -170,6 +236,9 @@ struct ConicCtx {
     }
     // out = (LDL')^{-1} in  (+ add, if given)
     CPG_DEV void ldl_apply(const LdsProg &SP, const double *in, double *out, const double *add) const {
+        CPG_CONIC_REPEAT(2) ldl_apply_once(SP, in, out, add);
+    }
+    CPG_DEV void ldl_apply_once(const LdsProg &SP, const double *in, double *out, const double *add) const {
         for (unsigned i = (unsigned)lane; i < N; i += 64u) B.w[i] = in[i];
         cpgw::lds_order();
 #ifdef CPG_GENC_HEADER
@@ -190,13 +259,15 @@ struct ConicCtx {
         double nb = 0.0;
         for (unsigned i = (unsigned)lane; i < N; i += 64u) nb = cpgw::dmax2(nb, fabs(B.rb[i]));
         nb = cpgw::wave_max_nonneg(nb);
-        double norme = kkt_residual(B.sol);
+        double norme = 0.0;
+        CPG_CONIC_REPEAT(4) norme = kkt_residual(B.sol);
 #pragma nounroll
         for (int it = 0; it < S.ir_max_iter; it++) {
             if (norme <= S.ir_abstol + S.ir_reltol * nb) break;
             const double last = norme;
             ldl_apply(SP, B.er, B.cand, B.sol);
-            const double nn = kkt_residual(B.cand);
+            double nn = 0.0;
+            CPG_CONIC_REPEAT(4) nn = kkt_residual(B.cand);
             const double ratio = nn > 0.0 ? last / nn : CPG_INFTY;
             const bool stop = ratio < S.ir_stop_ratio;
             if (!stop || ratio > 1.0) {
@@ -214,6 +285,17 @@ struct ConicCtx {
         double eps = 0.0;
         if (S.static_reg_enable) {
             double md = 0.0;
+#ifdef CPG_GENC_ROWS
+            if (rows) {
+                if ((unsigned)lane < n) {         // (n <= 64: row = lane)
+#pragma unroll
+                    for (int s = 0; s < CPG_GENC_ROWS_SP; s++) {
+                        const unsigned w = rows[ROWS_P + s * 64 + lane];
+                        if (CPG_GENC_ROW_VALID(w) && CPG_GENC_ROW_OP(w) == (unsigned)lane) md = cpgw::dmax2(md, fabs(B.P[CPG_GENC_ROW_ENT(w)]));
+                    }
+                }
+            } else
+#endif
             for (unsigned j = (unsigned)lane; j < n; j += 64u) {
                 const unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
                 for (unsigned k = a; k < e; k++)
@@ -390,6 +472,19 @@ struct ConicCtx {
         for (int k = lane; k < C.n_soc; k += 64) {
             const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
             double yy = 0.0, xy = 0.0, xx = 0.0;
+#ifdef CPG_GENC_SOC_MAXDIM
+            if (rows) {
+                double a[CPG_GENC_SOC_MAXDIM], b[CPG_GENC_SOC_MAXDIM];
+#pragma unroll
+                for (int r = 1; r < CPG_GENC_SOC_MAXDIM; r++) { a[r] = v[st + (unsigned)r]; b[r] = dv[st + (unsigned)r]; }
+#pragma unroll
+                for (int r = 1; r < CPG_GENC_SOC_MAXDIM; r++) {
+                    const bool in = (unsigned)r < dm;
+                    const double t0 = yy + b[r] * b[r], t1 = xy + a[r] * b[r], t2 = xx + a[r] * a[r];
+                    yy = in ? t0 : yy; xy = in ? t1 : xy; xx = in ? t2 : xx;
+                }
+            } else
+#endif
             for (unsigned r = 1; r < dm; r++) { yy += dv[st + r] * dv[st + r]; xy += v[st + r] * dv[st + r]; xx += v[st + r] * v[st + r]; }
             const double qa = dv[st] * dv[st] - yy;
             const double qb = 2.0 * (v[st] * dv[st] - xy);
@@ -503,18 +598,26 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
 #ifdef CPG_GENC_HEADER
     if (SPECIALISED) { CPG_GENC_SPECIALISE(C) }
 #endif
+    const genc_row_word *rows = nullptr;
     if (TABLES_IN_LDS) {
         double *cur = lds;
         const unsigned n1 = (unsigned)C.n + 1u, m1 = (unsigned)C.m + 1u, NN = (unsigned)(C.n + C.m);
         C.soc_start = conic_stage(C0.soc_start, (unsigned)C.n_soc, cur);
         C.soc_dim = conic_stage(C0.soc_dim, (unsigned)C.n_soc, cur);
         C.row_cone = conic_stage(C0.row_cone, (unsigned)C.m, cur);
-        C.Ap = conic_stage(C0.Ap, n1, cur); C.Ai = conic_stage(C0.Ai, (unsigned)C.nnzA, cur);
-        C.Arp = conic_stage(C0.Arp, m1, cur); C.Aent = conic_stage(C0.Aent, (unsigned)C.nnzA, cur);
-        C.Acol = conic_stage(C0.Acol, (unsigned)C.nnzA, cur);
-        C.Pp = conic_stage(C0.Pp, n1, cur); C.Pi = conic_stage(C0.Pi, (unsigned)C.nnzP, cur);
-        C.Prp = conic_stage(C0.Prp, n1, cur); C.Pent = conic_stage(C0.Pent, (unsigned)C.n_pfull, cur);
-        C.Pcol = conic_stage(C0.Pcol, (unsigned)C.n_pfull, cur);
+#ifdef CPG_GENC_ROWS
+        // the library's own family: the generated row words stand for every walk over the two patterns (ConicCtx::rows)
+        if (SPECIALISED) rows = conic_stage(genc_row_words, (unsigned)CPG_GENC_ROWS_WORDS, cur);
+        else
+#endif
+        {
+            C.Ap = conic_stage(C0.Ap, n1, cur); C.Ai = conic_stage(C0.Ai, (unsigned)C.nnzA, cur);
+            C.Arp = conic_stage(C0.Arp, m1, cur); C.Aent = conic_stage(C0.Aent, (unsigned)C.nnzA, cur);
+            C.Acol = conic_stage(C0.Acol, (unsigned)C.nnzA, cur);
+            C.Pp = conic_stage(C0.Pp, n1, cur); C.Pi = conic_stage(C0.Pi, (unsigned)C.nnzP, cur);
+            C.Prp = conic_stage(C0.Prp, n1, cur); C.Pent = conic_stage(C0.Pent, (unsigned)C.n_pfull, cur);
+            C.Pcol = conic_stage(C0.Pcol, (unsigned)C.n_pfull, cur);
+        }
         C.Lcol = conic_stage(C0.Lcol, (unsigned)C.nnzL, cur);
         C.ksrc_kind = conic_stage(C0.ksrc_kind, (unsigned)C.nnzL + NN, cur);
         C.ksrc_idx = conic_stage(C0.ksrc_idx, (unsigned)C.nnzL + NN, cur);
@@ -544,7 +647,7 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
     const int lane = cpgw::lane_id();
     const unsigned n = (unsigned)C.n, m = (unsigned)C.m, N = n + m;
     const ConicBuf B = conic_carve(lds + (size_t)cpgw::wave_in_block() * (size_t)C.lds_doubles, C);
-    const ConicCtx cx{C, S, B, lane, n, m, N};
+    const ConicCtx cx{C, S, B, lane, n, m, N, rows};
     LdsProg SP;
     SP.ctab = C.sol_ctab; SP.desc = C.sol_desc; SP.vals = B.sv; SP.cols = C.sol_cols;
     SP.n_chunks = C.sol_chunks; SP.dummy = (unsigned)C.sol_nnz - 1u; SP.rows16 = nullptr;
@@ -585,18 +688,30 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
             for (int it = 0; it < S.equilibrate_max_iter; it++) {
                 for (unsigned j = (unsigned)lane; j < n; j += 64u) {
                     double acc = 0.0;
-                    unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
-                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.P[(unsigned)cpgw::gld(C.Pent, k)]));
-                    a = (unsigned)cpgw::gld(C.Ap, j); e = (unsigned)cpgw::gld(C.Ap, j + 1u);
-                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.A[k]));
+#ifdef CPG_GENC_ROWS
+                    if (rows) acc = cx.template row_absmax<CPG_GENC_ROWS_SAT>(ConicCtx::ROWS_AT, j, cx.template row_absmax<CPG_GENC_ROWS_SP>(ConicCtx::ROWS_P, j, 0.0));
+                    else
+#endif
+                    {
+                        unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
+                        for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.P[(unsigned)cpgw::gld(C.Pent, k)]));
+                        a = (unsigned)cpgw::gld(C.Ap, j); e = (unsigned)cpgw::gld(C.Ap, j + 1u);
+                        for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.A[k]));
+                    }
                     acc = acc == 0.0 ? 1.0 : acc;
                     acc = acc < S.eq_min ? S.eq_min : (acc > S.eq_max ? S.eq_max : acc);
                     B.tx[j] = 1.0 / sqrt(acc);
                 }
                 for (unsigned i = (unsigned)lane; i < m; i += 64u) {
                     double acc = 0.0;
-                    const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
-                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.A[(unsigned)cpgw::gld(C.Aent, k)]));
+#ifdef CPG_GENC_ROWS
+                    if (rows) acc = cx.template row_absmax<CPG_GENC_ROWS_SA>(ConicCtx::ROWS_A, i, 0.0);
+                    else
+#endif
+                    {
+                        const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
+                        for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.A[(unsigned)cpgw::gld(C.Aent, k)]));
+                    }
                     acc = acc == 0.0 ? 1.0 : acc;
                     acc = acc < S.eq_min ? S.eq_min : (acc > S.eq_max ? S.eq_max : acc);
                     B.tz[i] = 1.0 / sqrt(acc);
@@ -604,10 +719,30 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                 cpgw::lds_order();
                 for (unsigned j = (unsigned)lane; j < n; j += 64u) {
                     const double dj = B.tx[j];
-                    unsigned a = (unsigned)cpgw::gld(C.Pp, j), e = (unsigned)cpgw::gld(C.Pp, j + 1u);
-                    for (unsigned k = a; k < e; k++) B.P[k] = (B.tx[(unsigned)cpgw::gld(C.Pi, k)] * B.P[k]) * dj;
-                    a = (unsigned)cpgw::gld(C.Ap, j); e = (unsigned)cpgw::gld(C.Ap, j + 1u);
-                    for (unsigned k = a; k < e; k++) B.A[k] = (B.tz[(unsigned)cpgw::gld(C.Ai, k)] * B.A[k]) * dj;
+#ifdef CPG_GENC_ROWS
+                    if (rows) {
+                        // an entry of the upper triangle of P is scaled by the lane of its ROW (operand = its column >= the row;
+                        // the mirrored occurrence in the column's list is skipped), an entry of A by the lane of its column
+#pragma unroll
+                        for (int s_ = 0; s_ < CPG_GENC_ROWS_SP; s_++) {
+                            const unsigned w = rows[ConicCtx::ROWS_P + s_ * 64 + (int)j];
+                            const unsigned e = CPG_GENC_ROW_ENT(w), o = CPG_GENC_ROW_OP(w);
+                            if (CPG_GENC_ROW_VALID(w) && o >= j) B.P[e] = (dj * B.P[e]) * B.tx[o];
+                        }
+#pragma unroll
+                        for (int s_ = 0; s_ < CPG_GENC_ROWS_SAT; s_++) {
+                            const unsigned w = rows[ConicCtx::ROWS_AT + s_ * 64 + (int)j];
+                            const unsigned e = CPG_GENC_ROW_ENT(w), o = CPG_GENC_ROW_OP(w);
+                            if (CPG_GENC_ROW_VALID(w)) B.P[e] = (B.tz[o] * B.P[e]) * dj;
+                        }
+                    } else
+#endif
+                    {
+                        unsigned a = (unsigned)cpgw::gld(C.Pp, j), e = (unsigned)cpgw::gld(C.Pp, j + 1u);
+                        for (unsigned k = a; k < e; k++) B.P[k] = (B.tx[(unsigned)cpgw::gld(C.Pi, k)] * B.P[k]) * dj;
+                        a = (unsigned)cpgw::gld(C.Ap, j); e = (unsigned)cpgw::gld(C.Ap, j + 1u);
+                        for (unsigned k = a; k < e; k++) B.A[k] = (B.tz[(unsigned)cpgw::gld(C.Ai, k)] * B.A[k]) * dj;
+                    }
                     B.q[j] = dj * B.q[j];
                     B.D[j] *= dj;
                 }
@@ -616,8 +751,14 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                 double psum = 0.0, qn = 0.0;
                 for (unsigned j = (unsigned)lane; j < n; j += 64u) {
                     double acc = 0.0;
-                    const unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
-                    for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.P[(unsigned)cpgw::gld(C.Pent, k)]));
+#ifdef CPG_GENC_ROWS
+                    if (rows) acc = cx.template row_absmax<CPG_GENC_ROWS_SP>(ConicCtx::ROWS_P, j, 0.0);
+                    else
+#endif
+                    {
+                        const unsigned a = (unsigned)cpgw::gld(C.Prp, j), e = (unsigned)cpgw::gld(C.Prp, j + 1u);
+                        for (unsigned k = a; k < e; k++) acc = cpgw::dmax2(acc, fabs(B.P[(unsigned)cpgw::gld(C.Pent, k)]));
+                    }
                     psum += acc;
                     qn = cpgw::dmax2(qn, fabs(B.q[j]));
                 }
@@ -645,8 +786,19 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                 const unsigned first = (unsigned)(C.n_zero + C.n_nonneg);
                 for (unsigned i = first + (unsigned)lane; i < m; i += 64u) {
                     const double ew = B.tz[i];
-                    const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
-                    for (unsigned k = a; k < e; k++) B.A[(unsigned)cpgw::gld(C.Aent, k)] *= ew;
+#ifdef CPG_GENC_ROWS
+                    if (rows) {
+#pragma unroll
+                        for (int s_ = 0; s_ < CPG_GENC_ROWS_SA; s_++) {
+                            const unsigned w = rows[ConicCtx::ROWS_A + s_ * 64 + (int)i];
+                            if (CPG_GENC_ROW_VALID(w)) B.P[CPG_GENC_ROW_ENT(w)] *= ew;
+                        }
+                    } else
+#endif
+                    {
+                        const unsigned a = (unsigned)cpgw::gld(C.Arp, i), e = (unsigned)cpgw::gld(C.Arp, i + 1u);
+                        for (unsigned k = a; k < e; k++) B.A[(unsigned)cpgw::gld(C.Aent, k)] *= ew;
+                    }
                     B.b[i] *= ew; B.E[i] *= ew;
                 }
                 cpgw::lds_order();
@@ -769,8 +921,10 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
             iter++;
 
             // scaling, factorisation, constant part (x2, z2) = K^{-1}(-q, b)
-            if (!cx.update_scaling()) { status = CPG_CL_NUMERICAL_ERROR; break; }
-            cx.factor();
+            bool scaled = true;
+            CPG_CONIC_REPEAT(8) scaled = cx.update_scaling();
+            if (!scaled) { status = CPG_CL_NUMERICAL_ERROR; break; }
+            CPG_CONIC_REPEAT(1) cx.factor();
             // The three solves of an iteration -- constant part (x2, z2) = K^{-1}(-q, b), affine step, combined step -- run
             // through ONE copy of kkt_solve (substitution sweeps + refinement): inlined three times, the loop body
             // outgrew the instruction cache two CUs share.  Same operations in the same order as the straight-line form.
@@ -784,7 +938,7 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                     for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = B.rx[j];
                     for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.dsc[i] = B.s[i]; B.rb[n + i] = B.s[i] - B.rz[i]; }
                 } else {                         // combined step
-                    cx.combined_ds_offset(sigma * mu);
+                    CPG_CONIC_REPEAT(32) cx.combined_ds_offset(sigma * mu);
                     rk = -sigma * mu + dtau * dkap + tau * kap;
                     for (unsigned j = (unsigned)lane; j < n; j += 64u) B.rb[j] = (1.0 - sigma) * B.rx[j];
                     for (unsigned i = (unsigned)lane; i < m; i += 64u) B.rb[n + i] = B.dsc[i] - (1.0 - sigma) * B.rz[i];
@@ -807,12 +961,14 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                 } else {
                     const double rhs_tau = pass == 1 ? rtau : (1.0 - sigma) * rtau;
                     const double rhs_kap = pass == 1 ? tau * kap : rk;
-                    conic_step(cx, rhs_tau, rhs_kap, tau, kap, den, dtau, dkap);
-                    alpha = 1.0;
-                    if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
-                    if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
-                    alpha = cx.step_length(B.z, B.dz, alpha);
-                    alpha = cx.step_length(B.s, B.ds, alpha);
+                    CPG_CONIC_REPEAT(64) conic_step(cx, rhs_tau, rhs_kap, tau, kap, den, dtau, dkap);
+                    CPG_CONIC_REPEAT(16) {
+                        alpha = 1.0;
+                        if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
+                        if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
+                        alpha = cx.step_length(B.z, B.dz, alpha);
+                        alpha = cx.step_length(B.s, B.ds, alpha);
+                    }
                     if (pass == 1) sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
                 }
             }

@@ -828,6 +828,37 @@ static int open_device(cpg_handle_t h, int device) {
     return CPG_OK;
 }
 
+#ifdef CPG_GENC_ROWS
+// The generated row words of the library's family (codegen.conic_row_tables) rebuilt from the patterns of the family handed
+// in -- rows of P (full symmetric view), columns of A, rows of A, [step][lane], same bit layout -- and hashed (FNV-1a over the
+// words as 32-bit little-endian): the specialised kernel walks the two patterns through the compiled-in words only.
+static unsigned conic_row_words_hash(const cpg_conic_family_t *f) {
+    const int n = f->n, m = f->m;
+    if (n > 64 || m > 64) return 0;
+    const bool shortw = f->nnzP + f->nnzA <= 0xFF;
+    const int ent_bits = shortw ? 8 : 16, top = shortw ? 15 : 31;
+    unsigned hsh = 2166136261u;
+    auto put = [&](unsigned w) { for (int b = 0; b < 4; b++) hsh = (hsh ^ ((w >> (8 * b)) & 0xFFu)) * 16777619u; };
+    auto pass = [&](int rows, const int *ptr, auto entry, auto operand) {
+        int S = 0;
+        for (int r = 0; r < rows; r++) S = std::max(S, ptr[r + 1] - ptr[r]);
+        for (int s = 0; s < S; s++)
+            for (int lane = 0; lane < 64; lane++) {
+                unsigned w = 0;
+                if (lane < rows && s < ptr[lane + 1] - ptr[lane]) {
+                    const int k = ptr[lane] + s;
+                    w = (1u << top) | ((unsigned)operand(k) << ent_bits) | (unsigned)entry(k);
+                }
+                put(w);
+            }
+    };
+    pass(n, f->Prp, [&](int k) { return f->Pent[k]; }, [&](int k) { return f->Pcol[k]; });
+    pass(n, f->Ap, [&](int k) { return f->nnzP + k; }, [&](int k) { return f->Ai[k]; });
+    pass(m, f->Arp, [&](int k) { return f->nnzP + f->Aent[k]; }, [&](int k) { return f->Acol[k]; });
+    return hsh;
+}
+#endif
+
 static bool conic_dims_equal(const cpg::DevConic &a, const cpg::DevConic &b) {
     return a.n == b.n && a.m == b.m && a.nnzP == b.nnzP && a.nnzA == b.nnzA && a.nnzL == b.nnzL && a.n_zero == b.n_zero &&
            a.n_nonneg == b.n_nonneg && a.n_soc == b.n_soc && a.is_max == b.is_max && a.p_is_zero == b.p_is_zero &&
@@ -956,6 +987,9 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
             cpg::DevConic Ck = Cs;
             { cpg::DevConic &Cref = Ck; CPG_GENC_SPECIALISE(Cref) }
             h->conic_specialised = conic_dims_equal(Cs, Ck) && !(getenv("CPG_CONIC_SPECIALISED") && atoi(getenv("CPG_CONIC_SPECIALISED")) == 0);
+#ifdef CPG_GENC_ROWS
+            if (h->conic_specialised && conic_row_words_hash(f) != CPG_GENC_ROWS_HASH) h->conic_specialised = false;   // same dimensions, other patterns
+#endif
         }
     }
 #endif
@@ -965,8 +999,16 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
         auto dbl = [](size_t count, size_t elem) { return (count * elem + 7) / 8; };
         size_t t = 0;
         t += 2 * dbl((size_t)f->n_soc, 4) + dbl((size_t)m, 4);
-        t += dbl((size_t)n + 1, 4) + dbl((size_t)f->nnzA, 4) + dbl((size_t)m + 1, 4) + 2 * dbl((size_t)f->nnzA, 4);
-        t += dbl((size_t)n + 1, 4) + dbl((size_t)f->nnzP, 4) + dbl((size_t)n + 1, 4) + 2 * dbl((size_t)C.n_pfull, 4);
+        bool row_words = false;
+#ifdef CPG_GENC_ROWS
+        // the library's own family: the generated row words instead of the CSR / CSC arrays of the two patterns
+        row_words = h->conic_specialised;
+        if (row_words) t += dbl((size_t)CPG_GENC_ROWS_WORDS, sizeof(cpg::genc_row_word));
+#endif
+        if (!row_words) {
+            t += dbl((size_t)n + 1, 4) + dbl((size_t)f->nnzA, 4) + dbl((size_t)m + 1, 4) + 2 * dbl((size_t)f->nnzA, 4);
+            t += dbl((size_t)n + 1, 4) + dbl((size_t)f->nnzP, 4) + dbl((size_t)n + 1, 4) + 2 * dbl((size_t)C.n_pfull, 4);
+        }
         t += dbl((size_t)f->nnzL, 4) + 2 * dbl((size_t)f->nnzL + N, 4);
         t += dbl((size_t)f->fac_chunks * 4, 4) + 2 * dbl((size_t)f->fac_chunks * 64, 4) + 3 * dbl((size_t)f->fac_triples, 4);
 #ifdef CPG_GENC_HEADER

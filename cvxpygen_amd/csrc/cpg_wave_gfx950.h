@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #define CPG_DEV __device__ __forceinline__
+#define CPG_DEV_DATA __device__        // a read-only table in global memory (generated headers)
 #define CPG_DEV_NOINLINE __device__ __attribute__((noinline))      // a real call: a register allocation of its own
 #define CPG_LANES 64
 

@@ -17,6 +17,7 @@
 #include <cstring>
 
 #define CPG_DEV inline
+#define CPG_DEV_DATA
 #define CPG_DEV_NOINLINE inline
 #define CPG_LANES 64
 

@@ -221,6 +221,39 @@ def test_generated_conic_executor_in_emulator(tmp_path):
     b2.close()
 
 
+def test_generated_row_words_in_emulator(tmp_path):
+    """the generated row words of a conic family library (codegen.conic_row_tables: rows of P, columns and rows of A as padded
+    per-lane lists, used by every sparse product and by the equilibration of the specialised kernel) on a family whose
+    second-order-cone rows ARE rescaled by the equilibration and whose P is empty: the table-driven kernel's bits"""
+    from tests.sim import build_sim
+    from cvxpygen_amd.ecos_front import ecos_from_conic, conic_from_ecos
+    from cvxpygen_amd import codegen
+    d = conic_from_ecos(ecos_from_conic(families.adp_norm()))
+    d = d[0] if isinstance(d, tuple) else d
+    cp = build_conic_plan(d)
+    assert '#define CPG_GENC_ROWS 1' in codegen.conic_row_tables(cp) and '#define CPG_GENC_ROWS_SP 0' in codegen.conic_row_tables(cp)
+    lib = build_sim.build_conic_family(cp, str(tmp_path), 'adpn')
+    assert '#define CPG_GENC_ROWS_HASH' in open(os.path.join(str(tmp_path), 'cpg_conic_adpn.h')).read()
+    th = np.tile(d.theta0, (3, 1))
+    th[1:, :-1] *= 1.0 + 0.05 * np.random.default_rng(3).standard_normal((2, th.shape[1] - 1))
+    bs = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+    bs.set_updated(None)
+    r = bs.solve(theta_var=th[:, :-1])
+    assert _fact(bs, 'specialised_kernel') == 1.0
+    os.environ['CPG_CONIC_GENERATED'] = '0'              # same library: table-driven executor, CSR / CSC loops
+    try:
+        bt = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+        bt.set_updated(None)
+        rt = bt.solve(theta_var=th[:, :-1])
+    finally:
+        del os.environ['CPG_CONIC_GENERATED']
+    assert _fact(bt, 'specialised_kernel') == 0.0
+    assert (r.status == 1).all() and r.iter.tolist() == rt.iter.tolist()
+    assert np.array_equal(r.sol_x, rt.sol_x) and np.array_equal(r.sol_y, rt.sol_y)
+    _assert_parity(r, cl.cpg_solve_batch(d, th), tol=1e-9)
+    bs.close(); bt.close()
+
+
 def test_infeasible_and_lp_instances_in_emulator(sim_lib):
     """status integers of the conic path (Clarabel numbering) and the P == 0 initialisation"""
     d = families.toy_box(solver='CLARABEL')
