@@ -101,7 +101,7 @@ BINDING = {
                             'barrier each, 4.6 us per iteration) and 300 dependent levels per factorisation (0.43 us per level on one wavefront); '
                             'nothing streamed per iteration (DESIGN.md 4.7; the streaming kernel it replaces: 484 phases per iteration each waiting '
                             'for HBM, 342 GB of fetches per launch, profiles/r4_final_pmc_allparams.txt)',
-    ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 83 % of the SIMD cycles (profiles/r3_conic_pmc_config4.txt)',
+    ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 91 % of the SIMD cycles at four wavefronts per SIMD, 42.9 k vector instructions per instance (profiles/r5_final_pmc_config4.txt)',
 }
 
 

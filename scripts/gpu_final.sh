@@ -52,5 +52,6 @@ if [[ "$SKIP" != *" pmc "* ]]; then
   $B 2>&1 | tail -1 | tee $OUT/bench_config2_traffic.json | python -c "$P"
   $B $W3 --steps 3 --warmup 1 2>&1 | tail -1 | tee $OUT/bench_config3_20k_traffic.json | python -c "$P"
   $B $WA --steps 3 --warmup 1 2>&1 | tail -1 | tee $OUT/bench_allparams_traffic.json | python -c "$P"
+  $B $W4 2>&1 | tail -1 | tee $OUT/bench_config4_traffic.json | python -c "$P"
 fi
 echo "== done"
