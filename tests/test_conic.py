@@ -221,6 +221,33 @@ def test_generated_conic_executor_in_emulator(tmp_path):
     b2.close()
 
 
+def test_row_words_decode_to_the_patterns():
+    """codegen.conic_row_tables: the words of every lane, decoded, are that row of P (full symmetric view), that column of A,
+    that row of A -- entries in the order of the kernel's table-driven loops -- for a family with 16-bit words; an operand or
+    entry count beyond one wavefront pass yields no tables"""
+    import re
+    import scipy.sparse as sp
+    from cvxpygen_amd import codegen
+    for d in (families.adp(), families.toy_box(solver='CLARABEL')):
+        cp = build_conic_plan(d)
+        t = codegen.conic_row_tables(cp)
+        S = [int(re.search(rf'#define CPG_GENC_ROWS_{k} (\d+)', t).group(1)) for k in ('SP', 'SAT', 'SA')]
+        words = [int(x, 16) for x in re.findall(r'0x[0-9a-f]{4}\b', t.split('genc_row_words[')[1])]
+        assert len(words) == 64 * sum(S) == int(re.search(r'#define CPG_GENC_ROWS_WORDS (\d+)', t).group(1))
+        lists = {'P': (0, S[0], [list(zip(cp.Pent[cp.Prp[j]:cp.Prp[j + 1]], cp.Pcol[cp.Prp[j]:cp.Prp[j + 1]])) for j in range(cp.n)]),
+                 'At': (S[0], S[1], [[(cp.nnzP + k, cp.Ai[k]) for k in range(cp.Ap[j], cp.Ap[j + 1])] for j in range(cp.n)]),
+                 'A': (S[0] + S[1], S[2], [list(zip(cp.nnzP + cp.Aent[cp.Arp[i]:cp.Arp[i + 1]], cp.Acol[cp.Arp[i]:cp.Arp[i + 1]])) for i in range(cp.m)])}
+        for first, steps, rows in lists.values():
+            assert steps == max(len(r) for r in rows)
+            for lane in range(64):
+                got = [(w & 0xFF, (w >> 8) & 0x7F) for w in (words[(first + s_) * 64 + lane] for s_ in range(steps)) if w >> 15]
+                want = [(int(a), int(b)) for a, b in rows[lane]] if lane < len(rows) else []
+                assert got == want
+    import types
+    big = types.SimpleNamespace(n=65, m=3, nnzP=0, nnzA=0)
+    assert codegen.conic_row_tables(big) == ''
+
+
 def test_generated_row_words_in_emulator(tmp_path):
     """the generated row words of a conic family library (codegen.conic_row_tables: rows of P, columns and rows of A as padded
     per-lane lists, used by every sparse product and by the equilibration of the specialised kernel) on a family whose
