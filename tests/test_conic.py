@@ -248,6 +248,53 @@ def test_row_words_decode_to_the_patterns():
     assert codegen.conic_row_tables(big) == ''
 
 
+def _dense_lp():
+    """minimise c'x  s.t.  G x <= h (24 dense rows), -1 <= x <= 1, x in R^20: 520 entries of A -> 32-bit row words"""
+    from cvxpygen_amd.canon_builder import CanonBuilder
+    rng = np.random.default_rng(11)
+    G = rng.standard_normal((24, 20))
+    cb = CanonBuilder('dense_lp')
+    c = cb.param('c', (20,))
+    h = cb.param('h', (24,))
+    x = cb.var('x', (20,))
+    for j in range(20):
+        cb.lin(x[j], {c.idx(j): 1.0})
+    rows = [cb.ineq([(x[j], float(G[i, j])) for j in range(20)], h[i]) for i in range(24)]
+    for j in range(20):
+        cb.ineq([(x[j], 1.0)], 1.0)
+        cb.ineq([(x[j], -1.0)], 1.0)
+    cb.dual('d0', rows, (24,))
+    return cb.build({'c': rng.standard_normal(20), 'h': 1.0 + rng.random(24)}, solver='CLARABEL')
+
+
+def test_generated_row_words_32_bit_in_emulator(tmp_path):
+    """a family with more than 255 matrix entries: 32-bit row words (codegen.conic_row_tables), table-driven bits, oracle parity"""
+    from tests.sim import build_sim
+    from cvxpygen_amd import codegen
+    d = _dense_lp()
+    cp = build_conic_plan(d)
+    assert cp.nnzP + cp.nnzA > 255 and 'typedef unsigned genc_row_word;' in codegen.conic_row_tables(cp)
+    lib = build_sim.build_conic_family(cp, str(tmp_path), 'dlp')
+    th = np.tile(d.theta0, (3, 1))
+    th[1:, :-1] += 0.1 * np.random.default_rng(5).standard_normal((2, th.shape[1] - 1))
+    bs = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+    bs.set_updated(None)
+    r = bs.solve(theta_var=th[:, :-1])
+    assert _fact(bs, 'specialised_kernel') == 1.0
+    os.environ['CPG_CONIC_GENERATED'] = '0'
+    try:
+        bt = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+        bt.set_updated(None)
+        rt = bt.solve(theta_var=th[:, :-1])
+    finally:
+        del os.environ['CPG_CONIC_GENERATED']
+    assert _fact(bt, 'specialised_kernel') == 0.0
+    assert (r.status == 1).all() and r.iter.tolist() == rt.iter.tolist()
+    assert np.array_equal(r.sol_x, rt.sol_x) and np.array_equal(r.sol_y, rt.sol_y)
+    _assert_parity(r, cl.cpg_solve_batch(d, th), tol=1e-8)
+    bs.close(); bt.close()
+
+
 def test_generated_row_words_in_emulator(tmp_path):
     """the generated row words of a conic family library (codegen.conic_row_tables: rows of P, columns and rows of A as padded
     per-lane lists, used by every sparse product and by the equilibration of the specialised kernel) on a family whose
