@@ -262,8 +262,12 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *family, int device, cpg_handle_
  * iterations, 9 numerical error, 10 insufficient progress) and the setting names are those of
  * cvxpygen/solvers/clarabel.py:63-119.  In a library compiled for one conic family
  * (cvxpygen_amd.codegen.build_conic_library) a handle of exactly that family runs the generated executor of
- * its substitution program with the family's dimensions compiled in; cpg_hip_get_setting reports it as
- * "generated_executor" / "specialised_kernel" (1.0 / 0.0); any other family runs the table-driven path. */
+ * its substitution program with the family's dimensions compiled in, and walks the patterns of P and A through the
+ * library's generated row words (cvxpygen_amd.codegen.conic_row_tables; guarded by a hash of the words rebuilt from
+ * `family`); cpg_hip_get_setting reports it as "generated_executor" / "specialised_kernel" (1.0 / 0.0); any other family
+ * runs the table-driven path.  Settings of the reference's Clarabel interface this backend cannot honour are REFUSED at
+ * any value but their default -- cpg_hip_set_setting returns CPG_E_UNSUPPORTED for time_limit (finite), direct_kkt_solver
+ * (0), presolve_enable (0) -- instead of being accepted and ignored. */
 int cpg_hip_create_clarabel(const cpg_conic_family_t *family, int device, cpg_handle_t *out);
 int cpg_hip_destroy(cpg_handle_t h);
 const char *cpg_hip_last_error(void);
@@ -309,7 +313,13 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *rf);
 /* cpg_hip_set_refactor(h, rf), and -- when this library carries the generated resident executor of exactly this
  * family (cvxpygen_amd.codegen.resident_header; the merged program's fingerprint decides) -- the resident kernel's
  * tables: solves then run cpg_osqp_resident.h instead of the streaming kernel.  cpg_hip_get_setting(h,
- * "resident_executor") reports which (1.0 / 0.0); any other library keeps the streaming kernel and returns CPG_OK. */
+ * "resident_executor") reports which (1.0 / 0.0); any other library keeps the streaming kernel and returns CPG_OK.
+ * A library generated with the TEAM executor (cvxpygen_amd.codegen.team_header: families whose merged program does not
+ * fit the registers of one wavefront, e.g. an MPC with every parameter per instance) takes the same tables and runs
+ * cpg_osqp_team.h -- one workgroup of W wavefronts per instance, the program split over them; "team_executor" reports the
+ * W in use (0.0: not).  The tables must be those of a plan built for that W and group limit (the header's
+ * `// CPG_GENT_GROUPS` line; cvxpygen_amd.runtime reads it back): another plan is refused by fingerprint and the handle
+ * keeps the streaming kernel. */
 int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *rf, const cpg_osqp_resident_t *rs);
 
 /* adjoint tables; requires cpg_hip_set_refactor on the same handle (canonical ordering) */
