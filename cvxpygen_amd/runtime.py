@@ -312,6 +312,7 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
                              devpos=devpos)
     pi = None
     bank_stats = {}
+    entry_order = False
     if bank_layout:
         # bank-aware numbering of the work-vector slots (cvxpygen_amd/slot_layout.py): the entries keep their
         # region -- x / rows, parameter-dependent first, rows additionally by class so that 64-row slots of
@@ -325,8 +326,16 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         ctz = np.asarray(plan.constr_type)[ordz]
         region[n:N] = np.where(np.arange(m) < int(vary_u.sum()), 10, 20 + (ctz + 1))
         stores = _sl.store_groups((rg0.desc & 0xFFFF).astype(np.int64), 0xFFFF)
-        pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0, idle_zero=pad0), region, seed=0, stores=stores,
-                                  sweeps=int(os.environ.get('CPG_BANK_SWEEPS', 60)))
+        # ... together with the order of every row's entries among the row's (lane, step) cells (round 6: the numbering alone
+        # left 0.85 extra LDS cycles per 32-lane gather group; with the entries free to choose their step, 0.14)
+        entry_order = os.environ.get('CPG_ENTRY_ORDER', '1') != '0'
+        if entry_order:
+            pi, eperm, pad_slot, c0, c1 = _sl.optimise_entries(rg0, region, pad0, seed=0, stores=stores,
+                                                               sweeps=int(os.environ.get('CPG_BANK_SWEEPS', 60)))
+        else:
+            pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0, idle_zero=pad0), region, seed=0, stores=stores,
+                                      sweeps=int(os.environ.get('CPG_BANK_SWEEPS', 60)))
+        pi_all = pi
         pi = pi[:rg0.n_slots]
         bank_stats = dict(bank_conflict_cycles_natural=int(c0), bank_conflict_cycles=int(c1))   # gathers + reduce-stores
         # the device ordering follows: the entry at device position p moves to position pi[p]
@@ -336,6 +345,14 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         posx[ordx] = np.arange(n); posz[ordz] = np.arange(m)
     kkt = _sp.pack(phases, N=N, slot_perm=pi)
     kkt_ragged = _sp.pack_ragged(phases, N, balanced=True, slot_perm=pi)
+    if pi is not None and entry_order:
+        kkt_ragged = _sl.apply_entries(kkt_ragged, eperm, pad_slot, pi_all)
+        gs_ = _sl.gather_groups(_sp.gathered_slots(kkt_ragged, idle_zero=pad0))
+        st_ = _sl.store_groups((kkt_ragged.desc & 0xFFFF).astype(np.int64), 0xFFFF)
+        ident_ = np.arange(len(region))
+        bank_stats['bank_conflict_cycles_gathers'] = int(_sl.conflict_cycles(gs_, ident_))
+        bank_stats['bank_conflict_cycles_stores'] = int(_sl.conflict_cycles(st_, ident_, [_sl.STORE_BANK_PAIRS] * len(st_)))
+        assert bank_stats['bank_conflict_cycles_gathers'] + bank_stats['bank_conflict_cycles_stores'] == bank_stats['bank_conflict_cycles']
     if pi is not None:
         # final_pos is indexed by the logical entry the phases were compiled with (= old device position)
         fp = np.empty(N, dtype=np.int64); fp[pi[:N]] = kkt.final_pos

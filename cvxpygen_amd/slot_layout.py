@@ -179,3 +179,334 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
     except OSError:
         pass
     return best_pi, cost0, best_cost
+
+
+# ------------------------------------------------------------------------------------------------
+# Joint optimisation of the slot numbering AND of the order of a row's entries (round 6).
+#
+# The numbering alone leaves ~0.85 extra LDS cycles per 32-lane gather group on MPC 12/4/10 (252 modelled cycles per
+# solve against 296 conflict-free gather cycles; SQ_LDS_BANK_CONFLICT = 26 % of SQ_LDS_IDX_ACTIVE with the LDS array
+# 85 % busy, profiles/r5_final_pmc_config2.txt).  A second freedom was unused: WHICH of its (lane, step) cells an
+# entry of a row occupies does not matter to the row's sum, so the entries of a row may be permuted among the row's
+# cells.  With every lane free to choose the step at which it reads a given operand, a (chunk, 32-lane half) is a
+# bipartite edge-colouring problem (lanes x bank pairs, colours = steps): conflict-free whenever no bank pair holds
+# more distinct operands of the half than the chunk has steps -- which the numbering can arrange.  Both freedoms are
+# annealed together on the exact cost (same model as `optimise`: calibrated with scripts/micro/lds_conflicts.hip).
+def entry_cells(prog, idle_zero: bool):
+    """The (lane, step) cells of a RaggedProgram's flat entry array: per entry e its gather group (2 * step + half, steps
+    numbered chunk by chunk as in `gathered_slots`), its row (unique per (chunk, row); pad cells of dummy lanes get a row of
+    their own), its slot (cols // 8) and whether it is a pad (zero coefficient: any address will do).  Also the
+    (group, slot) pairs of the idle lanes of partial steps when their offsets point at the zero slot (idle_zero)."""
+    n_ent = prog.nnz - 1
+    grp = np.zeros(n_ent, dtype=np.int64)
+    row = np.zeros(n_ent, dtype=np.int64)
+    slot = (prog.cols[:n_ent].astype(np.int64)) // 8
+    pad = np.asarray(prog.vals[:n_ent]) == 0.0
+    fixed = []
+    step0 = 0
+    next_row = 0
+    for c in range(prog.n_chunks):
+        L, _, first, kind = (int(v) for v in prog.ctab[c])
+        d = prog.desc[c]
+        ln = (((d >> 16) & 0xFFF) if (kind & 1) else (d >> 16)).astype(np.int64)
+        lr = prog.lane_row[c].astype(np.int64)
+        ids = {}
+        lane_rowid = np.zeros(64, dtype=np.int64)
+        for t in range(64):
+            key = int(lr[t]) if lr[t] >= 0 else -(t + 1)          # dummy lanes: a row each
+            if key not in ids:
+                ids[key] = next_row
+                next_row += 1
+            lane_rowid[t] = ids[key]
+        e = first
+        for s_ in range(L):
+            cnt = int((ln > s_).sum())
+            lanes = np.arange(cnt)
+            grp[e:e + cnt] = 2 * (step0 + s_) + lanes // GROUP
+            row[e:e + cnt] = lane_rowid[:cnt]
+            if idle_zero and cnt < 64:
+                zs = prog.n_slots + 16          # GEN_DUMMY_SLOTS: the slot that always holds 0.0
+                for h in range(2):
+                    if cnt < (h + 1) * GROUP:
+                        fixed.append((2 * (step0 + s_) + h, zs))
+            e += cnt
+        step0 += L
+    return grp, row, slot, pad, fixed, 2 * step0
+
+
+def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60, seed: int = 0,
+                     stores: List[np.ndarray] = ()) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int, int]:
+    """Returns (pi, eperm, pad_slot, cost before, cost after) for a RaggedProgram packed with the NATURAL numbering:
+    pi[slot] = new position (as `optimise`); eperm: the entry that moves to flat position e is the old entry eperm[e]
+    (entries only move between cells of their own row); pad_slot[e] >= 0: the (zero-coefficient) entry at position e
+    reads this OLD slot -- an address another lane of its gather group reads anyway (a broadcast costs nothing).
+    Cost: extra LDS cycles of all gathers and reduce-stores per run of the program."""
+    import hashlib
+    import os
+    n = region.shape[0]
+    grp, row, slot0, pad, fixed, n_groups = entry_cells(prog, idle_zero)
+    n_ent = len(grp)
+    hsh = hashlib.sha256()
+    hsh.update(_source_version())
+    for a_ in (grp, row, slot0, pad.astype(np.int64), np.asarray(fixed, dtype=np.int64).reshape(-1),
+               np.ascontiguousarray(region, dtype=np.int64), np.asarray([sweeps, seed, BANK_PAIRS, STORE_BANK_PAIRS, 6], dtype=np.int64), np.asarray([1e6 * float(os.environ.get(k_, v_)) for k_, v_ in (('CPG_ANNEAL_T0', 0.4), ('CPG_ANNEAL_T1', 0.05), ('CPG_ANNEAL_PENTRY', 0.6), ('CPG_ANNEAL_TENTRY', 0.3))], dtype=np.int64),
+               *[np.ascontiguousarray(g_, dtype=np.int64) for g_ in stores]):
+        hsh.update(np.ascontiguousarray(a_, dtype=np.int64).tobytes()); hsh.update(b'|')
+    cdir = os.environ.get('CPG_LAYOUT_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'generated', '.layout_cache'))
+    cfile = os.path.join(cdir, 'e' + hsh.hexdigest()[:31] + '.npz')
+    if os.path.exists(cfile):
+        try:
+            rec = np.load(cfile)
+            if rec['pi'].shape == (n,) and rec['eperm'].shape == (n_ent,):
+                return rec['pi'], rec['eperm'], rec['pad_slot'], int(rec['cost'][0]), int(rec['cost'][1])
+        except (OSError, ValueError, KeyError):
+            pass
+    import random
+    rnd = random.Random(seed)
+    NG = n_groups
+    MODG = BANK_PAIRS
+    # ---- state (plain Python containers: the moves touch a handful of small integers each)
+    pos = list(range(n))                                   # slot -> position
+    cell_slot = [(-1 if pad[e] else int(slot0[e])) for e in range(n_ent)]      # what the cell holds now (-1: a pad)
+    cell_src = list(range(n_ent))                          # ... and which old entry that is
+    cell_grp = [int(g_) for g_ in grp]
+    mult = [dict() for _ in range(NG)]                     # gather group -> {slot: multiplicity}
+    fixed_in = [set() for _ in range(NG)]
+    for g_, s_ in fixed:
+        fixed_in[g_].add(int(s_))
+    cnt = [[0] * MODG for _ in range(NG)]                  # distinct slots per bank pair
+    occ = [dict() for _ in range(n)]                       # slot -> {gather group: multiplicity}
+
+    def add(g_, x):
+        m_ = mult[g_]
+        k_ = m_.get(x, 0)
+        m_[x] = k_ + 1
+        if k_ == 0:
+            cnt[g_][pos[x] % MODG] += 1
+            occ[x][g_] = 1
+
+    def rem(g_, x):
+        m_ = mult[g_]
+        k_ = m_[x] - 1
+        if k_ == 0:
+            del m_[x]
+            cnt[g_][pos[x] % MODG] -= 1
+            del occ[x][g_]
+        else:
+            m_[x] = k_
+    for g_ in range(NG):
+        for x in fixed_in[g_]:
+            add(g_, x); add(g_, x)                         # (multiplicity 2: a fixed member never leaves)
+    for e in range(n_ent):
+        if cell_slot[e] >= 0:
+            add(cell_grp[e], cell_slot[e])
+    gmax = [max(c_) if any(c_) else 1 for c_ in cnt]
+    # store groups: static membership, modulus 16
+    st_groups = [[int(v) for v in g_] for g_ in stores]
+    st_of = [[] for _ in range(n)]
+    for k_, g_ in enumerate(st_groups):
+        for x in g_:
+            st_of[x].append(k_)
+    st_cnt = []
+    for g_ in st_groups:
+        c_ = [0] * STORE_BANK_PAIRS
+        for x in g_:
+            c_[pos[x] % STORE_BANK_PAIRS] += 1
+        st_cnt.append(c_)
+    st_max = [max(c_) for c_ in st_cnt]
+    cost = sum(gmax) - NG + sum(st_max) - len(st_groups)
+    cost0 = cost
+    # rows with more than one cell in different groups can move entries; slots of a region can swap
+    by_row = {}
+    for e in range(n_ent):
+        by_row.setdefault(int(row[e]), []).append(e)
+    rows_mv = [v for v in by_row.values() if len({cell_grp[e] for e in v}) > 1]
+    row_of_cell = {}
+    for v in rows_mv:
+        for e in v:
+            row_of_cell[e] = v
+    cells_of_grp = [[] for _ in range(NG)]
+    for e in range(n_ent):
+        if e in row_of_cell:
+            cells_of_grp[cell_grp[e]].append(e)
+    members = [np.nonzero(region == r)[0] for r in np.unique(region)]
+    members = [[int(v) for v in m_] for m_ in members if len(m_) > 1]
+    used = [bool(occ[x]) or bool(st_of[x]) for x in range(n)]
+    n_used = sum(used)
+    best = (cost, list(pos), list(cell_src), list(cell_slot))
+    n_moves = sweeps * (n_used + n_ent // 2)
+    T0, T1 = float(os.environ.get('CPG_ANNEAL_T0', 0.4)), float(os.environ.get('CPG_ANNEAL_T1', 0.05))
+    P_ENTRY = float(os.environ.get('CPG_ANNEAL_PENTRY', 0.6))
+    T_ENTRY = float(os.environ.get('CPG_ANNEAL_TENTRY', 0.3))
+    import math
+    hot = set(g_ for g_ in range(NG) if gmax[g_] > 1)
+    hot_list, hot_at = [], 0
+    for it in range(n_moves):
+        T = T0 * (T1 / T0) ** (it / max(1, n_moves - 1))
+        if rows_mv and T < T_ENTRY and rnd.random() < P_ENTRY:
+            # ---- entry move: two cells of one row exchange what they hold
+            if hot and rnd.random() < 0.7:
+                if it >= hot_at:
+                    hot_list = sorted(hot)
+                    hot_at = it + 64
+                g1 = rnd.choice(hot_list) if hot_list else 0
+                if gmax[g1] <= 1:
+                    continue
+                cl_ = cells_of_grp[g1]
+                if not cl_:
+                    hot.discard(g1)
+                    continue
+                # an entry of the most loaded bank pair of a conflicted group
+                bm = cnt[g1].index(gmax[g1])
+                cand = [e for e in cl_ if cell_slot[e] >= 0 and pos[cell_slot[e]] % MODG == bm]
+                e1 = rnd.choice(cand) if cand else rnd.choice(cl_)
+            else:
+                e1 = rnd.choice(rnd.choice(rows_mv))
+            e2 = rnd.choice(row_of_cell[e1])
+            g1, g2 = cell_grp[e1], cell_grp[e2]
+            x1, x2 = cell_slot[e1], cell_slot[e2]
+            if g1 == g2 or x1 == x2:
+                continue
+            if x1 >= 0:
+                rem(g1, x1)
+            if x2 >= 0:
+                rem(g2, x2)
+            if x1 >= 0:
+                add(g2, x1)
+            if x2 >= 0:
+                add(g1, x2)
+            m1, m2 = max(cnt[g1]), max(cnt[g2])
+            m1, m2 = max(m1, 1), max(m2, 1)
+            delta = m1 + m2 - gmax[g1] - gmax[g2]
+            if delta <= 0 or rnd.random() < math.exp(-delta / T):
+                gmax[g1], gmax[g2] = m1, m2
+                cell_slot[e1], cell_slot[e2] = x2, x1
+                cell_src[e1], cell_src[e2] = cell_src[e2], cell_src[e1]
+                cost += delta
+                for g_, m_ in ((g1, m1), (g2, m2)):
+                    if m_ > 1:
+                        hot.add(g_)
+                    else:
+                        hot.discard(g_)
+            else:
+                if x1 >= 0:
+                    rem(g2, x1)
+                if x2 >= 0:
+                    rem(g1, x2)
+                if x1 >= 0:
+                    add(g1, x1)
+                if x2 >= 0:
+                    add(g2, x2)
+        else:
+            # ---- slot move: two slots of one region exchange their positions
+            m_ = rnd.choice(members)
+            a, b = rnd.choice(m_), rnd.choice(m_)
+            pa, pb = pos[a], pos[b]
+            if pa % MODG == pb % MODG or not (used[a] or used[b]):
+                continue
+            oa, ob = occ[a], occ[b]
+            aff = [g_ for g_ in oa if g_ not in ob]
+            affb = [g_ for g_ in ob if g_ not in oa]
+            ca, cb = pa % MODG, pb % MODG
+            delta = 0
+            newmax = []
+            for g_ in aff:
+                c_ = cnt[g_]
+                c_[ca] -= 1; c_[cb] += 1
+                mm = max(c_)
+                newmax.append(mm)
+                delta += mm - gmax[g_]
+            for g_ in affb:
+                c_ = cnt[g_]
+                c_[cb] -= 1; c_[ca] += 1
+                mm = max(c_)
+                newmax.append(mm)
+                delta += mm - gmax[g_]
+            sa, sb = pa % STORE_BANK_PAIRS, pb % STORE_BANK_PAIRS
+            saff, sbff, snew = [], [], []
+            if sa != sb:
+                sta, stb = st_of[a], st_of[b]
+                saff = [k_ for k_ in sta if k_ not in stb]
+                sbff = [k_ for k_ in stb if k_ not in sta]
+                for k_ in saff:
+                    c_ = st_cnt[k_]
+                    c_[sa] -= 1; c_[sb] += 1
+                    mm = max(c_)
+                    snew.append(mm)
+                    delta += mm - st_max[k_]
+                for k_ in sbff:
+                    c_ = st_cnt[k_]
+                    c_[sb] -= 1; c_[sa] += 1
+                    mm = max(c_)
+                    snew.append(mm)
+                    delta += mm - st_max[k_]
+            if delta <= 0 or rnd.random() < math.exp(-delta / T):
+                pos[a], pos[b] = pb, pa
+                for g_, mm in zip(aff + affb, newmax):
+                    gmax[g_] = mm
+                    if mm > 1:
+                        hot.add(g_)
+                    else:
+                        hot.discard(g_)
+                for k_, mm in zip(saff + sbff, snew):
+                    st_max[k_] = mm
+                cost += delta
+            else:
+                for g_ in aff:
+                    c_ = cnt[g_]
+                    c_[ca] += 1; c_[cb] -= 1
+                for g_ in affb:
+                    c_ = cnt[g_]
+                    c_[cb] += 1; c_[ca] -= 1
+                for k_ in saff:
+                    c_ = st_cnt[k_]
+                    c_[sa] += 1; c_[sb] -= 1
+                for k_ in sbff:
+                    c_ = st_cnt[k_]
+                    c_[sb] += 1; c_[sa] -= 1
+        if cost < best[0]:
+            best = (cost, list(pos), list(cell_src), list(cell_slot))
+    cost1, pos_b, src_b, slot_b = best
+    pi = np.asarray(pos_b, dtype=np.int64)
+    eperm = np.asarray(src_b, dtype=np.int64)
+    # pads: an address some other lane of the gather group reads anyway (the group's first real entry; a group of pads only:
+    # its first fixed member, else slot 0)
+    pad_slot = np.full(n_ent, -1, dtype=np.int64)
+    first_real = {}
+    for e in range(n_ent):
+        if slot_b[e] >= 0 and cell_grp[e] not in first_real:
+            first_real[cell_grp[e]] = slot_b[e]
+    for e in range(n_ent):
+        if slot_b[e] < 0:
+            g_ = cell_grp[e]
+            pad_slot[e] = first_real.get(g_, min(fixed_in[g_]) if fixed_in[g_] else 0)
+    assert sorted(eperm.tolist()) == list(range(n_ent)) and sorted(pi.tolist()) == list(range(n))
+    try:
+        os.makedirs(cdir, exist_ok=True)
+        tmp = cfile + f'.{os.getpid()}.tmp.npz'
+        np.savez(tmp, pi=pi, eperm=eperm, pad_slot=pad_slot, cost=np.asarray([cost0, cost1], dtype=np.int64))
+        os.replace(tmp, cfile)
+    except OSError:
+        pass
+    return pi, eperm, pad_slot, int(cost0), int(cost1)
+
+
+def apply_entries(prog, eperm: np.ndarray, pad_slot: np.ndarray, pi=None):
+    """The RaggedProgram with its entries permuted (`optimise_entries`): vals / cols of flat position e come from old entry
+    eperm[e]; pads read pad_slot[e] (an OLD slot number: mapped through pi when the program was packed with it)."""
+    import dataclasses
+    n_ent = prog.nnz - 1
+    vals = prog.vals.copy()
+    cols = prog.cols.copy()
+    vals[:n_ent] = prog.vals[eperm]
+    cols[:n_ent] = prog.cols[eperm]
+    isp = pad_slot >= 0
+    assert (vals[:n_ent][isp] == 0.0).all() and (vals[:n_ent][~isp] != 0.0).all()
+    ps = pad_slot[isp]
+    if pi is not None:
+        pi = np.asarray(pi, dtype=np.int64)
+        ps = np.where(ps < len(pi), pi[np.minimum(ps, len(pi) - 1)], ps)
+    c2 = cols[:n_ent].astype(np.int64)
+    c2[isp] = 8 * ps
+    cols[:n_ent] = c2.astype(cols.dtype)
+    return dataclasses.replace(prog, vals=vals, cols=cols)

@@ -469,6 +469,9 @@ class RaggedProgram:
     n_slots: int
     final_pos: np.ndarray
     chunk_phase: Optional[np.ndarray] = None    # phase index of every chunk
+    # [n_chunks, 64]: the row (numbered inside its chunk) whose partial sum a lane accumulates, -1 for dummy lanes.  The entries
+    # of a row may sit in ANY of its (lane, step) cells -- slot_layout.optimise_entries permutes them to avoid LDS bank conflicts
+    lane_row: Optional[np.ndarray] = None
 
     @property
     def n_chunks(self) -> int:
@@ -599,7 +602,7 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
     outs, ins, n_slots, final_pos = assign_slots(phases, N, slot_perm)
     if n_slots * 8 > 0xFFFF:
         raise NotImplementedError('work vector too large for 16-bit byte offsets')
-    ctab, desc, vals, cols, chunk_phase = [], [], [], [], []
+    ctab, desc, vals, cols, chunk_phase, lane_row = [], [], [], [], [], []
     first = 0
     for pi, (ph, out_slots, col_slots) in enumerate(zip(phases, outs, ins)):
         lens = [len(c) for c in ph.cols]
@@ -618,10 +621,12 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
                 D = np.full(LANES, NO_ROW, dtype=np.uint32)
                 mask = np.zeros(LANES, dtype=np.uint32)
                 kmax = 1
+                lr = np.full(LANES, -1, dtype=np.int32)
                 for t, (rp, j, k, sr) in enumerate(ch):
                     if rp < 0:
                         lane_c[t], lane_v[t] = np.zeros(sr, dtype=np.int64), np.zeros(sr)
                         continue
+                    lr[t] = rp
                     c, v = np.asarray(col_slots[rp], dtype=np.int64), np.asarray(ph.vals[rp], dtype=np.float64)
                     cs, vs = c[j * sr:(j + 1) * sr], v[j * sr:(j + 1) * sr]
                     pad = sr - len(cs)
@@ -647,6 +652,7 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
                     n_ent += cnt
                 ctab.append([L, S, first, 1 | (2 if ph.accumulate else 0) | (4 if ph.deferred else 0)])
                 desc.append(D)
+                lane_row.append(lr)
                 first += n_ent
             continue
         _, _, plan = _chunk_plan(lens)
@@ -659,10 +665,12 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
             lane_c = [np.zeros(0, dtype=np.int64)] * LANES
             lane_v = [np.zeros(0)] * LANES
             D = np.full(LANES, NO_ROW, dtype=np.uint32)
+            lr = np.full(LANES, -1, dtype=np.int32)
             for k, oi in enumerate(order):
                 rp, seg = sel[oi], segs[oi]
                 base = k * g
                 D[base] = out_slots[rp]
+                lr[base:base + g] = rp
                 c, v = np.asarray(col_slots[rp], dtype=np.int64), np.asarray(ph.vals[rp], dtype=np.float64)
                 for t in range(g):
                     cs, vs = c[t * seg:(t + 1) * seg], v[t * seg:(t + 1) * seg]
@@ -681,6 +689,7 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
                 n_ent += cnt
             ctab.append([L, int(np.log2(g)), first, (2 if ph.accumulate else 0) | (4 if ph.deferred else 0)])
             desc.append(D)
+            lane_row.append(lr)
             first += n_ent
     vals.append(np.zeros(1))
     cols.append(np.zeros(1, dtype=np.uint16))
@@ -689,7 +698,8 @@ def _pack_ragged(phases: List[Phase], N: int, balanced=False, stage_scale: float
         desc=np.asarray(desc, dtype=np.uint32).reshape(-1, LANES),
         vals=np.concatenate(vals), cols=np.concatenate(cols).astype(np.uint16),
         n_phases=len(phases), n_slots=n_slots, final_pos=final_pos,
-        chunk_phase=np.asarray(chunk_phase, dtype=np.int32))
+        chunk_phase=np.asarray(chunk_phase, dtype=np.int32),
+        lane_row=np.asarray(lane_row, dtype=np.int32).reshape(-1, LANES))
 
 
 def execute_ragged(prog: RaggedProgram, w: np.ndarray) -> np.ndarray:
