@@ -116,6 +116,18 @@ def team_kernel_in_use(solver) -> bool:
     return v.value == 1.0
 
 
+def squad_kernel_in_use(solver) -> bool:
+    """does the shared-factor handle of this solver run the squad kernel (the family's solve program in registers, W instances per
+    workgroup of W wavefronts: cpg_osqp_squad.h)?"""
+    import ctypes as _C
+    h = getattr(solver, 'h_shared', None)
+    if h is None or not h.value:
+        return False
+    v = _C.c_double(0)
+    solver.lib.L.cpg_hip_get_setting(h, b'squad_executor', _C.byref(v))
+    return v.value == 1.0
+
+
 def resident_kernel_in_use(solver) -> bool:
     """does the per-instance factor handle of this solver run the resident kernel (family library with this family's resident executor)?"""
     import ctypes as _C
@@ -182,7 +194,7 @@ def _cpu_sweep(run, unit_per_probe: int, target_seconds: float, cap: int, unit: 
     best = max(sweep, key=sweep.get)
     Bf = int(max(2 * best, min(cap, 0.4 * target_seconds * sweep[best])))
     tf = run(Bf, 3, best)
-    return {'value': Bf / tf, 'unit': unit, 'cores': int(best), 'kind': 'port',
+    return {'value': Bf / tf, 'unit': unit, 'cores': int(best), 'kind': 'restatement', 'kind_contract': 'port',      # ("restatement" in every report; the bench contract's enum calls it a port)
             'single_thread': rate1, 'effective_cpus': int(eff), 'effective_cpus_from': how, 'omp_max_threads': omp_max,
             'thread_sweep': {str(k): round(v, 1) for k, v in sorted(sweep.items())},
             'sample': f'{Bf} instances of the same workload ({what}), OpenMP static over instances on {best} threads, {tf:.1f} s wall; '
@@ -421,11 +433,17 @@ def main():
         gather_ms += 1e3 * (time.perf_counter() - ts) - kernel_ms[-1]
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if dist is not None:
         import torch
+        mine_ms = 1e3 * elapsed / max(1, args.steps)
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own clock around the same steps: the spread says whether a rank (a GPU, its xGMI link to the root) lags
+        tl = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([mine_ms], dtype=torch.float64))
+        rank_ms = [float(v.item()) for v in tl]
 
     hybrid = desc.solver == 'OSQP' and bool(getattr(solver, '_hybrid', False)) and solver.h is solver.h_shared
     phase = solver.last_phase_ms() if hybrid else None      # split of the last step: (ms shared, ms per-instance, handed over)
@@ -439,8 +457,14 @@ def main():
         alli = gather.fetch('iter', dev._ptrs['iter'], 4, Btot, np.int32)
         alls = gather.fetch('status', dev._ptrs['status'], 4, Btot, np.int32)
         if rank == 0:
+            # the root must hold EVERY rank's rows after the last step: a shard the gather did not deliver would still carry the
+            # fill pattern of the root's buffers (iteration count 0 / status 0 are not results of any solve)
+            per_rank_ok = [bool((alli[r * B:(r + 1) * B] > 0).all() and np.isin(alls[r * B:(r + 1) * B], (1, 2, 3, 4, 5, 6, 7, 9)).all()) for r in range(world)]
+            if not all(per_rank_ok):
+                raise RuntimeError(f'gather incomplete: ranks whose rows are missing at the root: {[r for r, ok in enumerate(per_rank_ok) if not ok]}')
             stats = {'mean_iter': float(alli.mean()), 'max_iter': int(alli.max()),
-                     'solved': int((alls == 1).sum()), 'not_solved': int((alls != 1).sum())}
+                     'solved': int((alls == 1).sum()), 'not_solved': int((alls != 1).sum()),
+                     'ranks_delivered': int(sum(per_rank_ok))}
 
     # whole path from host memory (H2D of theta + kernel + D2H of the results), N = 1 only:
     # page-locked buffers, transfers of batch i +- 1 hidden behind the kernel of batch i
@@ -493,7 +517,7 @@ def main():
                     traffic = rec['fetch_bytes'] + rec['write_bytes']
                     binding = rec.get('binding_resource') or binding
                     binding_num = rec.get('binding')
-                    traffic_src = f"{rec.get('source')}; kernel {rec.get('kernel')}"
+                    traffic_src = f"{rec.get('source')}; recorded {rec.get('recorded', 'date not recorded')}; source fingerprint {rec.get('source_fingerprint')}; kernel {rec.get('kernel')}"
                 else:
                     traffic_stale = f"record {key} of profiles/hbm_traffic.json was taken on other kernel sources ({rec.get('source_fingerprint')}): refused"
         except (OSError, ValueError, KeyError):
@@ -502,7 +526,8 @@ def main():
                  'registers/LDS, so this path is latency / LDS bound, not HBM bound (DESIGN.md section 6)')
         per_instance_kernel = desc.solver == 'OSQP' and solver.h is solver.h_ref
         rpl = (getattr(solver, '_rplan_s', None) if hybrid else getattr(solver, '_rplan', None)) if desc.solver == 'OSQP' else None
-        kernel_name = ('clarabel_kernel' if args.workload == 'adp' else 'osqp_refactor_kernel' if per_instance_kernel else 'osqp_shared_kernel')
+        shared_kernel = 'osqp_squad_kernel' if (desc.solver == 'OSQP' and squad_kernel_in_use(solver)) else 'osqp_shared_kernel'
+        kernel_name = ('clarabel_kernel' if args.workload == 'adp' else 'osqp_refactor_kernel' if per_instance_kernel else shared_kernel)
         units = B
         stream = None
         out_plan_extra = {}
@@ -523,27 +548,25 @@ def main():
             gv = _C.c_double(0)
             solver.lib.L.cpg_hip_get_setting(solver.h_rs, b'generated_instance_executor', _C.byref(gv))
             inst_kernel = 'osqp_instance_kernel' if gv.value else 'osqp_refactor_kernel'
-            phases = {'shared_factor': {'kernel': 'osqp_shared_kernel', 'ms': ms1, 'instances': B,
+            phases = {'shared_factor': {'kernel': shared_kernel, 'ms': ms1, 'instances': B,
                                         'iterations_estimate': int(it1.sum())},
                       'per_instance_factor': {'kernel': inst_kernel, 'ms': ms2, 'instances': n_ho,
                                               'iterations_estimate': int((it - it1)[ho].sum()), 'handed_over_by_iteration_count': int(ho.sum()),
                                               'note': 'instances handed over after a rho change: numeric LDL\' for the new rho, then ADMM with their own factor'}}
-            # a kernel of the two-kernel step is priced for the algorithmic bytes IT moves: the shared-factor kernel reads theta of every
-            # instance and writes the results of the instances it finishes itself; the ones it hands over get theirs from the kernel behind it
+            # ONE accounting for the two-kernel step (round-5 review, item 5): a "launch" is the step's pair of kernels on one stream --
+            # every instance's theta goes in and every instance's solution comes out exactly once across the two --, so the algorithmic
+            # bytes are SURVEY 8(d)'s per-instance figure x all instances and the time is the sum of the two kernel times (HIP events:
+            # ev0 .. ev_mid .. ev1); the split per kernel is in `phases`
             units = B
-            algorithmic_bytes_launch = 8 * solver.np_var * B + (bytes_per_inst - 8 * solver.np_var) * max(0, B - int(n_ho))
-            if ms2 > ms1:
-                algorithmic_bytes_launch = (bytes_per_inst - 8 * solver.np_var) * int(n_ho)
-                kernel_name, units, k_ms = inst_kernel, n_ho, ms2
-                # the hand-over adds the workspace (n + 2m + 1 doubles) written by the kernel in front and read here
-                it2 = float((it - it1)[ho].mean()) if ho.any() else 0.0
-                stream = None if gv.value else {'bytes_per_instance': int(it2 * sv), 'what': f'{it2:.1f} iterations x {sv} B of per-instance substitution coefficients',
-                          'achieved': it2 * sv * n_ho / (ms2 * 1e-3) / 1e9}
-                rnote = ('dominant kernel of the two-kernel step: per-instance factor phase of the instances whose rho changed; `achieved` prices SURVEY.md 8(d) '
-                         'bytes per instance it serves' + ('; the generated instance executor keeps the factor in registers: no coefficient stream (DESIGN.md section 4.5)' if gv.value else
-                         ', `stream` the coefficients it actually streams per iteration (DESIGN.md section 4.5)'))
-            else:
-                k_ms = ms1
+            algorithmic_bytes_launch = bytes_per_inst * B
+            kernel_name = f'{shared_kernel} + {inst_kernel}'
+            k_ms = ms1 + ms2
+            it2 = float((it - it1)[ho].mean()) if ho.any() else 0.0
+            stream = None if gv.value else {'bytes_per_instance': int(it2 * sv), 'what': f'{it2:.1f} iterations x {sv} B of per-instance substitution coefficients',
+                      'achieved': it2 * sv * n_ho / (ms2 * 1e-3) / 1e9}
+            rnote = ('two kernels per step (shared factor until an instance\'s rho changes, per-instance factor behind it): `achieved` = SURVEY.md 8(d) bytes per '
+                     'instance x all instances / (sum of the two kernel times); compulsory traffic only -- the iteration state never leaves registers / LDS, '
+                     'the path is LDS / issue / latency bound, not HBM bound (DESIGN.md sections 4.5, 6)')
         elif per_instance_kernel and team_kernel_in_use(solver):
             # team per-instance factor kernel (cpg_osqp_team.h): one workgroup of W wavefronts per instance, coefficients, operand
             # offsets and output slots of a wavefront's steps in its registers -- no coefficient stream
@@ -620,9 +643,9 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': (f'REPLAYED, not measured in this run: bytes per step (all kernels of the step) from the rocprofv3 PMC '
                                           f'passes recorded in profiles/hbm_traffic.json ({traffic_src})') if traffic else traffic_stale,
-                         'frac_step': (bytes_per_inst * B / (1e-3 * 1e3 * elapsed / args.steps) / 1e9 / HBM_PEAK_GBS) if elapsed > 0 else 0.0,
                          'binding_resource': binding,
-                         'binding': next((dict(v, kernel=k) for k, v in (binding_num or {}).items() if kernel_name in k), None),
+                         # busy fractions per kernel of the step (LDS array, VALU, HBM side, share of wave cycles waiting) from the stamped PMC record
+                         'binding': [dict(v, kernel=k) for k, v in (binding_num or {}).items() if any(nm in k for nm in kernel_name.split(' + '))] or None,
                          'kernel': kernel_name, 'kernel_ms': k_ms, 'units_per_launch': int(units), 'algorithmic_bytes_per_launch': int(algorithmic_bytes_launch),
                          'algorithmic_bytes_per_instance': bytes_per_inst, 'stream': stream,
                          'note': rnote},
@@ -636,6 +659,10 @@ def main():
         if world > 1:
             out['config']['gather'] = ('left out of the timed steps (--no-gather)' if args.no_gather else gather_kind)
             out['config']['gather_ms_per_step_rank0'] = gather_ms / max(1, args.steps)
+            # what travels per step: every non-root rank's result rows (solutions + the five info scalars), point to point to the root
+            out['config']['gather_bytes_per_step'] = int(sum(rb for (rb, dt, tail, nm) in spec.values()) * B * (world - 1))
+            if rank_ms is not None:
+                out['config']['rank_ms_per_step'] = {'min': min(rank_ms), 'max': max(rank_ms), 'per_rank': [round(v, 3) for v in rank_ms]}
         if world == 1 and not args.no_cpu_baseline and not args.all_params:
             if args.workload == 'portfolio':
                 out['cpu_baseline'] = cpu_baseline_portfolio(desc, args.cpu_seconds, **oracle_mode)

@@ -15,6 +15,7 @@
 #include "cpg_osqp_refactor.h"
 #include "cpg_osqp_resident.h"
 #include "cpg_osqp_team.h"
+#include "cpg_osqp_squad.h"
 #include "cpg_clarabel_kernel.h"
 
 // ------------------------------------------------------------------------------------ runtime layer
@@ -60,7 +61,8 @@ struct cpg_solver_s {
     DevBuf g_theta, g_x, g_y, g_dprim, g_dtheta;
     cpg::DevSettings S{};
     int waves_per_block = 0, inst_per_wave = 1, blocks_per_cu = 0;
-    int program_in_lds = -1;            // -1 auto, 0 stream from L2/HBM, 1 resident in LDS
+    int program_in_lds = -1;            // -1 auto, 0 stream from L2/HBM, 1 resident in LDS, 3 squad executor (program in registers)
+    bool squad_ok = false;              // family library with this family's squad executor (cpg_osqp_squad.h)
     int num_cu = 256;
     size_t lds_limit = 160 * 1024;
     unsigned *d_counter = nullptr;
@@ -351,6 +353,25 @@ static int launch_team(cpg_handle_t h, rt_stream_t stream, const cpg::DevSetting
     return CPG_OK;
 }
 #endif
+#ifdef CPG_GENQ_HEADER
+// squad shared-factor kernel (cpg_osqp_squad.h): a workgroup of CPG_GENQ_W wavefronts solves CPG_GENQ_W instances at a time with the
+// family's solve program in its registers; two wavefronts per SIMD (256 VGPRs)
+template <int NSX, int NSZ, int NV>
+__global__ void __launch_bounds__(CPG_GENQ_W * 64, 2)
+osqp_squad_kernel(cpg::DevFamily F, cpg::DevUpdate U, cpg::DevSettings S, cpg::DevBatch Bt) {
+    extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
+    cpg::osqp_squad_body<NSX, NSZ, NV>(F, U, S, Bt, cpg_lds);
+}
+template <int NSX, int NSZ, int NV>
+static int launch_squad_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, size_t lds) {
+    auto kern = osqp_squad_kernel<NSX, NSZ, NV>;
+    if (lds > 48 * 1024)
+        RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(CPG_GENQ_W * 64), lds, h->stream, h->F, h->U, h->S, Bt);
+    RT_CHECK(hipGetLastError());
+    return CPG_OK;
+}
+#endif
 #ifndef CPG_KERNELS_REFACTOR
 #define CPG_KERNELS_REFACTOR(Z) Z(1, 1) Z(4, 4) Z(8, 8) Z(16, 16)
 #endif
@@ -455,6 +476,21 @@ static int launch(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves
     set_error("no compiled kernel for this family size / launch geometry");
     return CPG_E_UNSUPPORTED;
 }
+
+#ifdef CPG_GENQ_HEADER
+static int launch_squad(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, size_t lds) {
+    const int nsx = (h->F.n + 63) / 64, nsz = (h->F.m + 63) / 64;
+    const int nvx = (h->n_vary_x + 63) / 64, nvz = (h->n_vary_z + 63) / 64;
+    const int nv = nvx > nvz ? nvx : nvz;
+#define Y(a, b, v, g, wm)                                                                         \
+    if (nsx == a && nsz == b && (nv <= v || (v >= a && v >= b)) && g == 1)                        \
+        return launch_squad_t<a, b, v>(h, Bt, blocks, lds);
+    CPG_KERNELS_LDS(Y)
+#undef Y
+    set_error("no compiled squad kernel for this family size");
+    return CPG_E_UNSUPPORTED;
+}
+#endif
 
 // ------------------------------------------------------------------------------------ C-ABI
 extern "C" {
@@ -625,6 +661,7 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     else if (s == "adaptive_rho_tolerance") *v = h->S.adaptive_rho_tolerance;
     else if (s == "check_dualgap") *v = h->S.check_dualgap;
     // (read-only facts about the handle) 1: per-instance solves of this handle run the generated instance executor
+    else if (s == "squad_executor") *v = (!h->refactor_mode && !h->conic && h->squad_ok && h->program_in_lds == 3 && h->inst_per_wave == 1) ? 1.0 : 0.0;
     else if (s == "team_executor") *v = (h->refactor_mode && h->Rs.ok == 2 && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else if (s == "resident_executor") *v = (h->refactor_mode && h->Rs.ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else if (s == "generated_instance_executor") *v = (h->refactor_mode && h->R.gi_ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
@@ -794,6 +831,9 @@ int cpg_hip_create_osqp(const cpg_osqp_family_t *f, int device, cpg_handle_t *ou
         }
 #endif
         h->program_in_lds = 1;
+#ifdef CPG_GENQ_HEADER
+        h->squad_ok = true;          // (generated from the same plan as the LDS executor: CPG_GENQ_PARENT_FINGERPRINT, checked at compile time)
+#endif
     }
 #endif
     F.n_slots = f->n_slots;
@@ -1922,7 +1962,7 @@ static int ensure(DevBuf &b, size_t bytes) {
 }
 
 int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds) {
-    if (!h || in_lds < -1 || in_lds > 2) { set_error("in_lds must be -1, 0, 1 or 2"); return CPG_E_BADARG; }
+    if (!h || in_lds < -1 || in_lds > 3) { set_error("in_lds must be -1, 0, 1, 2 or 3"); return CPG_E_BADARG; }
     h->program_in_lds = in_lds;
     return CPG_OK;
 }
@@ -2129,6 +2169,47 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
     if (two_phase && !h->linked->refactor_mode) { set_error("linked handle has no per-instance factor tables (cpg_hip_set_refactor)"); return CPG_E_BADARG; }
     const int G = h->inst_per_wave;
     const size_t N = (size_t)(h->F.n + h->F.m);
+#ifdef CPG_GENQ_HEADER
+    if (h->squad_ok && G == 1 && h->program_in_lds == 3) {
+        // squad executor (on request: it lost the A/B against the LDS-resident program on MI355X, HISTORY.md round 6): CPG_GENQ_W
+        // instances per workgroup of CPG_GENQ_W wavefronts, the program in their registers
+        const size_t lds_q = cpg::squad_lds_bytes((unsigned)h->F.n, (unsigned)h->F.m);
+        if (lds_q <= h->lds_limit) {
+            int per_cu = (int)(h->lds_limit / lds_q);
+            const int by_regs = 8 / CPG_GENQ_W > 0 ? 8 / CPG_GENQ_W : 1;     // two wavefronts per SIMD
+            if (per_cu > by_regs) per_cu = by_regs;
+            if (h->blocks_per_cu > 0 && per_cu > h->blocks_per_cu) per_cu = h->blocks_per_cu;
+            long long blocks = (B + CPG_GENQ_W - 1) / CPG_GENQ_W;
+            const long long cap = (long long)h->num_cu * per_cu;
+            if (blocks > cap) blocks = cap;
+            cpg::DevBatch Bt = make_batch(B, d_theta, d_state_in, d_state_out, d_prim, d_dual, d_obj, d_iter, d_status, d_pri, d_dua);
+            Bt.counter = h->d_counter;
+            const size_t state_bytes = (size_t)B * ((size_t)h->F.n + 2 * (size_t)h->F.m + 1) * sizeof(double);
+            if (two_phase) {
+                if (!d_state_out) { if ((rc = ensure(h->ho_state, state_bytes))) return rc; }
+                if ((rc = ensure(h->ho_list, (size_t)B * sizeof(int)))) return rc;
+                Bt.ho_state = d_state_out ? d_state_out : (double *)h->ho_state.p;
+                Bt.ho_list = (int *)h->ho_list.p; Bt.ho_count = h->d_counter + 1;
+            }
+            RT_CHECK(hipMemsetAsync(h->d_counter, 0, 4 * sizeof(unsigned), h->stream));
+            RT_CHECK(hipEventRecord(h->ev0, h->stream));
+            rc = launch_squad(h, Bt, (int)blocks, lds_q);
+            if (rc) return rc;
+            h->two_phase_last = two_phase;
+            if (two_phase) {
+                RT_CHECK(hipEventRecord(h->ev_mid, h->stream));
+                cpg::DevBatch B2 = make_batch(B, d_theta, Bt.ho_state, d_state_out, d_prim, d_dual, d_obj, d_iter, d_status, d_pri, d_dua);
+                B2.counter = h->d_counter + 2; B2.list = Bt.ho_list; B2.list_count = h->d_counter + 1; B2.resume = 1;
+                rc = launch_per_instance(h->linked, h->stream, h->S, B2);
+                if (rc) return rc;
+            }
+            RT_CHECK(hipEventRecord(h->ev1, h->stream));
+            return CPG_OK;
+        }
+        if (h->program_in_lds == 3) { set_error("the squad executor's LDS need exceeds the device limit"); return CPG_E_UNSUPPORTED; }
+    }
+#endif
+    if (h->program_in_lds == 3) { set_error("this library carries no squad executor for the family (cpg_hip_set_program_placement(3))"); return CPG_E_UNSUPPORTED; }
 #if defined(CPG_GEN_HEADER) && defined(CPG_GEN_N)
     const size_t per_wave = (size_t)G * (h->F.n_slots + CPG_GEN_EXTRA_SLOTS) * sizeof(double);
 #else

@@ -23,8 +23,22 @@
 #include "cpg_osqp_kernel.h"
 
 #ifdef CPG_GENQ_HEADER
+// experiments only (-DCPG_SQUAD_PROBE): wavefront w of workgroup 0 leaves the shader clock behind every barrier of one run of
+// iterations in a device array and prints it when the kernel ends
+#ifdef CPG_SQUAD_PROBE
+namespace cpg { __device__ unsigned long long squad_probe[8 * 128]; __device__ int squad_probe_on; }
+#define CPG_SQUAD_TS(K) do { if (cpg::squad_probe_on && blockIdx.x == 0 && (threadIdx.x & 63) == 0) cpg::squad_probe[(threadIdx.x >> 6) * 128 + (K)] = __builtin_readcyclecounter(); } while (0)
+#ifdef CPG_SQUAD_PROBE_FINE
+#define CPG_SQUAD_TS2(K) CPG_SQUAD_TS(K)
+#else
+#define CPG_SQUAD_TS2(K) do { } while (0)
+#endif
+#else
+#define CPG_SQUAD_TS2(K) do { } while (0)
+#define CPG_SQUAD_TS(K) do { } while (0)
+#endif
 namespace cpg {
-struct alignas(16) SquadPair { double a, b; };
+typedef double SquadPair __attribute__((vector_size(16)));       // two instances' entries of one slot: a 16-byte LDS access
 }
 #include CPG_GENQ_HEADER
 
@@ -35,7 +49,6 @@ namespace cpg {
 #endif
 
 // bytes of LDS a squad needs: base vectors | control words | pair arrays | one plain vector per wavefront (termination test)
-CPG_DEV constexpr unsigned squad_ctl_doubles() { return 16u; }
 constexpr unsigned squad_lds_bytes(unsigned n, unsigned m) {
     return 8u * (n + m + ((n + m) & 1u)) + 8u * 16u + (CPG_GENQ_W / 2) * CPG_GENQ_PAIR_STRIDE + CPG_GENQ_W * 8u * (n + m + ((n + m) & 1u));
 }
@@ -78,14 +91,22 @@ CPG_DEV void osqp_squad_body(const DevFamily &F, const DevUpdate &U, const DevSe
     const double rho_eq = 1e3 * F.rho, rho_in = F.rho, rho_fr = 1e-6;
     const double ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in, ri_fr = 1.0 / rho_fr;
     signed char ct_reg[NSZ];
-    unsigned short fpx[NSX], fpz[NSZ];
+    // where the program leaves entry i of the solution: BYTE offsets into a pair array (slot * 16), two per register -- the read-out
+    // adds a half-word to the (per-iteration opaque) base: one instruction per entry, nothing to hoist and keep alive
+    unsigned fpp[(NSX + NSZ + 1) / 2];
 #pragma unroll
-    for (int s = 0; s < NSX; s++) { const unsigned i = (unsigned)lane0 + 64u * (unsigned)s; fpx[s] = (i < n_c) ? cpgw::gld(F.fpos, i) : 0; }
+    for (int s = 0; s < (NSX + NSZ + 1) / 2; s++) fpp[s] = 0u;
+#pragma unroll
+    for (int s = 0; s < NSX + NSZ; s++) {
+        const unsigned i = s < NSX ? (unsigned)lane0 + 64u * (unsigned)s : n_c + (unsigned)lane0 + 64u * (unsigned)(s - NSX);
+        const bool in = s < NSX ? i < n_c : i < N;
+        const unsigned fp = in ? 16u * (unsigned)cpgw::gld(F.fpos, i) : 0u;
+        fpp[s / 2] |= (s & 1) ? fp << 16 : fp;
+    }
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane0 + 64u * (unsigned)s;
         ct_reg[s] = (i < m_c) ? cpgw::gld(F.ctype, i) : 0;
-        fpz[s] = (i < m_c) ? cpgw::gld(F.fpos, n_c + i) : 0;
     }
     const int chk_int = S.check_termination;
     const int ad_int = (S.adaptive_rho && S.adaptive_rho_interval > 0) ? S.adaptive_rho_interval : 0;
@@ -234,6 +255,7 @@ CPG_DEV void osqp_squad_body(const DevFamily &F, const DevUpdate &U, const DevSe
             constexpr bool STASH = decltype(stash_c)::value;
             const int ln = cpgw::opaque(lane);
             cpgw::assume((unsigned)ln < 64u);
+            const CPG_LDS char *mine_o = cpgw::pin_lds(mine);
             signed char ct[NSZ];
 #pragma unroll
             for (int s = 0; s < NSZ; s++) ct[s] = (signed char)cpgw::opaque((int)ct_reg[s]);
@@ -248,7 +270,7 @@ CPG_DEV void osqp_squad_body(const DevFamily &F, const DevUpdate &U, const DevSe
                 for (int s = 0; s < NSX; s++) {
                     const unsigned i = (unsigned)ln + 64u * (unsigned)s;
                     if (i < n_c) {
-                        const double xn = F.alpha * *(const CPG_LDS double *)(mine + 16u * fpx[s]) + (1.0 - F.alpha) * I.x[s];
+                        const double xn = F.alpha * *(const CPG_LDS double *)(mine_o + ((s & 1) ? fpp[s / 2] >> 16 : fpp[s / 2] & 0xFFFFu)) + (1.0 - F.alpha) * I.x[s];
                         if (STASH) dxr[s] = xn - I.x[s];
                         I.x[s] = xn;
                     }
@@ -262,7 +284,7 @@ CPG_DEV void osqp_squad_body(const DevFamily &F, const DevUpdate &U, const DevSe
                         const double rv = cts == 1 ? rho_eq : (cts == 0 ? rho_in : rho_fr);
                         const double ri = cts == 1 ? ri_eq : (cts == 0 ? ri_in : ri_fr);
                         const double zp = I.z[s], yp = I.y[s];
-                        const double zt = (zp - ri * yp) + ri * *(const CPG_LDS double *)(mine + 16u * fpz[s]);
+                        const double zt = (zp - ri * yp) + ri * *(const CPG_LDS double *)(mine_o + (((NSX + s) & 1) ? fpp[(NSX + s) / 2] >> 16 : fpp[(NSX + s) / 2] & 0xFFFFu));
                         const double zr = F.alpha * zt + (1.0 - F.alpha) * zp;
                         const double uu = SharedCtx<NSX, NSZ, NV>{F, sh, shu, I, wp, ln}.u(s, i);
                         const double zn = cts == 1 ? uu : cpgw::dmin2(zr + ri * yp, uu);
@@ -273,17 +295,25 @@ CPG_DEV void osqp_squad_body(const DevFamily &F, const DevUpdate &U, const DevSe
                     CPG_FENCE_EVERY(s);
                 }
             }
+            cpgw::lds_order();          // the read-out above before the next right-hand side (other lanes' slots)
         };
         double dxr[NSX], dyr[NSZ];
         int it = 0;
 #pragma nounroll
         for (;;) {
             it++;
+#ifdef CPG_SQUAD_PROBE
+            if (blockIdx.x == 0 && lane == 0) squad_probe_on = (it == 7 && iter == 25) ? 1 : 0;
+#endif
+            CPG_SQUAD_TS(30);
             rhs();
+            CPG_SQUAD_TS(31);
             cpgw::block_sync();
+            CPG_SQUAD_TS(0);
             run_program_squad(cf, of, rw, pairs, wave);      // (ends with a barrier: every result is in place)
             if (it >= k) break;
             update(std::false_type{}, dxr, dyr);
+            CPG_SQUAD_TS(32);
         }
         update(std::true_type{}, dxr, dyr);
         if (active) {
@@ -294,6 +324,17 @@ CPG_DEV void osqp_squad_body(const DevFamily &F, const DevUpdate &U, const DevSe
             if (iter >= next_ev) event(dxr, dyr);
         }
     }
+#ifdef CPG_SQUAD_PROBE
+    if (blockIdx.x == 0 && lane0 == 0) {
+        const unsigned long long *t = squad_probe + wave * 128;
+        for (int v = 0; v < wave; v++) __builtin_amdgcn_s_sleep(127);
+        printf("squad probe wave %d: rhs %llu sync %llu\n", wave, t[31] - t[30], t[0] - t[31]);
+        for (int p = 1; p <= 20 && t[p]; p++)
+            printf("  wave %d phase %d: %llu  (gathers back %lld, multiply-adds issued %lld, reduce + stores done %lld, barrier %lld)\n", wave, p - 1, t[p] - t[p - 1],
+                   t[40 + 4 * (p - 1)] ? (long long)(t[40 + 4 * (p - 1)] - t[p - 1]) : -1ll, t[41 + 4 * (p - 1)] ? (long long)(t[41 + 4 * (p - 1)] - t[40 + 4 * (p - 1)]) : -1ll,
+                   t[41 + 4 * (p - 1)] ? (long long)(t[42 + 4 * (p - 1)] - t[41 + 4 * (p - 1)]) : -1ll, (long long)(t[p] - t[42 + 4 * (p - 1)]));
+    }
+#endif
 }
 
 }  // namespace cpg

@@ -68,6 +68,15 @@ CPG_DEV double seg_sum_first(double v, unsigned mask) {
     if (S >= 3) { const double t = row_shl<4>(v); v += (mask & 4u) ? t : 0.0; }
     return v;
 }
+// The same with the stage masks as 64-bit LANE masks known at code-generation time (lane t adds lane t + 2^j iff bit t of Mj):
+// two scalar moves and a select per stage -- no per-lane mask register, no compare
+template <int S>
+CPG_DEV double seg_sum_first_lit(double v, unsigned long long m0, unsigned long long m1, unsigned long long m2) {
+    if (S >= 1) v += lane_select(m0, row_shl<1>(v));
+    if (S >= 2) v += lane_select(m1, row_shl<2>(v));
+    if (S >= 3) v += lane_select(m2, row_shl<4>(v));
+    return v;
+}
 CPG_DEV double seg_sum_first_dyn(double v, unsigned mask, int stages) {   // stages wave-uniform
     switch (stages) {
         case 0: return v;

@@ -58,6 +58,14 @@ CPG_DEV double dpp_move_zero(double v) {   // invalid source lanes deliver 0 (bo
 template <int N>
 CPG_DEV double row_shl(double v) { return dpp_move_zero<0x100 + N>(v); }
 
+// v on the lanes whose bit of the (wave-uniform, here: literal) 64-bit mask is set, 0.0 on the others: v_cndmask with the mask in a
+// scalar register pair
+CPG_DEV double lane_select(unsigned long long mask, double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(lo) : "v"(lo), "s"(mask));
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(hi) : "v"(hi), "s"(mask));
+    return __hiloint2double(hi, lo);
+}
 CPG_DEV double read_lane(double v, int lane) {   // `lane` must be wave-uniform
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);

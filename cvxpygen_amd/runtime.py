@@ -246,6 +246,11 @@ class FamilyPlan:
     # path uses whose matrices are the code-generation-time ones -- the shared solve program and the
     # per-instance factors of shared-matrix mode (rho adaptation, rows that changed class)
     osqp_shared: Optional[_setup.OsqpPlan] = None
+    # what the solve program was packed from: its phases (logical entries = device positions before the bank-aware numbering)
+    # and that numbering -- codegen packs the same phases once more for the squad executor (pack_ragged(team=W))
+    phases: Optional[list] = None
+    slot_perm: Optional[np.ndarray] = None
+    kkt_squad: Optional[_sp.RaggedProgram] = None      # the same program packed for the squad executor (None: it does not fit / is off)
 
 
 def _instance_fingerprints(lib_path: str, stem: str = 'cpg_instance', prefix: str = 'GENI'):
@@ -329,15 +334,32 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         # ... together with the order of every row's entries among the row's (lane, step) cells (round 6: the numbering alone
         # left 0.85 extra LDS cycles per 32-lane gather group; with the entries free to choose their step, 0.14)
         entry_order = os.environ.get('CPG_ENTRY_ORDER', '1') != '0'
-        if entry_order:
-            pi, eperm, pad_slot, c0, c1 = _sl.optimise_entries(rg0, region, pad0, seed=0, stores=stores,
-                                                               sweeps=int(os.environ.get('CPG_BANK_SWEEPS', 60)))
+        sweeps = int(os.environ.get('CPG_BANK_SWEEPS', 60))
+        # the squad executor (codegen.emit_squad_program: the same phases packed for a team of W wavefronts, coefficients in
+        # registers; placement 3, an experiment that lost against the LDS-resident program: HISTORY.md round 6) shares the
+        # numbering -- chosen for the LDS executor's gathers -- and gets the order of its own entries for it (16-byte reads of a
+        # pair array: four groups of 16 lanes, slots collide modulo 16; stores in groups of 8 lanes, modulo 8)
+        from . import codegen as _cg
+        rq0 = None
+        if entry_order and _cg.SQUAD:
+            rq0 = _cg.pack_squad(phases, N)
+            if not _cg.squad_fits(desc, rq0, _cg.SQUAD_WAVES):
+                rq0 = None
+        if rq0 is not None:
+            if len(region) == rg0.n_slots:                 # (the squad's work vectors always carry the dummy slots and the zero slot)
+                region = np.concatenate([region, 1000 + np.arange(_sp.GEN_EXTRA_SLOTS)])
+            pi, eperm, pad_slot, c0, c1 = _sl.optimise_entries(rg0, region, pad0, seed=0, stores=stores, sweeps=sweeps)
+            stores_q = _sl.store_groups((rq0.desc & 0xFFFF).astype(np.int64), 0xFFFF, group=8)
+            _, eperm_q, pad_q, cq0, cq1 = _sl.optimise_entries(rq0, region, True, seed=0, stores=stores_q, sweeps=sweeps, keep_fresh=False,
+                                                               lane_group=_sl.B128_LANE_GROUP, mod=16, store_mod=8, pi0=pi, slot_moves=False)
+            bank_stats.update(squad_conflict_cycles_natural=int(cq0), squad_conflict_cycles=int(cq1))
+        elif entry_order:
+            pi, eperm, pad_slot, c0, c1 = _sl.optimise_entries(rg0, region, pad0, seed=0, stores=stores, sweeps=sweeps)
         else:
-            pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0, idle_zero=pad0), region, seed=0, stores=stores,
-                                      sweeps=int(os.environ.get('CPG_BANK_SWEEPS', 60)))
+            pi, c0, c1 = _sl.optimise(_sp.gathered_slots(rg0, idle_zero=pad0), region, seed=0, stores=stores, sweeps=sweeps)
         pi_all = pi
         pi = pi[:rg0.n_slots]
-        bank_stats = dict(bank_conflict_cycles_natural=int(c0), bank_conflict_cycles=int(c1))   # gathers + reduce-stores
+        bank_stats.update(bank_conflict_cycles_natural=int(c0), bank_conflict_cycles=int(c1))   # gathers + reduce-stores
         # the device ordering follows: the entry at device position p moves to position pi[p]
         ordx2 = np.empty_like(ordx); ordx2[pi[:n]] = ordx
         ordz2 = np.empty_like(ordz); ordz2[pi[n:N] - n] = ordz
@@ -352,7 +374,19 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
         ident_ = np.arange(len(region))
         bank_stats['bank_conflict_cycles_gathers'] = int(_sl.conflict_cycles(gs_, ident_))
         bank_stats['bank_conflict_cycles_stores'] = int(_sl.conflict_cycles(st_, ident_, [_sl.STORE_BANK_PAIRS] * len(st_)))
-        assert bank_stats['bank_conflict_cycles_gathers'] + bank_stats['bank_conflict_cycles_stores'] == bank_stats['bank_conflict_cycles']
+        # (the annealer's model = this recount when the offsets are stored for all 64 lanes of a step; in the ragged layout the idle
+        # lanes of a partial step read the entries that follow, which the recount sees and the annealer does not)
+        assert not pad0 or bank_stats['bank_conflict_cycles_gathers'] + bank_stats['bank_conflict_cycles_stores'] == bank_stats['bank_conflict_cycles']
+        bank_stats['bank_conflict_cycles'] = bank_stats['bank_conflict_cycles_gathers'] + bank_stats['bank_conflict_cycles_stores']
+    kkt_squad = None
+    if pi is not None and entry_order and rq0 is not None:
+        kkt_squad = _sl.apply_entries(_cg.pack_squad(phases, N, pi), eperm_q, pad_q, pi_all)
+        gq_ = _sl.gather_groups(_sp.gathered_slots(kkt_squad, idle_zero=True), _sl.B128_LANE_GROUP)
+        sq_ = _sl.store_groups((kkt_squad.desc & 0xFFFF).astype(np.int64), 0xFFFF, group=8)
+        ident_ = np.arange(len(region))
+        bank_stats['squad_conflict_cycles_gathers'] = int(_sl.conflict_cycles(gq_, ident_, [16] * len(gq_)))
+        bank_stats['squad_conflict_cycles_stores'] = int(_sl.conflict_cycles(sq_, ident_, [8] * len(sq_)))
+        assert bank_stats['squad_conflict_cycles_gathers'] + bank_stats['squad_conflict_cycles_stores'] == bank_stats['squad_conflict_cycles']
     if pi is not None:
         # final_pos is indexed by the logical entry the phases were compiled with (= old device position)
         fp = np.empty(N, dtype=np.int64); fp[pi[:N]] = kkt.final_pos
@@ -380,7 +414,7 @@ def build_family_plan(desc: FamilyDescriptor, ordering: str = 'mindeg', merge: b
                       n_vary_x=int(vary_q.sum()), n_vary_z=int(vary_u.sum()), kkt=kkt,
                       kkt_ragged=kkt_ragged, A_rows=A_rows,
                       P_rows=P_rows, At_rows=At_rows, prim_idx=prim_idx, dual_idx=dual_idx,
-                      stats=stats, osqp_shared=splan)
+                      stats=stats, osqp_shared=splan, phases=phases, slot_perm=pi, kkt_squad=kkt_squad)
 
 
 @dataclass

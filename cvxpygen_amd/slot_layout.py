@@ -31,13 +31,19 @@ BANK_PAIRS = 32          # 64 banks x 4 B; an 8-byte slot covers one aligned pai
 GROUP = 32               # lanes serviced together by a ds_read_b64
 
 
-def gather_groups(step_slots: np.ndarray) -> List[np.ndarray]:
+def gather_groups(step_slots: np.ndarray, lane_group=None) -> List[np.ndarray]:
     """step_slots [n_steps, 64]: slot gathered by every lane of every step (what the executor really
-    reads, idle lanes included).  Returns the distinct slots of every (step, 32-lane group)."""
+    reads, idle lanes included).  Returns the distinct slots of every (step, lane group): the two 32-lane halves of a
+    ds_read_b64, or the groups lane_group[lane] names (B128_LANE_GROUP: the four 16-lane groups of a ds_read_b128)."""
     out = []
     for row in step_slots:
-        for g in range(0, row.shape[0], GROUP):
-            out.append(np.unique(row[g:g + GROUP]))
+        if lane_group is None:
+            for g in range(0, row.shape[0], GROUP):
+                out.append(np.unique(row[g:g + GROUP]))
+        else:
+            lg = np.asarray(lane_group)
+            for g in range(int(lg.max()) + 1):
+                out.append(np.unique(row[lg == g]))
     return out
 
 
@@ -54,13 +60,13 @@ STORE_GROUP = 16         # lanes served together by a ds_write_b64 (four groups 
 STORE_BANK_PAIRS = 16    # ... over 32 four-byte banks: 8-byte slots collide modulo 16
 
 
-def store_groups(out_slots: np.ndarray, no_row: int) -> List[np.ndarray]:
+def store_groups(out_slots: np.ndarray, no_row: int, group: int = 16) -> List[np.ndarray]:
     """out_slots [n_chunks, 64]: slot every lane of a chunk's reduce-store writes (no_row: none, the lane
     writes a dummy slot).  Returns the distinct real slots of every (chunk, 16-lane group) with more than one."""
     out = []
     for row in out_slots:
-        for g in range(0, row.shape[0], STORE_GROUP):
-            sl = np.unique(row[g:g + STORE_GROUP])
+        for g in range(0, row.shape[0], group):
+            sl = np.unique(row[g:g + group])
             sl = sl[sl != no_row]
             if len(sl) > 1:
                 out.append(sl.astype(np.int64))
@@ -192,12 +198,14 @@ def optimise(step_slots: np.ndarray, region: np.ndarray, sweeps: int = 60, seed:
 # bipartite edge-colouring problem (lanes x bank pairs, colours = steps): conflict-free whenever no bank pair holds
 # more distinct operands of the half than the chunk has steps -- which the numbering can arrange.  Both freedoms are
 # annealed together on the exact cost (same model as `optimise`: calibrated with scripts/micro/lds_conflicts.hip).
-def entry_cells(prog, idle_zero: bool):
+def entry_cells(prog, idle_zero: bool, lane_group=None):
     """The (lane, step) cells of a RaggedProgram's flat entry array: per entry e its gather group (2 * step + half, steps
     numbered chunk by chunk as in `gathered_slots`), its row (unique per (chunk, row); pad cells of dummy lanes get a row of
     their own), its slot (cols // 8) and whether it is a pad (zero coefficient: any address will do).  Also the
     (group, slot) pairs of the idle lanes of partial steps when their offsets point at the zero slot (idle_zero)."""
     n_ent = prog.nnz - 1
+    lane_group = np.arange(64) // GROUP if lane_group is None else np.asarray(lane_group, dtype=np.int64)
+    NLG = int(lane_group.max()) + 1               # lane groups a gather instruction is served in
     grp = np.zeros(n_ent, dtype=np.int64)
     row = np.zeros(n_ent, dtype=np.int64)
     slot = (prog.cols[:n_ent].astype(np.int64)) // 8
@@ -222,20 +230,51 @@ def entry_cells(prog, idle_zero: bool):
         for s_ in range(L):
             cnt = int((ln > s_).sum())
             lanes = np.arange(cnt)
-            grp[e:e + cnt] = 2 * (step0 + s_) + lanes // GROUP
+            grp[e:e + cnt] = NLG * (step0 + s_) + lane_group[lanes]
             row[e:e + cnt] = lane_rowid[:cnt]
             if idle_zero and cnt < 64:
                 zs = prog.n_slots + 16          # GEN_DUMMY_SLOTS: the slot that always holds 0.0
-                for h in range(2):
-                    if cnt < (h + 1) * GROUP:
-                        fixed.append((2 * (step0 + s_) + h, zs))
+                for h in sorted({int(v) for v in lane_group[cnt:]}):
+                    fixed.append((NLG * (step0 + s_) + h, zs))
             e += cnt
         step0 += L
-    return grp, row, slot, pad, fixed, 2 * step0
+    return grp, row, slot, pad, fixed, NLG * step0
+
+
+def fresh_entries(prog) -> np.ndarray:
+    """per entry of the flat array: does it read a slot the PREVIOUS phase stores?  (The generated LDS executor issues the gathers
+    of a step before the previous phase has stored when no lane of the step does: codegen.emit_program_header `early`.)"""
+    n_ent = prog.nnz - 1
+    slot = prog.cols[:n_ent].astype(np.int64) // 8
+    fresh = np.zeros(n_ent, dtype=bool)
+    plist = sorted({int(p_) for p_ in prog.chunk_phase})
+    outs = {}
+    for c in range(prog.n_chunks):
+        o_ = (prog.desc[c] & 0xFFFF).astype(np.int64)
+        outs.setdefault(int(prog.chunk_phase[c]), set()).update(int(x) for x in o_ if int(x) != 0xFFFF)
+    for c in range(prog.n_chunks):
+        k_ = plist.index(int(prog.chunk_phase[c]))
+        if k_ == 0:
+            continue
+        prev = np.fromiter(outs[plist[k_ - 1]], dtype=np.int64)
+        first = int(prog.ctab[c, 2])
+        last = int(prog.ctab[c + 1, 2]) if c + 1 < prog.n_chunks else n_ent
+        fresh[first:last] = np.isin(slot[first:last], prev)
+    return fresh & (np.asarray(prog.vals[:n_ent]) != 0.0)
+
+
+# lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS section): four groups of 16 lanes, one LDS cycle each; 16-byte slots
+# collide modulo 16
+B128_LANE_GROUP = np.zeros(64, dtype=np.int64)
+for _g, _ranges in enumerate((((0, 4), (12, 16), (20, 28)), ((4, 12), (16, 20), (28, 32)), ((32, 36), (44, 48), (52, 60)), ((36, 44), (48, 52), (60, 64)))):
+    for _a, _b in _ranges:
+        B128_LANE_GROUP[_a:_b] = _g
 
 
 def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60, seed: int = 0,
-                     stores: List[np.ndarray] = ()) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int, int]:
+                     stores: List[np.ndarray] = (), keep_fresh: bool = True, lane_group=None, mod: int = BANK_PAIRS,
+                     store_mod: int = STORE_BANK_PAIRS, pi0=None, slot_moves: bool = True
+                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int, int]:
     """Returns (pi, eperm, pad_slot, cost before, cost after) for a RaggedProgram packed with the NATURAL numbering:
     pi[slot] = new position (as `optimise`); eperm: the entry that moves to flat position e is the old entry eperm[e]
     (entries only move between cells of their own row); pad_slot[e] >= 0: the (zero-coefficient) entry at position e
@@ -244,12 +283,16 @@ def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60
     import hashlib
     import os
     n = region.shape[0]
-    grp, row, slot0, pad, fixed, n_groups = entry_cells(prog, idle_zero)
+    grp, row, slot0, pad, fixed, n_groups = entry_cells(prog, idle_zero, lane_group)
     n_ent = len(grp)
+    # keep_fresh: an entry that reads what the previous phase stores only trades places with another one that does -- the steps
+    # whose gathers the LDS executor may issue early stay what they are
+    cls_ = fresh_entries(prog).astype(np.int64) if keep_fresh else np.zeros(n_ent, dtype=np.int64)
+    row = row * 2 + cls_
     hsh = hashlib.sha256()
     hsh.update(_source_version())
     for a_ in (grp, row, slot0, pad.astype(np.int64), np.asarray(fixed, dtype=np.int64).reshape(-1),
-               np.ascontiguousarray(region, dtype=np.int64), np.asarray([sweeps, seed, BANK_PAIRS, STORE_BANK_PAIRS, 6], dtype=np.int64), np.asarray([1e6 * float(os.environ.get(k_, v_)) for k_, v_ in (('CPG_ANNEAL_T0', 0.4), ('CPG_ANNEAL_T1', 0.05), ('CPG_ANNEAL_PENTRY', 0.6), ('CPG_ANNEAL_TENTRY', 0.3))], dtype=np.int64),
+               np.ascontiguousarray(region, dtype=np.int64), np.asarray([sweeps, seed, mod, store_mod, 7, int(keep_fresh), int(slot_moves)], dtype=np.int64), np.arange(n) if pi0 is None else np.asarray(pi0, dtype=np.int64), np.asarray([1e6 * float(os.environ.get(k_, v_)) for k_, v_ in (('CPG_ANNEAL_T0', 0.4), ('CPG_ANNEAL_T1', 0.05), ('CPG_ANNEAL_PENTRY', 0.6), ('CPG_ANNEAL_TENTRY', 0.3))], dtype=np.int64),
                *[np.ascontiguousarray(g_, dtype=np.int64) for g_ in stores]):
         hsh.update(np.ascontiguousarray(a_, dtype=np.int64).tobytes()); hsh.update(b'|')
     cdir = os.environ.get('CPG_LAYOUT_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'generated', '.layout_cache'))
@@ -264,9 +307,10 @@ def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60
     import random
     rnd = random.Random(seed)
     NG = n_groups
-    MODG = BANK_PAIRS
+    MODG = int(mod)
+    SMOD = int(store_mod)
     # ---- state (plain Python containers: the moves touch a handful of small integers each)
-    pos = list(range(n))                                   # slot -> position
+    pos = list(range(n)) if pi0 is None else [int(v) for v in pi0]        # slot -> position
     cell_slot = [(-1 if pad[e] else int(slot0[e])) for e in range(n_ent)]      # what the cell holds now (-1: a pad)
     cell_src = list(range(n_ent))                          # ... and which old entry that is
     cell_grp = [int(g_) for g_ in grp]
@@ -309,9 +353,9 @@ def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60
             st_of[x].append(k_)
     st_cnt = []
     for g_ in st_groups:
-        c_ = [0] * STORE_BANK_PAIRS
+        c_ = [0] * SMOD
         for x in g_:
-            c_[pos[x] % STORE_BANK_PAIRS] += 1
+            c_[pos[x] % SMOD] += 1
         st_cnt.append(c_)
     st_max = [max(c_) for c_ in st_cnt]
     cost = sum(gmax) - NG + sum(st_max) - len(st_groups)
@@ -343,7 +387,7 @@ def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60
     hot_list, hot_at = [], 0
     for it in range(n_moves):
         T = T0 * (T1 / T0) ** (it / max(1, n_moves - 1))
-        if rows_mv and T < T_ENTRY and rnd.random() < P_ENTRY:
+        if rows_mv and (not slot_moves or (T < T_ENTRY and rnd.random() < P_ENTRY)):
             # ---- entry move: two cells of one row exchange what they hold
             if hot and rnd.random() < 0.7:
                 if it >= hot_at:
@@ -399,10 +443,12 @@ def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60
                     add(g2, x2)
         else:
             # ---- slot move: two slots of one region exchange their positions
+            if not slot_moves or not members:
+                continue
             m_ = rnd.choice(members)
             a, b = rnd.choice(m_), rnd.choice(m_)
             pa, pb = pos[a], pos[b]
-            if pa % MODG == pb % MODG or not (used[a] or used[b]):
+            if (pa % MODG == pb % MODG and pa % SMOD == pb % SMOD) or not (used[a] or used[b]):
                 continue
             oa, ob = occ[a], occ[b]
             aff = [g_ for g_ in oa if g_ not in ob]
@@ -422,7 +468,7 @@ def optimise_entries(prog, region: np.ndarray, idle_zero: bool, sweeps: int = 60
                 mm = max(c_)
                 newmax.append(mm)
                 delta += mm - gmax[g_]
-            sa, sb = pa % STORE_BANK_PAIRS, pb % STORE_BANK_PAIRS
+            sa, sb = pa % SMOD, pb % SMOD
             saff, sbff, snew = [], [], []
             if sa != sb:
                 sta, stb = st_of[a], st_of[b]

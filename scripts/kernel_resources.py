@@ -37,13 +37,15 @@ def main(name):
             if 'LDS Size' in t:
                 print()
         txt = open(asm).read()
+        if len(sys.argv) > 2:
+            open(sys.argv[2], 'w').write(txt)
         for kern in re.findall(r'^(_Z\w+):', txt, re.M):
             body = txt[txt.index(kern + ':'):]
+            if 's_endpgm' not in body:
+                continue
             body = body[:body.index('s_endpgm')]
             st = len(re.findall(r'scratch_store', body)); ld = len(re.findall(r'scratch_load', body))
             print(kern[:40], 'scratch_store', st, 'scratch_load', ld, 'lines', body.count('\n'))
-        if len(sys.argv) > 2:
-            open(sys.argv[2], 'w').write(txt)
 
 
 if __name__ == '__main__':

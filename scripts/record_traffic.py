@@ -63,7 +63,8 @@ def main(key, instances, pmc_file, source=''):
                  'source_fingerprint matches the kernel sources it runs'}
     rec[key] = {'instances': int(instances), 'fetch_bytes': int(fetch), 'write_bytes': int(write),
                 'kernel': ' + '.join(sorted(k.split('(')[0][:40] for k in per_kernel)),
-                'per_kernel_KiB': per_kernel, 'binding': binding, 'source_fingerprint': source_fingerprint(), 'source': source or pmc_file}
+                'per_kernel_KiB': per_kernel, 'binding': binding, 'source_fingerprint': source_fingerprint(), 'source': source or pmc_file,
+                'recorded': __import__('datetime').datetime.now(__import__('datetime').timezone.utc).strftime('%Y-%m-%d %H:%M UTC')}
     json.dump(rec, open(path, 'w'), indent=1)
     print(key, 'fetch', int(fetch), 'write', int(write), 'fingerprint', rec[key]['source_fingerprint'])
 

@@ -92,6 +92,7 @@ inline double row_shl(double v) {
     wave_sync();
     return r;
 }
+inline double lane_select(unsigned long long mask, double v) { return ((mask >> cur->lane) & 1ull) ? v : 0.0; }
 inline double read_lane(double v, int lane) {
     SimWave *w = cur->wv;
     w->xch[cur->lane] = v;

@@ -116,6 +116,13 @@ def _bench_two_ranks(sim_lib, workload, B, steps, rccl_lib, log=None, extra=()):
     assert out['n_gpus'] == 2 and out['config']['instances_per_gpu'] == B and out['scaling'] == 'weak'
     assert out['config']['solved'] == 2 * B                  # the root saw both shards' statuses through the gather
     assert out['value'] > 0 and abs(out['ms_per_step'] * steps * out['value'] / 1e3 - 2 * B * steps) < 1e-6 * B
+    # first-contact insurance for the 8-GPU run (round-5 review, item 6): the line says what travelled, how the ranks' clocks
+    # compare, and that the root checked every rank's rows after the last step
+    cfg = out['config']
+    assert cfg['ranks_delivered'] == 2
+    assert cfg['gather_bytes_per_step'] > 0 and cfg['gather_bytes_per_step'] % B == 0
+    rm = cfg['rank_ms_per_step']
+    assert len(rm['per_rank']) == 2 and 0 < rm['min'] <= rm['max'] <= out['ms_per_step'] * 1.5 + 1.0
     return out, p.stderr
 
 
@@ -140,6 +147,7 @@ def test_bench_gpus_2_starts_two_ranks_and_gathers_over_one_rccl(sim_lib, tmp_pa
     first = sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in sends[:7])
     assert first == [B * rb for rb in row_bytes]
     assert sorted(int(ln.rsplit('bytes=', 1)[1]) for ln in recvs[:7]) == first
+    assert out['config']['gather_bytes_per_step'] == sum(first)           # one non-root rank's rows
 
 
 def test_bench_gpus_2_falls_back_to_the_host_gather_when_rccl_cannot_start(sim_lib, tmp_path):
@@ -214,8 +222,13 @@ def test_bench_single_rank_json_line_carries_the_contract(sim_lib):
     r = out['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert 'traffic' in r and r['kernel'] and r['kernel_ms'] <= out['ms_per_step'] + 1e-9
+    # ONE accounting: the step's two kernels are the launch the roofline object prices
+    assert r['kernel'] == 'osqp_shared_kernel + ' + out['phases']['per_instance_factor']['kernel']
+    assert r['algorithmic_bytes_per_launch'] == r['algorithmic_bytes_per_instance'] * r['units_per_launch'] and r['units_per_launch'] == B
+    assert abs(r['kernel_ms'] - (out['phases']['shared_factor']['ms'] + out['phases']['per_instance_factor']['ms'])) < 1e-9
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-9 * max(1.0, r['achieved']) and 'frac_step' not in r
     c = out['cpu_baseline']
-    assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['unit'] == out['unit'] and c['sample']
+    assert c['kind'] == 'restatement' and c['kind_contract'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['unit'] == out['unit'] and c['sample']
     assert set(out['phases']) == {'shared_factor', 'per_instance_factor'}            # default mode: two kernels per step
     assert out['phases']['shared_factor']['instances'] == B
     assert out['fixed_rho']['value'] > 0

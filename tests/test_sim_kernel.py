@@ -1,6 +1,8 @@
 """CPU tier for the kernel logic: the product's kernel sources compiled for the lock-step emulator
 (tests/sim/build_sim.py) and driven through the real C-ABI + Python runtime, compared with the C
 oracle.  Small batches only (64 host threads per emulated wavefront)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -377,3 +379,64 @@ def test_generated_streaming_executor_for_per_instance_matrices(sim_lib, oracle_
         bs.close()
     assert out['family'].iter.tolist() == out['generic'].iter.tolist()
     assert np.abs(out['family'].prim_flat - out['generic'].prim_flat).max() < 1e-9
+
+
+@pytest.mark.parametrize('fam', ['nnls', 'mpc6', 'toy_box'])
+def test_squad_executor_parity(oracle_lib, tmp_path, fam):
+    """csrc/cpg_osqp_squad.h + codegen.emit_squad_program (round 6): the family's solve program in the registers of a
+    squad of four wavefronts that solves four instances at a time -- placement 3 of a family library (an experiment: on MI355X
+    it lost against the LDS-resident program, HISTORY.md round 6; kept selectable and tested).
+    Against the oracle AND against the LDS-program executor of the same library (placement 1): batch sizes that do not fill
+    the last squad, one instance, events that are not aligned across a squad (check_termination 7 next to the adaptation
+    interval 50), the fixed-rho fork, max_iter reached, an infeasible instance among feasible ones."""
+    from cvxpygen_amd.runtime import build_family_plan, BUILD_OPTIONS_FIXED_RHO
+    from sim import build_sim
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    if fam == 'nnls':
+        d, name = families.nonneg_ls(), 'b'
+        draw = lambda B: rng.standard_normal((B, 3))
+    elif fam == 'mpc6':
+        d, name = families.mpc(6, 3, 10), 'x_init'
+        draw = lambda B: -2 + 4 * rng.random((B, 6))
+    else:
+        d, name = families.toy_box(), None
+    plan = build_family_plan(d)
+    assert plan.kkt_squad is not None and 'squad_conflict_cycles' in plan.stats
+    lib = build_sim.build_family(plan, str(tmp_path), fam)
+    assert os.path.exists(os.path.join(str(tmp_path), f'cpg_squad_{fam}.h'))
+
+    def run(vals, placement, build_options=None, **stg):
+        bs = BatchSolver(d, lib_path=lib, plan=plan, build_options=build_options or {})
+        bs.set_program_placement(placement)
+        r = bs.solve(vals, updated_params=list(vals.keys()), **stg)
+        v = C.c_double(0)
+        bs.lib.L.cpg_hip_get_setting(bs.h_shared, b'squad_executor', C.byref(v))
+        assert v.value == (1.0 if placement == 3 else 0.0)
+        bs.close()
+        return r
+    if fam == 'toy_box':
+        B = 6
+        th = np.tile(d.theta0, (B, 1))
+        th[1, d.param('lb').col], th[1, d.param('ub').col] = 2.0, 1.0      # infeasible
+        th[4, d.param('a').col] = 5.0                                      # active upper bound
+        vals = {p.name: th[:, p.col:p.col + p.size] for p in d.params}
+        r = run(vals, 3)
+        o, prim, dual = _oracle_flat(oracle_lib, d, th, None)
+        _assert_parity(r, o, prim, dual)
+        assert r.status[1] == 3 and r.obj_val[1] == np.inf
+        return
+    cases = [(5, {}, None), (1, {}, None), (9, dict(check_termination=7), None), (4, {}, dict(BUILD_OPTIONS_FIXED_RHO)),
+             (3, dict(max_iter=30), None), (2, dict(max_iter=0), None)]
+    if fam == 'mpc6':
+        cases = cases[:3]                   # (64 host fibers per emulated wavefront: keep the larger family short)
+    for B, stg, bo in cases:
+        v = draw(B)
+        mode = dict(adaptive_rho=0, check_dualgap=0) if bo else {}
+        o, prim, dual = _oracle_flat(oracle_lib, d, _theta(d, name, v), [name], **mode, **stg)
+        r3 = run({name: v}, 3, bo, **stg)
+        _assert_parity(r3, o, prim, dual)
+        r1 = run({name: v}, 1, bo, **stg)
+        assert r1.iter.tolist() == r3.iter.tolist() and r1.status.tolist() == r3.status.tolist()
+        ok = np.isin(r3.status, (1, 2, 7))
+        assert np.allclose(r1.prim_flat[ok], r3.prim_flat[ok], rtol=1e-9, atol=1e-11)
