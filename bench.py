@@ -113,7 +113,7 @@ def team_kernel_in_use(solver) -> bool:
         return False
     v = _C.c_double(0)
     solver.lib.L.cpg_hip_get_setting(h, b'team_executor', _C.byref(v))
-    return v.value == 1.0
+    return v.value > 0.0               # (the team's width W)
 
 
 def squad_kernel_in_use(solver) -> bool:
@@ -560,7 +560,7 @@ def main():
             units = B
             algorithmic_bytes_launch = bytes_per_inst * B
             kernel_name = f'{shared_kernel} + {inst_kernel}'
-            k_ms = ms1 + ms2
+            # (k_ms stays the mean over the timed steps of the span ev0 .. ev1 of both kernels; `phases` is the split of the LAST step)
             it2 = float((it - it1)[ho].mean()) if ho.any() else 0.0
             stream = None if gv.value else {'bytes_per_instance': int(it2 * sv), 'what': f'{it2:.1f} iterations x {sv} B of per-instance substitution coefficients',
                       'achieved': it2 * sv * n_ho / (ms2 * 1e-3) / 1e9}

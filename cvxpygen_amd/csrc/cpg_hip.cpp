@@ -662,8 +662,16 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     else if (s == "check_dualgap") *v = h->S.check_dualgap;
     // (read-only facts about the handle) 1: per-instance solves of this handle run the generated instance executor
     else if (s == "squad_executor") *v = (!h->refactor_mode && !h->conic && h->squad_ok && h->program_in_lds == 3 && h->inst_per_wave == 1) ? 1.0 : 0.0;
-    else if (s == "team_executor") *v = (h->refactor_mode && h->Rs.ok == 2 && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
-    else if (s == "resident_executor") *v = (h->refactor_mode && h->Rs.ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
+    else if (s == "team_executor") {
+        // wavefronts per instance of the team kernel this handle's per-instance solves run on; 0: another kernel (no team plan, the
+        // streaming placement was asked for, or the team's LDS need exceeds the device limit -- launch_per_instance's own test)
+        *v = 0.0;
+#ifdef CPG_GENT_HEADER
+        if (h->refactor_mode && h->Rs.ok == 2 && !h->R.shared_mats && h->program_in_lds != 0 && h->program_in_lds != 2 &&
+            ((size_t)CPG_TEAM_SLICE_OFF + (size_t)h->Rs.slice_doubles) * sizeof(double) <= h->lds_limit) *v = (double)CPG_GENT_W;
+#endif
+    }
+    else if (s == "resident_executor") *v = (h->refactor_mode && h->Rs.ok == 1 && !h->R.shared_mats && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else if (s == "generated_instance_executor") *v = (h->refactor_mode && h->R.gi_ok && h->program_in_lds != 0 && h->program_in_lds != 2) ? 1.0 : 0.0;
     else { set_error("Solver setting \"" + s + "\" not available."); return CPG_E_BADARG; }
     return CPG_OK;
@@ -2126,7 +2134,9 @@ int cpg_hip_solve_batch_device_state(cpg_handle_t h, int64_t B, const double *d_
             }
             W = best;
         }
-        const size_t lds = fixed + (size_t)W * per_wave;
+        // (+ 16 doubles behind the last wavefront's slice: the specialised kernel's per-cone loops are unrolled to the family's largest
+        // cone and load past the end of a shorter trailing cone before they mask the use -- inside the allocation with this pad)
+        const size_t lds = fixed + (size_t)W * per_wave + (fixed + (size_t)W * per_wave + 128 <= h->lds_limit ? 128 : 0);
         long long blocks = (B + W - 1) / W;
         int per_cu = (int)(h->lds_limit / lds); if (per_cu < 1) per_cu = 1;
         if (h->blocks_per_cu > 0 && per_cu > h->blocks_per_cu) per_cu = h->blocks_per_cu;

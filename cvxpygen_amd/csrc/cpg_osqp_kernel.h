@@ -448,6 +448,13 @@ CPG_DEV void run_program_lds(const LdsProg &P, double *w, int ldw, int lane) {
         _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
             w[(unsigned)(g_ * ldw) + row_] = cpgw::group_sum_first<LG>(A[g_]);                     \
     }
+// ... with the stage masks as 64-bit lane-mask literals (codegen.stage_masks): no shift / and / compare per stage
+#define CPG_GEN_SEGREDUCE_STORE_LIT(A, S, Q, J, M0, M1, M2)                                       \
+    {                                                                                              \
+        const unsigned row_ = CPG_GEN_ROW(Q, J) & CPG_GEN_SLOT_MASK;                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                           \
+            w[(unsigned)(g_ * ldw) + row_] = cpgw::seg_sum_first_lit<S>(A[g_], M0, M1, M2);        \
+    }
 #define CPG_GEN_SEGREDUCE_STORE(A, S, Q, J)                                                        \
     {                                                                                              \
         const unsigned e_ = CPG_GEN_ROW(Q, J);                                                     \

@@ -185,7 +185,11 @@ def _build(P, A, osqp, stage_scale, groups, team=1, inplace_x=True) -> ResidentP
     lev = _levels(N, Lp, Li)
     nlev = int(lev.max()) + 1 if N else 0
     groups = plan_groups(N, Lp, Li) if groups is None else list(groups)
-    assert groups and groups[0][0] == 0 and groups[-1][1] == nlev - 1
+    # (groups handed in -- a library's header records its own -- must tile the levels 0 .. nlev - 1 of THIS family's factor:
+    # a ValueError, not an assert, so that a caller can tell a foreign header from a bug, python -O or not)
+    if not groups or groups[0][0] != 0 or groups[-1][1] != nlev - 1 or any(a > b for a, b in groups) or \
+            any(groups[k + 1][0] != groups[k][1] + 1 for k in range(len(groups) - 1)):
+        raise ValueError(f'level groups do not tile the {nlev} levels of this family\'s factor')
     grp_of = np.zeros(N, dtype=np.int64)
     g_rows = []
     for gi, (a, b) in enumerate(groups):

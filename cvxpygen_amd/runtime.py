@@ -253,6 +253,26 @@ class FamilyPlan:
     kkt_squad: Optional[_sp.RaggedProgram] = None      # the same program packed for the squad executor (None: it does not fit / is off)
 
 
+def _header_defines(path: str) -> Dict[str, str]:
+    """`#define NAME value` lines of a generated header (the WHOLE file, line by line: a long comment or table in front of
+    the defines must not hide them) and its `// NAME value ...` record comments"""
+    out: Dict[str, str] = {}
+    try:
+        with open(path) as f:
+            for ln in f:
+                if ln.startswith('#define CPG_'):
+                    parts = ln.split(None, 2)
+                    if len(parts) == 3 and '(' not in parts[1]:
+                        out[parts[1]] = parts[2].strip()
+                elif ln.startswith('// CPG_'):
+                    parts = ln[3:].split(None, 1)
+                    if len(parts) == 2:
+                        out['//' + parts[0]] = parts[1].strip()
+    except OSError:
+        pass
+    return out
+
+
 def _instance_fingerprints(lib_path: str, stem: str = 'cpg_instance', prefix: str = 'GENI'):
     """CPG_GENI_FINGERPRINT of the generated instance headers next to a library (what it was compiled from); with
     stem 'cpg_resident' / prefix 'GENR' the same for the resident executors (codegen.resident_header)"""
@@ -260,31 +280,25 @@ def _instance_fingerprints(lib_path: str, stem: str = 'cpg_instance', prefix: st
     import re
     out = set()
     for h in glob.glob(os.path.join(os.path.dirname(os.path.abspath(lib_path)), stem + '_*.h')):
-        try:
-            m = re.search(r'#define CPG_' + prefix + r'_FINGERPRINT (\d+)u', open(h).read(4096))
-        except OSError:
-            m = None
+        m = re.fullmatch(r'(\d+)u', _header_defines(h).get(f'CPG_{prefix}_FINGERPRINT', ''))
         if m:
             out.add(int(m.group(1)))
     return out
 
 
 def _team_widths(lib_path: str):
-    """(CPG_GENT_W, CPG_GENT_MAX_GROUP_ROWS) of the generated team headers next to a library: what their plans were built with"""
+    """(CPG_GENT_W, CPG_GENT_MAX_GROUP_ROWS, level groups, dimensions) of the generated team headers next to a library: what their
+    plans were built with; dimensions = (N, M, NNZA, NNZP, NNZL) of the family the header was generated for"""
     import glob
-    import re
     out = set()
     for h in glob.glob(os.path.join(os.path.dirname(os.path.abspath(lib_path)), 'cpg_team_*.h')):
-        try:
-            txt = open(h).read(4096)
-        except OSError:
+        d = _header_defines(h)
+        if 'CPG_GENT_W' not in d:
             continue
-        m = re.search(r'#define CPG_GENT_W (\d+)', txt)
-        g = re.search(r'#define CPG_GENT_MAX_GROUP_ROWS (\d+)', txt)
-        gr = re.search(r'// CPG_GENT_GROUPS ([0-9\- ]+)', txt)
-        groups = tuple(tuple(int(v) for v in it.split('-')) for it in gr.group(1).split()) if gr else None
-        if m:
-            out.add((int(m.group(1)), int(g.group(1)) if g else None, groups))
+        gr = d.get('//CPG_GENT_GROUPS')
+        groups = tuple(tuple(int(v) for v in it.split('-')) for it in gr.split()) if gr else None
+        dims = tuple(int(d[k]) if k in d else None for k in ('CPG_GENT_N', 'CPG_GENT_M', 'CPG_GENT_NNZA', 'CPG_GENT_NNZP', 'CPG_GENT_NNZL'))
+        out.add((int(d['CPG_GENT_W']), int(d['CPG_GENT_MAX_GROUP_ROWS']) if 'CPG_GENT_MAX_GROUP_ROWS' in d else None, groups, dims))
     return out
 
 
@@ -597,15 +611,22 @@ class BatchSolver:
                     # ... or the team executor (csrc/cpg_osqp_team.h): the same plan with its programs planned for W wavefronts
                     # per instance -- W is what the header next to the library says
                     from . import codegen as _cg
-                    for Wt, Gt, groups in sorted(_team_widths(self.lib.path), key=lambda t_: (t_[0], t_[1] or 0)):
+                    mine = (desc.n_var, desc.m, int(desc.A.nnz))
+                    for Wt, Gt, groups, dims in sorted(_team_widths(self.lib.path), key=lambda t_: (t_[0], t_[1] or 0)):
+                        if any(dv is not None and dv != mv for dv, mv in zip(dims[:3], mine)):
+                            continue           # (a header of another family in the same directory: not worth a plan build)
                         try:
                             cand = _cg.build_team_plan(desc, o, Wt, Gt, groups=list(groups) if groups else None)
-                        except AssertionError:
-                            continue           # (groups of another family's header)
+                        except ValueError:
+                            continue           # (level groups that do not tile this family's factor)
                         if cand.sol.fingerprint() in fps_t:
                             self._rplan_res = cand
                             rplan = cand.base
                             break
+                    if rplan is None:
+                        import warnings
+                        warnings.warn(f'{self.lib.path} carries a team executor (cpg_team_*.h) but none of the headers next to it matches '
+                                      f'this family\'s plan: per-instance solves will run the streaming kernel', RuntimeWarning)
                 if rplan is None and _instance_fingerprints(self.lib.path, 'cpg_resident', 'GENR'):
                     from . import resident_plan as _rs
                     cand = _rs.build_resident_plan(desc.P, desc.A, o)

@@ -313,11 +313,11 @@ int cpg_hip_set_refactor(cpg_handle_t h, const cpg_osqp_refactor_t *rf);
 /* cpg_hip_set_refactor(h, rf), and -- when this library carries the generated resident executor of exactly this
  * family (cvxpygen_amd.codegen.resident_header; the merged program's fingerprint decides) -- the resident kernel's
  * tables: solves then run cpg_osqp_resident.h instead of the streaming kernel.  cpg_hip_get_setting(h,
- * "resident_executor") reports which (1.0 / 0.0); any other library keeps the streaming kernel and returns CPG_OK.
+ * "resident_executor") reports which (1.0 / 0.0; 0.0 for a team library); any other library keeps the streaming kernel and returns CPG_OK.
  * A library generated with the TEAM executor (cvxpygen_amd.codegen.team_header: families whose merged program does not
  * fit the registers of one wavefront, e.g. an MPC with every parameter per instance) takes the same tables and runs
  * cpg_osqp_team.h -- one workgroup of W wavefronts per instance, the program split over them; "team_executor" reports the
- * W in use (0.0: not).  The tables must be those of a plan built for that W and group limit (the header's
+ * W in use (0.0: not -- no team plan, the streaming placement was asked for, or the team's LDS slice exceeds the device limit).  The tables must be those of a plan built for that W and group limit (the header's
  * `// CPG_GENT_GROUPS` line; cvxpygen_amd.runtime reads it back): another plan is refused by fingerprint and the handle
  * keeps the streaming kernel. */
 int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *rf, const cpg_osqp_resident_t *rs);

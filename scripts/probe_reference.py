@@ -25,7 +25,9 @@ def probe():
     return found, missing
 
 
-def main() -> int:
+def main(capture: bool = True) -> int:
+    """capture=False: report only (what a test session does unless CPG_CAPTURE_REFERENCE=1: a pytest run -- and every xdist worker
+    of it -- must not write into the source tree or start an unbounded subprocess on its own)"""
     found, missing = probe()
     if os.path.exists(GOLD):
         print(f'reference probe: {GOLD} present (captured reference outputs): tests/test_reference_outputs.py runs')
@@ -34,8 +36,22 @@ def main() -> int:
         print('reference probe: PARITY UNPINNED -- not importable here: ' + ', '.join(missing) +
               ('; importable: ' + ', '.join(found) if found else '') + ' -> no capture of the reference possible in this environment')
         return 0
+    if not capture:
+        print('reference probe: cvxpy / osqp / clarabel / cvxpygen import and no capture exists: run `python scripts/capture_reference.py` '
+              '(or the tests with CPG_CAPTURE_REFERENCE=1) to pin the solver parity')
+        return 0
     print('reference probe: cvxpy / osqp / clarabel / cvxpygen import -> capturing the reference (scripts/capture_reference.py)')
-    rc = subprocess.call([sys.executable, os.path.join(ROOT, 'scripts', 'capture_reference.py')])
+    # one writer: concurrent sessions (xdist workers, a test run next to gpu_final.sh) serialise on a lock file and re-check
+    import fcntl
+    with open(os.path.join(ROOT, 'tests', 'golden', '.capture.lock'), 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if os.path.exists(GOLD):
+            print('reference probe: captured meanwhile by another session')
+            return 0
+        try:
+            rc = subprocess.call([sys.executable, os.path.join(ROOT, 'scripts', 'capture_reference.py')], timeout=3600)
+        except subprocess.TimeoutExpired:
+            rc = -1
     print(f'reference probe: capture_reference.py exit code {rc}' + ('; commit tests/golden/reference_outputs.npz' if rc == 0 else ''))
     return 0
 

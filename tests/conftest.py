@@ -14,12 +14,14 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    # parity-pin readiness: wherever the real reference imports, capture its outputs before the tests
-    # that replay them are collected; here it prints one "PARITY UNPINNED" line
+    # parity-pin readiness: one line that says whether the real reference imports here ("PARITY UNPINNED" in
+    # this environment).  A test session only REPORTS; with CPG_CAPTURE_REFERENCE=1 (or scripts/probe_reference.py /
+    # scripts/gpu_final.sh run by hand) it also captures the reference's outputs -- under a file lock -- before the tests that
+    # replay them are collected
     try:
         sys.path.insert(0, os.path.join(ROOT, 'scripts'))
         import probe_reference
-        probe_reference.main()
+        probe_reference.main(capture=os.environ.get('CPG_CAPTURE_REFERENCE', '0') == '1')
     except Exception as e:       # never in the way of the test run
         print(f'reference probe failed: {e}')
 

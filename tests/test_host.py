@@ -253,7 +253,7 @@ def test_generated_executor_schedule_invariants(opts):
         if m: ev.append(('W', int(m.group(1)))); continue
         m = re.match(r'\s*CPG_GEN_FMA_\w+\(a(\d+), (\d+)', ln)
         if m: ev.append(('F', int(m.group(2)), int(m.group(1)))); continue
-        m = re.match(r'\s*CPG_GEN_(?:SEG)?REDUCE_STORE\(a(\d+),', ln)
+        m = re.match(r'\s*CPG_GEN_(?:SEG)?REDUCE_STORE(?:_LIT)?\(a(\d+),', ln)
         if m: ev.append(('S', int(m.group(1))))
     pos = {}
     for k, e in enumerate(ev):

@@ -20,7 +20,7 @@ from test_resident import _dense_kkt, _portfolio_values, _random_values
 def _team_in_use(bs) -> bool:
     v = C.c_double(-1)
     bs.lib.check(bs.lib.L.cpg_hip_get_setting(bs.h_ref, b'team_executor', C.byref(v)), 'cpg_hip_get_setting')
-    return v.value == 1.0
+    return v.value > 0.0            # (the width W of the team)
 
 
 @pytest.mark.parametrize('fam', ['portfolio', 'mpc6'])
