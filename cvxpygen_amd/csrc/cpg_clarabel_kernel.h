@@ -89,6 +89,7 @@ struct DevConic {
     // [step / 4][lane][4] and output slots [chunk / 4][lane][4]; the entries get `sv_pad` trailing zeros and the work
     // vector `w_extra` slots (dummy store targets + the zero slot)
     int gc_ok, sv_pad, w_extra, gc_ncols, gc_nrows;
+    int gf_ok;                               // the numeric LDL' schedule handed in is the one this library's generated factorisation was emitted from
     const unsigned short *gc_cols, *gc_rows;
 };
 
@@ -116,6 +117,12 @@ CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
 #ifndef CPG_GENC_ROWS
 typedef unsigned genc_row_word;      // (no row words in this library: ConicCtx::rows stays null)
 #endif
+}  // namespace cpg
+#ifdef CPG_GENC_FACTOR_HEADER
+// generated straight-line numeric LDL' of this family (codegen.emit_conic_factor): cpg::conic_factor_gen(B, S, eps, lane)
+#include CPG_GENC_FACTOR_HEADER
+#endif
+namespace cpg {
 
 struct ConicCtx {
     const DevConic &C;
@@ -305,6 +312,12 @@ struct ConicCtx {
             md = cpgw::wave_max_nonneg(md);
             eps = S.static_const + S.static_prop * md;
         }
+#ifdef CPG_GENC_FACTOR_HEADER
+        if (C.gf_ok) conic_factor_gen(B, S, eps, lane);      // (this library's family: the schedule as straight-line code)
+        else {
+#else
+        {
+#endif
         int level_start = 0;
 #pragma nounroll
         for (int c = 0; c < C.fac_chunks; c++) {
@@ -359,6 +372,7 @@ struct ConicCtx {
                 cpgw::lds_order();
                 level_start = c + 1;
             }
+        }
         }
         for (unsigned e = (unsigned)lane; e < (unsigned)C.sol_nnz; e += 64u) {
             const int kind = cpgw::gld(C.sol_kind, e);

@@ -642,6 +642,8 @@ int cpg_hip_get_setting(cpg_handle_t h, const char *name, double *v) {
     if (h->conic) {
         // (read-only fact about the handle) 1: the substitution program runs on the library's generated executor
         if (s == "generated_executor") { *v = h->C.gc_ok ? 1.0 : 0.0; return CPG_OK; }
+        // ... 1: its factorisations run the library's generated straight-line schedule (codegen.emit_conic_factor)
+        if (s == "generated_factorisation") { *v = h->C.gf_ok ? 1.0 : 0.0; return CPG_OK; }
         // ... 1: the kernel instantiation with this family's dimensions compiled in is the one launched
         if (s == "specialised_kernel") { *v = h->conic_specialised ? 1.0 : 0.0; return CPG_OK; }
         if (double *d = conic_double_setting(h, s)) { *v = *d; return CPG_OK; }
@@ -876,6 +878,48 @@ static int open_device(cpg_handle_t h, int device) {
     return CPG_OK;
 }
 
+#ifdef CPG_GENC_FACTOR_HEADER
+// The per-lane words of the library's generated factorisation (codegen.conic_factor_words) rebuilt from the schedule handed in and
+// hashed (FNV-1a over the words as 32-bit little-endian): conic_factor_gen runs only the schedule it was emitted from.
+static unsigned conic_factor_words_hash(const cpg_conic_family_t *f) {
+    const int N = f->n + f->m;
+    if (f->nnzL > 0xFF || N > 0xFF || f->fac_chunks != CPG_GENC_FAC_NCHUNKS) return 0;
+    unsigned hsh = 2166136261u;
+    auto put = [&](unsigned w) { for (int b = 0; b < 4; b++) hsh = (hsh ^ ((w >> (8 * b)) & 0xFFu)) * 16777619u; };
+    std::vector<unsigned> tw;
+    for (int c = 0; c < f->fac_chunks; c++) {
+        const int L = f->fac_ctab[4 * c];
+        unsigned base = (unsigned)f->fac_ctab[4 * c + 2];
+        for (int s = 0; s < L; s++) {
+            unsigned cnt = 0;
+            for (int t = 0; t < 64; t++) {
+                const unsigned lw = f->fac_len[(size_t)c * 64 + t];
+                const int len = (int)(lw & 0xFFFFu), rlen = (int)(lw >> 16);
+                unsigned w = 0;
+                if (s < len) {
+                    if (s < rlen) { const unsigned e = base + cnt; w = f->fac_a[e] | (f->fac_b[e] << 8) | (f->fac_k[e] << 16) | (1u << 24); }
+                    cnt++;
+                }
+                put(w);
+            }
+            base += cnt;
+        }
+        for (int half = 0; half < 2; half++)
+            for (int t = 0; t < 64; t++) {
+                const unsigned tk = f->fac_task[(size_t)c * 64 + t];
+                unsigned w = half == 0 ? 0xFFFFu : 0u;
+                if (tk != 0xFFFFFFFFu) {
+                    const bool piv = tk >= (unsigned)f->nnzL;
+                    w = half == 0 ? (tk | ((unsigned)f->ksrc_kind[tk] << 16) | ((piv ? 1u : 0u) << 20) | ((piv ? 0u : (unsigned)f->Lcol[tk]) << 24))
+                                  : (unsigned)f->ksrc_idx[tk];
+                }
+                tw.push_back(w);
+            }
+    }
+    for (unsigned w : tw) put(w);
+    return hsh;
+}
+#endif
 #ifdef CPG_GENC_ROWS
 // The generated row words of the library's family (codegen.conic_row_tables) rebuilt from the patterns of the family handed
 // in -- rows of P (full symmetric view), columns of A, rows of A, [step][lane], same bit layout -- and hashed (FNV-1a over the
@@ -1015,6 +1059,10 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     TRY(upload_csr(h, own, f->map_q, &C.map_q)); TRY(upload_csr(h, own, f->map_b, &C.map_b));
     TRY(upload_csr(h, own, f->map_d, &C.map_d));
     C.gc_ok = 0; C.sv_pad = 0; C.w_extra = 0; C.gc_ncols = 0; C.gc_nrows = 0; C.gc_cols = nullptr; C.gc_rows = nullptr;
+    C.gf_ok = 0;
+#ifdef CPG_GENC_FACTOR_HEADER
+    C.gf_ok = (conic_factor_words_hash(f) == CPG_GENC_FAC_HASH && !(getenv("CPG_CONIC_FACTOR") && atoi(getenv("CPG_CONIC_FACTOR")) == 0)) ? 1 : 0;
+#endif
 #ifdef CPG_GENC_HEADER
     // a family library: its generated executor replaces the table-driven one when the substitution program handed in is
     // the one the executor was generated from

@@ -61,10 +61,10 @@ def build_streamed_family(plan, out_dir, name='family', verbose=False):
 def build_conic_family(cplan, out_dir, name='family', verbose=False):
     """emulator build of a conic family library (generated executor of the substitution program)"""
     os.makedirs(out_dir, exist_ok=True)
-    hdr = codegen.conic_header(cplan, out_dir, name)
+    defs, hdrs = codegen.conic_library_defs(cplan, out_dir, name)
     out = os.path.join(out_dir, f'libcpg_{name}_conic_sim.so')
     src, deps = codegen.source_files()
-    return codegen.compile_if_stale(_gxx_cmd(src, [f'-DCPG_GENC_HEADER="{hdr}"'], out), out, [hdr] + deps + SIM_HEADERS, verbose)
+    return codegen.compile_if_stale(_gxx_cmd(src, defs, out), out, hdrs + deps + SIM_HEADERS, verbose)
 
 
 if __name__ == '__main__':

@@ -212,7 +212,18 @@ def test_generated_conic_executor_in_emulator(tmp_path):
         del os.environ['CPG_CONIC_GENERATED']
     assert _fact(bt, 'generated_executor') == 0.0 and _fact(bt, 'specialised_kernel') == 0.0
     assert np.array_equal(r.sol_x, rt.sol_x) and np.array_equal(r.sol_y, rt.sol_y) and r.iter.tolist() == rt.iter.tolist()
-    bs.close(); bt.close()
+    # the factorisation schedule as straight-line code (codegen.emit_conic_factor, round 6) against the table walk of the same
+    # library: same arithmetic in the same order -- identical bits
+    assert _fact(bs, 'generated_factorisation') == 1.0 and os.path.exists(os.path.join(str(tmp_path), 'cpg_conic_adp_factor.h'))
+    os.environ['CPG_CONIC_FACTOR'] = '0'
+    try:
+        bf = ConicBatchSolver(d, lib_path=lib, plan=cp, full_output=True)
+        rf = bf.solve(pv)
+    finally:
+        del os.environ['CPG_CONIC_FACTOR']
+    assert _fact(bf, 'generated_factorisation') == 0.0 and _fact(bf, 'generated_executor') == 1.0
+    assert np.array_equal(r.sol_x, rf.sol_x) and np.array_equal(r.sol_y, rf.sol_y) and r.iter.tolist() == rf.iter.tolist()
+    bs.close(); bt.close(); bf.close()
     d2 = families.toy_box(solver='CLARABEL')             # another family through the ADP library
     th = np.tile(d2.theta0, (2, 1)); th[1, :3] = [0.3, 1.0, -1.0]
     b2 = ConicBatchSolver(d2, lib_path=lib, full_output=True)
