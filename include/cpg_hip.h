@@ -375,7 +375,12 @@ int cpg_hip_set_launch(cpg_handle_t h, int waves_per_block, int inst_per_wave, i
  * LDS resident; table-driven kernels: streamed for one instance per wave, which measures faster);
  * 2 = per-instance factor handles only: the streaming executor with its shared entry words in LDS even when the
  * library carries a generated (instance / resident) executor for the family -- the kernel those replaced, kept
- * selectable for comparison */
+ * selectable for comparison;
+ * 3 = shared-factor handles of a family library that carries the squad executor (cvxpygen_amd.codegen.squad_header;
+ * cpg_hip_get_setting(h, "squad_executor") reports 1.0 once selected): the solve program in the REGISTERS of a workgroup of
+ * four wavefronts that solves four instances at a time (csrc/cpg_osqp_squad.h) -- same results; measured slower than 1 on
+ * MI355X, kept selectable for comparison; a solve fails with CPG_E_UNSUPPORTED where the library has none.
+ * Replaces nothing of the reference's interface: the generated C has one placement, the CPU's (cvxpygen/solvers/osqp.py:62). */
 int cpg_hip_set_program_placement(cpg_handle_t h, int in_lds);
 
 /* ---- device memory helpers for the device-resident variant ---------------------------------------- */
