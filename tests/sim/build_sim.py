@@ -47,7 +47,7 @@ def build_family(plan, out_dir, name='family', verbose=False, **kw):
     hdr, defs = codegen.family_library_defs(plan, out_dir, name, **kw)
     out = os.path.join(out_dir, f'libcpg_{name}_sim.so')
     src, deps = codegen.source_files()
-    return codegen.compile_if_stale(_gxx_cmd(src, defs, out), out, [hdr] + deps + SIM_HEADERS, verbose)
+    return codegen.compile_if_stale(_gxx_cmd(src, defs, out), out, codegen.generated_headers(defs) + deps + SIM_HEADERS, verbose)
 
 
 def build_streamed_family(plan, out_dir, name='family', verbose=False):
