@@ -175,6 +175,41 @@ def test_generated_family_library_vs_oracle(oracle_lib, tmp_path):
     bs.close()
 
 
+def test_squad_executor_on_gpu(oracle_lib, tmp_path):
+    """csrc/cpg_osqp_squad.h (round 6; placement 3 of a family library): the family's solve program in the registers of a squad
+    of four wavefronts that solves four instances at a time -- against the oracle on a ragged batch (the last squad is not
+    full), in both forks of the default, and at the full batch size instance by instance against the LDS-resident executor of
+    the same library"""
+    import ctypes as C
+    from cvxpygen_amd import codegen
+    from cvxpygen_amd.runtime import build_family_plan, BUILD_OPTIONS_FIXED_RHO
+    d = families.mpc(12, 4, 10)
+    plan = build_family_plan(d)
+    assert plan.kkt_squad is not None
+    pre = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'cvxpygen_amd',
+                       'generated', 'mpc12', 'libcpg_mpc12.so')
+    lib = pre if os.path.exists(pre) else codegen.build_family_library(plan, str(tmp_path), 'mpc12')
+    x0 = -2 + 4 * np.random.default_rng(31).random((1001, 12))
+    for bo, mode in (({}, {}), (dict(BUILD_OPTIONS_FIXED_RHO), dict(adaptive_rho=0, check_dualgap=0))):
+        bs = BatchSolver(d, lib_path=lib, plan=plan, build_options=bo)
+        bs.set_program_placement(3)
+        r = bs.solve({'x_init': x0}, updated_params=['x_init'])
+        v = C.c_double(0)
+        bs.lib.L.cpg_hip_get_setting(bs.h_shared, b'squad_executor', C.byref(v))
+        assert v.value == 1.0
+        _check(r, oracle_lib.cpg_solve_batch(d, _theta(d, 'x_init', x0), ['x_init'], **mode), d)
+        bs.close()
+    x0 = -2 + 4 * np.random.default_rng(32).random((100_000, 12))
+    res = []
+    for placement in (1, 3):
+        bs = BatchSolver(d, lib_path=lib, plan=plan)
+        bs.set_program_placement(placement)
+        res.append(bs.solve({'x_init': x0}, updated_params=['x_init']))
+        bs.close()
+    assert (res[1].status == 1).all() and (res[0].iter == res[1].iter).all()
+    assert np.abs(res[0].prim_flat - res[1].prim_flat).max() <= 1e-9 * np.abs(res[0].prim_flat).max()
+
+
 @pytest.mark.parametrize('name', ['mpc8', 'nnls40'])
 def test_generated_executor_other_shapes(oracle_lib, tmp_path, name):
     """two more families through the generated executor (libraries built by __graft_entry__.build): step and chunk
