@@ -11,8 +11,14 @@ follows literally:
   * the call sequence per solve: copy canonical parameters, build a NEW solver object
     (equilibration + KKT assembly + factorisation from scratch), solve, read the solution
     (`cvxpygen/solvers/clarabel.py:172-204`),
-  * the problem form  minimise 1/2 x'Px + q'x  s.t.  Ax + s = b, s in K  with cones ordered zero,
-    nonnegative, second-order (`cvxpygen/solvers/clarabel.py:133-155, 308-323`),
+  * the problem form  minimise 1/2 x'Px + q'x  s.t.  Ax + s = b, s in K  with K a product of zero,
+    nonnegative, second-order, exponential and three-dimensional power cones
+    (`cvxpygen/solvers/clarabel.py:133-155, 308-323`).  ROW ORDER: zero | nonneg | soc | exp | p3d -- the order
+    in which cvxpy stacks the rows of A and b for this solver.  The reference's `cones` array lists the
+    exponential cones AHEAD of the second-order cones (clarabel.py:316-319); for a family that has both kinds
+    its solver is told cones that do not match the rows it is given.  Followed here: the rows' meaning; with
+    only one of the two kinds present -- every case in which the reference is right -- both orders coincide.
+    PSD cones: not restated (refused by the product at plan time),
   * every setting default (`cvxpygen/solvers/clarabel.py:63-119`),
   * the returned fields x, z, obj_val, iterations, status (integer), r_prim, r_dual
     (`cvxpygen/solvers/clarabel.py:37-46`).
@@ -20,7 +26,11 @@ The algorithm is restated from its published description (Goulart & Chen, "Clara
 interior-point solver for conic programs with quadratic objectives", 2024):
 homogeneous embedding with (tau, kappa), Ruiz equilibration, Nesterov-Todd scaling, quasi-definite
 KKT system with static / dynamic regularisation and iterative refinement, Mehrotra
-predictor-corrector with sigma = (1 - alpha)^3.  Where the paper leaves details open (order of the
+predictor-corrector with sigma = (1 - alpha)^3; for the exponential and power cones the paper's section on
+nonsymmetric cones: unit initialisation, the dual barrier's Hessian as scaling block (primal-dual form: a
+rank-three update H_s = s s'/<s,z> + ds ds'/<ds,dz> + t a a', fall-back mu * H*(z)), third-order correction
+eta = 1/2 D^3 f*(z)[H*^-1 ds_aff, dz_aff], backtracking step lengths and -- under the dual scaling strategy --
+the centrality test on the sum of the barriers.  Where the paper leaves details open (order of the
 equilibration clamps, which norms carry the cost scaling) the choice made is written next to the
 code.  The only numbers this file is pinned against are independent ones: tests/golden holds
 scipy solutions of the reference's ADP inputs (tests/test_E2E_SOCP.py:15-64).
@@ -53,17 +63,24 @@ UNSOLVED, SOLVED, PRIMAL_INFEASIBLE, DUAL_INFEASIBLE, ALMOST_SOLVED, ALMOST_PRIM
 
 
 class Cones:
-    """rows of s / z: [zero | nonneg | soc_1 | soc_2 | ...]"""
+    """rows of s / z: [zero | nonneg | soc_1 | soc_2 | ... | exp_1 | ... | pow_1 | ...] (exponential and power cones: 3 rows
+    each; `pow` lists the exponents alpha of x^alpha y^(1-alpha) >= |z|)"""
 
-    def __init__(self, zero, nonneg, soc):
+    def __init__(self, zero, nonneg, soc, exp=0, pow=()):
         self.zero, self.nonneg, self.soc = int(zero), int(nonneg), [int(d) for d in soc]
-        self.m = self.zero + self.nonneg + sum(self.soc)
+        self.exp, self.pow = int(exp), [float(a) for a in pow]
         self.soc_start = []
         o = self.zero + self.nonneg
         for d in self.soc:
             self.soc_start.append(o)
             o += d
-        self.degree = self.nonneg + len(self.soc)
+        self.ns = []                                  # nonsymmetric cones: (first row, alpha or None for the exponential cone)
+        for a in [None] * self.exp + self.pow:
+            self.ns.append((o, a))
+            o += 3
+        self.m = o
+        self.degree = self.nonneg + len(self.soc) + 3 * len(self.ns)
+        self.symmetric = not self.ns
         self.nn = slice(self.zero, self.zero + self.nonneg)
 
     def socs(self):
@@ -72,6 +89,232 @@ class Cones:
 
 def _soc_res(v):
     return v[0] * v[0] - float(v[1:] @ v[1:])
+
+
+# ------------------------------------------------------------------------------------------------ nonsymmetric cones
+# K_exp = {(x, y, z): y > 0, y e^(x / y) <= z},  K_pow(a) = {(x, y, z): x^a y^(1 - a) >= |z|, x, y >= 0}.  Both dual barriers
+# have the form  f*(z) = -log zeta(z) - sum_i c_i log |z_i|  (degree 3):
+#   exp:  zeta = z1 log(-z1 / z3) - z1 + z2,                         c = (1, 0, 1)
+#   pow:  zeta = (z1 / a)^(2a) (z2 / (1 - a))^(2 - 2a) - z3^2,       c = (1 - a, a, 0)
+# so gradient, Hessian and the third directional derivative follow from zeta's own derivatives by the chain rule.
+EXP_CENTRAL = (-1.051383945322714, 0.556409619469370, 1.258967884768947)
+
+
+def _logsafe(v):
+    return np.log(v) if v > 0.0 else -np.inf
+
+
+def ns_zeta(z, alpha):
+    """(zeta, grad zeta, hess zeta, c)"""
+    z0, z1, z2 = float(z[0]), float(z[1]), float(z[2])
+    if alpha is None:
+        l = np.log(-z0 / z2)
+        zeta = z0 * l - z0 + z1
+        g = np.array([l, 1.0, -z0 / z2])
+        H = np.array([[1.0 / z0, 0.0, -1.0 / z2], [0.0, 0.0, 0.0], [-1.0 / z2, 0.0, z0 / (z2 * z2)]])
+        return zeta, g, H, np.array([1.0, 0.0, 1.0])
+    a, b = 2.0 * alpha, 2.0 - 2.0 * alpha
+    phi = np.exp(a * np.log(z0 / alpha) + b * np.log(z1 / (1.0 - alpha)))
+    zeta = phi - z2 * z2
+    g = np.array([a * phi / z0, b * phi / z1, -2.0 * z2])
+    h01 = a * b * phi / (z0 * z1)
+    H = np.array([[a * (a - 1.0) * phi / (z0 * z0), h01, 0.0], [h01, b * (b - 1.0) * phi / (z1 * z1), 0.0], [0.0, 0.0, -2.0]])
+    return zeta, g, H, np.array([1.0 - alpha, alpha, 0.0])
+
+
+def ns_zeta3(z, alpha, u, v):
+    """D^3 zeta(z)[u, v]"""
+    z0, z1, z2 = float(z[0]), float(z[1]), float(z[2])
+    if alpha is None:
+        return np.array([-u[0] * v[0] / (z0 * z0) + u[2] * v[2] / (z2 * z2), 0.0,
+                         (u[0] * v[2] + u[2] * v[0]) / (z2 * z2) - 2.0 * z0 * u[2] * v[2] / (z2 * z2 * z2)])
+    a, b = 2.0 * alpha, 2.0 - 2.0 * alpha
+    phi = np.exp(a * np.log(z0 / alpha) + b * np.log(z1 / (1.0 - alpha)))
+    p000 = a * (a - 1.0) * (a - 2.0) * phi / (z0 * z0 * z0)
+    p001 = a * (a - 1.0) * b * phi / (z0 * z0 * z1)
+    p011 = a * b * (b - 1.0) * phi / (z0 * z1 * z1)
+    p111 = b * (b - 1.0) * (b - 2.0) * phi / (z1 * z1 * z1)
+    x = u[0] * v[1] + u[1] * v[0]
+    return np.array([p000 * u[0] * v[0] + p001 * x + p011 * u[1] * v[1],
+                     p001 * u[0] * v[0] + p011 * x + p111 * u[1] * v[1], 0.0])
+
+
+def ns_dual_feasible(z, alpha):
+    if alpha is None:
+        if z[2] > 0.0 and z[0] < 0.0:
+            return z[1] - z[0] - z[0] * np.log(-z[2] / z[0]) > 0.0
+        return False
+    if z[0] > 0.0 and z[1] > 0.0:
+        return np.exp(2.0 * alpha * np.log(z[0] / alpha) + (2.0 - 2.0 * alpha) * np.log(z[1] / (1.0 - alpha))) - z[2] * z[2] > 0.0
+    return False
+
+
+def ns_primal_feasible(s, alpha):
+    if alpha is None:
+        if s[2] > 0.0 and s[1] > 0.0:
+            return s[1] * np.log(s[2] / s[1]) - s[0] > 0.0
+        return False
+    if s[0] > 0.0 and s[1] > 0.0:
+        return np.exp(2.0 * alpha * np.log(s[0]) + (2.0 - 2.0 * alpha) * np.log(s[1])) - s[2] * s[2] > 0.0
+    return False
+
+
+def _inv_where(c, z):
+    """1 / z_i where the barrier has a log |z_i| term (c_i != 0), 0 elsewhere"""
+    return np.array([1.0 / zi if ci != 0.0 else 0.0 for ci, zi in zip(c, z)])
+
+
+def ns_dual_grad_hess(z, alpha):
+    """gradient and Hessian of f* at z"""
+    zeta, g, H, c = ns_zeta(z, alpha)
+    iz = _inv_where(c, z)
+    grad = -g / zeta - c * iz
+    hess = np.outer(g, g) / (zeta * zeta) - H / zeta + np.diag(c * iz * iz)
+    return grad, hess
+
+
+def ns_barrier_dual(z, alpha):
+    if not ns_dual_feasible(z, alpha):
+        return np.inf
+    zeta, _, _, c = ns_zeta(z, alpha)
+    return -_logsafe(zeta) - float(sum(ci * np.log(abs(zi)) for ci, zi in zip(c, z) if ci != 0.0))
+
+
+def wright_omega(x):
+    """omega + log(omega) = x for x >= 1 (Newton from x - log x: error < 1e-16 after a few steps)"""
+    w = x - np.log(x) if x > 1.0 else 1.0
+    for _ in range(8):
+        w = w - (w + np.log(w) - x) * w / (w + 1.0)
+    return w
+
+
+def _pow_root(s, alpha):
+    """p >= 0 with  log(p^2 + 2p) - log s3^2 = 2a log((1+a+a p)/(a s1)) + 2(1-a) log((2-a+(1-a) p)/((1-a) s2)):
+    the third component of the primal gradient is p / s3.  The left side minus the right increases in p from -inf to
+    log(s1^2a s2^(2-2a) / s3^2) > 0: bisection-safeguarded Newton."""
+    a = alpha
+    l0 = np.log(s[2] * s[2])
+
+    def F(p):
+        return (np.log(p * p + 2.0 * p) - l0 - 2.0 * a * np.log((1.0 + a + a * p) / (a * s[0]))
+                - 2.0 * (1.0 - a) * np.log((2.0 - a + (1.0 - a) * p) / ((1.0 - a) * s[1])))
+
+    def dF(p):
+        return (2.0 * p + 2.0) / (p * p + 2.0 * p) - 2.0 * a * a / (1.0 + a + a * p) - 2.0 * (1.0 - a) ** 2 / (2.0 - a + (1.0 - a) * p)
+    lo, hi = 0.0, 1.0
+    for _ in range(200):
+        if F(hi) > 0.0:
+            break
+        lo, hi = hi, 2.0 * hi
+    p = 0.5 * (lo + hi)
+    for _ in range(100):
+        f = F(p)
+        if f > 0.0:
+            hi = p
+        else:
+            lo = p
+        pn = p - f / dF(p)
+        if not (lo < pn < hi):
+            pn = 0.5 * (lo + hi)
+        if abs(pn - p) <= 1e-16 * pn:
+            p = pn
+            break
+        p = pn
+    return p
+
+
+def ns_gradient_primal(s, alpha):
+    """gradient of the primal barrier f(s) = sup_z {-<s, z> - f*(z)}:  g = -z~ with grad f*(z~) = -s"""
+    g = np.zeros(3)
+    if alpha is None:
+        w = wright_omega(1.0 - s[0] / s[1] - np.log(s[1] / s[2]))
+        g[0] = 1.0 / ((w - 1.0) * s[1])
+        g[1] = g[0] + g[0] * np.log(w * s[1] / s[2]) - 1.0 / s[1]
+        g[2] = w / ((1.0 - w) * s[2])
+        return g
+    if abs(s[2]) > np.finfo(float).eps:
+        p = _pow_root(s, alpha)
+        g[2] = p / s[2]
+    else:
+        p = 0.0
+    g[0] = -(1.0 + alpha + alpha * p) / s[0]
+    g[1] = -(2.0 - alpha + (1.0 - alpha) * p) / s[1]
+    return g
+
+
+def ns_barrier_primal(s, alpha):
+    """f(s) = <s, g(s)> - f*(-g(s)) = -3 - f*(-g(s))"""
+    if not ns_primal_feasible(s, alpha):
+        return np.inf
+    if alpha is None:
+        w = wright_omega(1.0 - s[0] / s[1] - np.log(s[1] / s[2]))
+        return -_logsafe((w - 1.0) * (w - 1.0) / w) - 2.0 * np.log(s[1]) - np.log(s[2]) - 3.0
+    return -3.0 - ns_barrier_dual(-ns_gradient_primal(s, alpha), alpha)
+
+
+def _chol3_solve(H, b):
+    """H u = b by an explicit 3 x 3 Cholesky; None when H is not positive definite"""
+    l00 = H[0, 0]
+    if not l00 > 0.0:
+        return None
+    l00 = np.sqrt(l00)
+    l10, l20 = H[1, 0] / l00, H[2, 0] / l00
+    t = H[1, 1] - l10 * l10
+    if not t > 0.0:
+        return None
+    l11 = np.sqrt(t)
+    l21 = (H[2, 1] - l20 * l10) / l11
+    t = H[2, 2] - l20 * l20 - l21 * l21
+    if not t > 0.0:
+        return None
+    l22 = np.sqrt(t)
+    y0 = b[0] / l00
+    y1 = (b[1] - l10 * y0) / l11
+    y2 = (b[2] - l20 * y0 - l21 * y1) / l22
+    u2 = y2 / l22
+    u1 = (y1 - l21 * u2) / l11
+    u0 = (y0 - l10 * u1 - l20 * u2) / l00
+    return np.array([u0, u1, u2])
+
+
+def ns_higher_correction(z, alpha, ds, dz):
+    """eta = 1/2 D^3 f*(z)[u, v],  u = (hess f*(z))^-1 ds,  v = dz"""
+    zeta, g, H, c = ns_zeta(z, alpha)
+    iz = _inv_where(c, z)
+    hess = np.outer(g, g) / (zeta * zeta) - H / zeta + np.diag(c * iz * iz)
+    u = _chol3_solve(hess, ds)
+    if u is None:
+        return np.zeros(3)
+    v = dz
+    gu, gv = float(g @ u), float(g @ v)
+    Hu, Hv = H @ u, H @ v
+    T = (-ns_zeta3(z, alpha, u, v) / zeta + (Hu * gv + Hv * gu + g * float(u @ Hv)) / (zeta * zeta)
+         - 2.0 * g * gu * gv / (zeta * zeta * zeta) - 2.0 * c * u * v * iz * iz * iz)
+    return 0.5 * T
+
+
+def ns_primal_dual_Hs(s, z, alpha, grad, hess):
+    """the scaling block of a nonsymmetric cone under the primal-dual strategy (grad, hess: of f* at z); mu * hess where
+    the rank-three form is not safe"""
+    st = grad
+    zt = ns_gradient_primal(s, alpha)
+    dot_sz = float(s @ z)
+    mu = dot_sz / 3.0
+    mut = float(zt @ st) / 3.0
+    ds_ = s + mu * st
+    dz_ = z + mu * zt
+    dot_dsz = float(ds_ @ dz_)
+    de1 = mu * mut - 1.0
+    de2 = float(zt @ (hess @ zt)) - 3.0 * mut * mut
+    eps = np.finfo(float).eps
+    if abs(de1) > np.sqrt(eps) and abs(de2) > eps and dot_sz > 0.0 and dot_dsz > 0.0:
+        tmp = mut * st - hess @ zt
+        M = hess - np.outer(st, st) / 3.0 - np.outer(tmp, tmp) / de2
+        t = mu * np.sqrt(float((M * M).sum()))
+        ax = np.array([z[1] * zt[2] - z[2] * zt[1], z[2] * zt[0] - z[0] * zt[2], z[0] * zt[1] - z[1] * zt[0]])
+        ax = ax / np.sqrt(float(ax @ ax))
+        return np.outer(s, s) / dot_sz + np.outer(ds_, ds_) / dot_dsz + t * np.outer(ax, ax)
+    return mu * hess
 
 
 def _ldl(K, signs, stg):
@@ -190,6 +433,12 @@ def equilibrate(P, q, A, b, cones, stg):
         A[sl, :] *= ew[:, None]
         b[sl] *= ew
         E[sl] *= ew
+    for st, _ in cones.ns:                  # exponential / power cones admit no row scaling at all: back to 1
+        sl = slice(st, st + 3)
+        ew = 1.0 / E[sl]
+        A[sl, :] *= ew[:, None]
+        b[sl] *= ew
+        E[sl] *= ew
     return P, q, A, b, D, E, c
 
 
@@ -239,6 +488,8 @@ class _Scaling:
 
     def identity(self):
         c = self.c
+        self.ns_grad = [np.zeros(3) for _ in c.ns]       # gradient of the dual barrier at z
+        self.ns_Hs = [np.eye(3) for _ in c.ns]           # scaling blocks of the nonsymmetric cones
         self.w = np.ones(c.m)
         self.lam = np.ones(c.m)
         self.eta = [1.0] * len(c.soc)
@@ -248,9 +499,14 @@ class _Scaling:
             v[0] = 1.0
             self.sw.append(v)
 
-    def update(self, s, z):
+    def update(self, s, z, mu=None, dual_strategy=False):
         c = self.c
         ok = True
+        for k, (st, alpha) in enumerate(c.ns):
+            zk, sk = z[st:st + 3], s[st:st + 3]
+            grad, hess = ns_dual_grad_hess(zk, alpha)
+            self.ns_grad[k] = grad
+            self.ns_Hs[k] = mu * hess if dual_strategy else ns_primal_dual_Hs(sk, zk, alpha, grad, hess)
         if c.nonneg:
             self.w[c.nn] = np.sqrt(s[c.nn] / z[c.nn])
             self.lam[c.nn] = np.sqrt(s[c.nn] * z[c.nn])
@@ -296,6 +552,8 @@ class _Scaling:
             J = -np.eye(len(w))
             J[0, 0] = 1.0
             H[sl, sl] = eta * eta * (2.0 * np.outer(w, w) - J)
+        for k, (st, _) in enumerate(c.ns):
+            H[st:st + 3, st:st + 3] = self.ns_Hs[k]
         return H
 
     def mul_Hs(self, v):
@@ -311,6 +569,8 @@ class _Scaling:
             o[0] -= vk[0]
             o[1:] += vk[1:]
             out[sl] = eta * eta * o
+        for k, (st, _) in enumerate(c.ns):
+            out[st:st + 3] = self.ns_Hs[k] @ v[st:st + 3]
         return out
 
     def mul_W(self, v, inv=False):
@@ -392,23 +652,34 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
     kkt = _Kkt(Ph, Ah, cones, stg)
     sc = _Scaling(cones)
 
-    # ---- initial point (symmetric cones, P != 0 or == 0 handled alike via the two-solve form)
-    Hs0 = np.zeros((m, m))
-    idx = np.arange(cones.zero, m)
-    Hs0[idx, idx] = 1.0
-    kkt.update(Hs0)
-    if p_is_zero is None:
-        p_is_zero = not np.any(Ph != 0.0)
-    if not p_is_zero:      # the structural test nnz(P) == 0 of the solver
-        x, z = kkt.solve(-qh, bh)
-        s = -z.copy()
+    if cones.symmetric:
+        # ---- initial point (symmetric cones, P != 0 or == 0 handled alike via the two-solve form)
+        Hs0 = np.zeros((m, m))
+        idx = np.arange(cones.zero, m)
+        Hs0[idx, idx] = 1.0
+        kkt.update(Hs0)
+        if p_is_zero is None:
+            p_is_zero = not np.any(Ph != 0.0)
+        if not p_is_zero:      # the structural test nnz(P) == 0 of the solver
+            x, z = kkt.solve(-qh, bh)
+            s = -z.copy()
+        else:
+            x, s = kkt.solve(np.zeros(n), bh)
+            s = -s
+            _, z = kkt.solve(-qh, np.zeros(m))
+        _shift_to_cone(cones, s, True)
+        _shift_to_cone(cones, z, False)
     else:
-        x, s = kkt.solve(np.zeros(n), bh)
-        s = -s
-        _, z = kkt.solve(-qh, np.zeros(m))
-    _shift_to_cone(cones, s, True)
-    _shift_to_cone(cones, z, False)
+        # ---- a nonsymmetric cone anywhere: every cone starts at its central point s = z = -grad f(s), x = 0
+        x, s = np.zeros(n), np.zeros(m)
+        s[cones.nn] = 1.0
+        for sl in cones.socs():
+            s[sl.start] = 1.0
+        for st, alpha in cones.ns:
+            s[st:st + 3] = EXP_CENTRAL if alpha is None else (np.sqrt(1.0 + alpha), np.sqrt(2.0 - alpha), 0.0)
+        z = s.copy()
     tau, kap = 1.0, 1.0
+    dual_strategy = False         # scaling strategy of the nonsymmetric cones: primal-dual until a checkpoint switches to dual
 
     status, it = UNSOLVED, 0
     info = {}
@@ -469,6 +740,11 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
             if (res_d > stg['tol_feas'] and res_d > 100.0 * prev['res_d']) or \
                     (res_p > stg['tol_feas'] and res_p > 100.0 * prev['res_p']):
                 status = INSUFFICIENT_PROGRESS
+            if status == INSUFFICIENT_PROGRESS and not cones.symmetric and not dual_strategy:
+                # strategy checkpoint: the primal-dual scaling gets a second chance as the dual scaling, from this iterate
+                status, dual_strategy = UNSOLVED, True
+                prev = dict(info)
+                continue
             if status == INSUFFICIENT_PROGRESS:
                 # "insufficient progress often involves actual degradation of results": back to the previous iterate
                 # and its cost / residual / gap figures (kappa/tau and the certificate quantities stay)
@@ -482,7 +758,7 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
         prev = dict(info)
         it += 1
         # ---- scaling, factor, constant part of the solution
-        if not sc.update(s, z):
+        if not sc.update(s, z, mu, dual_strategy):
             status = NUMERICAL_ERROR
             break
         kkt.update(sc.Hs())
@@ -507,10 +783,45 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
                 a = min(a, -tau / dtau)
             if dkap < 0.0:
                 a = min(a, -kap / dkap)
-            a = min(_step_length(cones, z, dz, a), _step_length(cones, s, ds, a))
+            a = min(_step_length(cones, z, dz, a), _step_length(cones, s, ds, a))      # symmetric cones first
+            if not cones.symmetric:
+                # back off from a full step so that the logarithms below are not taken at the boundary, then backtrack
+                a = min(a, stg['max_step_fraction'])
+                for st, alpha in cones.ns:
+                    for v, dv, inside in ((z, dz, ns_dual_feasible), (s, ds, ns_primal_feasible)):
+                        ak = a
+                        while not inside(v[st:st + 3] + ak * dv[st:st + 3], alpha):
+                            ak *= stg['linesearch_backtrack_step']
+                            if ak < stg['min_terminate_step_length']:
+                                ak = 0.0
+                                break
+                        a = min(a, ak)
             return a * stg['max_step_fraction'] if combined else a
+
+        def barrier(dz, ds, dtau, dkap, a):
+            """the centrality function of the dual scaling strategy at the trial point"""
+            ct, ck = tau + a * dtau, kap + a * dkap
+            sn, zn = s + a * ds, z + a * dz
+            mu_ = (float(sn @ zn) + ct * ck) / (cones.degree + 1)
+            val = (cones.degree + 1) * _logsafe(mu_) - _logsafe(ct) - _logsafe(ck)
+            for i in range(cones.zero, cones.zero + cones.nonneg):
+                val -= _logsafe(sn[i] * zn[i])
+            for sl in cones.socs():
+                rs_, rz_ = _soc_res(sn[sl]), _soc_res(zn[sl])
+                val += -0.5 * _logsafe(rs_ * rz_) if (rs_ > 0.0 and rz_ > 0.0) else np.inf
+            for st, alpha in cones.ns:
+                val += ns_barrier_dual(zn[st:st + 3], alpha) + ns_barrier_primal(sn[st:st + 3], alpha)
+            return val
         # ---- affine step
         dx, dz, ds, dtau, dkap = kkt_solve(rx, rz, rtau, tau * kap, s)
+        finite = np.isfinite(dtau) and np.isfinite(dz).all() and np.isfinite(dx).all()
+        if not finite and not cones.symmetric:
+            # strategy checkpoint (numerical error): dual scaling if not tried yet
+            if not dual_strategy:
+                dual_strategy = True
+                continue
+            status = NUMERICAL_ERROR
+            break
         alpha = step_len(dz, ds, dtau, dkap, False)
         sigma = (1.0 - alpha) ** 3
         # ---- combined step
@@ -522,9 +833,27 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
         d_s = sc.circ(sc.lam, sc.lam) + shift - sigma * mu * e
         d_s[:cones.zero] = 0.0
         rk = -sigma * mu + dtau * dkap + tau * kap
-        dx, dz, ds, dtau, dkap = kkt_solve((1.0 - sigma) * rx, (1.0 - sigma) * rz, (1.0 - sigma) * rtau, rk,
-                                           sc.ds_offset(d_s))
+        ds_const = sc.ds_offset(d_s)
+        for k, (st, alpha_k) in enumerate(cones.ns):       # ds = s + sigma mu grad f*(z) - eta, handed on as it is
+            eta = ns_higher_correction(z[st:st + 3], alpha_k, ds[st:st + 3], dz[st:st + 3])
+            ds_const[st:st + 3] = s[st:st + 3] + sigma * mu * sc.ns_grad[k] - eta
+        dx, dz, ds, dtau, dkap = kkt_solve((1.0 - sigma) * rx, (1.0 - sigma) * rz, (1.0 - sigma) * rtau, rk, ds_const)
+        finite = np.isfinite(dtau) and np.isfinite(dz).all() and np.isfinite(dx).all()
+        if not finite and not cones.symmetric:
+            if not dual_strategy:
+                dual_strategy = True
+                continue
+            status = NUMERICAL_ERROR
+            break
         alpha = step_len(dz, ds, dtau, dkap, True)
+        if not cones.symmetric and dual_strategy:
+            for _ in range(50):                                  # centrality: back to where the barrier sum is below 1
+                if barrier(dz, ds, dtau, dkap, alpha) < 1.0:
+                    break
+                alpha *= stg['linesearch_backtrack_step']
+        if not cones.symmetric and not dual_strategy and alpha < stg['min_switch_step_length']:
+            dual_strategy = True                                 # strategy checkpoint (small step): redo with the dual scaling
+            continue
         if alpha <= max(0.0, stg['min_terminate_step_length']):      # undersized step: stop where we are
             status = INSUFFICIENT_PROGRESS
             break
@@ -559,7 +888,7 @@ def cpg_solve_batch(desc, theta, **settings):
     B = theta.shape[0]
     if theta.shape[1] == desc.NP:
         theta = np.concatenate([theta, np.ones((B, 1))], axis=1)
-    cones = Cones(desc.cones['zero'], desc.cones['nonneg'], desc.cones['soc'])
+    cones = Cones(desc.cones['zero'], desc.cones['nonneg'], desc.cones['soc'], desc.cones.get('exp', 0), desc.cones.get('pow', ()))
     n, m = desc.n_var, desc.m
     Pp, Pi = desc.P.indptr, desc.P.indices
     Ap, Ai = desc.A.indptr, desc.A.indices
