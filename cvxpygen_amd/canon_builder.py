@@ -91,6 +91,8 @@ class CanonBuilder:
         self._d: Dict[int, float] = {}
         self._duals: List[Tuple[str, List[Tuple[str, int]], Tuple[int, ...]]] = []
         self._soc: List[List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]] = []
+        self._exp: List[List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]] = []
+        self._pow: List[Tuple[float, List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]]] = []
         self.is_maximization = False
 
     # ---- declarations -------------------------------------------------------------------------
@@ -140,6 +142,22 @@ class CanonBuilder:
         self._soc.append([([(int(c), _as_coef(v)) for c, v in entries], _as_coef(rhs)) for entries, rhs in rows])
         return ('soc', len(self._soc) - 1)
 
+    def exp_cone(self, rows: Sequence[Tuple[Iterable[Tuple[int, Coef]], Coef]]) -> Tuple[str, int]:
+        """exponential cone over three slack entries s_k = rhs_k - sum_j entries_kj * x_j:  s_1 > 0, s_1 exp(s_0 / s_1) <= s_2
+        (`cvxpygen/solvers/clarabel.py:136, 142`: ClarabelExponentialConeT)"""
+        if len(rows) != 3:
+            raise ValueError('an exponential cone has three rows')
+        self._exp.append([([(int(c), _as_coef(v)) for c, v in entries], _as_coef(rhs)) for entries, rhs in rows])
+        return ('exp', len(self._exp) - 1)
+
+    def pow_cone(self, alpha: float, rows: Sequence[Tuple[Iterable[Tuple[int, Coef]], Coef]]) -> Tuple[str, int]:
+        """three-dimensional power cone  s_0^alpha s_1^(1 - alpha) >= |s_2|, s_0, s_1 >= 0  (`cvxpygen/solvers/clarabel.py:139, 147`:
+        ClarabelPowerConeT(alpha)); alpha is structure, not a parameter"""
+        if len(rows) != 3 or not 0.0 < float(alpha) < 1.0:
+            raise ValueError('a power cone has three rows and an exponent in (0, 1)')
+        self._pow.append((float(alpha), [([(int(c), _as_coef(v)) for c, v in entries], _as_coef(rhs)) for entries, rhs in rows]))
+        return ('pow', len(self._pow) - 1)
+
     def quad(self, i: int, j: int, coef: Coef) -> None:
         """objective += 1/2 * coef * x_i x_j * (2 if i != j else 1), i.e. P[i, j] += coef (upper)."""
         i, j = (int(i), int(j)) if i <= j else (int(j), int(i))
@@ -174,9 +192,11 @@ class CanonBuilder:
 
     def build(self, values: Dict[str, np.ndarray], solver: str = 'OSQP') -> FamilyDescriptor:
         conic = solver != 'OSQP'
-        if self._soc and not conic:
-            raise ValueError('second-order cones need a conic solver')
-        soc_rows = [row for cone in self._soc for row in cone]
+        if (self._soc or self._exp or self._pow) and not conic:
+            raise ValueError('second-order, exponential and power cones need a conic solver')
+        # (rows behind the nonnegative cone in cvxpy's order for Clarabel: soc | exp | p3d)
+        soc_rows = [row for cone in self._soc for row in cone] + [row for cone in self._exp for row in cone] + \
+            [row for _, cone in self._pow for row in cone]
         n, n_eq, n_ineq = self.n_var, len(self._eq), len(self._ineq) + len(soc_rows)
         m = n_eq + n_ineq
 
@@ -234,6 +254,10 @@ class CanonBuilder:
         if conic:       # Ax + s = b, s in K: the same rows, one right-hand side b (clarabel.py:19-46)
             maps = {'P': map_P, 'q': map_q, 'd': map_d, 'A': map_A, 'b': map_u}
             cones = {'zero': n_eq, 'nonneg': len(self._ineq), 'soc': [len(c) for c in self._soc]}
+            if self._exp:
+                cones['exp'] = len(self._exp)
+            if self._pow:
+                cones['pow'] = [a for a, _ in self._pow]
         # p_id_to_changes: depends on any non-constant theta column
         # (`cvxpygen/canonicalizer.py:324`)
         changes = {}

@@ -8,7 +8,8 @@ in every interior-point iteration factors
     K = [[P + eps I, A'], [A, -(W'W) - eps I]]
 
 whose pattern is fixed for the family: P (upper), A, the diagonal of the (2,2) block and one dense
-block per second-order cone.  Everything structural is computed once here: fill-reducing
+block per second-order cone and per exponential / power cone (3 x 3: the scaling block H_s of a
+nonsymmetric cone stands where W'W stands for a symmetric one).  Everything structural is computed once here: fill-reducing
 permutation, symbolic LDL', where every KKT entry comes from, the level-scheduled dot-product
 schedule of the numeric factorisation and the ragged substitution program with value sources
 (shared machinery: refactor_plan.build_schedules).
@@ -29,7 +30,7 @@ from . import solve_program as _sp
 from .refactor_plan import RaggedTable, build_schedules
 
 # KKT value sources (device: cpg_clarabel_kernel.h)
-K_NONE, K_P, K_A, K_DIAGX, K_HDIAG, K_HSOC = 0, 1, 2, 3, 5, 6
+K_NONE, K_P, K_A, K_DIAGX, K_HDIAG, K_HSOC, K_HNS = 0, 1, 2, 3, 5, 6, 7
 # what the planner of the substitution program charges for a reduction stage, relative to the defaults
 # tuned on the large OSQP programs: small KKT systems (ADP: 36 rows) want wider rows and fewer steps
 # (29 -> 18 steps per solve, +5 % instances/s)
@@ -46,6 +47,8 @@ class ConicPlan:
     n_zero: int
     n_nonneg: int
     soc_dims: np.ndarray
+    n_exp: int
+    pow_alpha: np.ndarray            # exponents of the 3-d power cones (rows: zero | nonneg | soc | exp | pow)
     Ap: np.ndarray; Ai: np.ndarray
     Arp: np.ndarray; Aent: np.ndarray; Acol: np.ndarray
     Pp: np.ndarray; Pi: np.ndarray
@@ -84,15 +87,19 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
     if not desc.cones:
         raise ValueError('not a conic family')
     for key, val in desc.cones.items():
-        if key not in ('zero', 'nonneg', 'soc') and val:
-            # exponential / PSD / power cones (clarabel.py:140-155) have no kernel support yet
+        if key not in ('zero', 'nonneg', 'soc', 'exp', 'pow') and np.size(val) and np.any(val):
+            # PSD cones (clarabel.py:138, 146) have no kernel support
             raise NotImplementedError(f'cone type "{key}" is not supported by the interior-point kernel')
     P, A = sp.csc_matrix(desc.P), sp.csc_matrix(desc.A)
     n, m = desc.n_var, desc.m
     N = n + m
     nz, nn = int(desc.cones['zero']), int(desc.cones['nonneg'])
     soc = np.asarray(desc.cones.get('soc', []), dtype=np.int32)
-    if nz + nn + int(soc.sum()) != m:
+    n_exp = int(desc.cones.get('exp', 0) or 0)
+    pow_alpha = np.asarray(desc.cones.get('pow', []), dtype=np.float64).ravel()
+    if len(pow_alpha) and not ((pow_alpha > 0.0) & (pow_alpha < 1.0)).all():
+        raise ValueError('power cone exponents must lie in (0, 1)')
+    if nz + nn + int(soc.sum()) + 3 * (n_exp + len(pow_alpha)) != m:
         raise ValueError('cone dimensions do not add up to the number of rows')
     if N >= 0xFFFF:
         raise ValueError('family too large for 16-bit slot indices')
@@ -116,6 +123,11 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
             for b in range(a + 1, d):
                 src_nat[(n + o + a, n + o + b)] = (K_HSOC, (o + a) | ((o + b) << 16))
         o += int(d)
+    for _ in range(n_exp + len(pow_alpha)):          # 3 x 3 scaling blocks: off-diagonals (0,1), (0,2), (1,2) at wv[o + 0 .. 2]
+        src_nat[(n + o, n + o + 1)] = (K_HNS, o)
+        src_nat[(n + o, n + o + 2)] = (K_HNS, o + 1)
+        src_nat[(n + o + 1, n + o + 2)] = (K_HNS, o + 2)
+        o += 3
     keys = list(src_nat.keys())
     K = sp.csc_matrix((np.ones(len(keys)), ([k[0] for k in keys], [k[1] for k in keys])), shape=(N, N))
     perm = _setup.choose_ordering(K, ordering)
@@ -131,7 +143,7 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
         build_schedules(N, perm, Lp, Li, src, stage_scale=CONIC_STAGE_SCALE)
     stats = dict(stats)
     stats['etree_height'] = int(_ord.etree_height(etree))
-    return ConicPlan(n=n, m=m, nnzP=P.nnz, nnzA=A.nnz, nnzL=len(Li), n_zero=nz, n_nonneg=nn, soc_dims=soc,
+    return ConicPlan(n=n, m=m, nnzP=P.nnz, nnzA=A.nnz, nnzL=len(Li), n_zero=nz, n_nonneg=nn, soc_dims=soc, n_exp=n_exp, pow_alpha=pow_alpha,
                      Ap=A.indptr.astype(np.int32), Ai=A.indices.astype(np.int32), Arp=Arp, Aent=Aent,
                      Acol=Acol, Pp=P.indptr.astype(np.int32), Pi=P.indices.astype(np.int32), Prp=Prp,
                      Pent=Pent, Pcol=Pcol, perm=perm.astype(np.int32), Lp=np.asarray(Lp, dtype=np.int32),

@@ -45,7 +45,8 @@ class _ConicFamily(C.Structure):     # include/cpg_hip.h: cpg_conic_family_t
                 ('np_var', C.c_int32), ('P_base', _dp), ('A_base', _dp), ('q_base', _dp), ('b_base', _dp),
                 ('d_base', C.c_double),
                 ('map_P', _Csr), ('map_A', _Csr), ('map_q', _Csr), ('map_b', _Csr), ('map_d', _Csr),
-                ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip)]
+                ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip),
+                ('n_exp', C.c_int32), ('n_pow', C.c_int32), ('pow_alpha', _dp)]
 
 
 class _PlanView:
@@ -160,6 +161,9 @@ class ConicBatchSolver(BatchSolver):
 
         def u16(a):
             a = np.ascontiguousarray(a, dtype=np.uint16); keep.append(a); return a.ctypes.data_as(_u16p)
+
+        def f64(a):
+            a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); return a.ctypes.data_as(_dp)
         prim_idx = np.arange(desc.n_var, dtype=np.int32) if self.full_output else self.plan.prim_idx
         dual_idx = np.arange(desc.m, dtype=np.int32) if self.full_output else self.plan.dual_idx
         fam = _ConicFamily(
@@ -176,7 +180,8 @@ class ConicBatchSolver(BatchSolver):
             sol_kind=i32(cp.sol_kind), sol_idx=i32(cp.sol_idx), sol_fpos=u16(cp.sol.final_pos),
             np_var=len(cols), P_base=_d(Pb), A_base=_d(Ab), q_base=_d(qb), b_base=_d(bb), d_base=d_base,
             map_P=MP, map_A=MA, map_q=Mq, map_b=Mb, map_d=Md,
-            n_prim=len(prim_idx), prim_idx=i32(prim_idx), n_dual=len(dual_idx), dual_idx=i32(dual_idx))
+            n_prim=len(prim_idx), prim_idx=i32(prim_idx), n_dual=len(dual_idx), dual_idx=i32(dual_idx),
+            n_exp=cp.n_exp, n_pow=len(cp.pow_alpha), pow_alpha=f64(cp.pow_alpha))
         self.lib.check(self.lib.L.cpg_hip_create_clarabel(C.byref(fam), self.device, C.byref(self.h)),
                        'cpg_hip_create_clarabel')
         self._update_key, self._keep = key, keep

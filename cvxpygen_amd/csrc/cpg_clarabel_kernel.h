@@ -22,6 +22,7 @@
 // cpg::run_program_conic(entries, offsets, slots, w, lane)
 #include CPG_GENC_HEADER
 #endif
+#include "cpg_clarabel_nonsym.h"
 
 // (timing experiments, scripts/gpu_probe_conic.py: bit k set = piece k of an iteration is executed TWICE -- every piece is
 // idempotent, so results and control flow stay what they are and the time added is the piece's cost.  1 factorisation, 2 substitution
@@ -38,6 +39,7 @@ namespace cpg {
 #define CPG_CK_DIAGX 3
 #define CPG_CK_HDIAG 5
 #define CPG_CK_HSOC 6
+#define CPG_CK_HNS 7            // off-diagonal entry of an exponential / power cone's 3 x 3 scaling block: -wv[idx]
 
 // Clarabel's SolverStatus numbering (the reference hands the integer through: clarabel.py:37-46)
 #define CPG_CL_UNSOLVED 0
@@ -56,6 +58,7 @@ struct DevConicSettings {
         ir_max_iter;
     double max_step_fraction, tol_gap_abs, tol_gap_rel, tol_feas, tol_infeas_abs, tol_infeas_rel, eq_min, eq_max,
         static_const, static_prop, dyn_eps, dyn_delta, ir_reltol, ir_abstol, ir_stop_ratio, min_terminate_step;
+    double ls_backtrack, min_switch_step;      // nonsymmetric cones: backtracking factor, step length below which the scaling strategy switches
     // kappa/tau threshold of the infeasibility certificates and the reduced tolerances behind the "almost" statuses
     // (cvxpygen/solvers/clarabel.py:76-84)
     double tol_ktratio, red_gap_abs, red_gap_rel, red_feas, red_infeas_abs, red_infeas_rel, red_ktratio;
@@ -63,6 +66,8 @@ struct DevConicSettings {
 
 struct DevConic {
     int n, m, nnzP, nnzA, nnzL, n_zero, n_nonneg, n_soc, is_max, p_is_zero;
+    int n_ns;                                // exponential + power cones: the last 3 n_ns rows, three per cone
+    const double *ns_alpha;                  // [n_ns] exponent of a power cone, 0 for an exponential cone
     const int *soc_start, *soc_dim;          // [n_soc]
     const int *row_cone;                     // [m] first row of the row's second-order cone, -1 otherwise
     const int *Ap, *Ai, *Arp, *Aent, *Acol, *Pp, *Pi, *Prp, *Pent, *Pcol;
@@ -124,7 +129,11 @@ typedef unsigned genc_row_word;      // (no row words in this library: ConicCtx:
 #endif
 namespace cpg {
 
-struct ConicCtx {
+// NS: the family has exponential / power cones (a compile-time switch: the symmetric kernel carries none of their code).
+// Their scaling state sits in the per-row vectors of the slice: hd = diagonal of the cone's 3 x 3 block H_s,
+// wv = (H_s01, H_s02, H_s12), et = gradient of the dual barrier at z.
+template <bool NS>
+struct ConicCtxT {
     const DevConic &C;
     const DevConicSettings &S;
     ConicBuf B;
@@ -214,9 +223,17 @@ struct ConicCtx {
         }
         cpgw::lds_order();
     }
+    CPG_DEV unsigned ns_first() const { return m - 3u * (unsigned)C.n_ns; }
     // (W'W v)_i for row i; `dots` from soc_dots(v)
     CPG_DEV double hs_row(unsigned i, const double *v, const double *dots) const {
         if (i < (unsigned)C.n_zero) return 0.0;
+        if (NS && i >= ns_first()) {
+            const unsigned r = (i - ns_first()) % 3u, st = i - r;
+            const double v0 = v[st], v1 = v[st + 1u], v2 = v[st + 2u];
+            if (r == 0u) return (B.hd[st] * v0 + B.wv[st] * v1) + B.wv[st + 1u] * v2;
+            if (r == 1u) return (B.wv[st] * v0 + B.hd[st + 1u] * v1) + B.wv[st + 2u] * v2;
+            return (B.wv[st + 1u] * v0 + B.wv[st + 2u] * v1) + B.hd[st + 2u] * v2;
+        }
         const int st = cpgw::gld(C.row_cone, i);
         if (st < 0) return B.hd[i] * v[i];
         const double eta = B.et[i];
@@ -355,6 +372,7 @@ struct ConicCtx {
                     const unsigned i = idx & 0xFFFFu, j = idx >> 16;
                     kv = -((B.et[i] * B.et[i]) * (2.0 * (B.wv[i] * B.wv[j])));
                 }
+                else if (NS && kind == CPG_CK_HNS) kv = -B.wv[idx];
                 double v = kv - acc;
                 if (piv) {
                     if (S.dynamic_reg_enable && v * sign < S.dyn_eps) v = S.dyn_delta * sign;
@@ -433,9 +451,26 @@ struct ConicCtx {
         else if (mn < target) unit_shift(v, target - mn, primal);
         else unit_shift(v, 0.0, primal);
     }
-    // Nesterov-Todd scaling from (s, z); false if a second-order cone iterate left the cone
-    CPG_DEV bool update_scaling() const {
+    // Nesterov-Todd scaling from (s, z); false if a second-order cone iterate left the cone.  Exponential / power cones:
+    // gradient and Hessian of the dual barrier at z, block H_s by the strategy in force (mu: the iterate's duality measure)
+    CPG_DEV bool update_scaling(double mu, bool dual_strategy) const {
         bool ok = true;
+        if (NS) {
+            for (int k = lane; k < C.n_ns; k += 64) {
+                const unsigned st = ns_first() + 3u * (unsigned)k;
+                const double alpha = cpgw::gld(C.ns_alpha, (unsigned)k);
+                const double zk[3] = {B.z[st], B.z[st + 1u], B.z[st + 2u]}, sk[3] = {B.s[st], B.s[st + 1u], B.s[st + 2u]};
+                ns::Zeta Z;
+                ns::zeta(zk, alpha, Z);
+                double grad[3], H[6], Hs[6];
+                ns::dual_grad_hess(Z, grad, H);
+                if (dual_strategy) { for (int t = 0; t < 6; t++) Hs[t] = mu * H[t]; }
+                else ns::primal_dual_Hs(sk, zk, alpha, grad, H, Hs);
+                B.et[st] = grad[0]; B.et[st + 1u] = grad[1]; B.et[st + 2u] = grad[2];
+                B.hd[st] = Hs[0]; B.hd[st + 1u] = Hs[3]; B.hd[st + 2u] = Hs[5];
+                B.wv[st] = Hs[1]; B.wv[st + 1u] = Hs[2]; B.wv[st + 2u] = Hs[4];
+            }
+        }
         for (unsigned i = (unsigned)C.n_zero + (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {
             const double w = sqrt(B.s[i] / B.z[i]);
             B.wv[i] = w; B.et[i] = 1.0;
@@ -517,8 +552,77 @@ struct ConicCtx {
         }
         return cpgw::wave_min(a);
     }
-    // dsc = W'(lambda \ (lambda o lambda + (W^-1 ds) o (W dz) - sigma mu e)), zero-cone rows 0
+    // exponential / power cones: backtracking from a on the cone tests of z + a dz and s + a ds
+    CPG_DEV double ns_step_length(double a0) const {
+        double a = a0;
+        for (int k = lane; k < C.n_ns; k += 64) {
+            const unsigned st = ns_first() + 3u * (unsigned)k;
+            const double alpha = cpgw::gld(C.ns_alpha, (unsigned)k);
+#pragma nounroll
+            for (int side = 0; side < 2; side++) {
+                const double *v = side == 0 ? B.z : B.s, *dv = side == 0 ? B.dz : B.ds;
+                const double v0 = v[st], v1 = v[st + 1u], v2 = v[st + 2u], d0 = dv[st], d1 = dv[st + 1u], d2 = dv[st + 2u];
+                double ak = a0;
+#pragma nounroll
+                for (;;) {
+                    const double w[3] = {v0 + ak * d0, v1 + ak * d1, v2 + ak * d2};
+                    if (side == 0 ? ns::dual_feasible(w, alpha) : ns::primal_feasible(w, alpha)) break;
+                    ak *= S.ls_backtrack;
+                    if (ak < S.min_terminate_step) { ak = 0.0; break; }
+                }
+                a = cpgw::dmin2(a, ak);
+            }
+        }
+        return cpgw::wave_min(a);
+    }
+    // centrality function of the dual scaling strategy at the trial point (s + a ds, z + a dz, tau + a dtau, kappa + a dkappa)
+    CPG_DEV double barrier(double a, double tau, double kap, double dtau, double dkap) const {
+        const double ct = tau + a * dtau, ck = kap + a * dkap;
+        double sz = 0.0, acc = 0.0;
+        for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+            const double sn = B.s[i] + a * B.ds[i], zn = B.z[i] + a * B.dz[i];
+            sz = fma(sn, zn, sz);
+            if (i >= (unsigned)C.n_zero && i < (unsigned)(C.n_zero + C.n_nonneg)) acc -= ns::logsafe(sn * zn);
+        }
+        for (int k = lane; k < C.n_soc; k += 64) {
+            const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
+            double s0 = B.s[st] + a * B.ds[st], z0 = B.z[st] + a * B.dz[st], ss = 0.0, zz = 0.0;
+            for (unsigned r = 1; r < dm; r++) {
+                const double sn = B.s[st + r] + a * B.ds[st + r], zn = B.z[st + r] + a * B.dz[st + r];
+                ss += sn * sn; zz += zn * zn;
+            }
+            const double rs = s0 * s0 - ss, rz = z0 * z0 - zz;
+            acc += (rs > 0.0 && rz > 0.0) ? -0.5 * ns::logsafe(rs * rz) : CPG_NS_INF;
+        }
+        for (int k = lane; k < C.n_ns; k += 64) {
+            const unsigned st = ns_first() + 3u * (unsigned)k;
+            const double alpha = cpgw::gld(C.ns_alpha, (unsigned)k);
+            const double zn[3] = {B.z[st] + a * B.dz[st], B.z[st + 1u] + a * B.dz[st + 1u], B.z[st + 2u] + a * B.dz[st + 2u]};
+            const double sn[3] = {B.s[st] + a * B.ds[st], B.s[st + 1u] + a * B.ds[st + 1u], B.s[st + 2u] + a * B.ds[st + 2u]};
+            acc += ns::barrier_dual(zn, alpha) + ns::barrier_primal(sn, alpha);
+        }
+        sz = cpgw::wave_sum(sz);
+        const bool inf = cpgw::wave_any(!(acc < CPG_NS_INF));       // (+inf in any lane: the sum is +inf whatever the other lanes hold)
+        acc = cpgw::wave_sum(acc);
+        const int degree = C.n_nonneg + C.n_soc + 3 * C.n_ns;
+        const double mu = (sz + ct * ck) / (double)(degree + 1);
+        const double val = (double)(degree + 1) * ns::logsafe(mu) - ns::logsafe(ct) - ns::logsafe(ck) + acc;
+        return inf ? CPG_NS_INF : val;
+    }
+    // dsc = W'(lambda \ (lambda o lambda + (W^-1 ds) o (W dz) - sigma mu e)), zero-cone rows 0;
+    // exponential / power cones: dsc = s + sigma mu grad f*(z) - eta(ds, dz)
     CPG_DEV void combined_ds_offset(double sigmamu) const {
+        if (NS) {
+            for (int k = lane; k < C.n_ns; k += 64) {
+                const unsigned st = ns_first() + 3u * (unsigned)k;
+                const double alpha = cpgw::gld(C.ns_alpha, (unsigned)k);
+                const double zk[3] = {B.z[st], B.z[st + 1u], B.z[st + 2u]};
+                const double dsk[3] = {B.ds[st], B.ds[st + 1u], B.ds[st + 2u]}, dzk[3] = {B.dz[st], B.dz[st + 1u], B.dz[st + 2u]};
+                double eta[3];
+                ns::higher_correction(zk, alpha, dsk, dzk, eta);
+                for (unsigned r = 0; r < 3u; r++) B.dsc[st + r] = B.s[st + r] + sigmamu * B.et[st + r] - eta[r];
+            }
+        }
         for (unsigned i = (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {
             if (i < (unsigned)C.n_zero) { B.dsc[i] = 0.0; continue; }
             const double w = B.wv[i], lm = B.lam[i];
@@ -564,11 +668,13 @@ struct ConicCtx {
         cpgw::lds_order();
     }
 };
+typedef ConicCtxT<false> ConicCtx;
 
 // Solves rb = (rhs_x, dsc - rhs_z) and assembles the step (dx, dz, ds, dtau, dkappa) of the
 // homogeneous embedding; x2 / z2 is the constant part K^{-1}(-q, b), `den` its denominator.
 // (The solve sol = (x1, z1) = K^{-1} rb itself is issued by the caller: the iteration has ONE inlined copy of kkt_solve.)
-CPG_DEV void conic_step(const ConicCtx &cx, double rhs_tau, double rhs_kap, double tau, double kap,
+template <bool NS>
+CPG_DEV void conic_step(const ConicCtxT<NS> &cx, double rhs_tau, double rhs_kap, double tau, double kap,
                         double den, double &dtau, double &dkap) {
     const ConicBuf &B = cx.B;
     const unsigned n = cx.n, m = cx.m;
@@ -606,7 +712,7 @@ CPG_DEV const T *conic_stage(const T *src, unsigned count, double *&cur) {
 // are compile-time constants (CPG_GENC_SPECIALISE of the generated header), so every vector of the interior-point state
 // sits at a constant offset from the wave's LDS base, every staged table at a constant offset from the block's, and the
 // loops over n / m / nnz have known trip counts -- instead of ~80 wave-uniform pointers kept in (and spilled from) SGPRs.
-template <bool TABLES_IN_LDS, bool SPECIALISED = false>
+template <bool TABLES_IN_LDS, bool SPECIALISED = false, bool NONSYM = false>
 CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const DevBatch &Bt, double *lds, int /*wave_global*/) {
     DevConic C = C0;
 #ifdef CPG_GENC_HEADER
@@ -661,11 +767,11 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
     const int lane = cpgw::lane_id();
     const unsigned n = (unsigned)C.n, m = (unsigned)C.m, N = n + m;
     const ConicBuf B = conic_carve(lds + (size_t)cpgw::wave_in_block() * (size_t)C.lds_doubles, C);
-    const ConicCtx cx{C, S, B, lane, n, m, N, rows};
+    const ConicCtxT<NONSYM> cx{C, S, B, lane, n, m, N, rows};
     LdsProg SP;
     SP.ctab = C.sol_ctab; SP.desc = C.sol_desc; SP.vals = B.sv; SP.cols = C.sol_cols;
     SP.n_chunks = C.sol_chunks; SP.dummy = (unsigned)C.sol_nnz - 1u; SP.rows16 = nullptr;
-    const int degree = C.n_nonneg + C.n_soc;
+    const int degree = C.n_nonneg + C.n_soc + (NONSYM ? 3 * C.n_ns : 0);
     // zero padding behind the entries, dummy slots and zero slot behind the work vector (generated executor)
     for (int t = lane; t < C.sv_pad; t += 64) B.sv[C.sol_nnz + t] = 0.0;
     for (int t = lane; t < C.w_extra; t += 64) B.w[C.sol_slots + t] = 0.0;
@@ -795,8 +901,10 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                 const double mean = sum / (double)dm;
                 for (unsigned r = 0; r < dm; r++) B.tz[st + r] = mean / B.E[st + r];
             }
+            // exponential / power cones admit no row scaling at all: back to 1
+            if (NONSYM) for (unsigned i = cx.ns_first() + (unsigned)lane; i < m; i += 64u) B.tz[i] = 1.0 / B.E[i];
             cpgw::lds_order();
-            if (C.n_soc > 0) {
+            if (C.n_soc > 0 || (NONSYM && C.n_ns > 0)) {
                 const unsigned first = (unsigned)(C.n_zero + C.n_nonneg);
                 for (unsigned i = first + (unsigned)lane; i < m; i += 64u) {
                     const double ew = B.tz[i];
@@ -821,6 +929,23 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
         const double cinv = 1.0 / cs;
 
         // ---- 3. initial point: identity scaling, one factorisation, shift into the cones
+        if (NONSYM) {
+            // a nonsymmetric cone anywhere: x = 0 and every cone at its central point s = z
+            for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = 0.0;
+            for (unsigned i = (unsigned)lane; i < m; i += 64u) {
+                double v = 0.0;
+                if (i >= cx.ns_first()) {
+                    const unsigned r = (i - cx.ns_first()) % 3u;
+                    const double alpha = cpgw::gld(C.ns_alpha, (i - cx.ns_first()) / 3u);
+                    if (alpha == 0.0) v = r == 0u ? -1.051383945322714 : (r == 1u ? 0.556409619469370 : 1.258967884768947);
+                    else v = r == 0u ? sqrt(1.0 + alpha) : (r == 1u ? sqrt(2.0 - alpha) : 0.0);
+                } else if (i >= (unsigned)C.n_zero) {
+                    const int st = cpgw::gld(C.row_cone, i);
+                    v = (st < 0 || (unsigned)st == i) ? 1.0 : 0.0;
+                }
+                B.s[i] = v; B.z[i] = v;
+            }
+        } else {
         cx.identity_scaling();
         cx.factor();
         {   // one solve (x, z) = K^{-1}(-q, b), s = -z; for P == 0 two: (x, -s) = K^{-1}(0, b), then (., z) = K^{-1}(-q, 0).  One
@@ -846,7 +971,10 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
         cpgw::lds_order();
         cx.shift_to_cone(B.s, true);
         cx.shift_to_cone(B.z, false);
+        }
+        cpgw::lds_order();
         double tau = 1.0, kap = 1.0;
+        bool dual_strategy = false;      // scaling strategy of the nonsymmetric cones: primal-dual until a checkpoint switches to dual
 
         // ---- 4. interior-point iterations
         int status = CPG_CL_UNSOLVED, iter = 0, almost = CPG_CL_UNSOLVED;
@@ -917,6 +1045,12 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                     status = CPG_CL_INSUFFICIENT_PROGRESS;
                 if ((res_d > S.tol_feas && res_d > 100.0 * prev_res_d) || (res_p > S.tol_feas && res_p > 100.0 * prev_res_p))
                     status = CPG_CL_INSUFFICIENT_PROGRESS;
+                if (NONSYM && status == CPG_CL_INSUFFICIENT_PROGRESS && !dual_strategy) {
+                    // strategy checkpoint: the primal-dual scaling gets a second chance as the dual scaling, from this iterate
+                    status = CPG_CL_UNSOLVED; dual_strategy = true;
+                    prev_cost_p = cost_p; prev_res_p = res_p; prev_res_d = res_d; prev_gap_abs = gap_abs; prev_gap_rel = gap_rel;
+                    continue;
+                }
                 if (status == CPG_CL_INSUFFICIENT_PROGRESS) {
                     for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = B.px[j];
                     for (unsigned i = (unsigned)lane; i < m; i += 64u) { B.z[i] = B.pz[i]; B.s[i] = B.ps[i]; }
@@ -936,13 +1070,14 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
 
             // scaling, factorisation, constant part (x2, z2) = K^{-1}(-q, b)
             bool scaled = true;
-            CPG_CONIC_REPEAT(8) scaled = cx.update_scaling();
+            CPG_CONIC_REPEAT(8) scaled = cx.update_scaling(mu, dual_strategy);
             if (!scaled) { status = CPG_CL_NUMERICAL_ERROR; break; }
             CPG_CONIC_REPEAT(1) cx.factor();
             // The three solves of an iteration -- constant part (x2, z2) = K^{-1}(-q, b), affine step, combined step -- run
             // through ONE copy of kkt_solve (substitution sweeps + refinement): inlined three times, the loop body
             // outgrew the instruction cache two CUs share.  Same operations in the same order as the straight-line form.
             double den = 0.0, dtau = 0.0, dkap = 0.0, alpha = 1.0, sigma = 0.0, rk = 0.0;
+            bool nonfinite = false;
 #pragma nounroll
             for (int pass = 0; pass < 3; pass++) {
                 if (pass == 0) {
@@ -980,13 +1115,33 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                         alpha = 1.0;
                         if (dtau < 0.0) alpha = cpgw::dmin2(alpha, -tau / dtau);
                         if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
-                        alpha = cx.step_length(B.z, B.dz, alpha);
+                        alpha = cx.step_length(B.z, B.dz, alpha);         // (symmetric cones first)
                         alpha = cx.step_length(B.s, B.ds, alpha);
+                        // back off from a full step so that the logarithms are not taken at the boundary, then backtrack
+                        if (NONSYM) alpha = cx.ns_step_length(cpgw::dmin2(alpha, S.max_step_fraction));
+                    }
+                    if (NONSYM) {      // a step that is not finite: numerical-error checkpoint
+                        bool bad = !(fabs(dtau) < CPG_NS_INF);
+                        for (unsigned j = (unsigned)lane; j < n; j += 64u) bad = bad || !(fabs(B.dx[j]) < CPG_NS_INF);
+                        for (unsigned i = (unsigned)lane; i < m; i += 64u) bad = bad || !(fabs(B.dz[i]) < CPG_NS_INF);
+                        if (cpgw::wave_any(bad)) { nonfinite = true; break; }
                     }
                     if (pass == 1) sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
                 }
             }
+            if (NONSYM && nonfinite) {
+                if (!dual_strategy) { dual_strategy = true; continue; }
+                status = CPG_CL_NUMERICAL_ERROR; break;
+            }
             alpha *= S.max_step_fraction;
+            if (NONSYM && dual_strategy) {       // centrality: back to where the sum of the barriers is below 1
+#pragma nounroll
+                for (int t = 0; t < 50; t++) {
+                    if (cx.barrier(alpha, tau, kap, dtau, dkap) < 1.0) break;
+                    alpha *= S.ls_backtrack;
+                }
+            }
+            if (NONSYM && !dual_strategy && alpha < S.min_switch_step) { dual_strategy = true; continue; }   // small-step checkpoint
             if (alpha <= cpgw::dmax2(0.0, S.min_terminate_step)) { status = CPG_CL_INSUFFICIENT_PROGRESS; break; }   // undersized step
             for (unsigned j = (unsigned)lane; j < n; j += 64u) { const double v = B.x[j], d = B.dx[j]; B.px[j] = v; B.x[j] = v + alpha * d; }
             for (unsigned i = (unsigned)lane; i < m; i += 64u) {

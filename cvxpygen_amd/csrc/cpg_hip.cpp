@@ -72,7 +72,6 @@ struct cpg_solver_s {
     cpg::DevConic C{};
     cpg::DevConicSettings CS{};
     double time_limit = 1e10; int verbose = 1, direct_kkt_solver = 1, presolve_enable = 1;   // accepted, unused
-    double linesearch_backtrack_step = 0.8, min_switch_step_length = 0.1;   // asymmetric cones only: accepted, unused
     DevBuf scratch;                     // delta_x / delta_y stash, [waves][G][n + m]
     // staging for the host-pointer entry point
     DevBuf s_theta, s_prim, s_dual, s_obj, s_pri, s_dua, s_iter, s_status, s_state_in, s_state_out;
@@ -414,16 +413,17 @@ static int launch_refactor(cpg_handle_t h, rt_stream_t stream, const cpg::DevSet
 #ifndef CPG_CONIC_WAVES_PER_SIMD
 #define CPG_CONIC_WAVES_PER_SIMD 4   // <= 128 VGPRs
 #endif
-template <bool TABLES_IN_LDS, bool SPECIALISED>
+template <bool TABLES_IN_LDS, bool SPECIALISED, bool NONSYM>
 __global__ void __launch_bounds__(512, CPG_CONIC_WAVES_PER_SIMD)
 clarabel_kernel(cpg::DevConic C, cpg::DevConicSettings S, cpg::DevBatch Bt) {
     extern __shared__ __attribute__((aligned(16))) double cpg_lds[];
     const int wave_global = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    cpg::clarabel_body<TABLES_IN_LDS, SPECIALISED>(C, S, Bt, cpg_lds, wave_global);
+    cpg::clarabel_body<TABLES_IN_LDS, SPECIALISED, NONSYM>(C, S, Bt, cpg_lds, wave_global);
 }
-template <bool TABLES_IN_LDS, bool SPECIALISED>
+// NONSYM: families with exponential / power cones run an instantiation of their own -- the symmetric kernel carries none of that code
+template <bool TABLES_IN_LDS, bool SPECIALISED, bool NONSYM = false>
 static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds) {
-    auto kern = clarabel_kernel<TABLES_IN_LDS, SPECIALISED>;
+    auto kern = clarabel_kernel<TABLES_IN_LDS, SPECIALISED, NONSYM>;
     if (lds > 48 * 1024)
         RT_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds, h->stream, h->C, h->CS, Bt);
@@ -433,8 +433,11 @@ static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, i
 static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds, bool tables_in_lds) {
 #ifdef CPG_GENC_HEADER
     // the library's own family: dimensions as compile-time constants (clarabel_body<., true>)
-    if (h->conic_specialised && tables_in_lds) return launch_conic_t<true, true>(h, Bt, blocks, waves, lds);
+    if (h->conic_specialised && tables_in_lds)
+        return h->C.n_ns > 0 ? launch_conic_t<true, true, true>(h, Bt, blocks, waves, lds) : launch_conic_t<true, true>(h, Bt, blocks, waves, lds);
 #endif
+    if (h->C.n_ns > 0)
+        return tables_in_lds ? launch_conic_t<true, false, true>(h, Bt, blocks, waves, lds) : launch_conic_t<false, false, true>(h, Bt, blocks, waves, lds);
     return tables_in_lds ? launch_conic_t<true, false>(h, Bt, blocks, waves, lds) : launch_conic_t<false, false>(h, Bt, blocks, waves, lds);
 }
 
@@ -537,8 +540,8 @@ static double *conic_double_setting(cpg_handle_t h, const std::string &s) {
     if (s == "reduced_tol_ktratio") return &c.red_ktratio;
     if (s == "equilibrate_min_scaling") return &c.eq_min;
     if (s == "equilibrate_max_scaling") return &c.eq_max;
-    if (s == "linesearch_backtrack_step") return &h->linesearch_backtrack_step;
-    if (s == "min_switch_step_length") return &h->min_switch_step_length;
+    if (s == "linesearch_backtrack_step") return &c.ls_backtrack;          // (exponential / power cones only)
+    if (s == "min_switch_step_length") return &c.min_switch_step;
     if (s == "min_terminate_step_length") return &c.min_terminate_step;
     if (s == "static_regularization_constant") return &c.static_const;
     if (s == "static_regularization_proportional") return &c.static_prop;
@@ -578,7 +581,7 @@ int cpg_hip_set_default_settings(cpg_handle_t h) {
         c.ir_enable = 1; c.ir_reltol = 1e-13; c.ir_abstol = 1e-12; c.ir_max_iter = 10; c.ir_stop_ratio = 5.0;
         h->time_limit = 1e10; h->verbose = 1; h->direct_kkt_solver = 1; h->presolve_enable = 1;
         c.red_gap_abs = 5e-5; c.red_gap_rel = 5e-5; c.red_feas = 1e-4; c.red_infeas_abs = 5e-5; c.red_infeas_rel = 5e-5;
-        c.red_ktratio = 1e-4; c.tol_ktratio = 1e-6; h->linesearch_backtrack_step = 0.8; h->min_switch_step_length = 0.1;
+        c.red_ktratio = 1e-4; c.tol_ktratio = 1e-6; c.ls_backtrack = 0.8; c.min_switch_step = 0.1;
         return CPG_OK;
     }
     // defaults of the generated solver, cvxpygen/solvers/osqp.py:102-115
@@ -953,7 +956,7 @@ static unsigned conic_row_words_hash(const cpg_conic_family_t *f) {
 
 static bool conic_dims_equal(const cpg::DevConic &a, const cpg::DevConic &b) {
     return a.n == b.n && a.m == b.m && a.nnzP == b.nnzP && a.nnzA == b.nnzA && a.nnzL == b.nnzL && a.n_zero == b.n_zero &&
-           a.n_nonneg == b.n_nonneg && a.n_soc == b.n_soc && a.is_max == b.is_max && a.p_is_zero == b.p_is_zero &&
+           a.n_nonneg == b.n_nonneg && a.n_soc == b.n_soc && a.n_ns == b.n_ns && a.is_max == b.is_max && a.p_is_zero == b.p_is_zero &&
            a.fac_chunks == b.fac_chunks && a.sol_chunks == b.sol_chunks && a.sol_nnz == b.sol_nnz && a.sol_slots == b.sol_slots &&
            a.fac_triples == b.fac_triples && a.n_pfull == b.n_pfull && a.sv_pad == b.sv_pad && a.w_extra == b.w_extra &&
            a.gc_ncols == b.gc_ncols && a.gc_nrows == b.gc_nrows;
@@ -1017,6 +1020,10 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     if (f->n <= 0 || f->m < 0 || f->n + f->m >= 0xFFFF) { set_error("bad family dimensions"); return CPG_E_BADARG; }
     long long rows = (long long)f->n_zero + f->n_nonneg;
     for (int k = 0; k < f->n_soc; k++) { if (f->soc_dims[k] < 1) { set_error("second-order cone of dimension < 1"); return CPG_E_BADARG; } rows += f->soc_dims[k]; }
+    if (f->n_exp < 0 || f->n_pow < 0 || (f->n_pow > 0 && !f->pow_alpha)) { set_error("bad exponential / power cone counts"); return CPG_E_BADARG; }
+    for (int k = 0; k < f->n_pow; k++)
+        if (!(f->pow_alpha[k] > 0.0 && f->pow_alpha[k] < 1.0)) { set_error("power cone exponent outside (0, 1)"); return CPG_E_BADARG; }
+    rows += 3LL * ((long long)f->n_exp + f->n_pow);
     if (rows != f->m) { set_error("cone dimensions do not add up to m"); return CPG_E_BADARG; }
     if (f->sol_slots < f->n + f->m || f->sol_slots > 8191) { set_error("bad sol_slots"); return CPG_E_BADARG; }
     int rc = rt_set_device(device);
@@ -1027,7 +1034,7 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     cpg::DevConic &C = h->C;
     const int n = f->n, m = f->m, N = n + m;
     C.n = n; C.m = m; C.nnzP = f->nnzP; C.nnzA = f->nnzA; C.nnzL = f->nnzL; C.n_zero = f->n_zero;
-    C.n_nonneg = f->n_nonneg; C.n_soc = f->n_soc; C.is_max = f->is_maximization; C.p_is_zero = f->nnzP == 0;
+    C.n_nonneg = f->n_nonneg; C.n_soc = f->n_soc; C.n_ns = f->n_exp + f->n_pow; C.ns_alpha = nullptr; C.is_max = f->is_maximization; C.p_is_zero = f->nnzP == 0;
     C.fac_chunks = f->fac_chunks; C.sol_chunks = f->sol_chunks; C.sol_nnz = f->sol_nnz; C.sol_slots = f->sol_slots;
     C.np_var = f->np_var; C.d_base = f->d_base; C.n_prim = f->n_prim; C.n_dual = f->n_dual;
     h->F.n = n; h->F.m = m; h->F.n_prim = f->n_prim; h->F.n_dual = f->n_dual;   // staging sizes of the host entry point
@@ -1042,6 +1049,11 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     TRY(upload<int>(h, own, soc_start.data(), (size_t)f->n_soc, &C.soc_start));
     TRY(upload<int>(h, own, f->soc_dims, (size_t)f->n_soc, &C.soc_dim));
     TRY(upload<int>(h, own, row_cone.data(), (size_t)m, &C.row_cone));
+    if (C.n_ns > 0) {      // exponent per nonsymmetric cone, 0 = exponential cone (rows: exponential cones first)
+        std::vector<double> ns_alpha((size_t)C.n_ns, 0.0);
+        for (int k = 0; k < f->n_pow; k++) ns_alpha[(size_t)f->n_exp + k] = f->pow_alpha[k];
+        TRY(upload<double>(h, own, ns_alpha.data(), (size_t)C.n_ns, &C.ns_alpha));
+    }
     UP(int, Ap, n + 1); UP(int, Ai, f->nnzA); UP(int, Arp, m + 1); UP(int, Aent, f->nnzA); UP(int, Acol, f->nnzA);
     UP(int, Pp, n + 1); UP(int, Pi, f->nnzP); UP(int, Prp, n + 1);
     { const int npf = f->Prp[n]; UP(int, Pent, npf); UP(int, Pcol, npf); }

@@ -397,3 +397,60 @@ def toy_qa(n: int = 3, name: str = 'toy_qa') -> FamilyDescriptor:
 
 FAMILIES = {'nonneg_LS': nonneg_ls, 'MPC': mpc, 'portfolio': portfolio, 'toy_box': toy_box,
             'toy_lp': toy_lp, 'toy_qa': toy_qa, 'ADP': adp, 'ADP_norm': adp_norm, 'actuator': actuator}
+
+
+# ------------------------------------------------------------------------------------------------ exponential / power cones
+# Test families for the nonsymmetric cones of the conic path (ClarabelExponentialConeT / ClarabelPowerConeT,
+# `cvxpygen/solvers/clarabel.py:133-155`).  The reference's own tests hold no problem with these cones; each family below has a
+# closed-form answer (tests/test_nonsym_cones.py).
+def softmax_entropy(n: int = 4, name: str = 'softmax') -> FamilyDescriptor:
+    """minimise c'x - sum_i entr(x_i)  s.t.  sum x = 1   (cvxpy: cp.Minimize(c @ x - cp.sum(cp.entr(x))), [cp.sum(x) == 1]):
+    x* = softmax(-c), value -log sum exp(-c).  Conic form: t_i <= -x_i log x_i  <=>  (t_i, x_i, 1) in K_exp."""
+    cb = CanonBuilder(name)
+    c = cb.param('c', (n,))
+    x = cb.var('x', (n,))
+    t = cb.aux(n)
+    for i in range(n):
+        cb.lin(x[i], c[i])
+        cb.lin(t[i], -1.0)
+    r = cb.eq([(x[i], 1.0) for i in range(n)], 1.0)
+    for i in range(n):
+        cb.exp_cone([([(t[i], -1.0)], 0.0), ([(x[i], -1.0)], 0.0), ([], 1.0)])
+    cb.dual('nu', [r], (1,))
+    return cb.build({'c': np.linspace(-1.0, 1.0, n)}, solver='CLARABEL')
+
+
+def cobb_douglas(alpha: float = 0.3, name: str = 'cobb_douglas') -> FamilyDescriptor:
+    """maximise x^alpha y^(1 - alpha)  s.t.  p1 x + p2 y <= budget   (cvxpy: cp.Maximize(cp.geo_mean(..., p=[alpha, 1 - alpha]))):
+    x* = alpha budget / p1, y* = (1 - alpha) budget / p2.  The prices are a MATRIX parameter (a row of A)."""
+    cb = CanonBuilder(name)
+    p = cb.param('p', (2,))
+    budget = cb.param('budget', ())
+    v = cb.var('v', (2,))
+    z = cb.var('z', (1,))
+    cb.lin(z[0], -1.0)
+    cb.is_maximization = True
+    r = cb.ineq([(v[0], p[0]), (v[1], p[1])], {budget.up.col: 1.0})
+    cb.pow_cone(alpha, [([(v[0], -1.0)], 0.0), ([(v[1], -1.0)], 0.0), ([(z[0], -1.0)], 0.0)])
+    cb.dual('lam', [r], (1,))
+    return cb.build({'p': np.array([1.0, 2.0]), 'budget': 3.0}, solver='CLARABEL')
+
+
+def exp_prox(n: int = 3, radius: float = 10.0, name: str = 'exp_prox') -> FamilyDescriptor:
+    """minimise sum_i exp(x_i) + 1/2 ||x - a||^2  s.t.  ||x|| <= radius, x <= ub:  a quadratic objective, exponential,
+    second-order and nonnegative cones in one family.  With the ball and the bound inactive x_i = a_i - omega(a_i) (Wright omega)."""
+    cb = CanonBuilder(name)
+    a = cb.param('a', (n,))
+    ub = cb.param('ub', (n,))
+    x = cb.var('x', (n,))
+    t = cb.aux(n)
+    cb.sum_squares(x)                     # P = 2 I on x: 1/2 x'Px = ||x||^2 -> scale the rest by 2
+    for i in range(n):
+        cb.lin(x[i], cmul(a[i], -2.0))
+        cb.lin(t[i], 2.0)
+    rows = [cb.ineq([(x[i], 1.0)], ub[i]) for i in range(n)]
+    cb.soc([([], radius)] + [([(x[i], -1.0)], 0.0) for i in range(n)])
+    for i in range(n):
+        cb.exp_cone([([(x[i], -1.0)], 0.0), ([], 1.0), ([(t[i], -1.0)], 0.0)])      # exp(x_i) <= t_i
+    cb.dual('mu', rows, (n,))
+    return cb.build({'a': np.linspace(-1.0, 2.0, n), 'ub': 5.0 * np.ones(n)}, solver='CLARABEL')

@@ -220,8 +220,11 @@ typedef struct {
 /* Everything fixed at code-generation time for one CONIC problem family solved by the
  * interior-point kernel (reference: the Clarabel path, cvxpygen/solvers/clarabel.py:19-46, 133-204):
  *   minimise 1/2 x'Px + q'x + d   s.t.   Ax + s = b,  s in K,
- * rows ordered zero cone, nonnegative cone, second-order cones -- the `cones` array the reference
- * emits (clarabel.py:308-323).  The reference builds a new solver per solve
+ * rows ordered zero cone, nonnegative cone, second-order cones, exponential cones, three-dimensional power
+ * cones -- the cone types the reference's `cones` array can hold (clarabel.py:133-155, 308-323) except PSD, in the
+ * order in which cvxpy stacks the rows for this solver.  (The reference lists the exponential cones AHEAD of the
+ * second-order cones, clarabel.py:316-319: with both kinds present its cones do not match its rows; with one
+ * kind the orders coincide.)  The reference builds a new solver per solve
  * (clarabel_DefaultSolver_new, clarabel.py:201-204), so canonicalisation, equilibration and every
  * factorisation happen per instance inside the kernel; the tables below are the family's fixed
  * patterns and schedules (cvxpygen_amd/conic_plan.py).  Natural order (no device permutation). */
@@ -236,7 +239,9 @@ typedef struct {
     const int32_t *Prp, *Pent, *Pcol;   /* full symmetric row view of P */
     /* factor of K = [[P + eps I, A'], [A, -W'W - eps I]] (same table layout as cpg_osqp_refactor_t);
      * ksrc_kind: 1 P entry idx, 2 A entry idx, 3 eps only, 5 -(W'W)_ii - eps of row idx,
-     * 6 off-diagonal entry of a second-order-cone block, idx = row_i | row_j << 16 */
+     * 6 off-diagonal entry of a second-order-cone block, idx = row_i | row_j << 16,
+     * 7 off-diagonal entry of an exponential / power cone's 3 x 3 block: idx = first row of the cone + (0 for (0,1),
+     *   1 for (0,2), 2 for (1,2)) */
     const int32_t *Lcol, *ksrc_kind, *ksrc_idx;
     int32_t fac_chunks, fac_triples;
     const int32_t *fac_ctab;
@@ -251,6 +256,10 @@ typedef struct {
     cpg_csr_t map_P, map_A, map_q, map_b, map_d;
     int32_t n_prim; const int32_t *prim_idx;   /* user primal entries: indices into x */
     int32_t n_dual; const int32_t *dual_idx;   /* user dual entries: indices into z */
+    /* exponential cones {(x, y, z): y exp(x / y) <= z, y > 0} and power cones {x^a y^(1 - a) >= |z|, x, y >= 0}: three rows
+     * each, behind the second-order cones (ClarabelExponentialConeT / ClarabelPowerConeT(a), clarabel.py:136-147) */
+    int32_t n_exp, n_pow;
+    const double *pow_alpha;            /* [n_pow], each in (0, 1) */
 } cpg_conic_family_t;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */

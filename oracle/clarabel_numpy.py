@@ -216,7 +216,7 @@ def _pow_root(s, alpha):
         pn = p - f / dF(p)
         if not (lo < pn < hi):
             pn = 0.5 * (lo + hi)
-        if abs(pn - p) <= 1e-16 * pn:
+        if abs(pn - p) <= 1e-15 * pn:
             p = pn
             break
         p = pn
