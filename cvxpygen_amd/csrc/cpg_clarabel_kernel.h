@@ -931,6 +931,7 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
         // ---- 3. initial point: identity scaling, one factorisation, shift into the cones
         if (NONSYM) {
             // a nonsymmetric cone anywhere: x = 0 and every cone at its central point s = z
+            cx.identity_scaling();           // (the zero-cone rows of the scaling vectors are written here and nowhere else)
             for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = 0.0;
             for (unsigned i = (unsigned)lane; i < m; i += 64u) {
                 double v = 0.0;

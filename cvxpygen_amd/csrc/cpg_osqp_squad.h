@@ -87,6 +87,11 @@ CPG_DEV void osqp_squad_body(const DevFamily &F, const DevUpdate &U, const DevSe
     // the pair arrays start from zeros (idle lanes of partial steps gather with everybody else: every slot they can touch must
     // hold a finite number), the slot of zeros stays zero for the whole kernel
     for (unsigned t = cpgw::thread_in_block(); t < (W / 2) * (CPG_GENQ_PAIR_STRIDE / 8u); t += cpgw::block_threads()) ((CPG_LDS double *)pairs)[t] = 0.0;
+    // (N odd: the pad entry behind the base vectors and behind every plain vector is read by no one's arithmetic, but must not be left to chance)
+    // ... and so does the wavefront's plain vector: the first infeasibility test stages delta_y behind entry n and its row program's
+    // idle lanes multiply a zero coefficient into entry 0, which nobody has written yet -- whatever the LDS held, times zero, must be
+    // zero (found by the emulator's poisoned LDS, tests/sim/fake_hip: CPG_SIM_LDS_POISON)
+    for (unsigned t = (unsigned)lane0; t < NPAD; t += 64u) wp[t] = 0.0;
     cpgw::block_sync();
     const double rho_eq = 1e3 * F.rho, rho_in = F.rho, rho_fr = 1e-6;
     const double ri_eq = 1.0 / rho_eq, ri_in = 1.0 / rho_in, ri_fr = 1.0 / rho_fr;

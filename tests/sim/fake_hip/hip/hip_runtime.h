@@ -114,7 +114,10 @@ inline void run_block(unsigned b, unsigned nblocks, unsigned nthreads, size_t ld
     blk.block_bar.n = (int)nthreads;
     blk.body = std::move(body);
     blk.live = (int)nthreads;
-    memset(cpg_lds, 0, lds_bytes + 64 <= sizeof(cpg_lds) ? lds_bytes + 64 : sizeof(cpg_lds));
+    // (the GPU's LDS holds whatever the previous workgroup left; CPG_SIM_LDS_POISON=1 fills it with NaN bit patterns so that a
+    // read of a slot nobody wrote shows on the CPU tier instead of on the GPU)
+    static const int poison = getenv("CPG_SIM_LDS_POISON") ? atoi(getenv("CPG_SIM_LDS_POISON")) : 0;
+    memset(cpg_lds, poison ? 0xFF : 0, lds_bytes + 64 <= sizeof(cpg_lds) ? lds_bytes + 64 : sizeof(cpg_lds));
     char *stacks = (char *)mmap(nullptr, STACK_BYTES * nthreads, PROT_READ | PROT_WRITE,
                                 MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (stacks == (char *)MAP_FAILED) abort();
