@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
+# the lock-step emulator starts every workgroup with NaN bit patterns in its LDS instead of zeros (tests/sim/fake_hip): a slot read
+# before anybody wrote it shows here, not on the GPU
+os.environ.setdefault('CPG_SIM_LDS_POISON', '1')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
