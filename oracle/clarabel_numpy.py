@@ -63,28 +63,67 @@ UNSOLVED, SOLVED, PRIMAL_INFEASIBLE, DUAL_INFEASIBLE, ALMOST_SOLVED, ALMOST_PRIM
 
 
 class Cones:
-    """rows of s / z: [zero | nonneg | soc_1 | soc_2 | ... | exp_1 | ... | pow_1 | ...] (exponential and power cones: 3 rows
-    each; `pow` lists the exponents alpha of x^alpha y^(1-alpha) >= |z|)"""
+    """rows of s / z: [zero | nonneg | soc_1 | soc_2 | ... | psd_1 | ... | exp_1 | ... | pow_1 | ...] (exponential and power
+    cones: 3 rows each; `pow` lists the exponents alpha of x^alpha y^(1-alpha) >= |z|; `psd` lists matrix orders p, p (p + 1) / 2
+    rows each: the upper triangle column by column with the off-diagonal entries times sqrt 2)"""
 
-    def __init__(self, zero, nonneg, soc, exp=0, pow=()):
+    def __init__(self, zero, nonneg, soc, exp=0, pow=(), psd=()):
         self.zero, self.nonneg, self.soc = int(zero), int(nonneg), [int(d) for d in soc]
         self.exp, self.pow = int(exp), [float(a) for a in pow]
+        self.psd = [int(p_) for p_ in psd]
         self.soc_start = []
         o = self.zero + self.nonneg
         for d in self.soc:
             self.soc_start.append(o)
             o += d
+        self.psd_start = []
+        for p_ in self.psd:
+            self.psd_start.append(o)
+            o += p_ * (p_ + 1) // 2
         self.ns = []                                  # nonsymmetric cones: (first row, alpha or None for the exponential cone)
         for a in [None] * self.exp + self.pow:
             self.ns.append((o, a))
             o += 3
         self.m = o
-        self.degree = self.nonneg + len(self.soc) + 3 * len(self.ns)
+        self.degree = self.nonneg + len(self.soc) + sum(self.psd) + 3 * len(self.ns)
         self.symmetric = not self.ns
         self.nn = slice(self.zero, self.zero + self.nonneg)
 
     def socs(self):
         return [slice(a, a + d) for a, d in zip(self.soc_start, self.soc)]
+
+    def psds(self):
+        """(slice of rows, matrix order) per PSD cone"""
+        return [(slice(a, a + p_ * (p_ + 1) // 2), p_) for a, p_ in zip(self.psd_start, self.psd)]
+
+
+SQRT2 = np.sqrt(2.0)
+
+
+def svec_to_mat(v, p):
+    M = np.zeros((p, p))
+    k = 0
+    for j in range(p):
+        for i in range(j + 1):
+            M[i, j] = M[j, i] = v[k] if i == j else v[k] / SQRT2
+            k += 1
+    return M
+
+
+def mat_to_svec(M):
+    p = M.shape[0]
+    v = np.zeros(p * (p + 1) // 2)
+    k = 0
+    for j in range(p):
+        for i in range(j + 1):
+            v[k] = M[i, j] if i == j else M[i, j] * SQRT2
+            k += 1
+    return v
+
+
+def svec_diag(p):
+    """positions of the diagonal entries"""
+    return np.array([j * (j + 1) // 2 + j for j in range(p)])
 
 
 def _soc_res(v):
@@ -428,7 +467,7 @@ def equilibrate(P, q, A, b, cones, stg):
             P *= ct
             q *= ct
             c *= ct
-    for sl in cones.socs():
+    for sl in cones.socs() + [sl_ for sl_, _ in cones.psds()]:
         ew = E[sl].mean() / E[sl]
         A[sl, :] *= ew[:, None]
         b[sl] *= ew
@@ -452,6 +491,10 @@ def _margins(cones, v):
         a = v[sl][0] - np.sqrt(v[sl][1:] @ v[sl][1:])
         alpha = min(alpha, a)
         beta += max(0.0, a)
+    for sl, p in cones.psds():
+        e = np.linalg.eigvalsh(svec_to_mat(v[sl], p))
+        alpha = min(alpha, float(e.min()))
+        beta += float(np.maximum(e, 0.0).sum())
     return alpha, beta
 
 
@@ -460,6 +503,8 @@ def _unit_shift(cones, v, a, primal):
         v[cones.nn] += a
     for sl in cones.socs():
         v[sl.start] += a
+    for sl, p in cones.psds():
+        v[sl.start + svec_diag(p)] += a
     if primal and cones.zero:
         v[:cones.zero] = 0.0
 
@@ -480,7 +525,9 @@ def _shift_to_cone(cones, v, primal):
 
 
 class _Scaling:
-    """Nesterov-Todd scaling: nonneg w = sqrt(s/z); SOC W = eta [[w0, w1'], [w1, I + w1 w1'/(1+w0)]]"""
+    """Nesterov-Todd scaling: nonneg w = sqrt(s/z); SOC W = eta [[w0, w1'], [w1, I + w1 w1'/(1+w0)]]; PSD cone: with S = L1 L1',
+    Z = L2 L2' and the SVD L2'L1 = U diag(lambda) V':  R = L1 V diag(lambda)^-1/2, R^-1 = diag(lambda)^-1/2 U'L2',
+    W x = svec(R' mat(x) R), W'W x = svec(Q mat(x) Q) with Q = R R' (the cone's NT point), W z = W^-T s = svec(diag(lambda))"""
 
     def __init__(self, cones):
         self.c = cones
@@ -498,6 +545,9 @@ class _Scaling:
             v = np.zeros(d)
             v[0] = 1.0
             self.sw.append(v)
+        self.psd_R = [np.eye(p_) for p_ in c.psd]
+        self.psd_Rinv = [np.eye(p_) for p_ in c.psd]
+        self.psd_lam = [np.ones(p_) for p_ in c.psd]
 
     def update(self, s, z, mu=None, dual_strategy=False):
         c = self.c
@@ -525,7 +575,33 @@ class _Scaling:
             self.sw[k] = w
             self.eta[k] = np.sqrt(ss / zs)
             self.lam[sl] = self.mul_W_cone(k, zk)
+        for k, (sl, p_) in enumerate(c.psds()):
+            try:
+                L1 = np.linalg.cholesky(svec_to_mat(s[sl], p_))
+                L2 = np.linalg.cholesky(svec_to_mat(z[sl], p_))
+            except np.linalg.LinAlgError:
+                ok = False
+                continue
+            U, sig, Vt = np.linalg.svd(L2.T @ L1)
+            isq = 1.0 / np.sqrt(sig)
+            self.psd_R[k] = (L1 @ Vt.T) * isq[None, :]
+            self.psd_Rinv[k] = isq[:, None] * (U.T @ L2.T)
+            self.psd_lam[k] = sig
+            self.lam[sl] = mat_to_svec(np.diag(sig))
         return ok
+
+    def psd_Hs(self, k):
+        """dense (Q x_s Q): entry (a, b) = c_a c_b / 2 (Q_ik Q_jl + Q_il Q_jk), a <-> (i, j), b <-> (k, l), c = sqrt 2 off the diagonal"""
+        Q = self.psd_R[k] @ self.psd_R[k].T
+        p_ = Q.shape[0]
+        idx = [(i, j) for j in range(p_) for i in range(j + 1)]
+        H = np.zeros((len(idx), len(idx)))
+        for a, (i, j) in enumerate(idx):
+            ca = 1.0 if i == j else SQRT2
+            for b, (kk, l) in enumerate(idx):
+                cb = 1.0 if kk == l else SQRT2
+                H[a, b] = (ca * cb * 0.5) * (Q[i, kk] * Q[j, l] + Q[i, l] * Q[j, kk])
+        return H
 
     def mul_W_cone(self, k, v, inv=False):
         w, eta = self.sw[k], self.eta[k]
@@ -554,6 +630,8 @@ class _Scaling:
             H[sl, sl] = eta * eta * (2.0 * np.outer(w, w) - J)
         for k, (st, _) in enumerate(c.ns):
             H[st:st + 3, st:st + 3] = self.ns_Hs[k]
+        for k, (sl, _) in enumerate(c.psds()):
+            H[sl, sl] = self.psd_Hs(k)
         return H
 
     def mul_Hs(self, v):
@@ -571,15 +649,27 @@ class _Scaling:
             out[sl] = eta * eta * o
         for k, (st, _) in enumerate(c.ns):
             out[st:st + 3] = self.ns_Hs[k] @ v[st:st + 3]
+        for k, (sl, p_) in enumerate(c.psds()):
+            Q = self.psd_R[k] @ self.psd_R[k].T
+            out[sl] = mat_to_svec(Q @ svec_to_mat(v[sl], p_) @ Q)
         return out
 
-    def mul_W(self, v, inv=False):
+    def mul_W(self, v, inv=False, trans=False):
+        """W v, W'v, W^-1 v, W^-T v (the nonnegative and second-order cones' W is symmetric)"""
         c = self.c
         out = np.zeros(c.m)
         if c.nonneg:
             out[c.nn] = v[c.nn] / self.w[c.nn] if inv else v[c.nn] * self.w[c.nn]
         for k, sl in enumerate(c.socs()):
             out[sl] = self.mul_W_cone(k, v[sl], inv)
+        for k, (sl, p_) in enumerate(c.psds()):
+            X = svec_to_mat(v[sl], p_)
+            R, Ri = self.psd_R[k], self.psd_Rinv[k]
+            if not inv:
+                Y = R @ X @ R.T if trans else R.T @ X @ R
+            else:
+                Y = Ri @ X @ Ri.T if trans else Ri.T @ X @ Ri
+            out[sl] = mat_to_svec(Y)
         return out
 
     def circ(self, a, b):
@@ -589,6 +679,9 @@ class _Scaling:
         for sl in c.socs():
             out[sl.start] = float(a[sl] @ b[sl])
             out[sl.start + 1:sl.stop] = a[sl.start] * b[sl.start + 1:sl.stop] + b[sl.start] * a[sl.start + 1:sl.stop]
+        for sl, p_ in c.psds():
+            X, Y = svec_to_mat(a[sl], p_), svec_to_mat(b[sl], p_)
+            out[sl] = mat_to_svec(0.5 * (X @ Y + Y @ X))
         return out
 
     def inv_circ_lam(self, d):
@@ -602,11 +695,26 @@ class _Scaling:
             u0 = (lam[0] * dk[0] - float(lam[1:] @ dk[1:])) / p
             out[sl.start] = u0
             out[sl.start + 1:sl.stop] = (dk[1:] - u0 * lam[1:]) / lam[0]
+        for k, (sl, p_) in enumerate(c.psds()):
+            lm = self.psd_lam[k]
+            out[sl] = mat_to_svec(2.0 * svec_to_mat(d[sl], p_) / (lm[:, None] + lm[None, :]))
         return out
 
     def ds_offset(self, ds):
         """W'(lambda \\ ds)"""
-        return self.mul_W(self.inv_circ_lam(ds))            # W is symmetric
+        return self.mul_W(self.inv_circ_lam(ds), trans=True)
+
+    def psd_step_length(self, dz, ds, amax):
+        """largest a <= amax with lambda + a W dz and lambda + a W^-T ds in the cone: the smallest eigenvalue of
+        diag(lambda)^-1/2 mat(.) diag(lambda)^-1/2"""
+        a = amax
+        for v in (self.mul_W(dz), self.mul_W(ds, inv=True, trans=True)):
+            for k, (sl, p_) in enumerate(self.c.psds()):
+                isq = 1.0 / np.sqrt(self.psd_lam[k])
+                g = float(np.linalg.eigvalsh(isq[:, None] * svec_to_mat(v[sl], p_) * isq[None, :]).min())
+                if g < 0.0:
+                    a = min(a, -1.0 / g)
+        return a
 
 
 def _step_length(cones, v, dv, amax):
@@ -675,6 +783,8 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
         s[cones.nn] = 1.0
         for sl in cones.socs():
             s[sl.start] = 1.0
+        for sl, p_ in cones.psds():
+            s[sl.start + svec_diag(p_)] = 1.0
         for st, alpha in cones.ns:
             s[st:st + 3] = EXP_CENTRAL if alpha is None else (np.sqrt(1.0 + alpha), np.sqrt(2.0 - alpha), 0.0)
         z = s.copy()
@@ -784,6 +894,7 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
             if dkap < 0.0:
                 a = min(a, -kap / dkap)
             a = min(_step_length(cones, z, dz, a), _step_length(cones, s, ds, a))      # symmetric cones first
+            a = sc.psd_step_length(dz, ds, a)
             if not cones.symmetric:
                 # back off from a full step so that the logarithms below are not taken at the boundary, then backtrack
                 a = min(a, stg['max_step_fraction'])
@@ -811,6 +922,13 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
                 val += -0.5 * _logsafe(rs_ * rz_) if (rs_ > 0.0 and rz_ > 0.0) else np.inf
             for st, alpha in cones.ns:
                 val += ns_barrier_dual(zn[st:st + 3], alpha) + ns_barrier_primal(sn[st:st + 3], alpha)
+            for sl, p_ in cones.psds():
+                try:
+                    l1 = np.linalg.cholesky(svec_to_mat(sn[sl], p_))
+                    l2 = np.linalg.cholesky(svec_to_mat(zn[sl], p_))
+                    val -= 2.0 * float(np.log(np.diag(l1)).sum()) + 2.0 * float(np.log(np.diag(l2)).sum())
+                except np.linalg.LinAlgError:
+                    val = np.inf
             return val
         # ---- affine step
         dx, dz, ds, dtau, dkap = kkt_solve(rx, rz, rtau, tau * kap, s)
@@ -825,11 +943,13 @@ def solve(P, q, A, b, cones, p_is_zero=None, **settings):
         alpha = step_len(dz, ds, dtau, dkap, False)
         sigma = (1.0 - alpha) ** 3
         # ---- combined step
-        shift = sc.circ(sc.mul_W(ds, inv=True), sc.mul_W(dz))
+        shift = sc.circ(sc.mul_W(ds, inv=True, trans=True), sc.mul_W(dz))
         e = np.zeros(m)
         e[cones.nn] = 1.0
         for sl in cones.socs():
             e[sl.start] = 1.0
+        for sl, p_ in cones.psds():
+            e[sl.start + svec_diag(p_)] = 1.0
         d_s = sc.circ(sc.lam, sc.lam) + shift - sigma * mu * e
         d_s[:cones.zero] = 0.0
         rk = -sigma * mu + dtau * dkap + tau * kap
@@ -888,7 +1008,7 @@ def cpg_solve_batch(desc, theta, **settings):
     B = theta.shape[0]
     if theta.shape[1] == desc.NP:
         theta = np.concatenate([theta, np.ones((B, 1))], axis=1)
-    cones = Cones(desc.cones['zero'], desc.cones['nonneg'], desc.cones['soc'], desc.cones.get('exp', 0), desc.cones.get('pow', ()))
+    cones = Cones(desc.cones['zero'], desc.cones['nonneg'], desc.cones['soc'], desc.cones.get('exp', 0), desc.cones.get('pow', ()), desc.cones.get('psd', ()))
     n, m = desc.n_var, desc.m
     Pp, Pi = desc.P.indptr, desc.P.indices
     Ap, Ai = desc.A.indptr, desc.A.indices
