@@ -93,6 +93,7 @@ class CanonBuilder:
         self._soc: List[List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]] = []
         self._exp: List[List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]] = []
         self._pow: List[Tuple[float, List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]]] = []
+        self._psd: List[Tuple[int, List[Tuple[List[Tuple[int, Dict[int, float]]], Dict[int, float]]]]] = []
         self.is_maximization = False
 
     # ---- declarations -------------------------------------------------------------------------
@@ -158,6 +159,15 @@ class CanonBuilder:
         self._pow.append((float(alpha), [([(int(c), _as_coef(v)) for c, v in entries], _as_coef(rhs)) for entries, rhs in rows]))
         return ('pow', len(self._pow) - 1)
 
+    def psd_cone(self, p: int, rows: Sequence[Tuple[Iterable[Tuple[int, Coef]], Coef]]) -> Tuple[str, int]:
+        """PSD cone of order p over p (p + 1) / 2 slack entries: the upper triangle of the matrix column by column, the OFF-diagonal
+        rows carrying the entry times sqrt 2 (`cvxpygen/solvers/clarabel.py:138, 146`: ClarabelPSDTriangleConeT(p); cvxpy applies the
+        scaling when it stacks the rows for this solver)"""
+        if len(rows) != p * (p + 1) // 2:
+            raise ValueError('a PSD cone of order p has p (p + 1) / 2 rows')
+        self._psd.append((int(p), [([(int(c), _as_coef(v)) for c, v in entries], _as_coef(rhs)) for entries, rhs in rows]))
+        return ('psd', len(self._psd) - 1)
+
     def quad(self, i: int, j: int, coef: Coef) -> None:
         """objective += 1/2 * coef * x_i x_j * (2 if i != j else 1), i.e. P[i, j] += coef (upper)."""
         i, j = (int(i), int(j)) if i <= j else (int(j), int(i))
@@ -192,10 +202,11 @@ class CanonBuilder:
 
     def build(self, values: Dict[str, np.ndarray], solver: str = 'OSQP') -> FamilyDescriptor:
         conic = solver != 'OSQP'
-        if (self._soc or self._exp or self._pow) and not conic:
-            raise ValueError('second-order, exponential and power cones need a conic solver')
-        # (rows behind the nonnegative cone in cvxpy's order for Clarabel: soc | exp | p3d)
-        soc_rows = [row for cone in self._soc for row in cone] + [row for cone in self._exp for row in cone] + \
+        if (self._soc or self._exp or self._pow or self._psd) and not conic:
+            raise ValueError('second-order, PSD, exponential and power cones need a conic solver')
+        # (rows behind the nonnegative cone in cvxpy's order for Clarabel: soc | psd | exp | p3d)
+        soc_rows = [row for cone in self._soc for row in cone] + [row for _, cone in self._psd for row in cone] + \
+            [row for cone in self._exp for row in cone] + \
             [row for _, cone in self._pow for row in cone]
         n, n_eq, n_ineq = self.n_var, len(self._eq), len(self._ineq) + len(soc_rows)
         m = n_eq + n_ineq
@@ -254,6 +265,8 @@ class CanonBuilder:
         if conic:       # Ax + s = b, s in K: the same rows, one right-hand side b (clarabel.py:19-46)
             maps = {'P': map_P, 'q': map_q, 'd': map_d, 'A': map_A, 'b': map_u}
             cones = {'zero': n_eq, 'nonneg': len(self._ineq), 'soc': [len(c) for c in self._soc]}
+            if self._psd:
+                cones['psd'] = [q for q, _ in self._psd]
             if self._exp:
                 cones['exp'] = len(self._exp)
             if self._pow:

@@ -145,14 +145,14 @@ def descriptor_from_cvxpy(problem, solver: str = 'OSQP', solver_opts=None, name:
         cd = pp.cone_dims
         if solver == 'ECOS' and cd.exp > 0:                  # `solvers/ecos.py:121-125`
             raise ValueError('Code generation with ECOS and exponential cones is not supported yet.')
-        if len(cd.psd):
-            raise NotImplementedError('PSD cones are not supported by the HIP interior-point kernel')
         p3d = [float(a) for a in getattr(cd, 'p3d', [])]
-        if (cd.exp or p3d) and solver == 'ECOS':
-            raise NotImplementedError('exponential / power cones: CLARABEL only')
+        if (cd.exp or p3d or len(cd.psd)) and solver == 'ECOS':
+            raise NotImplementedError('exponential / power / PSD cones: CLARABEL only')
         n_var, n_eq, n_ineq = int(pp.x.size), int(cd.zero), int(data['A'].shape[0]) - int(cd.zero)
         # rows as cvxpy stacks them for this solver: zero | nonneg | soc | (psd) | exp | p3d
         cones = {'zero': int(cd.zero), 'nonneg': int(cd.nonneg), 'soc': [int(v) for v in cd.soc]}
+        if len(cd.psd):
+            cones['psd'] = [int(v) for v in cd.psd]
         if cd.exp:
             cones['exp'] = int(cd.exp)
         if p3d:

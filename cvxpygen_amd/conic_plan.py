@@ -30,7 +30,8 @@ from . import solve_program as _sp
 from .refactor_plan import RaggedTable, build_schedules
 
 # KKT value sources (device: cpg_clarabel_kernel.h)
-K_NONE, K_P, K_A, K_DIAGX, K_HDIAG, K_HSOC, K_HNS = 0, 1, 2, 3, 5, 6, 7
+K_NONE, K_P, K_A, K_DIAGX, K_HDIAG, K_HSOC, K_HNS, K_HPSD = 0, 1, 2, 3, 5, 6, 7, 8
+PSD_MAX = 8             # largest PSD cone order of the kernel (csrc/cpg_clarabel_psd.h)
 # what the planner of the substitution program charges for a reduction stage, relative to the defaults
 # tuned on the large OSQP programs: small KKT systems (ADP: 36 rows) want wider rows and fewer steps
 # (29 -> 18 steps per solve, +5 % instances/s)
@@ -48,7 +49,8 @@ class ConicPlan:
     n_nonneg: int
     soc_dims: np.ndarray
     n_exp: int
-    pow_alpha: np.ndarray            # exponents of the 3-d power cones (rows: zero | nonneg | soc | exp | pow)
+    pow_alpha: np.ndarray            # exponents of the 3-d power cones (rows: zero | nonneg | soc | psd | exp | pow)
+    psd_dims: np.ndarray             # matrix orders of the PSD cones
     Ap: np.ndarray; Ai: np.ndarray
     Arp: np.ndarray; Aent: np.ndarray; Acol: np.ndarray
     Pp: np.ndarray; Pi: np.ndarray
@@ -87,8 +89,7 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
     if not desc.cones:
         raise ValueError('not a conic family')
     for key, val in desc.cones.items():
-        if key not in ('zero', 'nonneg', 'soc', 'exp', 'pow') and np.size(val) and np.any(val):
-            # PSD cones (clarabel.py:138, 146) have no kernel support
+        if key not in ('zero', 'nonneg', 'soc', 'exp', 'pow', 'psd') and np.size(val) and np.any(val):
             raise NotImplementedError(f'cone type "{key}" is not supported by the interior-point kernel')
     P, A = sp.csc_matrix(desc.P), sp.csc_matrix(desc.A)
     n, m = desc.n_var, desc.m
@@ -99,7 +100,10 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
     pow_alpha = np.asarray(desc.cones.get('pow', []), dtype=np.float64).ravel()
     if len(pow_alpha) and not ((pow_alpha > 0.0) & (pow_alpha < 1.0)).all():
         raise ValueError('power cone exponents must lie in (0, 1)')
-    if nz + nn + int(soc.sum()) + 3 * (n_exp + len(pow_alpha)) != m:
+    psd = np.asarray(desc.cones.get('psd', []), dtype=np.int32).ravel()
+    if len(psd) and (psd.min() < 1 or psd.max() > PSD_MAX):
+        raise NotImplementedError(f'PSD cones of order 1 .. {PSD_MAX} only (the kernel factors them one cone per lane)')
+    if nz + nn + int(soc.sum()) + int((psd * (psd + 1) // 2).sum()) + 3 * (n_exp + len(pow_alpha)) != m:
         raise ValueError('cone dimensions do not add up to the number of rows')
     if N >= 0xFFFF:
         raise ValueError('family too large for 16-bit slot indices')
@@ -123,6 +127,17 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
             for b in range(a + 1, d):
                 src_nat[(n + o + a, n + o + b)] = (K_HSOC, (o + a) | ((o + b) << 16))
         o += int(d)
+    qoff = 0
+    for pp in (int(v) for v in psd):                 # PSD cones: dense block of W'W = Q (x)s Q over the svec rows; Q sits at `qoff` of the slice's PSD store
+        ij = [(i, j) for j in range(pp) for i in range(j + 1)]
+        for a, (i, j) in enumerate(ij):
+            for b in range(a + 1, len(ij)):
+                k, l = ij[b]
+                src_nat[(n + o + a, n + o + b)] = (K_HPSD, qoff | (pp << 12) | (i << 16) | (j << 19) | (k << 22) | (l << 25))
+        o += len(ij)
+        qoff += 3 * pp * pp + pp
+    if qoff > 0xFFF:
+        raise NotImplementedError('PSD cones too large for the 12-bit offsets of their KKT sources')
     for _ in range(n_exp + len(pow_alpha)):          # 3 x 3 scaling blocks: off-diagonals (0,1), (0,2), (1,2) at wv[o + 0 .. 2]
         src_nat[(n + o, n + o + 1)] = (K_HNS, o)
         src_nat[(n + o, n + o + 2)] = (K_HNS, o + 1)
@@ -143,7 +158,7 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
         build_schedules(N, perm, Lp, Li, src, stage_scale=CONIC_STAGE_SCALE)
     stats = dict(stats)
     stats['etree_height'] = int(_ord.etree_height(etree))
-    return ConicPlan(n=n, m=m, nnzP=P.nnz, nnzA=A.nnz, nnzL=len(Li), n_zero=nz, n_nonneg=nn, soc_dims=soc, n_exp=n_exp, pow_alpha=pow_alpha,
+    return ConicPlan(n=n, m=m, nnzP=P.nnz, nnzA=A.nnz, nnzL=len(Li), n_zero=nz, n_nonneg=nn, soc_dims=soc, n_exp=n_exp, pow_alpha=pow_alpha, psd_dims=psd,
                      Ap=A.indptr.astype(np.int32), Ai=A.indices.astype(np.int32), Arp=Arp, Aent=Aent,
                      Acol=Acol, Pp=P.indptr.astype(np.int32), Pi=P.indices.astype(np.int32), Prp=Prp,
                      Pent=Pent, Pcol=Pcol, perm=perm.astype(np.int32), Lp=np.asarray(Lp, dtype=np.int32),

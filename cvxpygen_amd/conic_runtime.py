@@ -46,7 +46,7 @@ class _ConicFamily(C.Structure):     # include/cpg_hip.h: cpg_conic_family_t
                 ('d_base', C.c_double),
                 ('map_P', _Csr), ('map_A', _Csr), ('map_q', _Csr), ('map_b', _Csr), ('map_d', _Csr),
                 ('n_prim', C.c_int32), ('prim_idx', _ip), ('n_dual', C.c_int32), ('dual_idx', _ip),
-                ('n_exp', C.c_int32), ('n_pow', C.c_int32), ('pow_alpha', _dp)]
+                ('n_exp', C.c_int32), ('n_pow', C.c_int32), ('pow_alpha', _dp), ('n_psd', C.c_int32), ('psd_dims', _ip)]
 
 
 class _PlanView:
@@ -181,7 +181,7 @@ class ConicBatchSolver(BatchSolver):
             np_var=len(cols), P_base=_d(Pb), A_base=_d(Ab), q_base=_d(qb), b_base=_d(bb), d_base=d_base,
             map_P=MP, map_A=MA, map_q=Mq, map_b=Mb, map_d=Md,
             n_prim=len(prim_idx), prim_idx=i32(prim_idx), n_dual=len(dual_idx), dual_idx=i32(dual_idx),
-            n_exp=cp.n_exp, n_pow=len(cp.pow_alpha), pow_alpha=f64(cp.pow_alpha))
+            n_exp=cp.n_exp, n_pow=len(cp.pow_alpha), pow_alpha=f64(cp.pow_alpha), n_psd=len(cp.psd_dims), psd_dims=i32(cp.psd_dims))
         self.lib.check(self.lib.L.cpg_hip_create_clarabel(C.byref(fam), self.device, C.byref(self.h)),
                        'cpg_hip_create_clarabel')
         self._update_key, self._keep = key, keep

@@ -23,6 +23,7 @@
 #include CPG_GENC_HEADER
 #endif
 #include "cpg_clarabel_nonsym.h"
+#include "cpg_clarabel_psd.h"
 
 // (timing experiments, scripts/gpu_probe_conic.py: bit k set = piece k of an iteration is executed TWICE -- every piece is
 // idempotent, so results and control flow stay what they are and the time added is the piece's cost.  1 factorisation, 2 substitution
@@ -40,6 +41,7 @@ namespace cpg {
 #define CPG_CK_HDIAG 5
 #define CPG_CK_HSOC 6
 #define CPG_CK_HNS 7            // off-diagonal entry of an exponential / power cone's 3 x 3 scaling block: -wv[idx]
+#define CPG_CK_HPSD 8           // off-diagonal entry of a PSD cone's block: idx = offset of Q in the slice's PSD store | p << 12 | i << 16 | j << 19 | k << 22 | l << 25
 
 // Clarabel's SolverStatus numbering (the reference hands the integer through: clarabel.py:37-46)
 #define CPG_CL_UNSOLVED 0
@@ -68,6 +70,10 @@ struct DevConic {
     int n, m, nnzP, nnzA, nnzL, n_zero, n_nonneg, n_soc, is_max, p_is_zero;
     int n_ns;                                // exponential + power cones: the last 3 n_ns rows, three per cone
     const double *ns_alpha;                  // [n_ns] exponent of a power cone, 0 for an exponential cone
+    // PSD cones (rows between the second-order and the exponential cones): first row, matrix order and offset of the cone's
+    // [Q | R | R^-1 | lambda] in the slice's PSD store, per cone (global memory); psd_first: first PSD row; psd_degree: sum of orders
+    int n_psd, psd_first, psd_doubles, psd_degree;
+    const int *psd_start, *psd_dim, *psd_off;
     const int *soc_start, *soc_dim;          // [n_soc]
     const int *row_cone;                     // [m] first row of the row's second-order cone, -1 otherwise
     const int *Ap, *Ai, *Arp, *Aent, *Acol, *Pp, *Pi, *Prp, *Pent, *Pcol;
@@ -100,9 +106,9 @@ struct DevConic {
 
 struct ConicBuf {
     double *P, *A, *q, *b, *D, *E, *x, *z, *s, *dx, *dz, *ds, *x2, *z2, *rx, *rz, *tx, *tz, *lam, *wv, *hd, *et,
-        *dsc, *rb, *sol, *er, *cand, *Lx, *Dg, *Dginv, *sv, *w, *px, *pz, *ps;
+        *dsc, *rb, *sol, *er, *cand, *Lx, *Dg, *Dginv, *sv, *w, *px, *pz, *ps, *psd;
 };
-// per-wavefront LDS: nnzP + nnzA + 7n + 14m + 6(n+m) + nnzL + sol_nnz + sv_pad + sol_slots + w_extra doubles (host: cpg_hip.cpp)
+// per-wavefront LDS: nnzP + nnzA + 7n + 14m + 6(n+m) + nnzL + sol_nnz + sv_pad + sol_slots + w_extra + psd_doubles doubles (host: cpg_hip.cpp)
 CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
     ConicBuf o;
     const int n = C.n, m = C.m, N = n + m;
@@ -113,6 +119,7 @@ CPG_DEV ConicBuf conic_carve(double *p, const DevConic &C) {
     o.et = p; p += m; o.dsc = p; p += m;
     o.rb = p; p += N; o.sol = p; p += N; o.er = p; p += N; o.cand = p; p += N; o.Dg = p; p += N; o.Dginv = p; p += N;
     o.Lx = p; p += C.nnzL; o.sv = p; p += C.sol_nnz + C.sv_pad; o.w = p;
+    o.psd = p + C.sol_slots + C.w_extra;         // (PSD cones: Q | R | R^-1 | lambda per cone, psd_doubles in all)
     // previous iterate (insufficient progress falls back to it): in the step's place -- a step is dead from the moment it
     // is applied until the next iteration's solves write a new one, which is after the progress test
     o.px = o.dx; o.pz = o.dz; o.ps = o.ds;
@@ -203,8 +210,29 @@ struct ConicCtxT {
         for (unsigned k = a; k < e; k++) acc = fma(B.A[k], v[(unsigned)cpgw::gld(C.Ai, k)], acc);
         return acc;
     }
-    // per-cone dot products  sum_r wv[r] v[r]  are written to tmp[first row of the cone]
+    struct PsdRef { unsigned st; int p, d; double *Q, *R, *Ri, *lam; };
+    CPG_DEV PsdRef psd_ref(int k) const {
+        PsdRef r;
+        r.st = (unsigned)cpgw::gld(C.psd_start, (unsigned)k); r.p = cpgw::gld(C.psd_dim, (unsigned)k);
+        r.d = r.p * (r.p + 1) / 2;
+        r.Q = B.psd + cpgw::gld(C.psd_off, (unsigned)k); r.R = r.Q + r.p * r.p; r.Ri = r.R + r.p * r.p; r.lam = r.Ri + r.p * r.p;
+        return r;
+    }
+    // compact p x p matrix of the slice <-> local matrix with leading dimension CPG_PSD_LD
+    CPG_DEV static void psd_load(int p, const double *src, double *M) { for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) M[i * CPG_PSD_LD + j] = src[i * p + j]; }
+    CPG_DEV static void psd_store(int p, const double *M, double *dst) { for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) dst[i * p + j] = M[i * CPG_PSD_LD + j]; }
+    // per-cone dot products  sum_r wv[r] v[r]  are written to tmp[first row of the cone]; PSD cones: ALL rows of W'W v = svec(Q V Q)
     CPG_DEV void soc_dots(const double *v, double *tmp) const {
+        if (NS) {
+            for (int k = lane; k < C.n_psd; k += 64) {
+                const PsdRef r = psd_ref(k);
+                double X[CPG_PSD_MAX * CPG_PSD_LD], Q[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], Y[CPG_PSD_MAX * CPG_PSD_LD];
+                psd::svec_to_mat(v + r.st, r.p, X);
+                psd_load(r.p, r.Q, Q);
+                psd::congruence(r.p, Q, false, X, T, Y);
+                psd::mat_to_svec(Y, r.p, tmp + r.st);
+            }
+        }
         for (int k = lane; k < C.n_soc; k += 64) {
             const unsigned st = (unsigned)cpgw::gld(C.soc_start, (unsigned)k), dm = (unsigned)cpgw::gld(C.soc_dim, (unsigned)k);
             double acc = 0.0;
@@ -227,6 +255,7 @@ struct ConicCtxT {
     // (W'W v)_i for row i; `dots` from soc_dots(v)
     CPG_DEV double hs_row(unsigned i, const double *v, const double *dots) const {
         if (i < (unsigned)C.n_zero) return 0.0;
+        if (NS && i >= (unsigned)C.psd_first && i < ns_first()) return dots[i];
         if (NS && i >= ns_first()) {
             const unsigned r = (i - ns_first()) % 3u, st = i - r;
             const double v0 = v[st], v1 = v[st + 1u], v2 = v[st + 2u];
@@ -373,6 +402,9 @@ struct ConicCtxT {
                     kv = -((B.et[i] * B.et[i]) * (2.0 * (B.wv[i] * B.wv[j])));
                 }
                 else if (NS && kind == CPG_CK_HNS) kv = -B.wv[idx];
+                else if (NS && kind == CPG_CK_HPSD)
+                    kv = -psd::kkt_entry(B.psd + (idx & 0xFFFu), (int)((idx >> 12) & 0xFu), (int)((idx >> 16) & 7u), (int)((idx >> 19) & 7u),
+                                         (int)((idx >> 22) & 7u), (int)((idx >> 25) & 7u));
                 double v = kv - acc;
                 if (piv) {
                     if (S.dynamic_reg_enable && v * sign < S.dyn_eps) v = S.dyn_delta * sign;
@@ -413,6 +445,15 @@ struct ConicCtxT {
             B.lam[i] = 1.0;
             B.hd[i] = i < (unsigned)C.n_zero ? 0.0 : 1.0;
         }
+        if (NS) {
+            for (int k = lane; k < C.n_psd; k += 64) {
+                const PsdRef r = psd_ref(k);
+                for (int i = 0; i < r.p; i++) {
+                    for (int j = 0; j < r.p; j++) { const double e = i == j ? 1.0 : 0.0; r.Q[i * r.p + j] = e; r.R[i * r.p + j] = e; r.Ri[i * r.p + j] = e; }
+                    r.lam[i] = 1.0;
+                }
+            }
+        }
         cpgw::lds_order();
     }
     // (min margin, sum of positive margins) of v over the nonnegative and second-order cones
@@ -430,6 +471,15 @@ struct ConicCtxT {
             a = cpgw::dmin2(a, mg);
             bsum += cpgw::dmax2(0.0, mg);
         }
+        if (NS) {
+            for (int k = lane; k < C.n_psd; k += 64) {
+                const PsdRef r = psd_ref(k);
+                double X[CPG_PSD_MAX * CPG_PSD_LD], ev[CPG_PSD_MAX];
+                psd::svec_to_mat(v + r.st, r.p, X);
+                psd::jacobi(r.p, X, nullptr, ev);
+                for (int i = 0; i < r.p; i++) { a = cpgw::dmin2(a, ev[i]); bsum += cpgw::dmax2(0.0, ev[i]); }
+            }
+        }
         mn = cpgw::wave_min(a);
         pos = cpgw::wave_sum(bsum);
     }
@@ -442,7 +492,7 @@ struct ConicCtxT {
         cpgw::lds_order();
     }
     CPG_DEV void shift_to_cone(double *v, bool primal) const {
-        const int degree = C.n_nonneg + C.n_soc;
+        const int degree = C.n_nonneg + C.n_soc + (NS ? C.psd_degree : 0);
         if (degree == 0) { unit_shift(v, 0.0, primal); return; }
         double mn, pos;
         margins(v, mn, pos);
@@ -469,6 +519,41 @@ struct ConicCtxT {
                 B.et[st] = grad[0]; B.et[st + 1u] = grad[1]; B.et[st + 2u] = grad[2];
                 B.hd[st] = Hs[0]; B.hd[st + 1u] = Hs[3]; B.hd[st + 2u] = Hs[5];
                 B.wv[st] = Hs[1]; B.wv[st + 1u] = Hs[2]; B.wv[st + 2u] = Hs[4];
+            }
+            // PSD cones: S = L1 L1', Z = L2 L2', L2'L1 = U diag(lambda) V' (through the eigenvectors of its Gram matrix),
+            // R = L1 V diag(lambda)^-1/2, R^-1 = diag(lambda)^-1/2 U'L2', Q = R R'
+            for (int k = lane; k < C.n_psd; k += 64) {
+                const PsdRef r = psd_ref(k);
+                const int p = r.p;
+                double A[CPG_PSD_MAX * CPG_PSD_LD], L1[CPG_PSD_MAX * CPG_PSD_LD], L2[CPG_PSD_MAX * CPG_PSD_LD], M[CPG_PSD_MAX * CPG_PSD_LD],
+                    V[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], sig[CPG_PSD_MAX], isq[CPG_PSD_MAX];
+                psd::svec_to_mat(B.s + r.st, p, A);
+                bool pd = psd::cholesky(p, A, L1);
+                psd::svec_to_mat(B.z + r.st, p, A);
+                pd = psd::cholesky(p, A, L2) && pd;
+                if (!pd) { ok = false; continue; }
+                psd::matmul(p, L2, true, L1, false, M);                 // M = L2'L1
+                psd::matmul(p, M, true, M, false, A);                   // M'M = V diag(lambda^2) V'
+                psd::jacobi(p, A, V, sig);
+                for (int i = 0; i < p; i++) { sig[i] = sqrt(sig[i]); isq[i] = 1.0 / sqrt(sig[i]); }
+                psd::matmul(p, L1, false, V, false, T);                 // R = L1 V diag(isq)
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) T[i * CPG_PSD_LD + j] *= isq[j];
+                psd_store(p, T, r.R);
+                psd::matmul(p, T, false, T, true, A);                   // Q = R R'
+                psd_store(p, A, r.Q);
+                psd::matmul(p, M, false, V, false, T);                  // U = M V diag(1 / lambda);  R^-1 = diag(isq) U'L2'
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) T[i * CPG_PSD_LD + j] /= sig[j];
+                psd::matmul(p, T, true, L2, true, M);
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) M[i * CPG_PSD_LD + j] *= isq[i];
+                psd_store(p, M, r.Ri);
+                int a = 0;
+                for (int j = 0; j < p; j++)
+                    for (int i = 0; i <= j; i++, a++) {
+                        B.lam[r.st + (unsigned)a] = i == j ? sig[i] : 0.0;
+                        B.hd[r.st + (unsigned)a] = psd::kkt_entry(r.Q, p, i, j, i, j);     // (Q just stored by this lane)
+                        B.et[r.st + (unsigned)a] = 1.0;
+                    }
+                for (int i = 0; i < p; i++) r.lam[i] = sig[i];
             }
         }
         for (unsigned i = (unsigned)C.n_zero + (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {
@@ -552,6 +637,26 @@ struct ConicCtxT {
         }
         return cpgw::wave_min(a);
     }
+    // PSD cones: largest a <= a0 with lambda + a W dz and lambda + a W^-T ds in the cone -- the smallest eigenvalue of
+    // diag(lambda)^-1/2 mat(.) diag(lambda)^-1/2
+    CPG_DEV double psd_step_length(double a0) const {
+        double a = a0;
+        for (int k = lane; k < C.n_psd; k += 64) {
+            const PsdRef r = psd_ref(k);
+            const int p = r.p;
+            double X[CPG_PSD_MAX * CPG_PSD_LD], Rm[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], Y[CPG_PSD_MAX * CPG_PSD_LD];
+#pragma nounroll
+            for (int side = 0; side < 2; side++) {
+                psd::svec_to_mat((side == 0 ? B.dz : B.ds) + r.st, p, X);
+                psd_load(p, side == 0 ? r.R : r.Ri, Rm);
+                psd::congruence(p, Rm, side == 0, X, T, Y);           // R' dZ R  |  R^-1 dS R^-T
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) Y[i * CPG_PSD_LD + j] *= (1.0 / sqrt(r.lam[i])) * (1.0 / sqrt(r.lam[j]));
+                const double g = psd::eig_min(p, Y);
+                if (g < 0.0) a = cpgw::dmin2(a, -1.0 / g);
+            }
+        }
+        return cpgw::wave_min(a);
+    }
     // exponential / power cones: backtracking from a on the cone tests of z + a dz and s + a ds
     CPG_DEV double ns_step_length(double a0) const {
         double a = a0;
@@ -601,10 +706,22 @@ struct ConicCtxT {
             const double sn[3] = {B.s[st] + a * B.ds[st], B.s[st + 1u] + a * B.ds[st + 1u], B.s[st + 2u] + a * B.ds[st + 2u]};
             acc += ns::barrier_dual(zn, alpha) + ns::barrier_primal(sn, alpha);
         }
+        for (int k = lane; k < C.n_psd; k += 64) {          // -log det of both trial matrices through their Cholesky factors
+            const PsdRef r = psd_ref(k);
+            double v[CPG_PSD_MAX * (CPG_PSD_MAX + 1) / 2], X[CPG_PSD_MAX * CPG_PSD_LD], L[CPG_PSD_MAX * CPG_PSD_LD];
+#pragma nounroll
+            for (int side = 0; side < 2; side++) {
+                const double *x = side == 0 ? B.s : B.z, *dx = side == 0 ? B.ds : B.dz;
+                for (int t = 0; t < r.d; t++) v[t] = x[r.st + (unsigned)t] + a * dx[r.st + (unsigned)t];
+                psd::svec_to_mat(v, r.p, X);
+                if (!psd::cholesky(r.p, X, L)) { acc = CPG_NS_INF; continue; }
+                for (int i = 0; i < r.p; i++) acc -= 2.0 * log(L[i * CPG_PSD_LD + i]);
+            }
+        }
         sz = cpgw::wave_sum(sz);
         const bool inf = cpgw::wave_any(!(acc < CPG_NS_INF));       // (+inf in any lane: the sum is +inf whatever the other lanes hold)
         acc = cpgw::wave_sum(acc);
-        const int degree = C.n_nonneg + C.n_soc + 3 * C.n_ns;
+        const int degree = C.n_nonneg + C.n_soc + 3 * C.n_ns + C.psd_degree;
         const double mu = (sz + ct * ck) / (double)(degree + 1);
         const double val = (double)(degree + 1) * ns::logsafe(mu) - ns::logsafe(ct) - ns::logsafe(ck) + acc;
         return inf ? CPG_NS_INF : val;
@@ -621,6 +738,30 @@ struct ConicCtxT {
                 double eta[3];
                 ns::higher_correction(zk, alpha, dsk, dzk, eta);
                 for (unsigned r = 0; r < 3u; r++) B.dsc[st + r] = B.s[st + r] + sigmamu * B.et[st + r] - eta[r];
+            }
+            // PSD cones: a = W^-T ds = R^-1 dS R^-T, b = W dz = R' dZ R, d = diag(lambda^2) + (a b + b a) / 2 - sigma mu I,
+            // u_ij = 2 d_ij / (lambda_i + lambda_j), dsc = W'u = R U R'
+            for (int k = lane; k < C.n_psd; k += 64) {
+                const PsdRef r = psd_ref(k);
+                const int p = r.p;
+                double X[CPG_PSD_MAX * CPG_PSD_LD], Rm[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], Am[CPG_PSD_MAX * CPG_PSD_LD],
+                    Bm[CPG_PSD_MAX * CPG_PSD_LD];
+                psd::svec_to_mat(B.ds + r.st, p, X);
+                psd_load(p, r.Ri, Rm);
+                psd::congruence(p, Rm, false, X, T, Am);
+                psd::svec_to_mat(B.dz + r.st, p, X);
+                psd_load(p, r.R, Rm);
+                psd::congruence(p, Rm, true, X, T, Bm);
+                psd::matmul(p, Am, false, Bm, false, T);
+                psd::matmul(p, Bm, false, Am, false, X);
+                for (int i = 0; i < p; i++)
+                    for (int j = 0; j < p; j++) {
+                        const double li = r.lam[i], lj = r.lam[j];
+                        const double d = (i == j ? li * li - sigmamu : 0.0) + 0.5 * (T[i * CPG_PSD_LD + j] + X[i * CPG_PSD_LD + j]);
+                        Am[i * CPG_PSD_LD + j] = 2.0 * d / (li + lj);
+                    }
+                psd::congruence(p, Rm, false, Am, T, X);               // R U R'
+                psd::mat_to_svec(X, p, B.dsc + r.st);
             }
         }
         for (unsigned i = (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {
@@ -771,7 +912,8 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
     LdsProg SP;
     SP.ctab = C.sol_ctab; SP.desc = C.sol_desc; SP.vals = B.sv; SP.cols = C.sol_cols;
     SP.n_chunks = C.sol_chunks; SP.dummy = (unsigned)C.sol_nnz - 1u; SP.rows16 = nullptr;
-    const int degree = C.n_nonneg + C.n_soc + (NONSYM ? 3 * C.n_ns : 0);
+    const int degree = C.n_nonneg + C.n_soc + (NONSYM ? 3 * C.n_ns + C.psd_degree : 0);
+    const bool nonsym = NONSYM && C.n_ns > 0;     // (the extended instantiation also serves families whose only extra cones are PSD: symmetric)
     // zero padding behind the entries, dummy slots and zero slot behind the work vector (generated executor)
     for (int t = lane; t < C.sv_pad; t += 64) B.sv[C.sol_nnz + t] = 0.0;
     for (int t = lane; t < C.w_extra; t += 64) B.w[C.sol_slots + t] = 0.0;
@@ -901,10 +1043,20 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                 const double mean = sum / (double)dm;
                 for (unsigned r = 0; r < dm; r++) B.tz[st + r] = mean / B.E[st + r];
             }
-            // exponential / power cones admit no row scaling at all: back to 1
-            if (NONSYM) for (unsigned i = cx.ns_first() + (unsigned)lane; i < m; i += 64u) B.tz[i] = 1.0 / B.E[i];
+            if (NONSYM) {
+                for (int k = lane; k < C.n_psd; k += 64) {        // PSD cones: one scale per cone as well
+                    const unsigned st = (unsigned)cpgw::gld(C.psd_start, (unsigned)k);
+                    const int pp = cpgw::gld(C.psd_dim, (unsigned)k), dm = pp * (pp + 1) / 2;
+                    double sum = 0.0;
+                    for (int r = 0; r < dm; r++) sum += B.E[st + (unsigned)r];
+                    const double mean = sum / (double)dm;
+                    for (int r = 0; r < dm; r++) B.tz[st + (unsigned)r] = mean / B.E[st + (unsigned)r];
+                }
+                // exponential / power cones admit no row scaling at all: back to 1
+                for (unsigned i = cx.ns_first() + (unsigned)lane; i < m; i += 64u) B.tz[i] = 1.0 / B.E[i];
+            }
             cpgw::lds_order();
-            if (C.n_soc > 0 || (NONSYM && C.n_ns > 0)) {
+            if (C.n_soc > 0 || (NONSYM && (C.n_ns > 0 || C.n_psd > 0))) {
                 const unsigned first = (unsigned)(C.n_zero + C.n_nonneg);
                 for (unsigned i = first + (unsigned)lane; i < m; i += 64u) {
                     const double ew = B.tz[i];
@@ -929,7 +1081,7 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
         const double cinv = 1.0 / cs;
 
         // ---- 3. initial point: identity scaling, one factorisation, shift into the cones
-        if (NONSYM) {
+        if (nonsym) {
             // a nonsymmetric cone anywhere: x = 0 and every cone at its central point s = z
             cx.identity_scaling();           // (the zero-cone rows of the scaling vectors are written here and nowhere else)
             for (unsigned j = (unsigned)lane; j < n; j += 64u) B.x[j] = 0.0;
@@ -1046,7 +1198,7 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                     status = CPG_CL_INSUFFICIENT_PROGRESS;
                 if ((res_d > S.tol_feas && res_d > 100.0 * prev_res_d) || (res_p > S.tol_feas && res_p > 100.0 * prev_res_p))
                     status = CPG_CL_INSUFFICIENT_PROGRESS;
-                if (NONSYM && status == CPG_CL_INSUFFICIENT_PROGRESS && !dual_strategy) {
+                if (nonsym && status == CPG_CL_INSUFFICIENT_PROGRESS && !dual_strategy) {
                     // strategy checkpoint: the primal-dual scaling gets a second chance as the dual scaling, from this iterate
                     status = CPG_CL_UNSOLVED; dual_strategy = true;
                     prev_cost_p = cost_p; prev_res_p = res_p; prev_res_d = res_d; prev_gap_abs = gap_abs; prev_gap_rel = gap_rel;
@@ -1118,10 +1270,11 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                         if (dkap < 0.0) alpha = cpgw::dmin2(alpha, -kap / dkap);
                         alpha = cx.step_length(B.z, B.dz, alpha);         // (symmetric cones first)
                         alpha = cx.step_length(B.s, B.ds, alpha);
+                        if (NONSYM && C.n_psd > 0) alpha = cx.psd_step_length(alpha);
                         // back off from a full step so that the logarithms are not taken at the boundary, then backtrack
-                        if (NONSYM) alpha = cx.ns_step_length(cpgw::dmin2(alpha, S.max_step_fraction));
+                        if (nonsym) alpha = cx.ns_step_length(cpgw::dmin2(alpha, S.max_step_fraction));
                     }
-                    if (NONSYM) {      // a step that is not finite: numerical-error checkpoint
+                    if (nonsym) {      // a step that is not finite: numerical-error checkpoint
                         bool bad = !(fabs(dtau) < CPG_NS_INF);
                         for (unsigned j = (unsigned)lane; j < n; j += 64u) bad = bad || !(fabs(B.dx[j]) < CPG_NS_INF);
                         for (unsigned i = (unsigned)lane; i < m; i += 64u) bad = bad || !(fabs(B.dz[i]) < CPG_NS_INF);
@@ -1130,19 +1283,19 @@ CPG_DEV void clarabel_body(const DevConic &C0, const DevConicSettings &S, const 
                     if (pass == 1) sigma = (1.0 - alpha) * (1.0 - alpha) * (1.0 - alpha);
                 }
             }
-            if (NONSYM && nonfinite) {
+            if (nonsym && nonfinite) {
                 if (!dual_strategy) { dual_strategy = true; continue; }
                 status = CPG_CL_NUMERICAL_ERROR; break;
             }
             alpha *= S.max_step_fraction;
-            if (NONSYM && dual_strategy) {       // centrality: back to where the sum of the barriers is below 1
+            if (nonsym && dual_strategy) {       // centrality: back to where the sum of the barriers is below 1
 #pragma nounroll
                 for (int t = 0; t < 50; t++) {
                     if (cx.barrier(alpha, tau, kap, dtau, dkap) < 1.0) break;
                     alpha *= S.ls_backtrack;
                 }
             }
-            if (NONSYM && !dual_strategy && alpha < S.min_switch_step) { dual_strategy = true; continue; }   // small-step checkpoint
+            if (nonsym && !dual_strategy && alpha < S.min_switch_step) { dual_strategy = true; continue; }   // small-step checkpoint
             if (alpha <= cpgw::dmax2(0.0, S.min_terminate_step)) { status = CPG_CL_INSUFFICIENT_PROGRESS; break; }   // undersized step
             for (unsigned j = (unsigned)lane; j < n; j += 64u) { const double v = B.x[j], d = B.dx[j]; B.px[j] = v; B.x[j] = v + alpha * d; }
             for (unsigned i = (unsigned)lane; i < m; i += 64u) {

@@ -431,12 +431,13 @@ static int launch_conic_t(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, i
     return CPG_OK;
 }
 static int launch_conic(cpg_handle_t h, const cpg::DevBatch &Bt, int blocks, int waves, size_t lds, bool tables_in_lds) {
+    const bool extended = h->C.n_ns > 0 || h->C.n_psd > 0;       // exponential / power / PSD cones: the instantiation that carries their code
 #ifdef CPG_GENC_HEADER
     // the library's own family: dimensions as compile-time constants (clarabel_body<., true>)
     if (h->conic_specialised && tables_in_lds)
-        return h->C.n_ns > 0 ? launch_conic_t<true, true, true>(h, Bt, blocks, waves, lds) : launch_conic_t<true, true>(h, Bt, blocks, waves, lds);
+        return extended ? launch_conic_t<true, true, true>(h, Bt, blocks, waves, lds) : launch_conic_t<true, true>(h, Bt, blocks, waves, lds);
 #endif
-    if (h->C.n_ns > 0)
+    if (extended)
         return tables_in_lds ? launch_conic_t<true, false, true>(h, Bt, blocks, waves, lds) : launch_conic_t<false, false, true>(h, Bt, blocks, waves, lds);
     return tables_in_lds ? launch_conic_t<true, false>(h, Bt, blocks, waves, lds) : launch_conic_t<false, false>(h, Bt, blocks, waves, lds);
 }
@@ -956,7 +957,8 @@ static unsigned conic_row_words_hash(const cpg_conic_family_t *f) {
 
 static bool conic_dims_equal(const cpg::DevConic &a, const cpg::DevConic &b) {
     return a.n == b.n && a.m == b.m && a.nnzP == b.nnzP && a.nnzA == b.nnzA && a.nnzL == b.nnzL && a.n_zero == b.n_zero &&
-           a.n_nonneg == b.n_nonneg && a.n_soc == b.n_soc && a.n_ns == b.n_ns && a.is_max == b.is_max && a.p_is_zero == b.p_is_zero &&
+           a.n_nonneg == b.n_nonneg && a.n_soc == b.n_soc && a.n_ns == b.n_ns && a.n_psd == b.n_psd && a.psd_first == b.psd_first &&
+           a.psd_doubles == b.psd_doubles && a.psd_degree == b.psd_degree && a.is_max == b.is_max && a.p_is_zero == b.p_is_zero &&
            a.fac_chunks == b.fac_chunks && a.sol_chunks == b.sol_chunks && a.sol_nnz == b.sol_nnz && a.sol_slots == b.sol_slots &&
            a.fac_triples == b.fac_triples && a.n_pfull == b.n_pfull && a.sv_pad == b.sv_pad && a.w_extra == b.w_extra &&
            a.gc_ncols == b.gc_ncols && a.gc_nrows == b.gc_nrows;
@@ -1024,6 +1026,11 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     for (int k = 0; k < f->n_pow; k++)
         if (!(f->pow_alpha[k] > 0.0 && f->pow_alpha[k] < 1.0)) { set_error("power cone exponent outside (0, 1)"); return CPG_E_BADARG; }
     rows += 3LL * ((long long)f->n_exp + f->n_pow);
+    if (f->n_psd < 0 || (f->n_psd > 0 && !f->psd_dims)) { set_error("bad PSD cone count"); return CPG_E_BADARG; }
+    for (int k = 0; k < f->n_psd; k++) {
+        if (f->psd_dims[k] < 1 || f->psd_dims[k] > CPG_PSD_MAX) { set_error("PSD cone order outside 1 .. 8"); return CPG_E_UNSUPPORTED; }
+        rows += (long long)f->psd_dims[k] * (f->psd_dims[k] + 1) / 2;
+    }
     if (rows != f->m) { set_error("cone dimensions do not add up to m"); return CPG_E_BADARG; }
     if (f->sol_slots < f->n + f->m || f->sol_slots > 8191) { set_error("bad sol_slots"); return CPG_E_BADARG; }
     int rc = rt_set_device(device);
@@ -1039,9 +1046,23 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     C.np_var = f->np_var; C.d_base = f->d_base; C.n_prim = f->n_prim; C.n_dual = f->n_dual;
     h->F.n = n; h->F.m = m; h->F.n_prim = f->n_prim; h->F.n_dual = f->n_dual;   // staging sizes of the host entry point
     std::vector<int> soc_start(f->n_soc > 0 ? f->n_soc : 1), row_cone(m > 0 ? m : 1, -1);
+    std::vector<int> psd_start((size_t)(f->n_psd > 0 ? f->n_psd : 1)), psd_off((size_t)(f->n_psd > 0 ? f->n_psd : 1));
+    C.n_psd = f->n_psd; C.psd_doubles = 0; C.psd_degree = 0;
+    C.psd_start = C.psd_dim = C.psd_off = nullptr;
     {
         int o = f->n_zero + f->n_nonneg;
         for (int k = 0; k < f->n_soc; k++) { soc_start[k] = o; for (int r = 0; r < f->soc_dims[k]; r++) row_cone[o + r] = o; o += f->soc_dims[k]; }
+        C.psd_first = o;
+        for (int k = 0; k < f->n_psd; k++) {
+            // row_cone of a PSD row: itself on the diagonal of the matrix (where a unit shift lands), the cone's first row elsewhere
+            const int pp = f->psd_dims[k];
+            psd_start[k] = o; psd_off[k] = C.psd_doubles;
+            C.psd_doubles += 3 * pp * pp + pp; C.psd_degree += pp;
+            int a = 0;
+            for (int j = 0; j < pp; j++) for (int i = 0; i <= j; i++, a++) row_cone[o + a] = i == j ? o + a : o;
+            o += pp * (pp + 1) / 2;
+        }
+        if (C.psd_doubles > 0xFFF) { set_error("PSD cones too large for the 12-bit offsets of their KKT sources"); cpg_hip_destroy(h); return CPG_E_UNSUPPORTED; }
     }
     std::vector<void *> &own = h->owned;
 #define TRY(x) do { rc = (x); if (rc) { cpg_hip_destroy(h); return rc; } } while (0)
@@ -1049,6 +1070,11 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
     TRY(upload<int>(h, own, soc_start.data(), (size_t)f->n_soc, &C.soc_start));
     TRY(upload<int>(h, own, f->soc_dims, (size_t)f->n_soc, &C.soc_dim));
     TRY(upload<int>(h, own, row_cone.data(), (size_t)m, &C.row_cone));
+    if (f->n_psd > 0) {
+        TRY(upload<int>(h, own, psd_start.data(), (size_t)f->n_psd, &C.psd_start));
+        TRY(upload<int>(h, own, f->psd_dims, (size_t)f->n_psd, &C.psd_dim));
+        TRY(upload<int>(h, own, psd_off.data(), (size_t)f->n_psd, &C.psd_off));
+    }
     if (C.n_ns > 0) {      // exponent per nonsymmetric cone, 0 = exponential cone (rows: exponential cones first)
         std::vector<double> ns_alpha((size_t)C.n_ns, 0.0);
         for (int k = 0; k < f->n_pow; k++) ns_alpha[(size_t)f->n_exp + k] = f->pow_alpha[k];
@@ -1128,7 +1154,7 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
         C.tab_doubles = (int)t;
     }
     {   // per-wavefront LDS slice, see conic_carve()
-        const long long d = (long long)f->nnzP + f->nnzA + 7LL * n + 14LL * m + 6LL * N + f->nnzL + f->sol_nnz + C.sv_pad + f->sol_slots + C.w_extra;
+        const long long d = (long long)f->nnzP + f->nnzA + 7LL * n + 14LL * m + 6LL * N + f->nnzL + f->sol_nnz + C.sv_pad + f->sol_slots + C.w_extra + C.psd_doubles;
         C.lds_doubles = (int)((d + 1) & ~1LL);
         if ((size_t)C.lds_doubles * 8 > h->lds_limit) {
             set_error("conic family too large: the interior-point state of one instance does not fit the LDS");

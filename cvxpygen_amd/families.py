@@ -454,3 +454,57 @@ def exp_prox(n: int = 3, radius: float = 10.0, name: str = 'exp_prox') -> Family
         cb.exp_cone([([(x[i], -1.0)], 0.0), ([], 1.0), ([(t[i], -1.0)], 0.0)])      # exp(x_i) <= t_i
     cb.dual('mu', rows, (n,))
     return cb.build({'a': np.linspace(-1.0, 2.0, n), 'ub': 5.0 * np.ones(n)}, solver='CLARABEL')
+
+
+# ------------------------------------------------------------------------------------------------ PSD cones
+_SQRT2 = float(np.sqrt(2.0))
+
+
+def _svec_pairs(p: int):
+    return [(i, j) for j in range(p) for i in range(j + 1)]
+
+
+def min_eig(p: int = 3, name: str = 'min_eig') -> FamilyDescriptor:
+    """maximise t  s.t.  C - t I >= 0 (PSD):  t* = lambda_min(C); C (symmetric, p x p) is the parameter
+    (cvxpy: cp.Maximize(t), [C - t * np.eye(p) >> 0])"""
+    cb = CanonBuilder(name)
+    C = cb.param('C', (p, p))
+    t = cb.var('t', (1,))
+    cb.lin(t[0], -1.0)
+    cb.is_maximization = True
+    cb.psd_cone(p, [([(t[0], 1.0)], C[i, j]) if i == j else ([], cmul(C[i, j], _SQRT2)) for i, j in _svec_pairs(p)])
+    A = np.arange(p * p, dtype=float).reshape(p, p) / p
+    return cb.build({'C': A + A.T}, solver='CLARABEL')
+
+
+def psd_projection(p: int = 3, name: str = 'psd_projection') -> FamilyDescriptor:
+    """minimise ||X - C||_F^2  s.t.  X >= 0 (PSD), over x = svec(X):  X* = C with its negative eigenvalues set to zero; value
+    ||X* - C||^2 - ||C||^2 in the canonical form (the constant ||C||^2 is not part of it)"""
+    cb = CanonBuilder(name)
+    C = cb.param('C', (p, p))
+    d = p * (p + 1) // 2
+    x = cb.var('x', (d,))
+    cb.sum_squares(x)
+    for k, (i, j) in enumerate(_svec_pairs(p)):
+        cb.lin(x[k], cmul(C[i, j], -2.0 if i == j else -2.0 * _SQRT2))
+    cb.psd_cone(p, [([(x[k], -1.0)], 0.0) for k in range(d)])
+    A = np.arange(p * p, dtype=float).reshape(p, p) / p - 1.0
+    return cb.build({'C': A + A.T}, solver='CLARABEL')
+
+
+def trace_sdp(p: int = 3, name: str = 'trace_sdp') -> FamilyDescriptor:
+    """minimise tr(C X)  s.t.  tr X = 1, X >= 0, exp(x_00) <= 5, ||x|| <= 10:  lambda_min(C) with a zero, a PSD, an exponential and a
+    second-order cone in one family (the last two inactive)"""
+    cb = CanonBuilder(name)
+    C = cb.param('C', (p, p))
+    pairs = _svec_pairs(p)
+    d = len(pairs)
+    x = cb.var('x', (d,))
+    for k, (i, j) in enumerate(pairs):
+        cb.lin(x[k], C[i, j] if i == j else cmul(C[i, j], _SQRT2))
+    cb.eq([(x[k], 1.0) for k, (i, j) in enumerate(pairs) if i == j], 1.0)
+    cb.soc([([], 10.0)] + [([(x[k], -1.0)], 0.0) for k in range(d)])
+    cb.psd_cone(p, [([(x[k], -1.0)], 0.0) for k in range(d)])
+    cb.exp_cone([([(x[0], -1.0)], 0.0), ([], 1.0), ([], 5.0)])
+    A = np.arange(p * p, dtype=float).reshape(p, p) / p
+    return cb.build({'C': A + A.T}, solver='CLARABEL')

@@ -220,8 +220,8 @@ typedef struct {
 /* Everything fixed at code-generation time for one CONIC problem family solved by the
  * interior-point kernel (reference: the Clarabel path, cvxpygen/solvers/clarabel.py:19-46, 133-204):
  *   minimise 1/2 x'Px + q'x + d   s.t.   Ax + s = b,  s in K,
- * rows ordered zero cone, nonnegative cone, second-order cones, exponential cones, three-dimensional power
- * cones -- the cone types the reference's `cones` array can hold (clarabel.py:133-155, 308-323) except PSD, in the
+ * rows ordered zero cone, nonnegative cone, second-order cones, PSD cones, exponential cones, three-dimensional power
+ * cones -- every cone type the reference's `cones` array can hold (clarabel.py:133-155, 308-323), in the
  * order in which cvxpy stacks the rows for this solver.  (The reference lists the exponential cones AHEAD of the
  * second-order cones, clarabel.py:316-319: with both kinds present its cones do not match its rows; with one
  * kind the orders coincide.)  The reference builds a new solver per solve
@@ -241,7 +241,9 @@ typedef struct {
      * ksrc_kind: 1 P entry idx, 2 A entry idx, 3 eps only, 5 -(W'W)_ii - eps of row idx,
      * 6 off-diagonal entry of a second-order-cone block, idx = row_i | row_j << 16,
      * 7 off-diagonal entry of an exponential / power cone's 3 x 3 block: idx = first row of the cone + (0 for (0,1),
-     *   1 for (0,2), 2 for (1,2)) */
+     *   1 for (0,2), 2 for (1,2)),
+     * 8 off-diagonal entry of a PSD cone's block between svec rows (i, j) and (k, l): idx = offset of the cone in the PSD store
+     *   (sum over the cones before it of 3 p^2 + p) | p << 12 | i << 16 | j << 19 | k << 22 | l << 25 */
     const int32_t *Lcol, *ksrc_kind, *ksrc_idx;
     int32_t fac_chunks, fac_triples;
     const int32_t *fac_ctab;
@@ -260,6 +262,11 @@ typedef struct {
      * each, behind the second-order cones (ClarabelExponentialConeT / ClarabelPowerConeT(a), clarabel.py:136-147) */
     int32_t n_exp, n_pow;
     const double *pow_alpha;            /* [n_pow], each in (0, 1) */
+    /* PSD cones of matrix order psd_dims[k] <= 8 (ClarabelPSDTriangleConeT, clarabel.py:138, 146): psd_dims[k] (psd_dims[k] + 1) / 2
+     * rows each -- the upper triangle column by column, off-diagonal entries times sqrt 2 --, between the second-order and the
+     * exponential cones */
+    int32_t n_psd;
+    const int32_t *psd_dims;            /* [n_psd] */
 } cpg_conic_family_t;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
