@@ -169,8 +169,8 @@ def test_plan_holds_the_scaling_blocks():
     assert (kinds == 7).sum() == 9 and (kinds == 6).sum() == 6           # three off-diagonals per exponential cone, C(4, 2) for the ball
     first = d.m - 9
     assert sorted(np.asarray(cp.ksrc_idx)[kinds == 7].tolist()) == list(range(first, d.m))
-    d.cones['psd'] = [3]
-    with pytest.raises(NotImplementedError, match='psd'):
+    d.cones['gen_pow'] = [3]                 # (a cone type the reference's array does not have)
+    with pytest.raises(NotImplementedError, match='gen_pow'):
         build_conic_plan(d)
 
 
