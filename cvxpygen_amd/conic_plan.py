@@ -8,8 +8,9 @@ in every interior-point iteration factors
     K = [[P + eps I, A'], [A, -(W'W) - eps I]]
 
 whose pattern is fixed for the family: P (upper), A, the diagonal of the (2,2) block and one dense
-block per second-order cone and per exponential / power cone (3 x 3: the scaling block H_s of a
-nonsymmetric cone stands where W'W stands for a symmetric one).  Everything structural is computed once here: fill-reducing
+block per second-order cone, per PSD cone (d x d over its svec rows, entries computed from the cone's
+NT point Q) and per exponential / power cone (3 x 3: the scaling block H_s of a nonsymmetric cone
+stands where W'W stands for a symmetric one).  Everything structural is computed once here: fill-reducing
 permutation, symbolic LDL', where every KKT entry comes from, the level-scheduled dot-product
 schedule of the numeric factorisation and the ragged substitution program with value sources
 (shared machinery: refactor_plan.build_schedules).

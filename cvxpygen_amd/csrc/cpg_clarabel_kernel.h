@@ -15,6 +15,10 @@
 // K = [[P + eps I, A'], [A, -W'W - eps I]] factored as LDL' (fixed pattern, level-scheduled
 // dot-product form) with dynamic pivot regularisation and iterative refinement against the
 // unregularised K; Mehrotra predictor-corrector with sigma = (1 - alpha)^3.
+//
+// Cones: zero, nonnegative, second-order in every instantiation; PSD (cpg_clarabel_psd.h), exponential and power cones
+// (cpg_clarabel_nonsym.h) in the extended one (template switch NS / NONSYM: the symmetric kernel carries none of their code) --
+// every type of the reference's `cones` array (clarabel.py:308-323), rows zero | nonneg | soc | psd | exp | pow.
 #pragma once
 #include "cpg_osqp_kernel.h"
 #ifdef CPG_GENC_HEADER

@@ -22,9 +22,9 @@ Conventions kept from the reference:
   * +-inf is stored as +-1e30 (`cvxpygen/utils.py:213-228`).
   * conic families (solver 'CLARABEL'; `cvxpygen/solvers/clarabel.py:19-46, 133-155`): canonical
     parameters {P, q, d, A, b} for  minimise 1/2 x'Px + q'x + d  s.t.  Ax + s = b, s in K, with the
-    rows ordered zero cone, nonnegative cone, second-order cones, exponential cones, 3-d power cones (cvxpy's
-    stacking for this solver); `cones` holds {'zero': int, 'nonneg': int, 'soc': [dims]} and, when present,
-    'exp': count, 'pow': [exponents]; n_eq = zero-cone rows, n_ineq = all other rows;
+    rows ordered zero cone, nonnegative cone, second-order cones, PSD cones, exponential cones, 3-d power cones
+    (cvxpy's stacking for this solver); `cones` holds {'zero': int, 'nonneg': int, 'soc': [dims]} and, when present,
+    'psd': [matrix orders], 'exp': count, 'pow': [exponents]; n_eq = zero-cone rows, n_ineq = all other rows;
     the dual vector is called 'z' (`cvxpygen/solvers/clarabel.py:33-35`).
 """
 

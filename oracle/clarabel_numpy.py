@@ -12,13 +12,13 @@ follows literally:
     (equilibration + KKT assembly + factorisation from scratch), solve, read the solution
     (`cvxpygen/solvers/clarabel.py:172-204`),
   * the problem form  minimise 1/2 x'Px + q'x  s.t.  Ax + s = b, s in K  with K a product of zero,
-    nonnegative, second-order, exponential and three-dimensional power cones
-    (`cvxpygen/solvers/clarabel.py:133-155, 308-323`).  ROW ORDER: zero | nonneg | soc | exp | p3d -- the order
+    nonnegative, second-order, PSD (triangle form: upper triangle column by column, off-diagonals times sqrt 2),
+    exponential and three-dimensional power cones -- every type of the reference's `cones` array
+    (`cvxpygen/solvers/clarabel.py:133-155, 308-323`).  ROW ORDER: zero | nonneg | soc | psd | exp | p3d -- the order
     in which cvxpy stacks the rows of A and b for this solver.  The reference's `cones` array lists the
     exponential cones AHEAD of the second-order cones (clarabel.py:316-319); for a family that has both kinds
     its solver is told cones that do not match the rows it is given.  Followed here: the rows' meaning; with
-    only one of the two kinds present -- every case in which the reference is right -- both orders coincide.
-    PSD cones: not restated (refused by the product at plan time),
+    only one of the two kinds present -- every case in which the reference is right -- both orders coincide,
   * every setting default (`cvxpygen/solvers/clarabel.py:63-119`),
   * the returned fields x, z, obj_val, iterations, status (integer), r_prim, r_dual
     (`cvxpygen/solvers/clarabel.py:37-46`).

@@ -42,3 +42,17 @@ run(d, pv, lambda r: np.abs(r.obj_val - val).max())
 cp = build_conic_plan(d)
 lib = codegen.build_conic_library(cp, os.path.join(ROOT, 'cvxpygen_amd', 'generated', 'exp_prox'), 'exp_prox')
 run(d, pv, lambda r: np.abs(r.obj_val - val).max(), lib=lib, plan=cp)
+# PSD cones
+for p_ in (3, 6):
+    G = rs.randn(B, p_, p_); Cm = G + G.transpose(0, 2, 1)
+    run(families.min_eig(p_), {'C': Cm}, lambda r: np.abs(r.obj_val - np.linalg.eigvalsh(Cm).min(axis=1)).max())
+G = rs.randn(B, 3, 3); Cm = G + G.transpose(0, 2, 1)
+d = families.psd_projection(3)
+w_, V_ = np.linalg.eigh(Cm)
+X_ = np.einsum('bij,bj,bkj->bik', V_, np.maximum(w_, 0.0), V_)
+val3 = ((X_ - Cm) ** 2).sum(axis=(1, 2)) - (Cm ** 2).sum(axis=(1, 2))
+run(d, {'C': Cm}, lambda r: np.abs(r.obj_val - val3).max())
+cp = build_conic_plan(d)
+lib = codegen.build_conic_library(cp, os.path.join(ROOT, 'cvxpygen_amd', 'generated', 'psd_projection'), 'psd_projection')
+run(d, {'C': Cm}, lambda r: np.abs(r.obj_val - val3).max(), lib=lib, plan=cp)
+run(families.trace_sdp(3), {'C': Cm}, lambda r: np.abs(r.obj_val - np.linalg.eigvalsh(Cm).min(axis=1)).max())

