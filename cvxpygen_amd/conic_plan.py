@@ -136,7 +136,7 @@ def build_conic_plan(desc, ordering: str = 'auto') -> ConicPlan:
                 k, l = ij[b]
                 src_nat[(n + o + a, n + o + b)] = (K_HPSD, qoff | (pp << 12) | (i << 16) | (j << 19) | (k << 22) | (l << 25))
         o += len(ij)
-        qoff += 3 * pp * pp + pp
+        qoff += 11 * pp * pp + 3 * pp          # (Q | R | R^-1 | lambda | workspace: csrc/cpg_clarabel_psd.h CPG_PSD_WORK)
     if qoff > 0xFFF:
         raise NotImplementedError('PSD cones too large for the 12-bit offsets of their KKT sources')
     for _ in range(n_exp + len(pow_alpha)):          # 3 x 3 scaling blocks: off-diagonals (0,1), (0,2), (1,2) at wv[o + 0 .. 2]

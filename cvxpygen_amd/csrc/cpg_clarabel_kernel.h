@@ -214,26 +214,27 @@ struct ConicCtxT {
         for (unsigned k = a; k < e; k++) acc = fma(B.A[k], v[(unsigned)cpgw::gld(C.Ai, k)], acc);
         return acc;
     }
-    struct PsdRef { unsigned st; int p, d; double *Q, *R, *Ri, *lam; };
+    // a PSD cone's part of the slice: the NT point Q = R R', R, R^-1, lambda, then its workspace (eight p x p matrices, two p-vectors)
+    struct PsdRef {
+        unsigned st; int p, d; double *Q, *R, *Ri, *lam, *W;
+        CPG_DEV double *mat(int i) const { return W + i * p * p; }
+        CPG_DEV double *vec(int i) const { return W + 8 * p * p + i * p; }
+    };
     CPG_DEV PsdRef psd_ref(int k) const {
         PsdRef r;
         r.st = (unsigned)cpgw::gld(C.psd_start, (unsigned)k); r.p = cpgw::gld(C.psd_dim, (unsigned)k);
         r.d = r.p * (r.p + 1) / 2;
-        r.Q = B.psd + cpgw::gld(C.psd_off, (unsigned)k); r.R = r.Q + r.p * r.p; r.Ri = r.R + r.p * r.p; r.lam = r.Ri + r.p * r.p;
+        r.Q = B.psd + cpgw::gld(C.psd_off, (unsigned)k); r.R = r.Q + r.p * r.p; r.Ri = r.R + r.p * r.p; r.lam = r.Ri + r.p * r.p; r.W = r.lam + r.p;
         return r;
     }
-    // compact p x p matrix of the slice <-> local matrix with leading dimension CPG_PSD_LD
-    CPG_DEV static void psd_load(int p, const double *src, double *M) { for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) M[i * CPG_PSD_LD + j] = src[i * p + j]; }
-    CPG_DEV static void psd_store(int p, const double *M, double *dst) { for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) dst[i * p + j] = M[i * CPG_PSD_LD + j]; }
     // per-cone dot products  sum_r wv[r] v[r]  are written to tmp[first row of the cone]; PSD cones: ALL rows of W'W v = svec(Q V Q)
     CPG_DEV void soc_dots(const double *v, double *tmp) const {
         if (NS) {
             for (int k = lane; k < C.n_psd; k += 64) {
                 const PsdRef r = psd_ref(k);
-                double X[CPG_PSD_MAX * CPG_PSD_LD], Q[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], Y[CPG_PSD_MAX * CPG_PSD_LD];
+                double *X = r.mat(0), *T = r.mat(1), *Y = r.mat(2);
                 psd::svec_to_mat(v + r.st, r.p, X);
-                psd_load(r.p, r.Q, Q);
-                psd::congruence(r.p, Q, false, X, T, Y);
+                psd::congruence(r.p, r.Q, false, X, T, Y);
                 psd::mat_to_svec(Y, r.p, tmp + r.st);
             }
         }
@@ -478,7 +479,7 @@ struct ConicCtxT {
         if (NS) {
             for (int k = lane; k < C.n_psd; k += 64) {
                 const PsdRef r = psd_ref(k);
-                double X[CPG_PSD_MAX * CPG_PSD_LD], ev[CPG_PSD_MAX];
+                double *X = r.mat(0), *ev = r.vec(0);
                 psd::svec_to_mat(v + r.st, r.p, X);
                 psd::jacobi(r.p, X, nullptr, ev);
                 for (int i = 0; i < r.p; i++) { a = cpgw::dmin2(a, ev[i]); bsum += cpgw::dmax2(0.0, ev[i]); }
@@ -529,8 +530,7 @@ struct ConicCtxT {
             for (int k = lane; k < C.n_psd; k += 64) {
                 const PsdRef r = psd_ref(k);
                 const int p = r.p;
-                double A[CPG_PSD_MAX * CPG_PSD_LD], L1[CPG_PSD_MAX * CPG_PSD_LD], L2[CPG_PSD_MAX * CPG_PSD_LD], M[CPG_PSD_MAX * CPG_PSD_LD],
-                    V[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], sig[CPG_PSD_MAX], isq[CPG_PSD_MAX];
+                double *A = r.mat(0), *L1 = r.mat(1), *L2 = r.mat(2), *M = r.mat(3), *V = r.mat(4), *T = r.mat(5), *sig = r.vec(0), *isq = r.vec(1);
                 psd::svec_to_mat(B.s + r.st, p, A);
                 bool pd = psd::cholesky(p, A, L1);
                 psd::svec_to_mat(B.z + r.st, p, A);
@@ -540,16 +540,13 @@ struct ConicCtxT {
                 psd::matmul(p, M, true, M, false, A);                   // M'M = V diag(lambda^2) V'
                 psd::jacobi(p, A, V, sig);
                 for (int i = 0; i < p; i++) { sig[i] = sqrt(sig[i]); isq[i] = 1.0 / sqrt(sig[i]); }
-                psd::matmul(p, L1, false, V, false, T);                 // R = L1 V diag(isq)
-                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) T[i * CPG_PSD_LD + j] *= isq[j];
-                psd_store(p, T, r.R);
-                psd::matmul(p, T, false, T, true, A);                   // Q = R R'
-                psd_store(p, A, r.Q);
+                psd::matmul(p, L1, false, V, false, r.R);               // R = L1 V diag(isq)
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) r.R[i * p + j] *= isq[j];
+                psd::matmul(p, r.R, false, r.R, true, r.Q);             // Q = R R'
                 psd::matmul(p, M, false, V, false, T);                  // U = M V diag(1 / lambda);  R^-1 = diag(isq) U'L2'
-                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) T[i * CPG_PSD_LD + j] /= sig[j];
-                psd::matmul(p, T, true, L2, true, M);
-                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) M[i * CPG_PSD_LD + j] *= isq[i];
-                psd_store(p, M, r.Ri);
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) T[i * p + j] /= sig[j];
+                psd::matmul(p, T, true, L2, true, r.Ri);
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) r.Ri[i * p + j] *= isq[i];
                 int a = 0;
                 for (int j = 0; j < p; j++)
                     for (int i = 0; i <= j; i++, a++) {
@@ -648,14 +645,14 @@ struct ConicCtxT {
         for (int k = lane; k < C.n_psd; k += 64) {
             const PsdRef r = psd_ref(k);
             const int p = r.p;
-            double X[CPG_PSD_MAX * CPG_PSD_LD], Rm[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], Y[CPG_PSD_MAX * CPG_PSD_LD];
+            double *X = r.mat(0), *T = r.mat(1), *Y = r.mat(2), *isq = r.vec(1);
+            for (int i = 0; i < p; i++) isq[i] = 1.0 / sqrt(r.lam[i]);
 #pragma nounroll
             for (int side = 0; side < 2; side++) {
                 psd::svec_to_mat((side == 0 ? B.dz : B.ds) + r.st, p, X);
-                psd_load(p, side == 0 ? r.R : r.Ri, Rm);
-                psd::congruence(p, Rm, side == 0, X, T, Y);           // R' dZ R  |  R^-1 dS R^-T
-                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) Y[i * CPG_PSD_LD + j] *= (1.0 / sqrt(r.lam[i])) * (1.0 / sqrt(r.lam[j]));
-                const double g = psd::eig_min(p, Y);
+                psd::congruence(p, side == 0 ? r.R : r.Ri, side == 0, X, T, Y);           // R' dZ R  |  R^-1 dS R^-T
+                for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) Y[i * p + j] *= isq[i] * isq[j];
+                const double g = psd::eig_min(p, Y, r.vec(0));
                 if (g < 0.0) a = cpgw::dmin2(a, -1.0 / g);
             }
         }
@@ -712,14 +709,14 @@ struct ConicCtxT {
         }
         for (int k = lane; k < C.n_psd; k += 64) {          // -log det of both trial matrices through their Cholesky factors
             const PsdRef r = psd_ref(k);
-            double v[CPG_PSD_MAX * (CPG_PSD_MAX + 1) / 2], X[CPG_PSD_MAX * CPG_PSD_LD], L[CPG_PSD_MAX * CPG_PSD_LD];
+            double *v = r.mat(2), *X = r.mat(0), *L = r.mat(1);
 #pragma nounroll
             for (int side = 0; side < 2; side++) {
                 const double *x = side == 0 ? B.s : B.z, *dx = side == 0 ? B.ds : B.dz;
                 for (int t = 0; t < r.d; t++) v[t] = x[r.st + (unsigned)t] + a * dx[r.st + (unsigned)t];
                 psd::svec_to_mat(v, r.p, X);
                 if (!psd::cholesky(r.p, X, L)) { acc = CPG_NS_INF; continue; }
-                for (int i = 0; i < r.p; i++) acc -= 2.0 * log(L[i * CPG_PSD_LD + i]);
+                for (int i = 0; i < r.p; i++) acc -= 2.0 * log(L[i * r.p + i]);
             }
         }
         sz = cpgw::wave_sum(sz);
@@ -748,24 +745,21 @@ struct ConicCtxT {
             for (int k = lane; k < C.n_psd; k += 64) {
                 const PsdRef r = psd_ref(k);
                 const int p = r.p;
-                double X[CPG_PSD_MAX * CPG_PSD_LD], Rm[CPG_PSD_MAX * CPG_PSD_LD], T[CPG_PSD_MAX * CPG_PSD_LD], Am[CPG_PSD_MAX * CPG_PSD_LD],
-                    Bm[CPG_PSD_MAX * CPG_PSD_LD];
+                double *X = r.mat(0), *T = r.mat(1), *Am = r.mat(2), *Bm = r.mat(3), *AB = r.mat(4), *BA = r.mat(5);
                 psd::svec_to_mat(B.ds + r.st, p, X);
-                psd_load(p, r.Ri, Rm);
-                psd::congruence(p, Rm, false, X, T, Am);
+                psd::congruence(p, r.Ri, false, X, T, Am);
                 psd::svec_to_mat(B.dz + r.st, p, X);
-                psd_load(p, r.R, Rm);
-                psd::congruence(p, Rm, true, X, T, Bm);
-                psd::matmul(p, Am, false, Bm, false, T);
-                psd::matmul(p, Bm, false, Am, false, X);
+                psd::congruence(p, r.R, true, X, T, Bm);
+                psd::matmul(p, Am, false, Bm, false, AB);
+                psd::matmul(p, Bm, false, Am, false, BA);
                 for (int i = 0; i < p; i++)
                     for (int j = 0; j < p; j++) {
                         const double li = r.lam[i], lj = r.lam[j];
-                        const double d = (i == j ? li * li - sigmamu : 0.0) + 0.5 * (T[i * CPG_PSD_LD + j] + X[i * CPG_PSD_LD + j]);
-                        Am[i * CPG_PSD_LD + j] = 2.0 * d / (li + lj);
+                        const double d = (i == j ? li * li - sigmamu : 0.0) + 0.5 * (AB[i * p + j] + BA[i * p + j]);
+                        X[i * p + j] = 2.0 * d / (li + lj);
                     }
-                psd::congruence(p, Rm, false, Am, T, X);               // R U R'
-                psd::mat_to_svec(X, p, B.dsc + r.st);
+                psd::congruence(p, r.R, false, X, T, Am);              // R U R'
+                psd::mat_to_svec(Am, p, B.dsc + r.st);
             }
         }
         for (unsigned i = (unsigned)lane; i < (unsigned)(C.n_zero + C.n_nonneg); i += 64u) {

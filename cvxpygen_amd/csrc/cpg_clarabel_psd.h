@@ -15,7 +15,10 @@
 #ifndef CPG_PSD_MAX
 #define CPG_PSD_MAX 8           // largest matrix order (36 rows)
 #endif
-#define CPG_PSD_LD CPG_PSD_MAX
+// Working matrices: compact p x p (leading dimension p) in the cone's workspace of the wavefront's LDS slice -- private arrays would live
+// in scratch memory (dynamic indices), and a cone's arithmetic is one lane's chain of dependent loads: 35 ms per instance at order 6 with
+// scratch, see DESIGN.md 4.4.
+#define CPG_PSD_WORK(p) (8 * (p) * (p) + 2 * (p))       // doubles of workspace per cone: eight matrices, two vectors
 
 namespace cpg {
 namespace psd {
@@ -23,28 +26,31 @@ namespace psd {
 #define CPG_PSD_SQRT2 1.4142135623730951
 #define CPG_PSD_ISQRT2 0.7071067811865476
 
-// matrices: row-major with leading dimension CPG_PSD_LD
+// matrices: row-major, compact (leading dimension p)
 CPG_DEV void svec_to_mat(const double *v, int p, double *M) {
+    const int ld = p;
     int k = 0;
     for (int j = 0; j < p; j++)
         for (int i = 0; i <= j; i++, k++) {
             const double x = i == j ? v[k] : v[k] * CPG_PSD_ISQRT2;
-            M[i * CPG_PSD_LD + j] = x; M[j * CPG_PSD_LD + i] = x;
+            M[i * ld + j] = x; M[j * ld + i] = x;
         }
 }
 CPG_DEV void mat_to_svec(const double *M, int p, double *v) {
+    const int ld = p;
     int k = 0;
     for (int j = 0; j < p; j++)
-        for (int i = 0; i <= j; i++, k++) v[k] = i == j ? M[i * CPG_PSD_LD + j] : M[i * CPG_PSD_LD + j] * CPG_PSD_SQRT2;
+        for (int i = 0; i <= j; i++, k++) v[k] = i == j ? M[i * ld + j] : M[i * ld + j] * CPG_PSD_SQRT2;
 }
 // C = op(A) op(B), op = transpose where the flag says so
 CPG_DEV void matmul(int p, const double *A, bool ta, const double *B, bool tb, double *C) {
+    const int ld = p;
     for (int i = 0; i < p; i++)
         for (int j = 0; j < p; j++) {
             double acc = 0.0;
             for (int k = 0; k < p; k++)
-                acc += (ta ? A[k * CPG_PSD_LD + i] : A[i * CPG_PSD_LD + k]) * (tb ? B[j * CPG_PSD_LD + k] : B[k * CPG_PSD_LD + j]);
-            C[i * CPG_PSD_LD + j] = acc;
+                acc += (ta ? A[k * ld + i] : A[i * ld + k]) * (tb ? B[j * ld + k] : B[k * ld + j]);
+            C[i * ld + j] = acc;
         }
 }
 // Y = A X A' (ta false) or A' X A (ta true); T: work
@@ -54,61 +60,62 @@ CPG_DEV void congruence(int p, const double *A, bool ta, const double *X, double
 }
 // lower Cholesky factor; false when A is not (numerically) positive definite
 CPG_DEV bool cholesky(int p, const double *A, double *L) {
+    const int ld = p;
     for (int i = 0; i < p; i++)
-        for (int j = 0; j < p; j++) L[i * CPG_PSD_LD + j] = 0.0;
+        for (int j = 0; j < p; j++) L[i * ld + j] = 0.0;
     for (int j = 0; j < p; j++) {
-        double d = A[j * CPG_PSD_LD + j];
-        for (int k = 0; k < j; k++) d -= L[j * CPG_PSD_LD + k] * L[j * CPG_PSD_LD + k];
+        double d = A[j * ld + j];
+        for (int k = 0; k < j; k++) d -= L[j * ld + k] * L[j * ld + k];
         if (!(d > 0.0)) return false;
         const double ljj = sqrt(d);
-        L[j * CPG_PSD_LD + j] = ljj;
+        L[j * ld + j] = ljj;
         for (int i = j + 1; i < p; i++) {
-            double v = A[i * CPG_PSD_LD + j];
-            for (int k = 0; k < j; k++) v -= L[i * CPG_PSD_LD + k] * L[j * CPG_PSD_LD + k];
-            L[i * CPG_PSD_LD + j] = v / ljj;
+            double v = A[i * ld + j];
+            for (int k = 0; k < j; k++) v -= L[i * ld + k] * L[j * ld + k];
+            L[i * ld + j] = v / ljj;
         }
     }
     return true;
 }
 // cyclic Jacobi on the symmetric matrix A (destroyed): eigenvalues ev, eigenvectors the COLUMNS of V (V == nullptr: values only)
 CPG_DEV void jacobi(int p, double *A, double *V, double *ev) {
+    const int ld = p;
     if (V)
         for (int i = 0; i < p; i++)
-            for (int j = 0; j < p; j++) V[i * CPG_PSD_LD + j] = i == j ? 1.0 : 0.0;
+            for (int j = 0; j < p; j++) V[i * ld + j] = i == j ? 1.0 : 0.0;
 #pragma nounroll
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0.0, dg = 0.0;
         for (int i = 0; i < p; i++) {
-            dg += A[i * CPG_PSD_LD + i] * A[i * CPG_PSD_LD + i];
-            for (int j = i + 1; j < p; j++) off += A[i * CPG_PSD_LD + j] * A[i * CPG_PSD_LD + j];
+            dg += A[i * ld + i] * A[i * ld + i];
+            for (int j = i + 1; j < p; j++) off += A[i * ld + j] * A[i * ld + j];
         }
         if (!(off > 1e-32 * dg)) break;
         for (int a = 0; a < p - 1; a++)
             for (int b = a + 1; b < p; b++) {
-                const double apq = A[a * CPG_PSD_LD + b];
+                const double apq = A[a * ld + b];
                 if (apq == 0.0) continue;
-                const double th = (A[b * CPG_PSD_LD + b] - A[a * CPG_PSD_LD + a]) / (2.0 * apq);
+                const double th = (A[b * ld + b] - A[a * ld + a]) / (2.0 * apq);
                 const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
                 for (int k = 0; k < p; k++) {          // columns a, b
-                    const double ka = A[k * CPG_PSD_LD + a], kb = A[k * CPG_PSD_LD + b];
-                    A[k * CPG_PSD_LD + a] = c * ka - s * kb; A[k * CPG_PSD_LD + b] = s * ka + c * kb;
+                    const double ka = A[k * ld + a], kb = A[k * ld + b];
+                    A[k * ld + a] = c * ka - s * kb; A[k * ld + b] = s * ka + c * kb;
                 }
                 for (int k = 0; k < p; k++) {          // rows a, b
-                    const double ak = A[a * CPG_PSD_LD + k], bk = A[b * CPG_PSD_LD + k];
-                    A[a * CPG_PSD_LD + k] = c * ak - s * bk; A[b * CPG_PSD_LD + k] = s * ak + c * bk;
+                    const double ak = A[a * ld + k], bk = A[b * ld + k];
+                    A[a * ld + k] = c * ak - s * bk; A[b * ld + k] = s * ak + c * bk;
                 }
                 if (V)
                     for (int k = 0; k < p; k++) {
-                        const double ka = V[k * CPG_PSD_LD + a], kb = V[k * CPG_PSD_LD + b];
-                        V[k * CPG_PSD_LD + a] = c * ka - s * kb; V[k * CPG_PSD_LD + b] = s * ka + c * kb;
+                        const double ka = V[k * ld + a], kb = V[k * ld + b];
+                        V[k * ld + a] = c * ka - s * kb; V[k * ld + b] = s * ka + c * kb;
                     }
             }
     }
-    for (int i = 0; i < p; i++) ev[i] = A[i * CPG_PSD_LD + i];
+    for (int i = 0; i < p; i++) ev[i] = A[i * ld + i];
 }
-CPG_DEV double eig_min(int p, double *A) {
-    double ev[CPG_PSD_MAX];
+CPG_DEV double eig_min(int p, double *A, double *ev) {
     jacobi(p, A, nullptr, ev);
     double m = ev[0];
     for (int i = 1; i < p; i++) m = ev[i] < m ? ev[i] : m;

@@ -1057,7 +1057,7 @@ int cpg_hip_create_clarabel(const cpg_conic_family_t *f, int device, cpg_handle_
             // row_cone of a PSD row: itself on the diagonal of the matrix (where a unit shift lands), the cone's first row elsewhere
             const int pp = f->psd_dims[k];
             psd_start[k] = o; psd_off[k] = C.psd_doubles;
-            C.psd_doubles += 3 * pp * pp + pp; C.psd_degree += pp;
+            C.psd_doubles += 3 * pp * pp + pp + CPG_PSD_WORK(pp); C.psd_degree += pp;      // (NT point, factors, lambda | workspace)
             int a = 0;
             for (int j = 0; j < pp; j++) for (int i = 0; i <= j; i++, a++) row_cone[o + a] = i == j ? o + a : o;
             o += pp * (pp + 1) / 2;

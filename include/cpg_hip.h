@@ -243,7 +243,7 @@ typedef struct {
      * 7 off-diagonal entry of an exponential / power cone's 3 x 3 block: idx = first row of the cone + (0 for (0,1),
      *   1 for (0,2), 2 for (1,2)),
      * 8 off-diagonal entry of a PSD cone's block between svec rows (i, j) and (k, l): idx = offset of the cone in the PSD store
-     *   (sum over the cones before it of 3 p^2 + p) | p << 12 | i << 16 | j << 19 | k << 22 | l << 25 */
+     *   (sum over the cones before it of 11 p^2 + 3 p: NT point, factors, workspace) | p << 12 | i << 16 | j << 19 | k << 22 | l << 25 */
     const int32_t *Lcol, *ksrc_kind, *ksrc_idx;
     int32_t fac_chunks, fac_triples;
     const int32_t *fac_ctab;
