@@ -721,6 +721,11 @@ def main():
             if args.workload == 'portfolio':
                 upd = list(pv.keys())
                 th[:, solver._var_cols] = theta[:nchk]            # theta_var columns of the varying parameters
+            elif args.all_params:
+                nchk = min(nchk, 64)                              # (a refactorisation per instance on the host)
+                th = th[:nchk]
+                upd = [q_.name for q_ in desc.params]
+                th[:, solver._var_cols] = theta[:nchk]
             else:
                 upd = ['x_init']
                 p = desc.param('x_init')

@@ -281,7 +281,11 @@ CPG_DEV_NOINLINE void team_setup(const DevRefactor &R_, const DevResident &Rs_, 
 #define CPG_TEAM_FAC_DEPTH 4
 #endif
 #ifndef CPG_TEAM_FAC_BATCH
+#ifdef CPG_GENT_FAC_BATCH
+#define CPG_TEAM_FAC_BATCH CPG_GENT_FAC_BATCH      // chosen per family by codegen.team_fac_batch (padding steps against batches)
+#else
 #define CPG_TEAM_FAC_BATCH 8          // steps per batch: a chain level of 5 - 7 steps is ONE batch = one LDS round trip
+#endif
 #endif
 struct alignas(16) TeamQuad { unsigned x, y, z, w; };
 // (CPG_TEAM_FACTOR_PROBE: experiments only -- two more time stamps inside the factorisation; merely carrying the pointer cost the
@@ -351,8 +355,8 @@ CPG_DEV void team_factor_batched(const DevResident &Rs, CPG_LDS double *fac_, in
 #if defined(CPG_TEAM_FAC_EXPERIMENT) && CPG_TEAM_FAC_EXPERIMENT == 3
                 av[k] = fac[w0 & 0xFFFFu]; bv[k] = 1.0; kv[k] = 1e-3; av[k + 1] = fac[w1 >> 16]; bv[k + 1] = 1.0; kv[k + 1] = 1e-3; (void)w2;
 #else
-                av[k] = fac[w0 & 0xFFFFu]; bv[k] = fac[w0 >> 16]; kv[k] = fac[w1 & 0xFFFFu];
-                av[k + 1] = fac[w1 >> 16]; bv[k + 1] = fac[w2 & 0xFFFFu]; kv[k + 1] = fac[w2 >> 16];
+                av[k] = *cpgw::lds_elem16<0>(fac, w0); bv[k] = *cpgw::lds_elem16<1>(fac, w0); kv[k] = *cpgw::lds_elem16<0>(fac, w1);
+                av[k + 1] = *cpgw::lds_elem16<1>(fac, w1); bv[k + 1] = *cpgw::lds_elem16<0>(fac, w2); kv[k + 1] = *cpgw::lds_elem16<1>(fac, w2);
 #endif
             }
 #pragma unroll

@@ -137,6 +137,18 @@ CPG_DEV CPG_LDS T *pin_lds(CPG_LDS T *p) {
     asm volatile("" : "+v"(a));          // (a vector register: a scalar one was refused inside loops with barriers, "illegal VGPR to SGPR copy")
     return (CPG_LDS T *)(__attribute__((address_space(3))) void *)(unsigned long long)a;
 }
+// Address of element number (16-bit field HI of the packed word w) of an LDS array of doubles: ONE vector instruction
+// (v_mad_u32_u16 with op_sel picking the half: field * 8 + base) where `base[w & 0xFFFF]` / `base[w >> 16]` compile to an extraction
+// and a shift-add.  The table walks of the factorisations run on one wavefront per SIMD, i.e. at one instruction per ~5 cycles whatever
+// its kind: two of a step's thirteen instructions per operand were address arithmetic (profiles/r6_t2_team_factor_knockouts.txt).
+template <int HI>
+CPG_DEV const CPG_LDS double *lds_elem16(const CPG_LDS double *base, unsigned w) {
+    const unsigned b = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)base;
+    unsigned a;
+    if (HI) asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "v"(b));
+    else asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[0,0,0,0]" : "=v"(a) : "v"(w), "v"(b));
+    return (const CPG_LDS double *)(__attribute__((address_space(3))) const void *)(unsigned long long)a;
+}
 // A flag in LDS between two wavefronts of one workgroup that do NOT meet at a barrier: the producer has finished a piece of work
 // (its LDS stores are complete: lds_order() in front), the consumer polls.  Release / acquire at workgroup scope.
 CPG_DEV void lds_signal(CPG_LDS unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }

@@ -158,6 +158,8 @@ inline int opaque(int v) { return v; }
 template <class T> inline T gld_stream(const T *base, unsigned idx) { return base[idx]; }
 template <class T> inline void gst_stream(T *base, unsigned idx, T v) { base[idx] = v; }
 template <class T> inline T *pin_lds(T *p) { return p; }
+// element `field HI of the packed word` of an LDS array of doubles (cpg_wave_gfx950.h: one v_mad_u32_u16)
+template <int HI> inline const double *lds_elem16(const double *base, unsigned w) { return base + ((w >> (16 * HI)) & 0xFFFFu); }
 inline void lds_signal(unsigned *p, unsigned v) { *(volatile unsigned *)p = v; }
 inline void lds_spin_until_ge(unsigned *p, unsigned v) { while (*(volatile unsigned *)p < v) fiber_yield(); }
 inline void assume(bool) {}
