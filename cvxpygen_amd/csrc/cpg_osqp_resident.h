@@ -650,7 +650,7 @@ CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ],
 #if CPG_RES_STEP_VALUES
         const double ri = riv[s];
 #else
-        const double ri = i < n_eq ? rr.ri_eq : (((free_rows >> s) & 1u) ? rr.ri_fr : rr.ri_in);
+        const double ri = i < n_eq ? +rr.ri_eq : (((free_rows >> s) & 1u) ? +rr.ri_fr : +rr.ri_in);
 #endif
         if (i < m) w[n + i] = z[s] - ri * y[s];
     }
@@ -670,8 +670,8 @@ CPG_DEV void resident_step(double (&x)[NSX], double (&z)[NSZ], double (&y)[NSZ],
         const double rv = rvv[s], ri = riv[s];
 #else
         const bool fr = (free_rows >> s) & 1u;
-        const double rv = eq ? rr.rho_eq : (fr ? rr.rho_fr : rr.rho_in);
-        const double ri = eq ? rr.ri_eq : (fr ? rr.ri_fr : rr.ri_in);
+        const double rv = eq ? +rr.rho_eq : (fr ? +rr.rho_fr : +rr.rho_in);
+        const double ri = eq ? +rr.ri_eq : (fr ? +rr.ri_fr : +rr.ri_in);
 #endif
         const double zp = z[s], yp = y[s];
         const double zt = (zp - ri * yp) + ri * (i < m ? w[n + i] : 0.0);
@@ -715,14 +715,17 @@ CPG_RES_ITERATE_LINKAGE void resident_iterate(ResState<NSX, NSZ> &st, const ResR
     CPG_LDS double *w = cpgw::lds_window3() + sl_off;
     const CPG_LDS double *qs = w + ldw, *us = qs + n;
     const ResRho rr = uniform_copy(rr_);
+    // (round 6: the members pinned in scalar registers as values -- cpgw::sgpr_value, what the team kernel does -- take the loop's
+    // scratch loads from 22 to 4 and make it SLOWER here, 51.5 against 50.8 ms per 20 000 instances in an A/B on one box
+    // (profiles/r6_t6_*): 30 more coefficient reads through v_accvgpr_read; the reloads are overlapped, as round 4 measured)
     // (step sizes per slot as per-lane values: only read with CPG_RES_STEP_VALUES, see resident_step)
     double riv[NSZ], rvv[NSZ];
 #pragma unroll
     for (int s = 0; s < NSZ; s++) {
         const unsigned i = (unsigned)lane + 64u * (unsigned)s;
         const bool eq = i < n_eq, fr = (free_rows >> s) & 1u;
-        riv[s] = eq ? rr.ri_eq : (fr ? rr.ri_fr : rr.ri_in);
-        rvv[s] = eq ? rr.rho_eq : (fr ? rr.rho_fr : rr.rho_in);
+        riv[s] = eq ? +rr.ri_eq : (fr ? +rr.ri_fr : +rr.ri_in);
+        rvv[s] = eq ? +rr.rho_eq : (fr ? +rr.rho_fr : +rr.rho_in);
     }
     // The coefficients: ~2 registers per step and lane, loaded once per call (one call = the iterations between two
     // termination tests; 74 KB per call on the portfolio family) and held in the wavefront's 512 registers -- which of them

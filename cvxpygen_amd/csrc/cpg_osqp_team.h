@@ -520,7 +520,7 @@ CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevRe
 template <int NX, int NZ>
 CPG_DEV void team_step(double (&x)[NX], double (&z)[NZ], double (&y)[NZ], const double (&cf)[CPG_GENT_NREGS],
                        const unsigned (&of)[CPG_GENT_NOFF], const unsigned (&rw)[CPG_GENT_NROW], CPG_LDS double *w,
-                       const CPG_LDS double *qs, const CPG_LDS double *us, const ResRho &rr, unsigned free_rows, int tid, int wave) {
+                       const CPG_LDS double *qs, const CPG_LDS double *us, const ResRho rr, unsigned free_rows, int tid, int wave) {
     constexpr unsigned n = CPG_GENT_N, m = CPG_GENT_M, n_eq = CPG_GENT_NEQ, T = CPG_TEAM_T;
     double qt[NX];
 #pragma unroll
@@ -530,7 +530,7 @@ CPG_DEV void team_step(double (&x)[NX], double (&z)[NZ], double (&y)[NZ], const 
 #pragma unroll
     for (int s = 0; s < NZ; s++) {
         const unsigned i = (unsigned)tid + T * (unsigned)s;
-        const double ri = i < n_eq ? rr.ri_eq : (((free_rows >> s) & 1u) ? rr.ri_fr : rr.ri_in);
+        const double ri = i < n_eq ? +rr.ri_eq : (((free_rows >> s) & 1u) ? +rr.ri_fr : +rr.ri_in);
         if (i < m) w[n + i] = z[s] - ri * y[s];
     }
     cpgw::block_sync();
@@ -546,8 +546,8 @@ CPG_DEV void team_step(double (&x)[NX], double (&z)[NZ], double (&y)[NZ], const 
         const unsigned i = (unsigned)tid + T * (unsigned)s;
         const bool eq = i < n_eq;
         const bool fr = (free_rows >> s) & 1u;
-        const double rv = eq ? rr.rho_eq : (fr ? rr.rho_fr : rr.rho_in);
-        const double ri = eq ? rr.ri_eq : (fr ? rr.ri_fr : rr.ri_in);
+        const double rv = eq ? +rr.rho_eq : (fr ? +rr.rho_fr : +rr.rho_in);
+        const double ri = eq ? +rr.ri_eq : (fr ? +rr.ri_fr : +rr.ri_in);
         const double zp = z[s], yp = y[s];
         const double zt = (zp - ri * yp) + ri * (i < m ? w[n + i] : 0.0);
         const double zr = rr.alpha * zt + (1.0 - rr.alpha) * zp;
@@ -576,7 +576,8 @@ CPG_DEV_NOINLINE void team_iterate(TeamState<NX, NZ> &st, const ResRho &rr_, con
     const unsigned *offp = cpgw::as_global((const unsigned *)uniform_ptr(offg)), *rowp = cpgw::as_global((const unsigned *)uniform_ptr(rowg));
     CPG_LDS double *w = cpgw::pin_lds(cpgw::lds_window3() + CPG_TEAM_SLICE_OFF);
     const CPG_LDS double *qs = w + ldw, *us = qs + n;
-    const ResRho rr = uniform_copy(rr_);
+    const ResRho rr{cpgw::sgpr_value(rr_.rho_eq), cpgw::sgpr_value(rr_.rho_in), cpgw::sgpr_value(rr_.rho_fr), cpgw::sgpr_value(rr_.ri_eq),
+                    cpgw::sgpr_value(rr_.ri_in), cpgw::sgpr_value(rr_.ri_fr), cpgw::sgpr_value(rr_.sigma), cpgw::sgpr_value(rr_.alpha)};     // (values, not a struct in scratch behind the selects of the step)
     double cf[CPG_GENT_NREGS];
     unsigned of[CPG_GENT_NOFF], rw[CPG_GENT_NROW];
 #pragma unroll

@@ -137,6 +137,15 @@ CPG_DEV CPG_LDS T *pin_lds(CPG_LDS T *p) {
     asm volatile("" : "+v"(a));          // (a vector register: a scalar one was refused inside loops with barriers, "illegal VGPR to SGPR copy")
     return (CPG_LDS T *)(__attribute__((address_space(3))) void *)(unsigned long long)a;
 }
+// A wave-uniform double pinned in a scalar register pair as a VALUE the optimiser cannot trace back to the memory it was loaded from:
+// a select between two members of a struct that arrived by reference is otherwise rewritten into a select between their ADDRESSES and
+// a load -- of a struct that then has to live in scratch, one memory round trip per use (the resident kernel's ADMM loop: 22 per iteration).
+CPG_DEV double sgpr_value(double v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(v)), hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(v));
+    unsigned long long u = ((unsigned long long)hi << 32) | lo;
+    asm("" : "+s"(u));
+    return __longlong_as_double((long long)u);
+}
 // Address of element number (16-bit field HI of the packed word w) of an LDS array of doubles: ONE vector instruction
 // (v_mad_u32_u16 with op_sel picking the half: field * 8 + base) where `base[w & 0xFFFF]` / `base[w >> 16]` compile to an extraction
 // and a shift-add.  The table walks of the factorisations run on one wavefront per SIMD, i.e. at one instruction per ~5 cycles whatever

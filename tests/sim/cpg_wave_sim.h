@@ -158,6 +158,7 @@ inline int opaque(int v) { return v; }
 template <class T> inline T gld_stream(const T *base, unsigned idx) { return base[idx]; }
 template <class T> inline void gst_stream(T *base, unsigned idx, T v) { base[idx] = v; }
 template <class T> inline T *pin_lds(T *p) { return p; }
+inline double sgpr_value(double v) { return v; }
 // element `field HI of the packed word` of an LDS array of doubles (cpg_wave_gfx950.h: one v_mad_u32_u16)
 template <int HI> inline const double *lds_elem16(const double *base, unsigned w) { return base + ((w >> (16 * HI)) & 0xFFFFu); }
 inline void lds_signal(unsigned *p, unsigned v) { *(volatile unsigned *)p = v; }
