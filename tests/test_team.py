@@ -23,6 +23,22 @@ def _team_in_use(bs) -> bool:
     return v.value > 0.0            # (the width W of the team)
 
 
+def test_factor_batch_size_follows_the_schedule(monkeypatch):
+    """steps per batch of the factorisation table walk (codegen.team_fac_batch -> CPG_GENT_FAC_BATCH): a chunk of L steps costs
+    ceil(L / S) batches of S step slots each, padding included -- chains of 6- and 12-step levels want S = 6 (what the all-parameters
+    MPC 12/4/10 family has: 143 -> 123 us of LDL' chain on MI355X, profiles/r6_t3_*), long chunks S = 8, 4-step levels S = 4;
+    an even number always (two steps share three table words); the environment overrides"""
+    import types
+    monkeypatch.delenv('CPG_TEAM_FAC_BATCH', raising=False)
+    mk = lambda lens: types.SimpleNamespace(f_ctab=np.array([[L, 1, 0, 0] for L in lens], dtype=np.int32))
+    assert codegen.team_fac_batch(mk([6] * 72 + [12] * 74 + [5] * 36 + [7] * 31 + [4] * 13)) == 6
+    assert codegen.team_fac_batch(mk([64, 48, 40, 33] * 20)) == 8
+    assert codegen.team_fac_batch(mk([4, 3, 4, 2] * 50)) == 4
+    assert codegen.team_fac_batch(mk([0, 0, 6])) in (4, 6, 8)          # (empty chunks still cost a batch)
+    monkeypatch.setenv('CPG_TEAM_FAC_BATCH', '8')
+    assert codegen.team_fac_batch(mk([6] * 10)) == 8
+
+
 @pytest.mark.parametrize('fam', ['portfolio', 'mpc6'])
 @pytest.mark.parametrize('W', [1, 2, 4])
 def test_team_plan_solves_the_kkt_system(fam, W):
