@@ -462,11 +462,10 @@ CPG_DEV void load_instance_coefficients(const DevRefactor &R, const double *Ml, 
         // L-entry branch below, a second dependent L2 round trip per register)
         const unsigned col = (unsigned)cpgw::opaque((int)cpgw::gld(R.gi_lcol, (unsigned)t * 64u + ln));
         const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
-        double v = 0.0;
-        if (kind == 1u) v = 1.0;
-        else if (kind == 2u) v = -(Ml[idx] * Dil[col]);
-        else if (kind == 3u) v = Dil[idx];
-        cf[t] = v;
+        // (both reads UNCONDITIONAL, the kinds selected afterwards: as `if (kind == 2) v = -(Ml[idx] * Dil[col]); else if ...` every
+        // register was a branch tree with an LDS round trip of its own)
+        const double a = kind == 3u ? Dil[idx] : Ml[kind == 2u ? idx : 0u], b = Dil[kind == 2u ? col : 0u];
+        cf[t] = kind == 2u ? -(a * b) : (kind == 3u ? a : (kind == 1u ? 1.0 : 0.0));
     }
 }
 #endif

@@ -188,6 +188,32 @@ CPG_DEV void resident_factor(const DevResident &Rs, double *fac, int lane) {
 
 // the iterates of an instance between two calls / the step sizes of an ADMM iteration (both kernels)
 struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha; };
+// KKT value of a destination from its source word (kind << 28 | index): P, A and 1 / rho_vec live in ONE per-wavefront buffer
+// (res_carve: A first), so the source is one element offset from B.A and the load is UNCONDITIONAL -- written as `if (kind == P) v =
+// P[idx]; else if (kind == A) ...` every destination was a branch tree with a wait of its own: a batch's loads went out one memory
+// round trip at a time (round 6: config 3 393.6 -> 399.6 k/s with this and coefficient_source below, config 2's instance kernel 10.2 ->
+// 10.1 ms with the same rewrite of load_instance_coefficients -- A/B on one box, profiles/r6_t7_*; the team kernel's two stages written
+// this way measured SLOWER, 312.4 -> 308.3 k/s: its store stage 25.8 -> 28.9 us, and were left as they were).
+CPG_DEV unsigned kkt_source_element(const ResBuf &B, unsigned code) {
+    const unsigned kind = (code >> 28) & 7u, idx = code & 0x0FFFFFFFu;
+    const unsigned oP = (unsigned)(B.P - B.A), oR = (unsigned)(B.rinv - B.A);
+    return kind == CPG_K_P ? oP + idx : (kind == CPG_K_A ? idx : (kind == CPG_K_RHO ? oR + idx : 0u));
+}
+CPG_DEV double kkt_source_value(unsigned code, double raw) {
+    const unsigned kind = (code >> 28) & 7u;
+    return (kind == CPG_K_P || kind == CPG_K_A) ? raw : (kind == CPG_K_RHO ? -raw : 0.0);
+}
+// A substitution coefficient from its source word: 1 | -M_ij / d_j | 1 / d_i | X_ij, as the product of two UNCONDITIONAL reads of the
+// factor array (its slots `one` = 1.0 and `one + 1` = 0.0 stand in where a factor is missing: x * 1.0 and 0.0 * 1.0 are exact)
+struct CoefSource { unsigned a, b; bool neg; };
+CPG_DEV CoefSource coefficient_source(unsigned code, unsigned col, unsigned nnzL, unsigned X0, unsigned one) {
+    const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
+    CoefSource c;
+    c.a = kind == 2u ? idx : (kind == 3u ? nnzL + idx : (kind == 4u ? X0 + idx : (kind == 1u ? one : one + 1u)));
+    c.b = kind == 2u ? nnzL + col : one;
+    c.neg = kind == 2u;
+    return c;
+}
 #endif  // CPG_GENR_HEADER || CPG_GENT_HEADER
 
 #ifdef CPG_GENR_HEADER
@@ -201,6 +227,7 @@ CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, 
 #pragma unroll
     for (int t0 = 0; t0 < CPG_GENR_NREGS; t0 += NB) {
         unsigned code[NB], col[NB];
+        double va[NB], vb[NB];
 #pragma unroll
         for (int u = 0; u < NB; u++) {
             const int t = t0 + u;
@@ -211,13 +238,15 @@ CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, 
         for (int u = 0; u < NB; u++) {
             const int t = t0 + u;
             if (t >= CPG_GENR_NREGS) break;
-            const unsigned kind = code[u] >> 28, idx = code[u] & 0x0FFFFFFFu;
-            double v = 0.0;
-            if (kind == 1u) v = 1.0;
-            else if (kind == 2u) v = -(fac[idx] * fac[nnzL + col[u]]);
-            else if (kind == 3u) v = fac[nnzL + idx];
-            else if (kind == 4u) v = fac[X0 + idx];
-            cpgw::gst(B.cf, (unsigned)t * 64u + ln, v);
+            const CoefSource cs = coefficient_source(code[u], col[u], nnzL, X0, (unsigned)Rs.fac_len - 2u);
+            va[u] = fac[cs.a]; vb[u] = fac[cs.b];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int t = t0 + u;
+            if (t >= CPG_GENR_NREGS) break;
+            const double pr = va[u] * vb[u];
+            cpgw::gst(B.cf, (unsigned)t * 64u + ln, (code[u] >> 28) == 2u ? -pr : pr);
         }
     }
 }
@@ -548,12 +577,10 @@ CPG_DEV_NOINLINE void resident_factorise(const DevRefactor &R_, const DevResiden
                 for (int u = 0; u < KB; u++) { const unsigned d = lk + 64u * (unsigned)(t0 + u); code[u] = (t0 + u < KD && d < nd) ? cpgw::gld(Rs.k_src, d) : 0u; }
 #pragma unroll
                 for (int u = 0; u < KB; u++) {
-                    const unsigned kind = (code[u] >> 28) & 7u, idx = code[u] & 0x0FFFFFFFu;
-                    v[u] = 0.0;
-                    if (kind == CPG_K_P) v[u] = cpgw::gld((const double *)B.P, idx);
-                    else if (kind == CPG_K_A) v[u] = cpgw::gld((const double *)B.A, idx);
-                    else if (kind == CPG_K_RHO) v[u] = -cpgw::gld((const double *)B.rinv, idx);
+                    v[u] = cpgw::gld((const double *)B.A, kkt_source_element(B, code[u]));
                 }
+#pragma unroll
+                for (int u = 0; u < KB; u++) v[u] = kkt_source_value(code[u], v[u]);
 #pragma unroll
                 for (int u = 0; u < KB; u++) {
                     const unsigned d = lk + 64u * (unsigned)(t0 + u), kind = (code[u] >> 28) & 7u;
