@@ -1922,6 +1922,18 @@ int cpg_hip_set_resident(cpg_handle_t h, const cpg_osqp_refactor_t *r, const cpg
     if ((rc = upload<unsigned>(h, own, ksrc.data(), ksrc.size(), &Rs.k_src))) return rc;
     if ((rc = upload<unsigned>(h, own, gsrc.data(), gsrc.size(), &Rs.g_src))) return rc;
     if ((rc = upload<unsigned short>(h, own, glcol.data(), glcol.size(), &Rs.g_lcol))) return rc;
+    {
+        // the same sources as POSITIONS in the factor array [M | 1 / d | X | 1.0 | 0.0], two words per (register, lane): a coefficient is
+        // +-(fac[a] * fac[b]) -- -M_ij * (1 / d_j), (1 / d_i) * 1.0, X_ij * 1.0, 1.0 * 1.0, 0.0 * 1.0 -- read without a branch on its kind
+        std::vector<unsigned> gpos(2 * gsrc.size());
+        for (size_t at = 0; at < gsrc.size(); at++) {
+            const unsigned kind = gsrc[at] >> 28, idx = gsrc[at] & 0x0FFFFFFFu;
+            const unsigned a = kind == 2u ? idx : kind == 3u ? (unsigned)nnzL + idx : kind == 4u ? (unsigned)X0 + idx : kind == 1u ? (unsigned)ONE : (unsigned)ZERO;
+            const unsigned b = kind == 2u ? (unsigned)nnzL + glcol[at] : (unsigned)ONE;
+            gpos[2 * at] = a | (kind == 2u ? 0x80000000u : 0u); gpos[2 * at + 1] = b;
+        }
+        if ((rc = upload<unsigned>(h, own, gpos.data(), gpos.size(), &Rs.g_pos))) return rc;
+    }
     if ((rc = upload<unsigned short>(h, own, gcols.data(), gcols.size(), &Rs.g_cols))) return rc;
     if ((rc = upload<unsigned short>(h, own, grows.data(), grows.size(), &Rs.g_rows))) return rc;
     if ((rc = upload<unsigned>(h, own, entA.data(), entA.size(), &Rs.entA))) return rc;

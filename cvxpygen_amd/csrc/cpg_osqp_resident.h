@@ -60,6 +60,7 @@ struct DevResident {
                                            // dot product (store the reciprocal right away)
     const unsigned *g_src;                 // [NREGS][64] coefficient source of (register, lane): kind << 28 | index
     const unsigned short *g_lcol;          // ... and the column of the L entry behind a kind-2 coefficient
+    const unsigned *g_pos;                 // the same as two positions in the factor array per (register, lane): a | negate << 31, b  (+-(fac[a] * fac[b]))
     const unsigned short *g_cols, *g_rows; // operand offsets / output slots of the generated executor (LDS tables)
     DevEll eP, eA, eq, eu;
     const unsigned *entA, *entP;           // row | column << 16 of every stored entry
@@ -108,7 +109,7 @@ CPG_DEV void globalise(ResBuf &B) { CPG_G(B.A); CPG_G(B.P); CPG_G(B.D); CPG_G(B.
 CPG_DEV void globalise(DevStreamTab &T) { CPG_G(T.stab); CPG_G(T.cr); CPG_G(T.src); CPG_G(T.gcols); CPG_G(T.grows); }
 CPG_DEV void globalise(DevEll &E) { CPG_G(E.idx); CPG_G(E.coef); }
 CPG_DEV void globalise(DevResident &Rs) {
-    CPG_G(Rs.f_ctl); CPG_G(Rs.f_ent); CPG_G(Rs.k_src); CPG_G(Rs.g_src); CPG_G(Rs.g_lcol); CPG_G(Rs.g_cols); CPG_G(Rs.g_rows);
+    CPG_G(Rs.f_ctl); CPG_G(Rs.f_ent); CPG_G(Rs.k_src); CPG_G(Rs.g_src); CPG_G(Rs.g_lcol); CPG_G(Rs.g_pos); CPG_G(Rs.g_cols); CPG_G(Rs.g_rows);
     globalise(Rs.eP); globalise(Rs.eA); globalise(Rs.eq); globalise(Rs.eu); CPG_G(Rs.entA); CPG_G(Rs.entP); CPG_G(Rs.gf_tri); CPG_G(Rs.gf_dk);
     globalise(Rs.pA); globalise(Rs.pP); globalise(Rs.pAt);
     CPG_G(Rs.t_off); CPG_G(Rs.t_row); CPG_G(Rs.bf_hdr); CPG_G(Rs.bf_ctl); CPG_G(Rs.bf_dk); CPG_G(Rs.bf_tri);
@@ -191,9 +192,11 @@ struct ResRho { double rho_eq, rho_in, rho_fr, ri_eq, ri_in, ri_fr, sigma, alpha
 // KKT value of a destination from its source word (kind << 28 | index): P, A and 1 / rho_vec live in ONE per-wavefront buffer
 // (res_carve: A first), so the source is one element offset from B.A and the load is UNCONDITIONAL -- written as `if (kind == P) v =
 // P[idx]; else if (kind == A) ...` every destination was a branch tree with a wait of its own: a batch's loads went out one memory
-// round trip at a time (round 6: config 3 393.6 -> 399.6 k/s with this and coefficient_source below, config 2's instance kernel 10.2 ->
-// 10.1 ms with the same rewrite of load_instance_coefficients -- A/B on one box, profiles/r6_t7_*; the team kernel's two stages written
-// this way measured SLOWER, 312.4 -> 308.3 k/s: its store stage 25.8 -> 28.9 us, and were left as they were).
+// round trip at a time (round 6: config 3 393.6 -> 399.6 k/s with this and unconditional coefficient reads, config 2's instance kernel
+// 10.2 -> 10.1 ms with the same rewrite of load_instance_coefficients -- A/B on one box, profiles/r6_t7_*; in the team kernel the
+// unconditional KKT loads changed nothing and are not in).  With the coefficient sources as POSITIONS precomputed on the host
+// (DevResident::g_pos, below) the selects between source kinds are gone too: config 3 394 -> 406 k/s, the team kernel's store stage
+// 25.9 -> 12.9 us and 312 -> 322 k/s (profiles/r6_t8_*).
 CPG_DEV unsigned kkt_source_element(const ResBuf &B, unsigned code) {
     const unsigned kind = (code >> 28) & 7u, idx = code & 0x0FFFFFFFu;
     const unsigned oP = (unsigned)(B.P - B.A), oR = (unsigned)(B.rinv - B.A);
@@ -203,17 +206,9 @@ CPG_DEV double kkt_source_value(unsigned code, double raw) {
     const unsigned kind = (code >> 28) & 7u;
     return (kind == CPG_K_P || kind == CPG_K_A) ? raw : (kind == CPG_K_RHO ? -raw : 0.0);
 }
-// A substitution coefficient from its source word: 1 | -M_ij / d_j | 1 / d_i | X_ij, as the product of two UNCONDITIONAL reads of the
-// factor array (its slots `one` = 1.0 and `one + 1` = 0.0 stand in where a factor is missing: x * 1.0 and 0.0 * 1.0 are exact)
-struct CoefSource { unsigned a, b; bool neg; };
-CPG_DEV CoefSource coefficient_source(unsigned code, unsigned col, unsigned nnzL, unsigned X0, unsigned one) {
-    const unsigned kind = code >> 28, idx = code & 0x0FFFFFFFu;
-    CoefSource c;
-    c.a = kind == 2u ? idx : (kind == 3u ? nnzL + idx : (kind == 4u ? X0 + idx : (kind == 1u ? one : one + 1u)));
-    c.b = kind == 2u ? nnzL + col : one;
-    c.neg = kind == 2u;
-    return c;
-}
+// A substitution coefficient -- 1 | -M_ij / d_j | 1 / d_i | X_ij -- is +-(fac[a] * fac[b]) with the two positions precomputed on the host
+// (DevResident::g_pos; the array's slots 1.0 and 0.0 stand in where a factor is missing: x * 1.0 and 0.0 * 1.0 are exact): two
+// UNCONDITIONAL reads per register, no branch on the kind.
 #endif  // CPG_GENR_HEADER || CPG_GENT_HEADER
 
 #ifdef CPG_GENR_HEADER
@@ -221,32 +216,30 @@ CPG_DEV CoefSource coefficient_source(unsigned code, unsigned col, unsigned nnzL
 // register, lane), to the wavefront's buffer in the layout the iteration function loads them in ([register][lane])
 CPG_DEV void resident_coefficients(const DevRefactor &R, const DevResident &Rs, const ResBuf &B, const double *fac, int lane) {
     const unsigned ln = (unsigned)cpgw::opaque(lane);            // (see load_instance_coefficients: addresses local to this block)
-    const unsigned nnzL = (unsigned)R.nnzL, X0 = (unsigned)(Rs.fac_len - 2 - Rs.nnzX);
+    (void)R;
     // (the source words of 48 registers requested together: with one wavefront per SIMD every batch is an exposed round trip)
     constexpr int NB = 48;
 #pragma unroll
     for (int t0 = 0; t0 < CPG_GENR_NREGS; t0 += NB) {
-        unsigned code[NB], col[NB];
+        unsigned long long pos[NB];
         double va[NB], vb[NB];
 #pragma unroll
         for (int u = 0; u < NB; u++) {
             const int t = t0 + u;
-            code[u] = t < CPG_GENR_NREGS ? cpgw::gld(Rs.g_src, (unsigned)t * 64u + ln) : 0u;
-            col[u] = t < CPG_GENR_NREGS ? (unsigned)cpgw::gld(Rs.g_lcol, (unsigned)t * 64u + ln) : 0u;
+            pos[u] = t < CPG_GENR_NREGS ? cpgw::gld((const unsigned long long *)Rs.g_pos, (unsigned)t * 64u + ln) : 0ull;
         }
 #pragma unroll
         for (int u = 0; u < NB; u++) {
             const int t = t0 + u;
             if (t >= CPG_GENR_NREGS) break;
-            const CoefSource cs = coefficient_source(code[u], col[u], nnzL, X0, (unsigned)Rs.fac_len - 2u);
-            va[u] = fac[cs.a]; vb[u] = fac[cs.b];
+            va[u] = fac[(unsigned)pos[u] & 0x7FFFFFFFu]; vb[u] = fac[(unsigned)(pos[u] >> 32)];
         }
 #pragma unroll
         for (int u = 0; u < NB; u++) {
             const int t = t0 + u;
             if (t >= CPG_GENR_NREGS) break;
             const double pr = va[u] * vb[u];
-            cpgw::gst(B.cf, (unsigned)t * 64u + ln, (code[u] >> 28) == 2u ? -pr : pr);
+            cpgw::gst(B.cf, (unsigned)t * 64u + ln, ((unsigned)pos[u] >> 31) ? -pr : pr);
         }
     }
 }

@@ -462,28 +462,31 @@ CPG_DEV_NOINLINE void team_store_coefficients(const DevRefactor &R_, const DevRe
     constexpr int ldw = CPG_GENT_NSLOTS + CPG_GEN_EXTRA_SLOTS;
     {
         const unsigned ln = (unsigned)cpgw::opaque(lane);
-        const unsigned nnzL = (unsigned)CPG_GENT_NNZL, X0 = (unsigned)(Rs.fac_len - 2 - Rs.nnzX);
         const unsigned base = (unsigned)wave * (unsigned)CPG_GENT_NREGS * 64u;
         constexpr int NB = CPG_GENT_NREGS < 32 ? CPG_GENT_NREGS : 32;
 #pragma unroll
         for (int t0 = 0; t0 < CPG_GENT_NREGS; t0 += NB) {
-            unsigned code[NB], col[NB];
+            // (two positions in the factor array per register and lane, precomputed on the host -- DevResident::g_pos --: the
+            // coefficient is +-(sl[a] * sl[b]), both reads unconditional, no branch on its kind)
+            unsigned long long pos[NB];
+            double va[NB], vb[NB];
 #pragma unroll
             for (int u = 0; u < NB; u++) {
                 const int t = t0 + u;
-                code[u] = t < CPG_GENT_NREGS ? cpgw::gld(Rs.g_src, base + (unsigned)t * 64u + ln) : 0u;
-                col[u] = t < CPG_GENT_NREGS ? (unsigned)cpgw::gld(Rs.g_lcol, base + (unsigned)t * 64u + ln) : 0u;
+                pos[u] = t < CPG_GENT_NREGS ? cpgw::gld((const unsigned long long *)Rs.g_pos, base + (unsigned)t * 64u + ln) : 0ull;
             }
 #pragma unroll
             for (int u = 0; u < NB; u++) {
                 const int t = t0 + u;
                 if (t >= CPG_GENT_NREGS) break;
-                const unsigned kind = code[u] >> 28, idx = code[u] & 0x0FFFFFFFu;
-                double v = 0.0;
-                if (kind == 1u) v = 1.0;
-                else if (kind == 2u) v = -(sl[idx] * sl[nnzL + col[u]]);
-                else if (kind == 3u) v = sl[nnzL + idx];
-                else if (kind == 4u) v = sl[X0 + idx];
+                va[u] = sl[(unsigned)pos[u] & 0x7FFFFFFFu]; vb[u] = sl[(unsigned)(pos[u] >> 32)];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int t = t0 + u;
+                if (t >= CPG_GENT_NREGS) break;
+                const double pr = va[u] * vb[u];
+                const double v = ((unsigned)pos[u] >> 31) ? -pr : pr;
 #ifdef CPG_TEAM_STREAM_HINTS
                 cpgw::gst_stream(B.cf, base + (unsigned)t * 64u + ln, v);
 #else
