@@ -88,20 +88,20 @@ def adp_params(B: int, seed: int):
 BINDING = {
     # (workload, all parameters per instance, fixed-rho fork) -> what binds the dominant kernel, from the PMC passes under profiles/
     # (busy fractions: counter x 4 / (1024 SIMDs x kernel cycles) for the quad-cycle counters, / (256 CUs x cycles) for the LDS ones)
-    ('mpc12', False, False): 'LDS throughput, then latency: the shared-factor kernel (12.2 of the 22.4 ms) keeps the LDS pipe 83 % busy, 26 % of '
-                             'it bank conflicts, VALU 50 %; the per-instance factor kernel behind it (10.2 ms) keeps no unit busy -- VALU 49 %, '
-                             'LDS pipe 54 %, 50 % of the wave cycles waiting at two wavefronts per SIMD and 256 VGPRs (profiles/r4_final_pmc_config2.txt)',
+    ('mpc12', False, False): 'LDS throughput, then latency: the shared-factor kernel (11.8 of the 21.9 ms) keeps the LDS pipe 80 % busy, 18 % of '
+                             'it bank conflicts, VALU 50 %; the per-instance factor kernel behind it (10.1 ms) keeps no unit busy -- VALU 47 %, '
+                             'LDS pipe 54 %, 51 % of the wave cycles waiting at two wavefronts per SIMD and 256 VGPRs (profiles/r6_final4_pmc_config2.txt)',
     ('mpc12', False, True): 'LDS throughput: SQ_LDS_IDX_ACTIVE 84 % of the CU cycles, 24 % of it bank conflicts; VALU 50 % (profiles/r2_final6_pmc_config2.txt)',
     ('mpc6', False, False): 'as mpc12: an LDS-bound shared-factor kernel in front of a latency-bound per-instance factor kernel',
-    ('portfolio', False, False): 'latency: resident per-instance factor kernel at ONE wavefront per SIMD on three of the four SIMDs of a CU: VALU 22 % of '
-                                 'all SIMD cycles (30 % of the occupied ones), LDS pipe 22 %, 43 % of the wave cycles waiting; HBM-side traffic '
-                                 '80.6 GB per launch = 1.59 TB/s = 20 % of the peak (profiles/r4_final_pmc_config3.txt, r4_s13_probe_resident.txt)',
+    ('portfolio', False, False): 'instruction rate of ONE wavefront per SIMD (three of the four SIMDs of a CU): VALU 24 % of all SIMD cycles, LDS pipe '
+                                 '25 %, 40 % of the wave cycles waiting; HBM-side traffic 82 GB per launch = 1.66 TB/s = 21 % of the peak '
+                                 '(profiles/r6_final4_pmc_config3.txt, r4_s13_probe_resident.txt)',
     ('portfolio', False, True): 'latency (as the default mode; fewer termination tests and no refactorisations)',
     ('mpc12', True, False): 'latency at ONE instance per CU (team kernel, four wavefronts per instance): 17 dependent phases per ADMM iteration (one '
-                            'barrier each, 4.6 us per iteration) and 300 dependent levels per factorisation (0.43 us per level on one wavefront); '
+                            'barrier each, 4.3 us per iteration) and a factorisation table walk of 2 472 step slots at the instruction rate of one wavefront (~97 cycles per slot); '
                             'nothing streamed per iteration (DESIGN.md 4.7; the streaming kernel it replaces: 484 phases per iteration each waiting '
                             'for HBM, 342 GB of fetches per launch, profiles/r4_final_pmc_allparams.txt)',
-    ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 91 % of the SIMD cycles at four wavefronts per SIMD, 42.9 k vector instructions per instance (profiles/r5_final_pmc_config4.txt)',
+    ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 91 % of the SIMD cycles at four wavefronts per SIMD, 42.9 k vector instructions per instance (profiles/r6_final4_pmc_config4.txt)',
 }
 
 
