@@ -101,7 +101,7 @@ BINDING = {
                             'barrier each, 4.3 us per iteration) and a factorisation table walk of 2 472 step slots at the instruction rate of one wavefront (~97 cycles per slot); '
                             'nothing streamed per iteration (DESIGN.md 4.7; the streaming kernel it replaces: 484 phases per iteration each waiting '
                             'for HBM, 342 GB of fetches per launch, profiles/r4_final_pmc_allparams.txt)',
-    ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 91 % of the SIMD cycles at four wavefronts per SIMD, 42.9 k vector instructions per instance (profiles/r6_final4_pmc_config4.txt)',
+    ('adp', False, False): 'VALU issue: SQ_ACTIVE_INST_VALU 91 % of the SIMD cycles at four wavefronts per SIMD, 41.0 k vector instructions per instance (profiles/r6_final4_pmc_config4.txt)',
 }
 
 
